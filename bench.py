@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — SDF-query throughput of the NPHM identity field (BASELINE.json metric).
+
+A "step" = one dense extraction of the NPHM 39-anchor identity SDF on the res^3 lattice of the
+reference (bounds fitting_pointclouds.py:166-167): latent prologue (anchors + folded biases) +
+fused grid kernel (+ all-gather of the x-slabs when N > 1), output resident in HBM.  Inputs
+(packed weights, latent, axis vectors) are resident before the timed region.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_DENSE = 9_616_000            # reference formulation, 40 x 2 x 120 200
+FLOP_MEMBER_FOLDED = 2 * 81_800   # one member, one point, latent folded
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--prune-tol", type=float, default=None)
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3"])
+    ap.add_argument("--chunk", type=int, default=25000, help="get_logits chunk whose last voxel is overwritten (eval mode)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=40000)
+    return ap.parse_args()
+
+
+def cpu_baseline(net, lat, axes, n_sample):
+    """The oracle (numpy port of the reference arithmetic) on the host cores, on the first
+    n_sample lattice points of the same workload."""
+    from oracle import nphm_oracle as O
+    import _util as U
+    params, amean = U.np_state(net), U.anchors_mean()
+    g = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
+    # a z-column prefix would be all far-field; take a strided sample of whole-volume points
+    idx = np.linspace(0, g.shape[0] - 1, n_sample).astype(np.int64)
+    pts = g[idx][None].astype(np.float32)
+    latn = lat.cpu().numpy()[None, None]
+    t0 = time.perf_counter()
+    O.nphm_identity_forward(params, amean, pts, latn, training=False)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt / 1e6, "unit": "Mpoints/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_sample} lattice points (uniform stride over the {len(axes[0])}^3 volume), "
+                      f"oracle/nphm_oracle.py numpy fp32, dense 40-member evaluation, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import _util as U
+    from nphm_amd import _lib
+    from nphm_amd import reconstruction as R
+
+    net = U.build_identity(device=dev).eval()
+    if args.prune_tol is not None:
+        net.prune_tol = args.prune_tol
+    if args.precision is not None:
+        net.precision = args.precision
+    lat = U.sample_latent(0).to(dev)
+    axes = R.grid_axes(U.MINI, U.MAXI, args.res)
+    axes_dev = [torch.from_numpy(a).to(dev) for a in axes]
+    rx = ry = rz = args.res
+    n_total = rx * ry * rz
+    i0, i1 = R.slab_bounds(rx, world, rank)
+    plane = ry * rz
+    per = (rx + world - 1) // world
+
+    lib = _lib.load()
+    stats = torch.zeros(2, dtype=torch.int64, device=dev)
+    shard = torch.zeros(per * plane, dtype=torch.float32, device=dev)
+    full = torch.empty(world * per * plane, dtype=torch.float32, device=dev) if world > 1 else None
+    ev_k0, ev_k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kernel_ms = []
+
+    def step(timed):
+        packed, state, _ = net.prepare_latent(lat[None])
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if timed:
+            ev_k0.record()
+        _lib.check(lib.nphm_identity_eval_grid(
+            packed.data_ptr(), state.data_ptr(), axes_dev[0].data_ptr(), axes_dev[1].data_ptr(),
+            axes_dev[2].data_ptr(), rx, ry, rz, i0, i1, args.chunk, float(net.prune_tol),
+            net._precision_code(), shard.data_ptr(), stats.data_ptr() if timed else None, stream), "eval_grid")
+        if timed:
+            ev_k1.record()
+        if world > 1:
+            dist.all_gather_into_tensor(full, shard)
+        return ev_k0, ev_k1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        # HIP events on the launch stream bracket only the dominant kernel
+        ev_k1.synchronize()
+        kernel_ms.append(ev_k0.elapsed_time(ev_k1))
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        n_local = (i1 - i0) * plane
+        k_ms = float(np.mean(kernel_ms))
+        active = stats.cpu().numpy()
+        mean_active = float(active[0]) / max(1, args.steps) / n_local     # evaluated member-points / point
+        exec_flops = mean_active * FLOP_MEMBER_FOLDED * n_local
+        peak = PEAK_TFLOPS[net.precision]
+        achieved = exec_flops / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "SDF query throughput, NPHM 39-anchor identity field, dense lattice extraction",
+            "value": n_total * args.steps / dt / 1e6, "unit": "Mpoints/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if net.precision == "f32" else "bf16x3(split-bf16 MFMA, fp32 accumulate)",
+            "data": "synthetic (seeded random-init weights, latent ~ shipped mean/std x0.85)",
+            "config": {"workload": f"NPHM 39-anchor identity net, {args.res}^3 lattice extraction "
+                                   f"(BASELINE.json configs[1]), eval-mode get_logits chunk {args.chunk}",
+                       "res": args.res, "prune_tol": net.prune_tol, "precision": net.precision,
+                       "parallelism": f"x-slab x{world}" + (" + all_gather" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": "nphm::eval_kernel<1,%d>" % net._precision_code(),
+                         "kernel_ms": k_ms, "points_per_launch": n_local,
+                         "executed_flops_per_point": mean_active * FLOP_MEMBER_FOLDED,
+                         "mean_active_members": mean_active,
+                         "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(net, lat, axes, args.cpu_sample)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

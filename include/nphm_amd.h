@@ -1,0 +1,100 @@
+/*
+ * nphm_amd.h — C ABI of libnphm_amd.so: MI355X (gfx950) kernels for NPHM's batched
+ * neural-field evaluation hot path.
+ *
+ * The reference (SimonGiebenhain/NPHM) has no FFI of its own: the boundary of this path is
+ * the Python nn.Module surface.  Each entry point below is what a binding of
+ * that surface calls; the reference code it replaces is cited per function
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM, fp32 unless stated) owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     stream-ordered, nothing synchronises the host;
+ *   - return value: 0 = ok, <0 = error (message via nphm_last_error());
+ *   - no ownership transfer, no hidden allocation: the caller provides the packed-weight and
+ *     latent-state buffers (sizes from the *_bytes() queries).
+ */
+#ifndef NPHM_AMD_H
+#define NPHM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPHM_AMD_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------ */
+int nphm_abi_version(void);
+const char* nphm_last_error(void);
+
+/* ---- NPHM identity field: FastEnsembleDeepSDFMirrored -------------------------------- */
+/* Architecture the fused kernel is specialised for (scripts/configs/nphm.yaml:1-7):
+ * lat_dim_glob 64, lat_dim_loc 32, n_loc 39, n_symm_pairs 16, hidden 200, n_layers 4,
+ * out_dim 1, input_dim 3.  Returns 1 if (and only if) the arguments equal that config. */
+int nphm_identity_supported(int lat_dim_glob, int lat_dim_loc, int n_loc, int n_symm_pairs,
+                            int hidden_dim, int n_layers, int out_dim, int input_dim);
+
+/* Precision of the per-member MLP GEMMs. */
+#define NPHM_PREC_F32     0   /* v_mfma_f32_32x32x2_f32: exact fp32 products            */
+#define NPHM_PREC_BF16X3  1   /* split-bf16 (hi*hi + hi*lo + lo*hi) on 32x32x16 bf16 MFMA */
+
+size_t nphm_identity_packed_bytes(void);
+size_t nphm_identity_latent_state_bytes(int n_rows);
+
+/* Re-lay the state_dict tensors `ensembled_deep_sdf.lin{0..4}.{weight,bias}`
+ * ([24,200,99],[24,101,200],[24,200,200],[24,200,200],[24,1,200] + biases) into MFMA
+ * fragment order.  Replaces the per-call repeat_interleave/cat/permute of
+ * EnsembledLinear.forward (src/NPHM/models/EnsembledDeepSDF.py:43-54). */
+int nphm_identity_pack(const float* const lin_weight[5], const float* const lin_bias[5],
+                       void* packed, void* stream);
+
+/* Per latent code (one per batch row): predicted anchors = mlp_pos(z_glob) + mean anchors
+ * (EnsembledDeepSDF.py:228-229) and the constant-latent part of lin0 / lin2 folded into
+ * per-member bias vectors (replaces the cond tensor of EnsembledDeepSDF.py:247-255).
+ *   lat_rows   [n_rows, 1344]   row 0 of lat_rep for every batch row
+ *   mlp_pos_*  state_dict tensors mlp_pos.{0,2,4}.{weight,bias}; pos_mlp_dim = 256 or 128
+ *   anchors_mean [39,3]
+ *   anchors_out  [n_rows,39,3]  (second return value of forward()) */
+int nphm_identity_prepare_latent(const void* packed,
+                                 const float* const lin_weight[5], const float* const lin_bias[5],
+                                 const float* const mlp_pos_weight[3], const float* const mlp_pos_bias[3],
+                                 int pos_mlp_dim, const float* anchors_mean,
+                                 const float* lat_rows, int n_rows,
+                                 void* latent_state, float* anchors_out, void* stream);
+
+/* FastEnsembleDeepSDFMirrored.forward for latents that are constant along the point axis
+ * (EnsembledDeepSDF.py:203-267):  sdf_out[b,n] for xyz[b,n,:].
+ *   hack_chunk > 0 reproduces the eval-mode overwrite (EnsembledDeepSDF.py:260-261) of the last
+ *   point of every forward() call when the n_points of a row are evaluated in chunks of
+ *   hack_chunk points: indices i with (i+1) % hack_chunk == 0 or i == n_points-1 get
+ *   sum(w)/(sum(w)+1e-6).  hack_chunk = n_points is a single eval-mode forward(); 0 = train mode.
+ *   prune_tol: members whose normalised blend weight is <= prune_tol for all 32 points of a
+ *   wavefront are skipped (|error| <= 40*prune_tol*max|f_k|); < 0 evaluates all 40 members.
+ *   stats (nullable, device): stats[0] += evaluated (point, member) pairs, stats[1] += points —
+ *   the executed-work counter behind bench.py's roofline figure. */
+int nphm_identity_eval_points(const void* packed, const void* latent_state,
+                              const float* xyz, int n_rows, int64_t n_points,
+                              int64_t hack_chunk, float prune_tol, int precision,
+                              float* sdf_out, unsigned long long* stats, void* stream);
+
+/* Dense-grid evaluation = get_logits(decoder, lat, create_grid_points_from_bounds(...))
+ * (src/NPHM/models/reconstruction.py:6-25, src/NPHM/utils/reconstruction.py:5-20) for the
+ * x-slab [ix0, ix1) of an [rx,ry,rz] 'ij'-ordered grid (x slowest, z fastest).
+ *   axis_x/y/z : fp32 axis coordinates (float32(np.linspace(min,max,res)))
+ *   hack_chunk : >0 reproduces get_logits' per-chunk eval-mode overwrite: flat indices i with
+ *                (i+1) % hack_chunk == 0 or i == rx*ry*rz-1 get sum(w)/(sum(w)+1e-6); 0 = off
+ *   sdf_out    : [(ix1-ix0)*ry*rz] (slab-local, same flattened order) */
+int nphm_identity_eval_grid(const void* packed, const void* latent_state,
+                            const float* axis_x, const float* axis_y, const float* axis_z,
+                            int rx, int ry, int rz, int ix0, int ix1,
+                            int64_t hack_chunk, float prune_tol, int precision,
+                            float* sdf_out, unsigned long long* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPHM_AMD_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libnphm_amd.so (C ABI declared in include/nphm_amd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``nphm_amd.build``; there is no
+fallback: if it is missing or fails to load, every HIP-backed entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnphm_amd.so")
+
+NPHM_PREC_F32 = 0
+NPHM_PREC_BF16X3 = 1
+
+_PtrArr5 = c_void_p * 5
+_PtrArr3 = c_void_p * 3
+
+# name -> (restype, argtypes); must list every symbol of include/nphm_amd.h
+SYMBOLS = {
+    "nphm_abi_version": (c_int, []),
+    "nphm_last_error": (c_char_p, []),
+    "nphm_identity_supported": (c_int, [c_int] * 8),
+    "nphm_identity_packed_bytes": (c_size_t, []),
+    "nphm_identity_latent_state_bytes": (c_size_t, [c_int]),
+    "nphm_identity_pack": (c_int, [_PtrArr5, _PtrArr5, c_void_p, c_void_p]),
+    "nphm_identity_prepare_latent": (c_int, [c_void_p, _PtrArr5, _PtrArr5, _PtrArr3, _PtrArr3, c_int,
+                                             c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_eval_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_float,
+                                          c_int, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_eval_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_int, c_int, c_int, c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class NphmAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libnphm_amd.so (once).  Raises NphmAmdError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NphmAmdError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  nphm_amd has no non-HIP fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nphm_abi_version() != 1:
+        raise NphmAmdError("libnphm_amd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().nphm_last_error()
+        raise NphmAmdError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr_array5(tensors):
+    return _PtrArr5(*[t.data_ptr() for t in tensors])
+
+
+def ptr_array3(tensors):
+    return _PtrArr3(*[t.data_ptr() for t in tensors])

@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's global DeepSDF and forward-deformation network
+(src/NPHM/models/deepSDF.py): same class names, constructor signatures, attributes, ``forward``
+contracts and ``state_dict`` layout (``lin{i}.{weight,bias}``, ``compressor.0.*``,
+``defDeepSDF.lin{i}.*``).
+
+The MLP body is evaluated by ``DeepSDF.evaluate``: the latent columns of the first layer and of
+the skip layer are applied once per latent row (``lat_rep.shape[1] == 1`` or a row-constant
+latent) instead of once per point.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .ensembled_deepsdf import sample_point_feature  # noqa: F401  (re-exported like the reference)
+
+_SQRT2 = float(np.sqrt(2))
+
+
+class DeepSDF(nn.Module):
+    """Skip-MLP SDF / vector field (deepSDF.py:6-89).  dims = [d_in] + [hidden]*nlayers + [out];
+    the input is re-injected (concatenated, divided by sqrt 2) before layer ``nlayers//2``;
+    Softplus(beta) activations (ReLU if beta <= 0); optional geometric init of the last layer."""
+
+    def __init__(self, lat_dim, hidden_dim, nlayers=8, geometric_init=True, radius_init=1, beta=100,
+                 out_dim=1, num_freq_bands=None, input_dim=3):
+        super().__init__()
+        d_spatial = input_dim if num_freq_bands is None else input_dim * (2 * num_freq_bands + 1)
+        d_in = lat_dim + d_spatial
+        self.lat_dim = lat_dim
+        self.input_dim = input_dim
+        self.d_spatial = d_spatial
+        print(d_in)
+        print(hidden_dim)
+        dims = [d_in] + [hidden_dim] * nlayers + [out_dim]
+        self.num_layers = len(dims)
+        self.skip_in = [nlayers // 2]
+        self.num_freq_bands = num_freq_bands
+        if num_freq_bands is not None:
+            self.freq_bands = 2 ** torch.arange(num_freq_bands)
+        for layer in range(self.num_layers - 1):
+            fan_out = dims[layer + 1] - d_in if (layer + 1) in self.skip_in else dims[layer + 1]
+            lin = nn.Linear(dims[layer], fan_out)
+            if geometric_init and layer == self.num_layers - 2:
+                nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[layer]), std=0.00001)
+                nn.init.constant_(lin.bias, -radius_init)
+            setattr(self, f"lin{layer}", lin)
+        self.activation = nn.Softplus(beta=beta) if beta > 0 else nn.ReLU()
+
+    def _embed(self, xyz):
+        if self.num_freq_bands is None:
+            return xyz
+        parts = [xyz]
+        for freq in self.freq_bands:
+            parts.append(torch.sin(xyz * freq))
+            parts.append(torch.cos(xyz * freq))
+        return torch.cat(parts, dim=-1)
+
+    def evaluate(self, pos, lat):
+        """pos [B,N,d_spatial]; lat [B,Lr,lat_dim], Lr in {1,N}."""
+        D = pos.shape[-1]
+        last = self.num_layers - 2
+        x = None
+        for layer in range(self.num_layers - 1):
+            lin = getattr(self, f"lin{layer}")
+            W, b = lin.weight, lin.bias
+            if layer == 0 or layer in self.skip_in:
+                n_prev = 0 if layer == 0 else x.shape[-1]
+                scale = 1.0 if layer == 0 else 1.0 / _SQRT2
+                lat_term = (lat @ W[:, n_prev + D:].t()) * scale + b          # [B,Lr,out]
+                y = (pos @ W[:, n_prev:n_prev + D].t()) * scale
+                if layer != 0:
+                    y = y + (x @ W[:, :n_prev].t()) * scale
+                x = y + lat_term
+            else:
+                x = x @ W.t() + b
+            if layer < last:
+                x = self.activation(x)
+        return x
+
+    def forward(self, xyz, lat_rep, anchors=None):
+        return self.evaluate(self._embed(xyz), lat_rep), None
+
+
+class DeformationNetwork(nn.Module):
+    """Forward deformation field F_ex (deepSDF.py:118-239).  Conditioning modes: 'glob_only',
+    'expr_only', 'interpolate', 'compress' (the NPHM one: identity code + anchors are projected to
+    32 dims from ROW 0 of the latent and concatenated with the expression code), 'GNN'."""
+
+    def __init__(self, mode, lat_dim_expr, lat_dim_id, lat_dim_glob_shape, lat_dim_loc_shape, n_loc,
+                 anchors, hidden_dim, nlayers=8, out_dim=1, input_dim=3):
+        super().__init__()
+        self.mode = mode
+        self.lat_dim_glob_shape = lat_dim_glob_shape
+        self.lat_dim_loc_shape = lat_dim_loc_shape
+        self.lat_dim_expr = lat_dim_expr
+        self.input_dim = input_dim
+        self.num_kps = n_loc
+        self.out_dim = out_dim + 1
+
+        if mode == "glob_only":
+            self.lat_dim = lat_dim_glob_shape + lat_dim_expr
+        elif mode == "expr_only":
+            self.lat_dim = lat_dim_expr
+        elif mode == "interpolate":
+            self.lat_dim = lat_dim_glob_shape + lat_dim_expr + lat_dim_loc_shape
+        elif mode == "compress":
+            self.lat_dim = lat_dim_expr + lat_dim_id
+            self.compressor = nn.Sequential(
+                nn.Linear((lat_dim_loc_shape + 3) * n_loc + lat_dim_loc_shape + lat_dim_glob_shape, 32))
+        elif mode == "GNN":
+            self.lat_dim = lat_dim_expr * 2
+            self.pos_enc = nn.Sequential(nn.Linear(3, lat_dim_loc_shape), nn.ReLU(),
+                                         nn.Linear(lat_dim_loc_shape, lat_dim_loc_shape))
+            self.local_combiner = nn.Sequential(nn.Linear(lat_dim_loc_shape, lat_dim_loc_shape), nn.ReLU(),
+                                                nn.Linear(lat_dim_loc_shape, lat_dim_loc_shape))
+            self.global_combiner = nn.Sequential(
+                nn.Linear(lat_dim_glob_shape + n_loc * lat_dim_loc_shape, 512), nn.ReLU(),
+                nn.Linear(512, lat_dim_expr))
+        else:
+            raise ValueError("Unknown mode!")
+
+        print("creating DeepSDF with...")
+        print("lat dim", self.lat_dim)
+        print("hidden_dim", hidden_dim)
+        self.defDeepSDF = DeepSDF(lat_dim=self.lat_dim, hidden_dim=hidden_dim, nlayers=nlayers,
+                                  geometric_init=False, out_dim=out_dim, input_dim=input_dim).float()
+        self.anchors = anchors
+
+    def _condition(self, xyz, lat_rep, anchors):
+        """Conditioning vector [B,Lr,lat_dim] (Lr = 1 when it is constant along the points)."""
+        B, N, _ = xyz.shape
+        e = self.lat_dim_expr
+        g = self.lat_dim_glob_shape
+        if self.mode == "glob_only":
+            return torch.cat([lat_rep[..., :g], lat_rep[..., -e:]], dim=-1)
+        if self.mode == "expr_only":
+            return lat_rep[..., -e:]
+        if self.mode == "interpolate":
+            loc = lat_rep[:, 0, g:-e - self.lat_dim_loc_shape].view(B, self.num_kps, self.lat_dim_loc_shape)
+            interp = sample_point_feature(xyz[..., :3], anchors[:, 0, :, :3], loc.unsqueeze(1), background=False)
+            Lr = lat_rep.shape[1]
+            head = lat_rep[..., :g] if Lr == N else lat_rep[..., :g].expand(B, N, g)
+            tail = lat_rep[..., -e:] if Lr == N else lat_rep[..., -e:].expand(B, N, e)
+            return torch.cat([head, interp, tail], dim=-1)
+        if self.mode == "compress":
+            a0 = anchors[:, 0] if anchors.dim() == 4 else anchors              # row 0 only
+            packed = torch.cat([lat_rep[:, 0, :-e], a0.reshape(B, -1)], dim=-1)
+            comp = self.compressor(packed).unsqueeze(1)                         # [B,1,32]
+            if self.training:
+                comp = comp + torch.randn(B, N, comp.shape[-1], device=comp.device) / 200
+            Lr = max(comp.shape[1], lat_rep.shape[1])
+            return torch.cat([comp.expand(B, Lr, -1), lat_rep[..., -e:].expand(B, Lr, e)], dim=-1)
+        if self.mode == "GNN":
+            pos = self.pos_enc(anchors[:, 0, :, :])
+            loc = lat_rep[:, 0, g:g + self.num_kps * self.lat_dim_loc_shape].view(B, self.num_kps, 32)
+            loc = self.local_combiner(pos + loc)
+            comb = self.global_combiner(torch.cat([lat_rep[:, 0, :g], loc.view(B, -1)], dim=-1)).unsqueeze(1)
+            Lr = lat_rep.shape[1]
+            return torch.cat([comb.expand(B, Lr, -1), lat_rep[..., -e:]], dim=-1)
+        raise ValueError("Unknown mode")
+
+    def forward(self, xyz: torch.Tensor, lat_rep: torch.Tensor, anchors: Optional[torch.Tensor]):
+        """xyz [B,N,3]; lat_rep [B,N or 1,·] = [z_id | z_ex]; anchors [B,N,K,3] or [B,K,3].
+        Returns (offsets pred[..., :3], remaining features pred[..., -1:])."""
+        if xyz.dim() < 3:
+            xyz = xyz.unsqueeze(0)
+        cond = self._condition(xyz, lat_rep, anchors)
+        pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
+        return pred[..., :3], pred[..., -1:]

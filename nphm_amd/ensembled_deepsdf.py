@@ -1,0 +1,303 @@
+"""Host-side mirror of the reference's NPHM identity field
+(src/NPHM/models/EnsembledDeepSDF.py): same class names, constructor signatures, attributes,
+``forward`` contracts and ``state_dict`` layout, so checkpoints load with ``strict=True`` and
+the reference's callers (get_logits, fitting loop, trainers) run unchanged.
+
+Execution tiers of ``FastEnsembleDeepSDFMirrored.forward``:
+
+* **HIP** (``libnphm_amd.so``, gfx950): used whenever no autograd graph is needed, the tensors
+  live on a ROCm device, the architecture is the NPHM one (nphm.yaml) and the latent is constant
+  along the point axis (what get_logits / the fitting loop pass).  One fused kernel evaluates the
+  40-member ensemble and the Gaussian blend; if the library is missing this tier raises.
+* **composite**: a differentiable PyTorch formulation (latent columns of lin0 / the skip layer are
+  applied once per latent instead of once per point).  Used when gradients are required
+  (fitting / training, incl. double backward), for per-point latents and for other architectures.
+  It is never chosen silently on a CPU tensor: that needs ``module.backend = "composite"``.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_SQRT2 = float(np.sqrt(2))
+
+
+def _member_sets(ensemble_size: int, n_symm: int) -> torch.Tensor:
+    """member k -> index of its weight set: the first n_symm sets serve two members each
+    (reference: repeat_interleave(2) + cat, EnsembledDeepSDF.py:43-45)."""
+    idx = [k // 2 if k < 2 * n_symm else n_symm + (k - 2 * n_symm) for k in range(ensemble_size)]
+    return torch.tensor(idx, dtype=torch.long)
+
+
+class EnsembledLinear(nn.Module):
+    """``ensemble_size`` linear layers evaluated at once; the first ``n_symm`` parameter sets are
+    shared by two (mirror-symmetric) members each.  Parameters: ``weight``
+    [ensemble_size - n_symm, out, in], ``bias`` [ensemble_size - n_symm, out]
+    (EnsembledDeepSDF.py:8-55)."""
+
+    def __init__(self, ensemble_size, n_symm, in_features, out_features, bias=True):
+        super().__init__()
+        self.ensemble_size = ensemble_size
+        self.n_symm = n_symm
+        self.in_features = in_features
+        self.out_features = out_features
+        n_sets = ensemble_size - n_symm
+        self.weight = nn.Parameter(torch.empty(n_sets, out_features, in_features))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(n_sets, out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.register_buffer("_sets", _member_sets(ensemble_size, n_symm), persistent=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # every parameter set gets nn.Linear's default init on its own (same RNG consumption
+        # order as the reference, so a seeded construction yields identical weights)
+        bound_b = 1.0 / math.sqrt(self.in_features) if self.in_features > 0 else 0.0
+        with torch.no_grad():
+            for s in range(self.weight.shape[0]):
+                nn.init.kaiming_uniform_(self.weight[s], a=math.sqrt(5))
+                if self.bias is not None:
+                    nn.init.uniform_(self.bias[s], -bound_b, bound_b)
+
+    def member_weight(self):
+        return self.weight.index_select(0, self._sets)
+
+    def member_bias(self):
+        return None if self.bias is None else self.bias.index_select(0, self._sets)
+
+    def forward(self, input):
+        # input [A, P, in] -> [A, P, out]
+        w = self.member_weight()
+        if self.bias is None:
+            return torch.bmm(input, w.transpose(1, 2))
+        return torch.baddbmm(self.member_bias().unsqueeze(1), input, w.transpose(1, 2))
+
+
+class EnsembledDeepSDF(nn.Module):
+    """A bank of DeepSDF MLPs with a skip connection into layer ``nlayers//2``
+    (EnsembledDeepSDF.py:58-126)."""
+
+    def __init__(self, ensemble_size, n_symm, lat_dim, hidden_dim, nlayers, out_dim=1, input_dim=3):
+        super().__init__()
+        d_in = input_dim + lat_dim
+        self.ensemble_size = ensemble_size
+        self.n_symm = n_symm
+        self.lat_dim = lat_dim
+        self.input_dim = input_dim
+        dims = [d_in] + [hidden_dim] * nlayers + [out_dim]
+        self.num_layers = len(dims)
+        self.skip_in = [nlayers // 2]
+        for layer in range(self.num_layers - 1):
+            fan_out = dims[layer + 1] - d_in if (layer + 1) in self.skip_in else dims[layer + 1]
+            setattr(self, f"lin{layer}", EnsembledLinear(ensemble_size, n_symm, dims[layer], fan_out))
+        self.activation = nn.Softplus(beta=100)
+
+    def _lin(self, i) -> EnsembledLinear:
+        return getattr(self, f"lin{i}")
+
+    def forward(self, xyz, lat_rep):
+        # xyz [A,B,N,3], lat_rep [A,B,N,F] -> [A,B,N,out]
+        return self.evaluate(xyz, lat_rep)
+
+    def evaluate(self, coords, cond):
+        """coords [A,B,N,D]; cond [A,B,Lr,F] with Lr in {1, N}.  The latent columns of the first
+        and of the skip layer are multiplied once per latent row and broadcast over the points."""
+        A, B, N, D = coords.shape
+        Lr = cond.shape[2]
+        last = self.num_layers - 2
+        x = None
+        for layer in range(self.num_layers - 1):
+            lin = self._lin(layer)
+            W = lin.member_weight()                       # [A,out,in]
+            b = lin.member_bias()                         # [A,out]
+            if layer == 0 or layer in self.skip_in:
+                n_prev = 0 if layer == 0 else x.shape[-1]
+                scale = 1.0 if layer == 0 else 1.0 / _SQRT2
+                Wc = W[:, :, n_prev:n_prev + D]
+                Wl = W[:, :, n_prev + D:]
+                lat_term = torch.einsum("ablf,aof->ablo", cond, Wl) * scale + b[:, None, None, :]
+                y = torch.einsum("abnd,aod->abno", coords, Wc) * scale
+                if layer != 0:
+                    y = y + torch.einsum("abnk,aok->abno", x, W[:, :, :n_prev]) * scale
+                x = y + (lat_term if Lr == N else lat_term.expand(A, B, N, -1))
+            else:
+                x = torch.einsum("abnk,aok->abno", x, W) + b[:, None, None, :]
+            if layer < last:
+                x = self.activation(x)
+        return x
+
+
+def sample_point_feature(q, p, fea, var=0.1 ** 2, background=False):
+    """Gaussian-of-distance blend of per-anchor features (EnsembledDeepSDF.py:129-150).
+    q [B,N,3], p [B,K,3], fea [B,N,K(+1),C] -> [B,N,C]."""
+    d = (p[:, None, :, :] - q[:, :, None, :]).norm(dim=3)
+    logit = -((d + 10e-6) ** 2)
+    if background:
+        logit = torch.cat([logit, torch.full_like(logit[:, :, :1], -0.2)], dim=-1)
+    w = (logit / var).exp()
+    w = w / (w.sum(dim=2, keepdim=True) + 1e-6)
+    return (w.unsqueeze(-1) * fea).sum(dim=2)
+
+
+class FastEnsembleDeepSDFMirrored(nn.Module):
+    """NPHM identity SDF: one small MLP per facial anchor (+ one background MLP), evaluated in
+    anchor-local coordinates (odd member of each symmetric pair mirrored in x) and blended by a
+    Gaussian of the anchor distance (EnsembledDeepSDF.py:153-267)."""
+
+    def __init__(self, lat_dim_glob: int, lat_dim_loc: int, n_loc: int, n_symm_pairs: int,
+                 anchors: torch.Tensor, hidden_dim: int, n_layers: int, pos_mlp_dim: int = 256,
+                 out_dim: int = 1, input_dim: int = 3):
+        super().__init__()
+        self.lat_dim_glob = lat_dim_glob
+        self.lat_dim_loc = lat_dim_loc
+        self.lat_dim = lat_dim_glob + (n_loc + 1) * lat_dim_loc
+        self.input_dim = input_dim
+        self.out_dim = out_dim
+        self.pos_mlp_dim = pos_mlp_dim
+        self.num_kps = n_loc
+        self.num_symm_pairs = n_symm_pairs
+        self.hidden_dim = hidden_dim
+        self.n_layers = n_layers
+
+        self.ensembled_deep_sdf = EnsembledDeepSDF(ensemble_size=n_loc + 1, n_symm=n_symm_pairs,
+                                                   lat_dim=lat_dim_glob + lat_dim_loc,
+                                                   hidden_dim=hidden_dim, nlayers=n_layers,
+                                                   out_dim=out_dim, input_dim=input_dim).float()
+        # plain attribute like the reference: not a buffer, absent from state_dict
+        self.anchors = anchors
+        self.mlp_pos = nn.Sequential(
+            nn.Linear(lat_dim_glob, pos_mlp_dim), nn.ReLU(),
+            nn.Linear(pos_mlp_dim, pos_mlp_dim), nn.ReLU(),
+            nn.Linear(pos_mlp_dim, n_loc * 3))
+
+        # ---- execution knobs (defaults keep reference numerics within 1e-4) -------------------
+        self.backend = "hip"            # "hip" | "composite"
+        self.prune_tol = float(os.environ.get("NPHM_AMD_PRUNE_TOL", "1e-7"))
+        self.precision = os.environ.get("NPHM_AMD_PRECISION", "f32")   # "f32" | "bf16x3"
+        self._pack_cache = None         # (key, packed tensor)
+
+    # ------------------------------------------------------------------------------------------
+    def hip_supported(self) -> bool:
+        lib = _lib.load()
+        return bool(lib.nphm_identity_supported(self.lat_dim_glob, self.lat_dim_loc, self.num_kps,
+                                                self.num_symm_pairs, self.hidden_dim, self.n_layers,
+                                                self.out_dim, self.input_dim)) and self.pos_mlp_dim <= 256
+
+    def _lin_params(self):
+        e = self.ensembled_deep_sdf
+        ws = [e._lin(i).weight for i in range(5)]
+        bs = [e._lin(i).bias for i in range(5)]
+        return ws, bs
+
+    def _packed(self, device):
+        """Packed (MFMA-fragment order) copy of the ensemble weights on ``device``; rebuilt when
+        any parameter changed (optimizer step, load_state_dict, .to())."""
+        ws, bs = self._lin_params()
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in ws + bs) + (str(device),)
+        if self._pack_cache is not None and self._pack_cache[0] == key:
+            return self._pack_cache[1]
+        lib = _lib.load()
+        for t in ws + bs:
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.NphmAmdError("ensemble parameters must be contiguous fp32 on the query device")
+        packed = torch.empty(lib.nphm_identity_packed_bytes(), dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.nphm_identity_pack(_lib.ptr_array5(ws), _lib.ptr_array5(bs), packed.data_ptr(), stream),
+                   "nphm_identity_pack")
+        self._pack_cache = (key, packed)
+        return packed
+
+    def prepare_latent(self, lat_rows: torch.Tensor):
+        """lat_rows [B, lat_dim] -> (latent_state, anchors [B,n_loc,3]) via the HIP prologue kernel."""
+        lib = _lib.load()
+        device = lat_rows.device
+        packed = self._packed(device)
+        B = lat_rows.shape[0]
+        lat_rows = lat_rows.contiguous().float()
+        state = torch.empty(lib.nphm_identity_latent_state_bytes(B), dtype=torch.uint8, device=device)
+        anchors = torch.empty(B, self.num_kps, 3, dtype=torch.float32, device=device)
+        mean = self.anchors.reshape(self.num_kps, 3).to(device=device, dtype=torch.float32).contiguous()
+        ws, bs = self._lin_params()
+        pw = [self.mlp_pos[i].weight for i in (0, 2, 4)]
+        pb = [self.mlp_pos[i].bias for i in (0, 2, 4)]
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.nphm_identity_prepare_latent(
+            packed.data_ptr(), _lib.ptr_array5(ws), _lib.ptr_array5(bs), _lib.ptr_array3(pw),
+            _lib.ptr_array3(pb), self.pos_mlp_dim, mean.data_ptr(), lat_rows.data_ptr(), B,
+            state.data_ptr(), anchors.data_ptr(), stream), "nphm_identity_prepare_latent")
+        return packed, state, anchors
+
+    def _precision_code(self):
+        return {"f32": _lib.NPHM_PREC_F32, "bf16x3": _lib.NPHM_PREC_BF16X3}[self.precision]
+
+    def _forward_hip(self, xyz, lat_rows):
+        lib = _lib.load()
+        B, N, _ = xyz.shape
+        packed, state, anchors = self.prepare_latent(lat_rows)
+        xyz = xyz.contiguous().float()
+        out = torch.empty(B, N, 1, dtype=torch.float32, device=xyz.device)
+        stream = torch.cuda.current_stream(xyz.device).cuda_stream
+        _lib.check(lib.nphm_identity_eval_points(
+            packed.data_ptr(), state.data_ptr(), xyz.data_ptr(), B, N, 0 if self.training else N,
+            float(self.prune_tol), self._precision_code(), out.data_ptr(), None, stream),
+            "nphm_identity_eval_points")
+        return out, anchors
+
+    def _forward_composite(self, xyz, lat_rep):
+        B, N, _ = xyz.shape
+        A = self.num_kps + 1
+        Lr = lat_rep.shape[1]
+        g = self.lat_dim_glob
+        anchors = self.mlp_pos(lat_rep[:, 0, :g]).view(B, self.num_kps, 3)
+        anchors = anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
+        origin = torch.cat([anchors, torch.zeros_like(anchors[:, :1])], dim=1)            # [B,A,3]
+        local = xyz[:, None, :, :] - origin[:, :, None, :]                               # [B,A,N,3]
+        flip = torch.ones(A, 3, dtype=xyz.dtype, device=xyz.device)
+        flip[1:2 * self.num_symm_pairs:2, 0] = -1.0
+        local = (local * flip[None, :, None, :]).permute(1, 0, 2, 3)                      # [A,B,N,3]
+        z_loc = lat_rep[..., g:].reshape(B, Lr, A, self.lat_dim_loc)
+        cond = torch.cat([lat_rep[:, :, None, :g].expand(B, Lr, A, g), z_loc], dim=-1)
+        cond = cond.permute(2, 0, 1, 3)                                                   # [A,B,Lr,F]
+        f = self.ensembled_deep_sdf.evaluate(local, cond)                                 # [A,B,N,1]
+        if not self.training:
+            # reference quirk (EnsembledDeepSDF.py:260-261): in eval mode every member's value of
+            # the LAST point of each batch row is overwritten with 1
+            keep = torch.ones(N, dtype=f.dtype, device=f.device)
+            keep[-1] = 0.0
+            f = f * keep[None, None, :, None] + (1.0 - keep)[None, None, :, None]
+        pred = sample_point_feature(xyz[..., :3], anchors, f.permute(1, 2, 0, 3), background=True, var=0.1 ** 2)
+        return pred, anchors
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, xyz: torch.Tensor, lat_rep: torch.Tensor, anchors_gt: Optional[torch.Tensor] = None):
+        """xyz [B,N,3] (or [N,3]); lat_rep [B,N or 1,lat_dim] laid out as
+        [z_glob | z_1, z*_1, ..., z_16, z*_16 | z_mid.. | z_bg]; ``anchors_gt`` is ignored (as in the
+        reference).  Returns (sdf [B,N,1], anchors [B,n_loc,3])."""
+        if xyz.dim() < 3:
+            xyz = xyz.unsqueeze(0)
+        B, N, _ = xyz.shape
+        assert self.lat_dim == lat_rep.shape[-1], "lat dim {}, lat_rep {}".format(self.lat_dim, lat_rep.shape)
+
+        needs_graph = torch.is_grad_enabled() and (
+            xyz.requires_grad or lat_rep.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if self.backend == "composite":
+            return self._forward_composite(xyz, lat_rep)
+        if not xyz.is_cuda:
+            raise _lib.NphmAmdError(
+                "FastEnsembleDeepSDFMirrored: tensors are on the CPU; the HIP path needs a ROCm device "
+                "(set module.backend = 'composite' explicitly for the PyTorch formulation)")
+        if needs_graph or not self.hip_supported() or xyz.dtype != torch.float32:
+            return self._forward_composite(xyz, lat_rep)
+        if lat_rep.shape[1] != 1:
+            # get_logits passes encoding.repeat(1, N, 1): constant along the point axis
+            if lat_rep.shape[1] != N or not bool((lat_rep == lat_rep[:, :1]).all()):
+                return self._forward_composite(xyz, lat_rep)
+        return self._forward_hip(xyz, lat_rep[:, 0, :])

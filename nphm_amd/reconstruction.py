@@ -1,0 +1,233 @@
+"""Dense-grid / chunked field evaluation with the reference's call signatures
+(src/NPHM/models/reconstruction.py:6-88, src/NPHM/utils/reconstruction.py:5-20), plus the fused
+grid evaluator and its multi-GPU (x-slab + RCCL all-gather) form.
+
+``get_logits`` returns exactly what the reference returns — a float32 numpy array of
+``decoder(points, lat)`` evaluated chunk by chunk, INCLUDING the eval-mode overwrite of the last
+point of every chunk — but when the decoder is the HIP-backed NPHM identity field the whole
+volume is produced by one kernel launch with no per-chunk latent repeat and no per-chunk
+device->host copy.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ensembled_deepsdf import FastEnsembleDeepSDFMirrored
+
+
+# ----------------------------------------------------------------------------------------------
+# grids
+# ----------------------------------------------------------------------------------------------
+def create_grid_points_from_bounds(minimun, maximum, res, scale=None):
+    """float64 [res^3, 3] lattice in 'ij' order — x slowest, z fastest
+    (utils/reconstruction.py:5-20)."""
+    if scale is not None:
+        res = int(scale * res)
+        minimun = scale * minimun
+        maximum = scale * maximum
+    axes = [np.linspace(minimun[d], maximum[d], res) for d in range(3)]
+    gx, gy, gz = np.meshgrid(*axes, indexing="ij")
+    return np.stack([gx.ravel(), gy.ravel(), gz.ravel()], axis=1)
+
+
+def grid_axes(minimun, maximum, res):
+    """The three fp32 axis vectors of the lattice above, cast exactly like the reference casts the
+    full lattice (float64 linspace -> float32, fitting_pointclouds.py:168-169)."""
+    if np.isscalar(res):
+        res = (res, res, res)
+    return tuple(np.linspace(minimun[d], maximum[d], res[d]).astype(np.float32) for d in range(3))
+
+
+def _as_lat_row(encoding: torch.Tensor, lat_dim: int) -> torch.Tensor:
+    enc = encoding.reshape(-1, encoding.shape[-1])
+    if enc.shape[0] != 1 or enc.shape[1] != lat_dim:
+        raise ValueError(f"expected a single latent code of width {lat_dim}, got {tuple(encoding.shape)}")
+    return enc
+
+
+def _detect_lattice(points: torch.Tensor):
+    """If ``points`` [1,n,3] is a full 'ij' lattice (any per-axis resolutions) return its axis
+    tensors, else None.  One fused compare on the device + one host sync."""
+    if points.dim() != 3 or points.shape[0] != 1 or points.shape[2] != 3 or points.shape[1] < 8:
+        return None
+    p = points[0]
+    n = p.shape[0]
+    head = p[: min(n, 1 << 16)]
+    # z is fastest: rz = first index where z wraps back to its first value
+    z0 = head[0, 2]
+    wrap = (head[1:, 2] == z0).nonzero()
+    if wrap.numel() == 0:
+        return None
+    rz = int(wrap[0, 0]) + 1
+    if n % rz:
+        return None
+    y0 = p[0, 1]
+    ycol = p[::rz, 1]
+    wrap = (ycol[1:] == y0).nonzero()
+    ry = int(wrap[0, 0]) + 1 if wrap.numel() else ycol.shape[0]
+    if n % (rz * ry):
+        return None
+    rx = n // (rz * ry)
+    ax = p[:: rz * ry, 0].contiguous()
+    ay = p[: rz * ry: rz, 1].contiguous()
+    az = p[:rz, 2].contiguous()
+    g = p.view(rx, ry, rz, 3)
+    ok = (g[..., 0] == ax[:, None, None]).all() & (g[..., 1] == ay[None, :, None]).all() & \
+         (g[..., 2] == az[None, None, :]).all()
+    return (ax, ay, az) if bool(ok) else None
+
+
+# ----------------------------------------------------------------------------------------------
+# fused grid evaluation (NPHM identity field)
+# ----------------------------------------------------------------------------------------------
+def _hip_ready(decoder, device) -> bool:
+    return (isinstance(decoder, FastEnsembleDeepSDFMirrored) and decoder.backend == "hip"
+            and device.type == "cuda" and decoder.hip_supported())
+
+
+def evaluate_grid(decoder: FastEnsembleDeepSDFMirrored, encoding: torch.Tensor, axes: Sequence,
+                  *, hack_chunk: Optional[int] = None, x_range=None, out: Optional[torch.Tensor] = None,
+                  return_anchors: bool = False):
+    """SDF of the NPHM identity field on the 'ij' lattice spanned by ``axes`` (three fp32 vectors),
+    restricted to the x-planes ``x_range = (ix0, ix1)``; returns a device tensor
+    [(ix1-ix0)*ry*rz] in the flattened order of the reference lattice.
+
+    hack_chunk: chunk length whose last point get_logits would overwrite in eval mode
+    (None -> off when decoder.training else whole volume as one chunk; 0 -> off).
+    """
+    lib = _lib.load()
+    device = encoding.device
+    if not _hip_ready(decoder, device):
+        raise _lib.NphmAmdError("evaluate_grid needs the HIP-backed NPHM identity field on a ROCm device")
+    ax, ay, az = [torch.as_tensor(a, dtype=torch.float32, device=device).contiguous() for a in axes]
+    rx, ry, rz = ax.numel(), ay.numel(), az.numel()
+    ix0, ix1 = (0, rx) if x_range is None else x_range
+    if hack_chunk is None:
+        hack_chunk = 0 if decoder.training else rx * ry * rz
+    lat = _as_lat_row(encoding.to(device=device, dtype=torch.float32), decoder.lat_dim)
+    packed, state, anchors = decoder.prepare_latent(lat)
+    n = (ix1 - ix0) * ry * rz
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=device)
+    elif out.numel() != n or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous fp32 tensor with (ix1-ix0)*ry*rz elements")
+    stream = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(lib.nphm_identity_eval_grid(
+        packed.data_ptr(), state.data_ptr(), ax.data_ptr(), ay.data_ptr(), az.data_ptr(), rx, ry, rz,
+        ix0, ix1, int(hack_chunk), float(decoder.prune_tol), decoder._precision_code(),
+        out.data_ptr(), None, stream), "nphm_identity_eval_grid")
+    return (out, anchors) if return_anchors else out
+
+
+def slab_bounds(rx: int, world_size: int, rank: int):
+    """Contiguous x-slab of rank ``rank``: ceil(rx/world) planes each, last ranks may be short."""
+    per = (rx + world_size - 1) // world_size
+    return min(rank * per, rx), min((rank + 1) * per, rx)
+
+
+def evaluate_grid_sharded(decoder, encoding, axes, *, hack_chunk: Optional[int] = None, group=None,
+                          evaluate=None):
+    """Multi-GPU grid evaluation: every rank evaluates its x-slab (contiguous in the flattened
+    volume) and one all_gather_into_tensor (RCCL over xGMI on ROCm) reassembles the full volume on
+    every rank.  ``evaluate(x_range) -> tensor`` can be injected (CPU/gloo tests)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rx, ry, rz = (len(a) for a in axes)
+    per = (rx + world - 1) // world
+    i0, i1 = slab_bounds(rx, world, rank)
+    if evaluate is None:
+        if hack_chunk is None:
+            hack_chunk = 0 if decoder.training else rx * ry * rz
+        evaluate = lambda xr: evaluate_grid(decoder, encoding, axes, hack_chunk=hack_chunk, x_range=xr)
+    plane = ry * rz
+    if i1 > i0:
+        local = evaluate((i0, i1))
+    else:
+        local = torch.empty(0, dtype=torch.float32, device=encoding.device)
+    shard = torch.zeros(per * plane, dtype=torch.float32, device=local.device)
+    shard[: local.numel()] = local
+    full = torch.empty(world * per * plane, dtype=torch.float32, device=local.device)
+    dist.all_gather_into_tensor(full, shard, group=group)
+    return full[: rx * plane]
+
+
+# ----------------------------------------------------------------------------------------------
+# reference-signature entry points
+# ----------------------------------------------------------------------------------------------
+def get_logits(decoder, encoding, grid_points, nbatch_points=100000, return_anchors=False):
+    """models/reconstruction.py:6-25."""
+    device = grid_points.device
+    if _hip_ready(decoder, device) and grid_points.dtype == torch.float32 and grid_points.shape[0] == 1:
+        lat = _as_lat_row(encoding, decoder.lat_dim)
+        hack = 0 if decoder.training else int(nbatch_points)
+        lattice = _detect_lattice(grid_points)
+        if lattice is not None:
+            vol, anchors = evaluate_grid(decoder, lat, lattice, hack_chunk=hack, return_anchors=True)
+        else:
+            lib = _lib.load()
+            packed, state, anchors = decoder.prepare_latent(lat.to(device))
+            pts = grid_points.contiguous()
+            vol = torch.empty(pts.shape[1], dtype=torch.float32, device=device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.nphm_identity_eval_points(
+                packed.data_ptr(), state.data_ptr(), pts.data_ptr(), 1, pts.shape[1], hack,
+                float(decoder.prune_tol), decoder._precision_code(), vol.data_ptr(), None, stream),
+                "nphm_identity_eval_points")
+        logits = vol.cpu().numpy()
+        return (logits, anchors) if return_anchors else logits
+
+    # generic decoders: the reference's chunk loop (latent broadcast instead of repeat)
+    enc = encoding.reshape(1, 1, -1)
+    chunks = []
+    anchors = None
+    for points in torch.split(grid_points, nbatch_points, dim=1):
+        with torch.no_grad():
+            logits, anchors = decoder(points, enc.expand(1, points.shape[1], -1), None)
+            chunks.append(logits.reshape(-1).detach().cpu())
+    logits = torch.cat(chunks, dim=0).numpy()
+    return (logits, anchors) if return_anchors else logits
+
+
+def get_logits_backward(decoder_shape, decoder_expr, encoding_shape, encoding_expr, grid_points,
+                        nbatch_points=100000, return_anchors=False):
+    """models/reconstruction.py:28-56: canonicalise with the deformation field, then query the
+    identity field (two-stage evaluation)."""
+    enc_s = encoding_shape.reshape(1, 1, -1)
+    chunks = []
+    anchors = None
+    for points in torch.split(grid_points, nbatch_points, dim=1):
+        with torch.no_grad():
+            if encoding_expr is not None:
+                enc_e = encoding_expr.reshape(1, 1, -1)
+                offsets, _ = decoder_expr(points, enc_e.expand(1, points.shape[1], -1), None)
+                points_can = points + offsets
+            else:
+                points_can = points
+            logits, anchors = decoder_shape(points_can, enc_s.expand(1, points.shape[1], -1), None)
+            chunks.append(logits.reshape(-1).detach().cpu())
+    logits = torch.cat(chunks, dim=0).numpy()
+    return (logits, anchors) if return_anchors else logits
+
+
+def deform_mesh(mesh, deformer, lat_rep, anchors, lat_rep_shape=None):
+    """models/reconstruction.py:59-88: displace mesh vertices by the deformation field."""
+    verts = torch.from_numpy(np.asarray(mesh.vertices)).float().unsqueeze(0).to(lat_rep.device)
+    cond = lat_rep if lat_rep_shape is None else torch.cat([lat_rep_shape, lat_rep], dim=-1)
+    with torch.no_grad():
+        parts = []
+        for pts in torch.split(verts, 1 << 16, dim=1):
+            d, _ = deformer(pts, cond, anchors)
+            parts.append(d)
+        delta = torch.cat(parts, dim=1)
+    posed = (verts[:, :, :3] + delta).squeeze(0).cpu().numpy()
+    try:
+        import trimesh
+        return trimesh.Trimesh(posed, mesh.faces, process=False)
+    except ImportError:
+        return SimpleNamespace(vertices=posed, faces=np.asarray(mesh.faces))
