@@ -60,36 +60,24 @@ __global__ void pack_f32_kernel(PackArgs a) {
     const int h = q & 1, r = (q >> 1) & 15, b = q >> 5;
     const int f = feat_of(b, r, h);
     if (f < HID && c < 3) val = a.w[0][(size_t(s) * HID + f) * D_IN + c];
-  } else if (e < OFF_L1B) {
+  } else if (e < OFF_L2A) {
     const int x = e - OFF_L1A;
     const int c = x & 3, lane = (x >> 2) & 63, gg = x >> 8;
     const int g = gg % (L1_KS / 4), ob = gg / (L1_KS / 4);
     const int ks = 4 * g + c;
     val = layer_weight(a, 1, s, 32 * ob + (lane & 31), feat_of(ks_block(ks, 6), ks_reg(ks, 6), lane >> 5));
-  } else if (e < OFF_L2A) {
-    const int x = e - OFF_L1B;
-    const int row = feat_of(x >> 5, x & 15, (x >> 4) & 1);
-    if (row < L1_OUT) val = a.b[1][s * L1_OUT + row];
   } else if (e < OFF_L3A) {
     const int x = e - OFF_L2A;
     const int c = x & 3, lane = (x >> 2) & 63, gg = x >> 8;
     const int g = gg % (L2_KS / 4), ob = gg / (L2_KS / 4);
     const int ks = 4 * g + c;
     val = layer_weight(a, 2, s, 32 * ob + (lane & 31), feat_of(ks_block(ks, 3), ks_reg(ks, 3), lane >> 5));
-  } else if (e < OFF_L3B) {
+  } else if (e < OFF_L4B) {
     const int x = e - OFF_L3A;
     const int c = x & 3, lane = (x >> 2) & 63, gg = x >> 8;
     const int g = gg % (L3_KS / 4), ob = gg / (L3_KS / 4);
     const int ks = 4 * g + c;
     val = layer_weight(a, 3, s, 32 * ob + (lane & 31), feat_of(ks_block(ks, 6), ks_reg(ks, 6), lane >> 5));
-  } else if (e < OFF_L4W) {
-    const int x = e - OFF_L3B;
-    const int row = feat_of(x >> 5, x & 15, (x >> 4) & 1);
-    if (row < HID) val = a.b[3][s * HID + row];
-  } else if (e < OFF_L4B) {
-    const int x = e - OFF_L4W;
-    const int row = feat_of(x >> 5, x & 15, (x >> 4) & 1);
-    if (row < HID) val = a.w[4][s * HID + row];
   } else if (e == OFF_L4B) {
     val = a.b[4][s];
   }
@@ -160,7 +148,15 @@ __global__ __launch_bounds__(256) void prepare_latent_kernel(PrepArgs a) {
         }
       }
       st[LS_OFF_B0 + k * 224 + t] = v0;
-      st[LS_OFF_B2 + k * 224 + t] = v2;
+      // chunk tails: accumulator init per 32-row block (+ lin4 weights for the L3 blocks)
+      float* tail = st + LS_OFF_TAIL + size_t(k) * CHUNKS_PER_MEMBER * TAIL_FLOATS;
+      const int hr = t & 31;                                   // h * 16 + r
+      if (b < L1_OB) tail[b * TAIL_FLOATS + hr] = f < L1_OUT ? a.b[1][s * L1_OUT + f] : 0.f;
+      tail[(L1_OB + b) * TAIL_FLOATS + hr] = v2;
+      tail[(L1_OB + L2_OB + b) * TAIL_FLOATS + hr] = f < HID ? a.b[3][s * HID + f] : 0.f;
+      tail[(L1_OB + L2_OB + b) * TAIL_FLOATS + 32 + hr] = f < HID ? a.w[4][s * HID + f] : 0.f;
+      if (b < L1_OB) tail[b * TAIL_FLOATS + 32 + hr] = 0.f;
+      tail[(L1_OB + b) * TAIL_FLOATS + 32 + hr] = 0.f;
     }
   } else {
     // anchors = mlp_pos(z_glob) + mean anchors (EnsembledDeepSDF.py:228-229)
@@ -205,21 +201,32 @@ struct EvalArgs {
   // MODE 1 (grid)
   const float* ax; const float* ay; const float* az;
   int rx, ry, rz, ix0, ix1;
-  int nbx, nby, nbz;        // bricks per axis (4,4,8 voxels)
+  int nbx, nby, nbz;        // bricks per axis
+  int nsx, nsy, nsz;        // super-bricks (2x4x4 bricks) per axis
   int64_t hack_chunk;
 };
 
 // nn.Softplus(beta=100, threshold=20) (EnsembledDeepSDF.py:99): for 100x > 20 PyTorch returns x;
 // here log(1 + exp(-|100x|)) is already 0 in fp32 for |100x| > 16.7, so the two agree to < 1e-9.
 __device__ __forceinline__ float softplus100(float x) {
-  const float t = __expf(-100.f * fabsf(x));
-  return fmaxf(x, 0.f) + 0.01f * __logf(1.f + t);
+  // raw v_exp_f32 / v_log_f32 (base 2): the argument of the log is in [1, 2], no range fix-ups
+  const float t = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(x));      // exp(-100|x|)
+  return fmaf(0.0069314718055994531f, __builtin_amdgcn_logf(1.f + t), fmaxf(x, 0.f));
+}
+
+// Pin a block of activations at this program point.  Without a use in the producing basic block
+// LLVM sinks the (pure) softplus arithmetic across the next workgroup barrier, next to the MFMAs
+// that consume it, which keeps pre- AND post-activation values live and spills.
+__device__ __forceinline__ void pin16(f32x16& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[r]));
 }
 
 __device__ __forceinline__ f32x16 softplus100_v(f32x16 d) {
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = softplus100(d[r]);
+  pin16(o);
   return o;
 }
 
@@ -235,18 +242,97 @@ __device__ __forceinline__ f32x16 load_frag16(const float* p) {
   return o;
 }
 
-// One GEMM layer on fp32 MFMA: D[ob] = bias + sum_ks A(ob,ks) x IN(block(ks))[reg(ks)].
-// NKS K-steps, FULL full input blocks.  Afrag: [ob][ks/4][lane][4].
+__device__ __forceinline__ f32x16 load_frag16_lds(unsigned int lds_byte_addr) {
+  typedef __attribute__((address_space(3))) const f32x4* lds_v4;
+  lds_v4 q = (lds_v4)(size_t)lds_byte_addr;
+  f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+  f32x16 o;
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+  o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  o[8] = c[0]; o[9] = c[1]; o[10] = c[2]; o[11] = c[3];
+  o[12] = d[0]; o[13] = d[1]; o[14] = d[2]; o[15] = d[3];
+  return o;
+}
+
+// ---- weight streaming: global -> LDS ring, shared by the 4 wavefronts of a workgroup -----------
+// A member's GEMM weights are consumed as 18 chunks (one per 32-row output block):
+//   L1 ob0..3 (25 groups of 1 KiB), L2 ob0..6 (13 groups), L3 ob0..6 (25 groups)
+// plus a 256-byte tail per chunk (accumulator init / lin4 weights, from the per-latent state).
+// Chunk c+2 is fetched with global_load_lds (no VGPR staging) while chunk c is consumed.
+constexpr int CHUNK_FLOATS = (L1_KS / 4) * 256;            // 6400 floats = 25 KiB (largest chunk)
+constexpr int SLOT_FLOATS = CHUNK_FLOATS + TAIL_FLOATS;
+constexpr int RING = 3;
+
+__device__ __forceinline__ int chunk_offset(int ci) {       // offset (floats) inside a weight set
+  return ci < L1_OB ? OFF_L1A + ci * (L1_KS / 4) * 256
+       : ci < L1_OB + L2_OB ? OFF_L2A + (ci - L1_OB) * (L2_KS / 4) * 256
+                            : OFF_L3A + (ci - L1_OB - L2_OB) * (L3_KS / 4) * 256;
+}
+__device__ __forceinline__ int chunk_groups(int ci) {       // 1 KiB groups in the chunk
+  return (ci >= L1_OB && ci < L1_OB + L2_OB) ? (L2_KS / 4) : (L1_KS / 4);
+}
+
+// NW = wavefronts per workgroup (all of them share one LDS ring): 8 -> 256 points per weight pass
+#ifndef NPHM_NW
+#define NPHM_NW 8
+#endif
+constexpr int NW = NPHM_NW;
+// voxel brick of a workgroup in grid mode: every wavefront owns a 4x4x2 sub-brick
+constexpr int BRX = NW == 8 ? 8 : 4, BRY = NW == 8 ? 8 : 4, BRZ = NW == 8 ? 4 : 8;
+// bricks are enumerated super-brick by super-brick (2x4x4 bricks) so that the workgroups resident
+// on one XCD at any time cover a compact region and stream the same few members (L2 reuse)
+constexpr int SBX = 2, SBY = 4, SBZ = 4;
+
+struct Streamer {
+  const float* packed;
+  const float* tails;          // per-latent state: chunk tails of this batch row
+  float* ring;                 // LDS, RING * SLOT_FLOATS floats
+  const unsigned char* list;   // LDS, active member ids of this workgroup
+  int n_active;
+  int mi;                      // index (into list) of the member being consumed
+  int wave, lane;
+
+  // fetch chunk `ci` (compile-time) of list member `m` into ring slot `slot`
+  __device__ __forceinline__ void issue(int m, const int ci, const int slot) const {
+    if (m >= n_active) return;
+    const int k = __builtin_amdgcn_readfirstlane(int(list[m]));
+    int l = lane;
+    asm volatile("" : "+v"(l));           // per-site addresses are recomputed, not hoisted (VGPRs)
+    const float* src = packed + size_t(member_set(k)) * SET_STRIDE + chunk_offset(ci) + l * 4;
+    float* dst = ring + slot * SLOT_FLOATS;
+    const int ng = chunk_groups(ci);
+#pragma unroll 1
+    for (int g = wave; g < ng; g += NW)
+      __builtin_amdgcn_global_load_lds(src + g * 256, (__attribute__((address_space(3))) void*)(dst + g * 256), 16, 0, 0);
+    if (wave == (ci & (NW - 1)))
+      __builtin_amdgcn_global_load_lds(tails + (k * CHUNKS_PER_MEMBER + ci) * TAIL_FLOATS + l,
+                                       (__attribute__((address_space(3))) void*)(dst + CHUNK_FLOATS), 4, 0, 0);
+  }
+  // Every wavefront of the workgroup calls this once per chunk, in lockstep order.  CI = index of
+  // the chunk inside its member (18 % RING == 0, so ring slots are compile-time constants).
+  __device__ __forceinline__ const float* acquire(const int CI) {
+    __syncthreads();                      // chunk CI has landed (own loads waited, then barrier)
+    // the buffer of the previous chunk is free: prefetch two chunks ahead
+    issue(CI + 2 < CHUNKS_PER_MEMBER ? mi : mi + 1, (CI + 2) % CHUNKS_PER_MEMBER, (CI + 2) % RING);
+    return ring + (CI % RING) * SLOT_FLOATS;
+  }
+  __device__ __forceinline__ void next_member() {
+    ++mi;
+    asm volatile("" : "+s"(mi));          // opaque: no per-site precomputation hoisted out of the loop
+  }
+};
+
+// One 32-row output block on fp32 MFMA: acc += sum_ks A(ks) x IN(block(ks))[reg(ks)].
+// A fragments come from LDS: [ks/4][lane][4].
 template <int NKS, int FULL, int NIN>
-__device__ __forceinline__ f32x16 gemm_block_f32(const float* __restrict__ afrag_ob, f32x16 acc,
+__device__ __forceinline__ f32x16 gemm_block_f32(const float* afrag, f32x16 acc,
                                                  const f32x16 (&in)[NIN], int lane) {
-  const f32x4* A = reinterpret_cast<const f32x4*>(afrag_ob) + lane;
+  const f32x4* A = reinterpret_cast<const f32x4*>(afrag) + lane;
 #pragma unroll
   for (int g = 0; g < NKS / 4; ++g) {
     const f32x4 a = A[g * 64];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      constexpr int dummy = 0; (void)dummy;
       const int ks = 4 * g + c;
       const int b = ks < 16 * FULL ? (ks >> 4) : FULL;
       const int r = ks < 16 * FULL ? (ks & 15) : ks - 16 * FULL;
@@ -256,11 +342,24 @@ __device__ __forceinline__ f32x16 gemm_block_f32(const float* __restrict__ afrag
   return acc;
 }
 
+// bijective XCD-aware remap: hardware places block b on XCD b % 8; give every XCD a contiguous
+// range of bricks so the members its CUs stream at any time fit its 4 MiB L2
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n >> 3, r = n & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 template <int MODE, int PREC>
-__global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int h = lane >> 5;
+__global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
+  __shared__ float ring[RING * SLOT_FLOATS];
+  __shared__ unsigned int wg_mask[2];
+  __shared__ unsigned char wg_list[N_MEMBERS];
+
+  const int lane_inv = threadIdx.x & 63;
+  const int lane = lane_inv;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h_inv = lane >> 5;
+  const int h = h_inv;
   const int j = lane & 31;
 
   // ---- locate this lane's query point ------------------------------------------------------
@@ -271,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
   int row = 0;
   if (MODE == 0) {
     row = blockIdx.y;
-    const int64_t i = (int64_t(blockIdx.x) * 4 + wave) * 32 + j;
+    const int64_t i = (int64_t(blockIdx.x) * NW + wave) * 32 + j;
     valid = i < p.n_points;
     const int64_t ic = valid ? i : (p.n_points - 1);
     const float* q = p.xyz + (int64_t(row) * p.n_points + ic) * 3;
@@ -279,14 +378,24 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
     out_idx = int64_t(row) * p.n_points + ic;
     if (p.hack_chunk > 0) hack = ((ic + 1) % p.hack_chunk == 0) || (ic == p.n_points - 1);
   } else {
-    // brick id -> (bx, by, bz), z fastest; 4x4x8 voxels per brick, wave owns 4x4x2
-    int bid = blockIdx.x;
-    const int bz = bid % p.nbz; bid /= p.nbz;
-    const int by = bid % p.nby; bid /= p.nby;
-    const int bx = bid;
-    const int ix = p.ix0 + bx * 4 + (j >> 3);
-    const int iy = by * 4 + ((j >> 1) & 3);
-    const int iz = bz * 8 + wave * 2 + (j & 1);
+    // block -> super-brick (z fastest) -> brick inside it (z fastest) -> wave sub-brick 4x4x2
+    // The hardware places block b on XCD b % 8: XCD x works on super-bricks x, x+8, x+16, ...
+    // (interleaved, so every XCD sees the same mix of near-surface and empty space) and its
+    // consecutive blocks are the bricks of ONE super-brick.
+    constexpr int SBN = SBX * SBY * SBZ;
+    const int local = blockIdx.x >> 3;
+    const int inner = local % SBN;
+    int bid = (local / SBN) * 8 + (blockIdx.x & 7);          // super-brick index
+    const int sz = bid % p.nsz; bid /= p.nsz;
+    const int sy = bid % p.nsy; bid /= p.nsy;
+    const int bx = bid * SBX + inner / (SBY * SBZ);
+    const int by = sy * SBY + (inner / SBZ) % SBY;
+    const int bz = sz * SBZ + inner % SBZ;
+    const int wx = NW == 8 ? (wave & 1) : 0, wy = NW == 8 ? ((wave >> 1) & 1) : 0;
+    const int wz = NW == 8 ? (wave >> 2) : wave;
+    const int ix = p.ix0 + bx * BRX + wx * 4 + (j >> 3);
+    const int iy = by * BRY + wy * 4 + ((j >> 1) & 3);
+    const int iz = bz * BRZ + wz * 2 + (j & 1);
     valid = ix < p.ix1 && iy < p.ry && iz < p.rz;
     const int cx_ = min(ix, p.ix1 - 1), cy_ = min(iy, p.ry - 1), cz_ = min(iz, p.rz - 1);
     qx = p.ax[cx_]; qy = p.ay[cy_]; qz = p.az[cz_];
@@ -295,7 +404,6 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
     if (p.hack_chunk > 0)
       hack = ((gi + 1) % p.hack_chunk == 0) || (gi == int64_t(p.rx) * p.ry * p.rz - 1);
   }
-  if (__ballot(valid) == 0ull) return;
 
   const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
   const float* anch = st + LS_OFF_ANCH;
@@ -312,9 +420,10 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
   S += w_bg;
   const float denom = S + 1e-6f;
   const float thr = p.prune_tol * denom;
-  uint64_t wmask = 0;
+  uint64_t wmask = 0;                    // members this wavefront evaluates (wave-uniform)
+  const bool any_valid = __ballot(valid) != 0ull;
   if (p.prune_tol < 0.f) {
-    wmask = (1ull << N_MEMBERS) - 1;
+    wmask = any_valid ? (1ull << N_MEMBERS) - 1 : 0ull;
   } else {
 #pragma unroll 1
     for (int k = 0; k < N_MEMBERS; ++k) {
@@ -328,17 +437,47 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
     }
   }
 
+  const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
   if (p.stats && lane == 0) {
-    const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
     atomicAdd(p.stats, nv * __popcll(wmask));
     atomicAdd(p.stats + 1, nv);
   }
 
+  // ---- union over the workgroup: the members whose weights get streamed ----------------------
+  if (threadIdx.x < 2) wg_mask[threadIdx.x] = 0u;
+  __syncthreads();
+  if (lane == 0) {
+    atomicOr(&wg_mask[0], (unsigned int)(wmask & 0xffffffffull));
+    atomicOr(&wg_mask[1], (unsigned int)(wmask >> 32));
+  }
+  __syncthreads();
+  const uint64_t gmask = (uint64_t(wg_mask[1]) << 32) | wg_mask[0];
+  const int n_active = __popcll(gmask);
+  if (threadIdx.x < N_MEMBERS) {
+    if ((gmask >> threadIdx.x) & 1ull)
+      wg_list[__popcll(gmask & ((1ull << threadIdx.x) - 1))] = (unsigned char)threadIdx.x;
+  }
+  __syncthreads();
+  Streamer ws{p.packed_f32, st + LS_OFF_TAIL, ring, wg_list, n_active, 0, wave, lane};
+  ws.issue(0, 0, 0);
+  ws.issue(0, 1, 1);
+
   float acc = 0.f;
 
 #pragma unroll 1
-  for (int k = 0; k < N_MEMBERS; ++k) {
-    if (!((wmask >> k) & 1ull)) continue;
+  for (int mi = 0; mi < n_active; ++mi) {
+    const int k = wg_list[mi];
+    if (!((wmask >> k) & 1ull)) {
+      // this wavefront's 32 points do not need member k: keep the ring moving only
+#pragma unroll
+      for (int c = 0; c < CHUNKS_PER_MEMBER; ++c) (void)ws.acquire(c);
+      ws.next_member();
+      continue;
+    }
+    // lane-derived values are re-materialised per member (opaque to LICM): hoisting the dozens of
+    // per-site lane offsets out of this loop costs more registers than recomputing them
+    int h = h_inv, lane = lane_inv;
+    asm volatile("" : "+v"(h), "+v"(lane));
     const int s = member_set(k);
     const float* setp = p.packed_f32 + size_t(s) * SET_STRIDE;
 
@@ -369,6 +508,10 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
           const f32x4 w = l0w[(b * 16 + r) * 2 + h];
           H[b][r] = softplus100(fmaf(w[0], cx, fmaf(w[1], cy, fmaf(w[2], cz, bias[r]))));
         }
+        // pin block b here: without a use in this basic block LLVM sinks the softplus arithmetic
+        // below the next barrier while the 100 weight loads stay above it (and get spilled)
+        pin16(H[b]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 
@@ -376,8 +519,9 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
     f32x16 G[4];
 #pragma unroll
     for (int ob = 0; ob < L1_OB; ++ob) {
-      f32x16 d = load_frag16(setp + OFF_L1B + (ob * 2 + h) * 16);
-      d = gemm_block_f32<L1_KS, 6, 7>(setp + OFF_L1A + ob * (L1_KS / 4) * 256, d, H, lane);
+      const float* buf = ws.acquire(ob);
+      f32x16 d = load_frag16(buf + CHUNK_FLOATS + h * 16);
+      d = gemm_block_f32<L1_KS, 6, 7>(buf, d, H, lane);
       G[ob] = softplus100_v(d);
     }
     // skip connection: features 101..103 of lin2's input are the local coords
@@ -388,11 +532,11 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
 
     // ---- L2: 104 -> 200 (7 row blocks), bias carries the folded latent ------------------------
     {
-      const float* b2 = st + LS_OFF_B2 + k * 224;
 #pragma unroll
       for (int ob = 0; ob < L2_OB; ++ob) {
-        f32x16 d = load_frag16(b2 + (ob * 2 + h) * 16);
-        d = gemm_block_f32<L2_KS, 3, 4>(setp + OFF_L2A + ob * (L2_KS / 4) * 256, d, G, lane);
+        const float* buf = ws.acquire(L1_OB + ob);
+        f32x16 d = load_frag16(buf + CHUNK_FLOATS + h * 16);
+        d = gemm_block_f32<L2_KS, 3, 4>(buf, d, G, lane);
         H[ob] = softplus100_v(d);
       }
     }
@@ -401,16 +545,22 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(EvalArgs p) {
     float part = 0.f;
 #pragma unroll
     for (int ob = 0; ob < L3_OB; ++ob) {
-      f32x16 d = load_frag16(setp + OFF_L3B + (ob * 2 + h) * 16);
-      d = gemm_block_f32<L3_KS, 6, 7>(setp + OFF_L3A + ob * (L3_KS / 4) * 256, d, H, lane);
-      const f32x16 w4 = load_frag16(setp + OFF_L4W + (ob * 2 + h) * 16);
+      const float* buf = ws.acquire(L1_OB + L2_OB + ob);
+      f32x16 d = load_frag16(buf + CHUNK_FLOATS + h * 16);
+      d = gemm_block_f32<L3_KS, 6, 7>(buf, d, H, lane);
+      // read the lin4 fragment AFTER the GEMM (hoisted above it, it only gets spilled)
+      unsigned int w4a = (unsigned int)(size_t)(__attribute__((address_space(3))) const float*)(buf + CHUNK_FLOATS + 32 + h * 16);
+      asm volatile("" : "+v"(w4a) : "v"(d[15]));
+      const f32x16 w4 = load_frag16_lds(w4a);
 #pragma unroll
       for (int r = 0; r < 16; ++r) part = fmaf(softplus100(d[r]), w4[r], part);
+      asm volatile("" : "+v"(part));      // finish this block's epilogue here (see pin16)
     }
     const float f = part + __shfl_xor(part, 32) + setp[OFF_L4B];
 
     // ---- Gaussian blend (EnsembledDeepSDF.py:144-149) ------------------------------------------
     acc = fmaf(wk / denom, f, acc);
+    ws.next_member();
   }
 
   // eval-mode overwrite (EnsembledDeepSDF.py:260-261): every member predicts 1 for this point
@@ -527,9 +677,9 @@ int nphm_identity_eval_points(const void* packed, const void* latent_state,
   a.xyz = xyz;
   a.n_points = n_points;
   a.hack_chunk = hack_chunk;
-  const int64_t tiles = (n_points + 127) / 128;
+  const int64_t tiles = (n_points + 32 * nphm::NW - 1) / (32 * nphm::NW);
   if (tiles > 0x7fffffffLL) return fail_msg("nphm_identity_eval_points: too many points");
-  hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), dim3((unsigned)tiles, n_rows), dim3(256), 0,
+  hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), dim3((unsigned)tiles, n_rows), dim3(64 * nphm::NW), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("nphm_identity_eval_points launch", e);
@@ -556,11 +706,15 @@ int nphm_identity_eval_grid(const void* packed, const void* latent_state,
   a.prune_tol = prune_tol;
   a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
   a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
-  a.nbx = (ix1 - ix0 + 3) / 4; a.nby = (ry + 3) / 4; a.nbz = (rz + 7) / 8;
+  a.nbx = (ix1 - ix0 + nphm::BRX - 1) / nphm::BRX; a.nby = (ry + nphm::BRY - 1) / nphm::BRY;
+  a.nbz = (rz + nphm::BRZ - 1) / nphm::BRZ;
+  a.nsx = (a.nbx + nphm::SBX - 1) / nphm::SBX; a.nsy = (a.nby + nphm::SBY - 1) / nphm::SBY;
+  a.nsz = (a.nbz + nphm::SBZ - 1) / nphm::SBZ;
   a.hack_chunk = hack_chunk;
-  const int64_t bricks = int64_t(a.nbx) * a.nby * a.nbz;
+  const int64_t supers = (int64_t(a.nsx) * a.nsy * a.nsz + 7) / 8 * 8;       // padded to the 8 XCDs
+  const int64_t bricks = supers * (nphm::SBX * nphm::SBY * nphm::SBZ);
   if (bricks > 0x7fffffffLL) return fail_msg("nphm_identity_eval_grid: slab too large for one launch");
-  hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), dim3((unsigned)bricks), dim3(256), 0,
+  hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), dim3((unsigned)bricks), dim3(64 * nphm::NW), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("nphm_identity_eval_grid launch", e);

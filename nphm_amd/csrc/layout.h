@@ -58,18 +58,19 @@ constexpr int OFF_L0W = 0;                                  // float4 (wx,wy,wz,
 constexpr int SZ_L0W = 7 * 16 * 2 * 4;
 constexpr int OFF_L1A = OFF_L0W + SZ_L0W;
 constexpr int SZ_L1A = L1_OB * (L1_KS / 4) * 64 * 4;
-constexpr int OFF_L1B = OFF_L1A + SZ_L1A;                   // bias in D layout [ob][h][r]
-constexpr int SZ_L1B = L1_OB * 32;
-constexpr int OFF_L2A = OFF_L1B + SZ_L1B;
+constexpr int OFF_L2A = OFF_L1A + SZ_L1A;
 constexpr int SZ_L2A = L2_OB * (L2_KS / 4) * 64 * 4;
 constexpr int OFF_L3A = OFF_L2A + SZ_L2A;
 constexpr int SZ_L3A = L3_OB * (L3_KS / 4) * 64 * 4;
-constexpr int OFF_L3B = OFF_L3A + SZ_L3A;
-constexpr int SZ_L3B = L3_OB * 32;
-constexpr int OFF_L4W = OFF_L3B + SZ_L3B;                   // lin4 weight in D layout [ob][h][r]
-constexpr int SZ_L4W = L3_OB * 32;
-constexpr int OFF_L4B = OFF_L4W + SZ_L4W;
+constexpr int OFF_L4B = OFF_L3A + SZ_L3A;                   // lin4 bias (scalar)
 constexpr int SET_STRIDE = OFF_L4B + 4;                     // floats per weight set
+
+// The GEMM weights of a member are consumed as 18 chunks, one per 32-row output block:
+// L1 ob 0..3, L2 ob 0..6, L3 ob 0..6.  Every chunk has a 64-float "tail" in the per-latent state:
+// [h][r] accumulator init (layer bias, for L2 with the latent folded in) and, for L3, [h][r] lin4
+// weights for the fused 200->1 epilogue.
+constexpr int CHUNKS_PER_MEMBER = L1_OB + L2_OB + L3_OB;   // 18
+constexpr int TAIL_FLOATS = 64;
 
 // ---- split-bf16 path (32x32x16 bf16 MFMA): one K-step = 16 k-slots -------------------------
 // k-slot 8*h + i of K-step (b, s) is feature feat_of(b, 8*s + i, h); A fragments are 8 bf16 per
@@ -92,8 +93,8 @@ constexpr size_t PACKED_BYTES = PACKED_F32_FLOATS * 4 + PACKED_BF16_HALFS * 2;
 
 // ---- per-latent state (one per batch row), in floats -----------------------------------------
 constexpr int LS_OFF_B0 = 0;                       // folded lin0 bias, D layout [member][b][h][r]
-constexpr int LS_OFF_B2 = LS_OFF_B0 + N_MEMBERS * 224;   // folded lin2 bias
-constexpr int LS_OFF_ANCH = LS_OFF_B2 + N_MEMBERS * 224; // predicted anchors [39][3]
+constexpr int LS_OFF_TAIL = LS_OFF_B0 + N_MEMBERS * 224; // chunk tails [member][chunk][64]
+constexpr int LS_OFF_ANCH = LS_OFF_TAIL + N_MEMBERS * CHUNKS_PER_MEMBER * TAIL_FLOATS;  // anchors [39][3]
 constexpr int LS_ROW_STRIDE = LS_OFF_ANCH + 120;
 
 __host__ __device__ constexpr int member_set(int k) {
