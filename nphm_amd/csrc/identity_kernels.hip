@@ -206,6 +206,8 @@ struct EvalArgs {
   int64_t hack_chunk;
 };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 // nn.Softplus(beta=100, threshold=20) (EnsembledDeepSDF.py:99): for 100x > 20 PyTorch returns x;
 // here log(1 + exp(-|100x|)) is already 0 in fp32 for |100x| > 16.7, so the two agree to < 1e-9.
 __device__ __forceinline__ float softplus100(float x) {
@@ -214,9 +216,9 @@ __device__ __forceinline__ float softplus100(float x) {
   return fmaf(0.0069314718055994531f, __builtin_amdgcn_logf(1.f + t), fmaxf(x, 0.f));
 }
 
-// Pin a block of activations at this program point.  Without a use in the producing basic block
-// LLVM sinks the (pure) softplus arithmetic across the next workgroup barrier, next to the MFMAs
-// that consume it, which keeps pre- AND post-activation values live and spills.
+// Pin values at this program point.  Without a use in the producing basic block LLVM sinks the
+// (pure) softplus arithmetic across the next workgroup barrier, next to the MFMAs that consume it,
+// which keeps pre- AND post-activation values live and spills.
 __device__ __forceinline__ void pin16(f32x16& v) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[r]));
@@ -228,6 +230,31 @@ __device__ __forceinline__ f32x16 softplus100_v(f32x16 d) {
   for (int r = 0; r < 16; ++r) o[r] = softplus100(d[r]);
   pin16(o);
   return o;
+}
+
+// one 32-feature block of activations as split-bf16 B operands of v_mfma_f32_32x32x16_bf16:
+// K-step s consumes registers 8s..8s+7 of the block (k-slot 8h+i <-> register 8s+i)
+struct ActB {
+  bf16x8 hi[2], lo[2];
+};
+
+__device__ __forceinline__ void split_block(const f32x16& v, ActB& o) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = v[8 * s + i];
+      const __bf16 hb = (__bf16)x;
+      o.hi[s][i] = hb;
+      o.lo[s][i] = (__bf16)(x - (float)hb);
+    }
+  }
+  // pin the packed operands (same reason as pin16)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    asm volatile("" : "+v"(o.hi[s]));
+    asm volatile("" : "+v"(o.lo[s]));
+  }
 }
 
 __device__ __forceinline__ f32x16 load_frag16(const float* p) {
@@ -254,23 +281,43 @@ __device__ __forceinline__ f32x16 load_frag16_lds(unsigned int lds_byte_addr) {
   return o;
 }
 
-// ---- weight streaming: global -> LDS ring, shared by the 4 wavefronts of a workgroup -----------
-// A member's GEMM weights are consumed as 18 chunks (one per 32-row output block):
-//   L1 ob0..3 (25 groups of 1 KiB), L2 ob0..6 (13 groups), L3 ob0..6 (25 groups)
+// ---- weight streaming: global -> LDS ring, shared by the NW wavefronts of a workgroup ----------
+// A member's GEMM weights are consumed as 18 chunks (one per 32-row output block, layout.h), in
+// 1 KiB groups (one global_load_lds_dwordx4 of a wavefront):
+//   fp32 : L1 25, L2 13, L3 25 groups ([ks/4][lane][4] floats)
+//   bf16 : L1 26, L2 14, L3 26 groups ([ks][hi|lo][lane][8] bf16)
 // plus a 256-byte tail per chunk (accumulator init / lin4 weights, from the per-latent state).
 // Chunk c+2 is fetched with global_load_lds (no VGPR staging) while chunk c is consumed.
-constexpr int CHUNK_FLOATS = (L1_KS / 4) * 256;            // 6400 floats = 25 KiB (largest chunk)
-constexpr int SLOT_FLOATS = CHUNK_FLOATS + TAIL_FLOATS;
+template <int PREC> struct Stream;
+template <> struct Stream<0> {
+  static constexpr int MAIN_BYTES = (L1_KS / 4) * 1024;
+  __device__ static __forceinline__ const char* set_base(const EvalArgs& p, int s) {
+    return reinterpret_cast<const char*>(p.packed_f32 + size_t(s) * SET_STRIDE);
+  }
+  __device__ static __forceinline__ int offset(int ci) {   // bytes inside a weight set
+    return 4 * (ci < L1_OB ? OFF_L1A + ci * (L1_KS / 4) * 256
+              : ci < L1_OB + L2_OB ? OFF_L2A + (ci - L1_OB) * (L2_KS / 4) * 256
+                                   : OFF_L3A + (ci - L1_OB - L2_OB) * (L3_KS / 4) * 256);
+  }
+  __device__ static __forceinline__ int groups(int ci) {
+    return (ci >= L1_OB && ci < L1_OB + L2_OB) ? (L2_KS / 4) : (L1_KS / 4);
+  }
+};
+template <> struct Stream<1> {
+  static constexpr int MAIN_BYTES = L1_KS16 * 2 * 1024;
+  __device__ static __forceinline__ const char* set_base(const EvalArgs& p, int s) {
+    return reinterpret_cast<const char*>(p.packed_bf16 + size_t(s) * BF_SET_STRIDE);
+  }
+  __device__ static __forceinline__ int offset(int ci) {
+    return 2 * (ci < L1_OB ? BF_OFF_L1A + ci * L1_KS16 * 1024
+              : ci < L1_OB + L2_OB ? BF_OFF_L2A + (ci - L1_OB) * L2_KS16 * 1024
+                                   : BF_OFF_L3A + (ci - L1_OB - L2_OB) * L3_KS16 * 1024);
+  }
+  __device__ static __forceinline__ int groups(int ci) {
+    return (ci >= L1_OB && ci < L1_OB + L2_OB) ? 2 * L2_KS16 : 2 * L1_KS16;
+  }
+};
 constexpr int RING = 3;
-
-__device__ __forceinline__ int chunk_offset(int ci) {       // offset (floats) inside a weight set
-  return ci < L1_OB ? OFF_L1A + ci * (L1_KS / 4) * 256
-       : ci < L1_OB + L2_OB ? OFF_L2A + (ci - L1_OB) * (L2_KS / 4) * 256
-                            : OFF_L3A + (ci - L1_OB - L2_OB) * (L3_KS / 4) * 256;
-}
-__device__ __forceinline__ int chunk_groups(int ci) {       // 1 KiB groups in the chunk
-  return (ci >= L1_OB && ci < L1_OB + L2_OB) ? (L2_KS / 4) : (L1_KS / 4);
-}
 
 // NW = wavefronts per workgroup (all of them share one LDS ring): 8 -> 256 points per weight pass
 #ifndef NPHM_NW
@@ -283,10 +330,12 @@ constexpr int BRX = NW == 8 ? 8 : 4, BRY = NW == 8 ? 8 : 4, BRZ = NW == 8 ? 4 : 
 // on one XCD at any time cover a compact region and stream the same few members (L2 reuse)
 constexpr int SBX = 2, SBY = 4, SBZ = 4;
 
+template <int PREC>
 struct Streamer {
-  const float* packed;
+  static constexpr int SLOT_BYTES = Stream<PREC>::MAIN_BYTES + TAIL_FLOATS * 4;
+  const EvalArgs& p;
   const float* tails;          // per-latent state: chunk tails of this batch row
-  float* ring;                 // LDS, RING * SLOT_FLOATS floats
+  char* ring;                  // LDS, RING * SLOT_BYTES
   const unsigned char* list;   // LDS, active member ids of this workgroup
   int n_active;
   int mi;                      // index (into list) of the member being consumed
@@ -298,34 +347,37 @@ struct Streamer {
     const int k = __builtin_amdgcn_readfirstlane(int(list[m]));
     int l = lane;
     asm volatile("" : "+v"(l));           // per-site addresses are recomputed, not hoisted (VGPRs)
-    const float* src = packed + size_t(member_set(k)) * SET_STRIDE + chunk_offset(ci) + l * 4;
-    float* dst = ring + slot * SLOT_FLOATS;
-    const int ng = chunk_groups(ci);
+    const char* src = Stream<PREC>::set_base(p, member_set(k)) + Stream<PREC>::offset(ci) + l * 16;
+    char* dst = ring + slot * SLOT_BYTES;
+    const int ng = Stream<PREC>::groups(ci);
 #pragma unroll 1
     for (int g = wave; g < ng; g += NW)
-      __builtin_amdgcn_global_load_lds(src + g * 256, (__attribute__((address_space(3))) void*)(dst + g * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src + g * 1024, (__attribute__((address_space(3))) void*)(dst + g * 1024), 16, 0, 0);
     if (wave == (ci & (NW - 1)))
       __builtin_amdgcn_global_load_lds(tails + (k * CHUNKS_PER_MEMBER + ci) * TAIL_FLOATS + l,
-                                       (__attribute__((address_space(3))) void*)(dst + CHUNK_FLOATS), 4, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + Stream<PREC>::MAIN_BYTES), 4, 0, 0);
   }
   // Every wavefront of the workgroup calls this once per chunk, in lockstep order.  CI = index of
   // the chunk inside its member (18 % RING == 0, so ring slots are compile-time constants).
-  __device__ __forceinline__ const float* acquire(const int CI) {
+  __device__ __forceinline__ const char* acquire(const int CI) {
     __syncthreads();                      // chunk CI has landed (own loads waited, then barrier)
     // the buffer of the previous chunk is free: prefetch two chunks ahead
     issue(CI + 2 < CHUNKS_PER_MEMBER ? mi : mi + 1, (CI + 2) % CHUNKS_PER_MEMBER, (CI + 2) % RING);
-    return ring + (CI % RING) * SLOT_FLOATS;
+    return ring + (CI % RING) * SLOT_BYTES;
   }
   __device__ __forceinline__ void next_member() {
     ++mi;
     asm volatile("" : "+s"(mi));          // opaque: no per-site precomputation hoisted out of the loop
+  }
+  __device__ static __forceinline__ const float* tail_of(const char* buf) {
+    return reinterpret_cast<const float*>(buf + Stream<PREC>::MAIN_BYTES);
   }
 };
 
 // One 32-row output block on fp32 MFMA: acc += sum_ks A(ks) x IN(block(ks))[reg(ks)].
 // A fragments come from LDS: [ks/4][lane][4].
 template <int NKS, int FULL, int NIN>
-__device__ __forceinline__ f32x16 gemm_block_f32(const float* afrag, f32x16 acc,
+__device__ __forceinline__ f32x16 gemm_block_f32(const char* afrag, f32x16 acc,
                                                  const f32x16 (&in)[NIN], int lane) {
   const f32x4* A = reinterpret_cast<const f32x4*>(afrag) + lane;
 #pragma unroll
@@ -342,16 +394,29 @@ __device__ __forceinline__ f32x16 gemm_block_f32(const float* afrag, f32x16 acc,
   return acc;
 }
 
-// bijective XCD-aware remap: hardware places block b on XCD b % 8; give every XCD a contiguous
-// range of bricks so the members its CUs stream at any time fit its 4 MiB L2
-__device__ __forceinline__ int xcd_remap(int bid, int n) {
-  const int q = n >> 3, r = n & 7, x = bid & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+// The same block on split-bf16 MFMA: x*w ~= xh*wh + xl*wh + xh*wl (fp32 accumulate); the dropped
+// xl*wl term is 2^-16 relative.  A fragments from LDS: [ks][hi|lo][lane][8].
+template <int NKS16, int FULL, int NIN>
+__device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
+                                                  const ActB (&in)[NIN], int lane) {
+  const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
+#pragma unroll
+  for (int ks = 0; ks < NKS16; ++ks) {
+    const bf16x8 wh = A[(2 * ks) * 64];
+    const bf16x8 wl = A[(2 * ks + 1) * 64];
+    const int b = ks < 2 * FULL ? (ks >> 1) : FULL;
+    const int s = ks < 2 * FULL ? (ks & 1) : 0;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in[b].hi[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in[b].lo[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, in[b].hi[s], acc, 0, 0, 0);
+  }
+  return acc;
 }
 
 template <int MODE, int PREC>
 __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
-  __shared__ float ring[RING * SLOT_FLOATS];
+  using WS = Streamer<PREC>;
+  __shared__ __attribute__((aligned(16))) char ring[RING * WS::SLOT_BYTES];
   __shared__ unsigned int wg_mask[2];
   __shared__ unsigned char wg_list[N_MEMBERS];
 
@@ -378,7 +443,6 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     out_idx = int64_t(row) * p.n_points + ic;
     if (p.hack_chunk > 0) hack = ((ic + 1) % p.hack_chunk == 0) || (ic == p.n_points - 1);
   } else {
-    // block -> super-brick (z fastest) -> brick inside it (z fastest) -> wave sub-brick 4x4x2
     // The hardware places block b on XCD b % 8: XCD x works on super-bricks x, x+8, x+16, ...
     // (interleaved, so every XCD sees the same mix of near-surface and empty space) and its
     // consecutive blocks are the bricks of ONE super-brick.
@@ -458,7 +522,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       wg_list[__popcll(gmask & ((1ull << threadIdx.x) - 1))] = (unsigned char)threadIdx.x;
   }
   __syncthreads();
-  Streamer ws{p.packed_f32, st + LS_OFF_TAIL, ring, wg_list, n_active, 0, wave, lane};
+  WS ws{p, st + LS_OFF_TAIL, ring, wg_list, n_active, 0, wave, lane};
   ws.issue(0, 0, 0);
   ws.issue(0, 1, 1);
 
@@ -494,11 +558,13 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     }
     if (k < 2 * N_SYMM && (k & 1)) cx = -cx;
 
-    // ---- L0: 3 -> 200 on the VALU, latent folded into the bias -------------------------------
-    f32x16 H[7];
-    {
-      const f32x4* l0w = reinterpret_cast<const f32x4*>(setp + OFF_L0W);
-      const float* b0 = st + LS_OFF_B0 + k * 224;
+    const f32x4* l0w = reinterpret_cast<const f32x4*>(setp + OFF_L0W);
+    const float* b0 = st + LS_OFF_B0 + k * 224;
+    float part = 0.f;
+
+    if constexpr (PREC == 0) {
+      // ---- L0: 3 -> 200 on the VALU, latent folded into the bias -----------------------------
+      f32x16 H[7];
 #pragma unroll
       for (int b = 0; b < 7; ++b) {
         const f32x16 bias = load_frag16(b0 + (b * 2 + h) * 16);
@@ -508,53 +574,99 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           const f32x4 w = l0w[(b * 16 + r) * 2 + h];
           H[b][r] = softplus100(fmaf(w[0], cx, fmaf(w[1], cy, fmaf(w[2], cz, bias[r]))));
         }
-        // pin block b here: without a use in this basic block LLVM sinks the softplus arithmetic
-        // below the next barrier while the 100 weight loads stay above it (and get spilled)
         pin16(H[b]);
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
-
-    // ---- L1: 200 -> 101 (4 row blocks) ------------------------------------------------------
-    f32x16 G[4];
+      // ---- L1: 200 -> 101 (4 row blocks) ----------------------------------------------------
+      f32x16 G[4];
 #pragma unroll
-    for (int ob = 0; ob < L1_OB; ++ob) {
-      const float* buf = ws.acquire(ob);
-      f32x16 d = load_frag16(buf + CHUNK_FLOATS + h * 16);
-      d = gemm_block_f32<L1_KS, 6, 7>(buf, d, H, lane);
-      G[ob] = softplus100_v(d);
-    }
-    // skip connection: features 101..103 of lin2's input are the local coords
-    // (block 3, regs 1..3 of the upper half-wave); 1/sqrt(2) lives in the packed weights
-    G[3][1] = h ? cx : G[3][1];
-    G[3][2] = h ? cy : G[3][2];
-    G[3][3] = h ? cz : G[3][3];
-
-    // ---- L2: 104 -> 200 (7 row blocks), bias carries the folded latent ------------------------
-    {
+      for (int ob = 0; ob < L1_OB; ++ob) {
+        const char* buf = ws.acquire(ob);
+        f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
+        d = gemm_block_f32<L1_KS, 6, 7>(buf, d, H, lane);
+        G[ob] = softplus100_v(d);
+      }
+      // skip connection: features 101..103 of lin2's input are the local coords
+      // (block 3, regs 1..3 of the upper half-wave); 1/sqrt(2) lives in the packed weights
+      G[3][1] = h ? cx : G[3][1];
+      G[3][2] = h ? cy : G[3][2];
+      G[3][3] = h ? cz : G[3][3];
+      // ---- L2: 104 -> 200 (7 row blocks), accumulator init carries the folded latent -----------
 #pragma unroll
       for (int ob = 0; ob < L2_OB; ++ob) {
-        const float* buf = ws.acquire(L1_OB + ob);
-        f32x16 d = load_frag16(buf + CHUNK_FLOATS + h * 16);
+        const char* buf = ws.acquire(L1_OB + ob);
+        f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
         d = gemm_block_f32<L2_KS, 3, 4>(buf, d, G, lane);
         H[ob] = softplus100_v(d);
       }
-    }
-
-    // ---- L3: 200 -> 200, L4 (200 -> 1) fused into the epilogue ---------------------------------
-    float part = 0.f;
+      // ---- L3: 200 -> 200, L4 (200 -> 1) fused into the epilogue -------------------------------
 #pragma unroll
-    for (int ob = 0; ob < L3_OB; ++ob) {
-      const float* buf = ws.acquire(L1_OB + L2_OB + ob);
-      f32x16 d = load_frag16(buf + CHUNK_FLOATS + h * 16);
-      d = gemm_block_f32<L3_KS, 6, 7>(buf, d, H, lane);
-      // read the lin4 fragment AFTER the GEMM (hoisted above it, it only gets spilled)
-      unsigned int w4a = (unsigned int)(size_t)(__attribute__((address_space(3))) const float*)(buf + CHUNK_FLOATS + 32 + h * 16);
-      asm volatile("" : "+v"(w4a) : "v"(d[15]));
-      const f32x16 w4 = load_frag16_lds(w4a);
+      for (int ob = 0; ob < L3_OB; ++ob) {
+        const char* buf = ws.acquire(L1_OB + L2_OB + ob);
+        f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
+        d = gemm_block_f32<L3_KS, 6, 7>(buf, d, H, lane);
+        // read the lin4 fragment AFTER the GEMM (hoisted above it, it only gets spilled)
+        unsigned int w4a = (unsigned int)(size_t)(__attribute__((address_space(3))) const float*)(WS::tail_of(buf) + 32 + h * 16);
+        asm volatile("" : "+v"(w4a) : "v"(d[15]));
+        const f32x16 w4 = load_frag16_lds(w4a);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part = fmaf(softplus100(d[r]), w4[r], part);
-      asm volatile("" : "+v"(part));      // finish this block's epilogue here (see pin16)
+        for (int r = 0; r < 16; ++r) part = fmaf(softplus100(d[r]), w4[r], part);
+        asm volatile("" : "+v"(part));      // finish this block's epilogue here (see pin16)
+      }
+    } else {
+      // ================= split-bf16 path: same dataflow, operands as bf16 hi/lo pairs ==========
+      ActB H[7];
+#pragma unroll
+      for (int b = 0; b < 7; ++b) {
+        const f32x16 bias = load_frag16(b0 + (b * 2 + h) * 16);
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (b == 6 && r >= 4) { v[r] = 0.f; continue; }
+          const f32x4 w = l0w[(b * 16 + r) * 2 + h];
+          v[r] = softplus100(fmaf(w[0], cx, fmaf(w[1], cy, fmaf(w[2], cz, bias[r]))));
+        }
+        split_block(v, H[b]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ActB G[4];
+#pragma unroll
+      for (int ob = 0; ob < L1_OB; ++ob) {
+        const char* buf = ws.acquire(ob);
+        f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
+        d = gemm_block_bf16<L1_KS16, 6, 7>(buf, d, H, lane);
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = softplus100(d[r]);
+        if (ob == 3) {                       // skip connection: coords into features 101..103
+          v[1] = h ? cx : v[1];
+          v[2] = h ? cy : v[2];
+          v[3] = h ? cz : v[3];
+        }
+        split_block(v, G[ob]);
+      }
+#pragma unroll
+      for (int ob = 0; ob < L2_OB; ++ob) {
+        const char* buf = ws.acquire(L1_OB + ob);
+        f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
+        d = gemm_block_bf16<L2_KS16, 3, 4>(buf, d, G, lane);
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = softplus100(d[r]);
+        split_block(v, H[ob]);
+      }
+#pragma unroll
+      for (int ob = 0; ob < L3_OB; ++ob) {
+        const char* buf = ws.acquire(L1_OB + L2_OB + ob);
+        f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
+        d = gemm_block_bf16<L3_KS16, 6, 7>(buf, d, H, lane);
+        unsigned int w4a = (unsigned int)(size_t)(__attribute__((address_space(3))) const float*)(WS::tail_of(buf) + 32 + h * 16);
+        asm volatile("" : "+v"(w4a) : "v"(d[15]));
+        const f32x16 w4 = load_frag16_lds(w4a);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = fmaf(softplus100(d[r]), w4[r], part);
+        asm volatile("" : "+v"(part));
+      }
     }
     const float f = part + __shfl_xor(part, 32) + setp[OFF_L4B];
 
@@ -655,7 +767,8 @@ int nphm_identity_prepare_latent(const void* packed,
 }
 
 static int check_prec(int precision) {
-  if (precision != NPHM_PREC_F32) return fail_msg("nphm_identity_eval: unsupported precision mode");
+  if (precision != NPHM_PREC_F32 && precision != NPHM_PREC_BF16X3)
+    return fail_msg("nphm_identity_eval: unsupported precision mode");
   return 0;
 }
 
@@ -679,8 +792,12 @@ int nphm_identity_eval_points(const void* packed, const void* latent_state,
   a.hack_chunk = hack_chunk;
   const int64_t tiles = (n_points + 32 * nphm::NW - 1) / (32 * nphm::NW);
   if (tiles > 0x7fffffffLL) return fail_msg("nphm_identity_eval_points: too many points");
-  hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), dim3((unsigned)tiles, n_rows), dim3(64 * nphm::NW), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (precision == NPHM_PREC_F32)
+    hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), dim3((unsigned)tiles, n_rows), dim3(64 * nphm::NW), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL((nphm::eval_kernel<0, 1>), dim3((unsigned)tiles, n_rows), dim3(64 * nphm::NW), 0,
+                       static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("nphm_identity_eval_points launch", e);
   return 0;
@@ -714,8 +831,12 @@ int nphm_identity_eval_grid(const void* packed, const void* latent_state,
   const int64_t supers = (int64_t(a.nsx) * a.nsy * a.nsz + 7) / 8 * 8;       // padded to the 8 XCDs
   const int64_t bricks = supers * (nphm::SBX * nphm::SBY * nphm::SBZ);
   if (bricks > 0x7fffffffLL) return fail_msg("nphm_identity_eval_grid: slab too large for one launch");
-  hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), dim3((unsigned)bricks), dim3(64 * nphm::NW), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (precision == NPHM_PREC_F32)
+    hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), dim3((unsigned)bricks), dim3(64 * nphm::NW), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL((nphm::eval_kernel<1, 1>), dim3((unsigned)bricks), dim3(64 * nphm::NW), 0,
+                       static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("nphm_identity_eval_grid launch", e);
   return 0;
