@@ -1,0 +1,722 @@
+// eval_kernel.hip — the hot kernel: fused 40-member MLP ensemble + Gaussian blend of the NPHM
+// identity field (FastEnsembleDeepSDFMirrored.forward, src/NPHM/models/EnsembledDeepSDF.py:203-267
+// of the reference; chunked grid form: get_logits, src/NPHM/models/reconstruction.py:6-25).
+//
+// Structure (see DESIGN.md for the numbers):
+//   * one wavefront owns 32 query points for the whole network; activations never leave registers
+//     (layout.h); one workgroup = NW wavefronts = a compact brick of 32*NW points;
+//   * members whose normalised blend weight is <= prune_tol for every point of a wavefront are
+//     skipped; the workgroup streams the union of its wavefronts' members;
+//   * weights are streamed HBM/L2 -> LDS by LDS-DMA (global_load_lds) into a 5-slot ring shared by
+//     the workgroup, one 32-row output block ("chunk") at a time, two chunks ahead of their use;
+//   * per chunk: GEMM on the matrix pipe (fp32 MFMA, or 3 bf16 MFMAs per fp32 product), epilogue
+//     (bias is the accumulator init; base-2 softplus; re-split to bf16 hi/lo) on the vector pipe;
+//     the two wavefronts of a SIMD run half a phase apart so both pipes stay busy;
+//   * MODE 0 reads xyz[n,3]; MODE 1 generates the 'ij' lattice from three axis arrays, bricks are
+//     enumerated so that each XCD works on a compact region (L2 reuse of the streamed members).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <type_traits>
+
+#include "capi_common.h"
+#include "layout.h"
+
+namespace nphm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct EvalArgs {
+  const float* packed_f32;
+  const uint16_t* packed_bf16;
+  const float* state;       // [n_rows, LS_ROW_STRIDE]
+  float* out;
+  unsigned long long* stats;
+  float prune_tol;
+  // MODE 0 (points)
+  const float* xyz;         // [n_rows, n_points, 3]
+  int64_t n_points;
+  // MODE 1 (grid)
+  const float* ax; const float* ay; const float* az;
+  int rx, ry, rz, ix0, ix1;
+  int nbx, nby, nbz;        // bricks per axis
+  int nsx, nsy, nsz;        // super-bricks (2x4x4 bricks) per axis
+  int64_t hack_chunk;
+};
+
+#ifndef NPHM_PROF
+#define NPHM_PROF 0  // 1: per-phase s_memtime accounting into stats[2..8] (timing builds only)
+#endif
+#if NPHM_PROF
+#define PROF_T(var) const long long var = clock64()
+#define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t0, t1)
+#endif
+
+// nn.Softplus(beta=100, threshold=20) (EnsembledDeepSDF.py:99) in the scaled domain of layout.h:
+// d' = k d, returns k softplus(d) = max(d',0) + log2(1 + 2^-|d'|).  For 100 d > 20 PyTorch returns d;
+// here the log term is already 0 in fp32 for 100 d > 16.7, so the two agree to < 1e-9 in d units.
+__device__ __forceinline__ float softplus2(float d) {
+  const float t = __builtin_amdgcn_exp2f(-fabsf(d));                 // raw v_exp_f32
+  return __builtin_amdgcn_fmed3f(d, 0.f, __builtin_inff()) +         // relu without a canonicalize
+         __builtin_amdgcn_logf(1.f + t);                             // raw v_log_f32, arg in [1,2]
+}
+
+// Pin values at this program point.  Without a use in the producing basic block LLVM sinks the
+// (pure) softplus arithmetic across the next workgroup barrier, next to the MFMAs that consume it,
+// which keeps pre- AND post-activation values live and spills.
+__device__ __forceinline__ void pin16(f32x16& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[r]));
+}
+
+// one 32-feature block of activations as split-bf16 B operands of v_mfma_f32_32x32x16_bf16:
+// K-step s consumes registers 8s..8s+7 of the block (k-slot 8h+i <-> register 8s+i)
+struct ActB {
+  bf16x8 hi[2], lo[2];
+};
+
+__device__ __forceinline__ void split_block(const f32x16& v, ActB& o) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = v[8 * s + i];
+      const __bf16 hb = (__bf16)x;
+      o.hi[s][i] = hb;
+      o.lo[s][i] = (__bf16)(x - (float)hb);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {            // pin the packed operands (same reason as pin16)
+    asm volatile("" : "+v"(o.hi[s]));
+    asm volatile("" : "+v"(o.lo[s]));
+  }
+}
+
+__device__ __forceinline__ f32x16 load_frag16(const float* p) {
+  // 16 consecutive floats (64-byte aligned) -> f32x16
+  const f32x4* q = reinterpret_cast<const f32x4*>(p);
+  f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+  f32x16 o;
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+  o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  o[8] = c[0]; o[9] = c[1]; o[10] = c[2]; o[11] = c[3];
+  o[12] = d[0]; o[13] = d[1]; o[14] = d[2]; o[15] = d[3];
+  return o;
+}
+
+__device__ __forceinline__ f32x16 load_frag16_lds(unsigned int lds_byte_addr) {
+  typedef __attribute__((address_space(3))) const f32x4* lds_v4;
+  lds_v4 q = (lds_v4)(size_t)lds_byte_addr;
+  f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+  f32x16 o;
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+  o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  o[8] = c[0]; o[9] = c[1]; o[10] = c[2]; o[11] = c[3];
+  o[12] = d[0]; o[13] = d[1]; o[14] = d[2]; o[15] = d[3];
+  return o;
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// ---- workgroup geometry ----------------------------------------------------------------------
+// NW = wavefronts per workgroup (all of them share one LDS ring): 8 -> 256 points per weight pass
+#ifndef NPHM_NW
+#define NPHM_NW 8
+#endif
+constexpr int NW = NPHM_NW;
+// voxel brick of a workgroup in grid mode: every wavefront owns a 4x4x2 sub-brick
+constexpr int BRX = NW == 8 ? 8 : 4, BRY = NW == 8 ? 8 : 4, BRZ = NW == 8 ? 4 : 8;
+// bricks are enumerated super-brick by super-brick (2x4x4 bricks) so that the workgroups resident
+// on one XCD at any time cover a compact region and stream the same few members (L2 reuse)
+constexpr int SBX = 2, SBY = 4, SBZ = 4;
+
+// ---- weight streaming: global -> LDS ring, shared by the NW wavefronts of a workgroup ----------
+// Units of 1 KiB "groups" (one global_load_lds_dwordx4 of a wavefront).  Chunk 0 of a member is its
+// L0 block (8 groups, per-latent state); chunks 1..18 are GEMM blocks of the packed weight set:
+//   fp32 : L1 25, L2 13, L3 25 groups ([ks/4][lane][4] floats)
+//   bf16 : L1 26, L2 14, L3 26 groups ([ks][hi|lo][lane][8] bf16)
+// plus a 256-byte tail (accumulator init / lin4 weights).  (19 + 1 phantom) % RING == 0 keeps the
+// ring slot of every chunk a compile-time constant.
+constexpr int RING = 5;
+static_assert((CHUNKS_PER_MEMBER + 1) % RING == 0, "ring slots must be static per chunk index");
+
+template <int PREC> struct Stream;
+template <> struct Stream<0> {
+  static constexpr int MAIN_BYTES = (L1_KS / 4) * 1024;
+  __device__ static __forceinline__ const char* set_base(const EvalArgs& p, int s) {
+    return reinterpret_cast<const char*>(p.packed_f32 + size_t(s) * SET_STRIDE);
+  }
+  static constexpr int LS_OFF_L0 = LS_OFF_L0F;
+  __host__ __device__ static constexpr int offset(int g) {   // bytes inside a weight set, g = GEMM chunk
+    return 4 * (g < L1_OB ? OFF_L1A + g * (L1_KS / 4) * 256
+              : g < L1_OB + L2_OB ? OFF_L2A + (g - L1_OB) * (L2_KS / 4) * 256
+                                  : OFF_L3A + (g - L1_OB - L2_OB) * (L3_KS / 4) * 256);
+  }
+  __host__ __device__ static constexpr int groups(int ci) {  // ci = chunk index inside the member
+    return ci == 0 ? 8 : (ci - 1 >= L1_OB && ci - 1 < L1_OB + L2_OB) ? (L2_KS / 4) : (L1_KS / 4);
+  }
+};
+template <> struct Stream<1> {
+  static constexpr int MAIN_BYTES = L1_KS16 * 2 * 1024;
+  __device__ static __forceinline__ const char* set_base(const EvalArgs& p, int s) {
+    return reinterpret_cast<const char*>(p.packed_bf16 + size_t(s) * BF_SET_STRIDE);
+  }
+  static constexpr int LS_OFF_L0 = LS_OFF_L0B;
+  __host__ __device__ static constexpr int offset(int g) {
+    return 2 * (g < L1_OB ? BF_OFF_L1A + g * L1_KS16 * 1024
+              : g < L1_OB + L2_OB ? BF_OFF_L2A + (g - L1_OB) * L2_KS16 * 1024
+                                  : BF_OFF_L3A + (g - L1_OB - L2_OB) * L3_KS16 * 1024);
+  }
+  __host__ __device__ static constexpr int groups(int ci) {
+    return ci == 0 ? 8 : (ci - 1 >= L1_OB && ci - 1 < L1_OB + L2_OB) ? 2 * L2_KS16 : 2 * L1_KS16;
+  }
+};
+
+template <int PREC>
+struct Streamer {
+  static constexpr int SLOT_BYTES = Stream<PREC>::MAIN_BYTES + TAIL_FLOATS * 4;
+  const EvalArgs& p;
+  const float* st;             // per-latent state of this batch row
+  char* ring;                  // LDS, RING * SLOT_BYTES
+  const unsigned char* list;   // LDS, active member ids of this workgroup
+  int n_active;
+  int mi;                      // index (into list) of the member being consumed
+  int wave, lane;
+
+  // LDS-DMA through inline asm: hipcc does not see these loads, so it neither drains them with a
+  // vmcnt(0) in front of every later ds_read (which it does for the builtin: the DMA is a pending
+  // LDS write it cannot disambiguate) nor counts them - sync() waits for exactly the chunk it
+  // needs.  M0 (DMA destination base) is saved/restored inside the statement.
+  __device__ static __forceinline__ void dma16(const char* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  }
+  __device__ static __forceinline__ void dma4(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  }
+  __device__ static __forceinline__ unsigned lds_addr(const char* q) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)q;
+  }
+
+  int k_cur, k_nxt;            // ids of the member being consumed and of the next one (-1: none)
+
+  __device__ __forceinline__ void load_ids() {
+    k_cur = mi < n_active ? __builtin_amdgcn_readfirstlane(int(list[mi])) : -1;
+    k_nxt = mi + 1 < n_active ? __builtin_amdgcn_readfirstlane(int(list[mi + 1])) : -1;
+  }
+  // fetch chunk `ci` (compile-time) of the current (next = false) or the next member into its slot
+  __device__ __forceinline__ void issue(const bool next, const int ci) const {
+    const int k = next ? k_nxt : k_cur;
+    if (k < 0) return;
+    int l = lane;
+    asm volatile("" : "+v"(l));           // per-site addresses are recomputed, not hoisted (VGPRs)
+    const char* src = ci == 0
+        ? reinterpret_cast<const char*>(st + Stream<PREC>::LS_OFF_L0 + k * L0_BLOCK_FLOATS) + l * 16
+        : Stream<PREC>::set_base(p, member_set(k)) + Stream<PREC>::offset(ci - 1) + l * 16;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(ring + (ci % RING) * SLOT_BYTES));
+    constexpr int MAXG = 32;
+    const int ng = Stream<PREC>::groups(ci);
+#pragma unroll
+    for (int i = 0; i < (MAXG + NW - 1) / NW; ++i) {
+      const int g = wave + i * NW;
+      if (i * NW < ng && g < ng) dma16(src + g * 1024, dst + g * 1024);
+    }
+    if (ci > 0 && wave == (ci & (NW - 1)))
+      dma4(st + LS_OFF_TAIL + (k * GEMM_CHUNKS + ci - 1) * TAIL_FLOATS + l, dst + Stream<PREC>::MAIN_BYTES);
+  }
+  template <int N> __device__ static __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
+  }
+  // Every wavefront of the workgroup calls sync<CI>() exactly once per chunk, in the same order.
+  template <int CI> __device__ __forceinline__ void sync() {
+    // chunk CI (issued two syncs ago) must have landed.  The only younger DMAs of this wavefront are
+    // those of the next chunk: at least groups/NW of them.  VMEM completes in order, so waiting until
+    // at most that many operations are outstanding retires every load of chunk CI.
+    constexpr int NXT = (CI + 1) % CHUNKS_PER_MEMBER;
+    constexpr int YOUNGER = Stream<PREC>::groups(NXT) / NW;
+    const bool has_next = CI + 1 < CHUNKS_PER_MEMBER || k_nxt >= 0;
+#if NPHM_PROF
+    const long long ta = clock64();
+#endif
+    if (has_next) wait_vm<YOUNGER>(); else wait_vm<0>();
+#if NPHM_PROF
+    const long long tb = clock64();
+#endif
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#if NPHM_PROF
+    const long long tc = clock64();
+#endif
+    // every wavefront is past chunk CI-3 (its epilogue included), whose slot chunk CI+2 reuses
+    if constexpr (CI + 2 < CHUNKS_PER_MEMBER) issue(false, CI + 2);
+    else issue(true, CI + 2 - CHUNKS_PER_MEMBER);
+#if NPHM_PROF
+    const long long td = clock64();
+    sprof[0] += tb - ta; sprof[1] += tc - tb; sprof[2] += td - tc;
+#endif
+  }
+#if NPHM_PROF
+  long long sprof[3] = {0, 0, 0};   // vmcnt wait, barrier wait, DMA issue
+#endif
+  __device__ __forceinline__ const char* slot(const int CI) const { return ring + (CI % RING) * SLOT_BYTES; }
+  __device__ __forceinline__ void next_member() {
+    ++mi;
+    k_cur = k_nxt;
+    k_nxt = mi + 1 < n_active ? __builtin_amdgcn_readfirstlane(int(list[mi + 1])) : -1;
+    asm volatile("" : "+s"(k_cur), "+s"(k_nxt));   // opaque: nothing per-site hoisted out of the loop
+  }
+  __device__ static __forceinline__ const float* tail_of(const char* buf) {
+    return reinterpret_cast<const float*>(buf + Stream<PREC>::MAIN_BYTES);
+  }
+};
+
+// One 32-row output block on fp32 MFMA: acc += sum_ks A(ks) x IN(block(ks))[reg(ks)].
+// A fragments come from LDS: [ks/4][lane][4].
+template <int NKS, int FULL, int NIN>
+__device__ __forceinline__ f32x16 gemm_block_f32(const char* afrag, f32x16 acc,
+                                                 const f32x16 (&in)[NIN], int lane) {
+  const f32x4* A = reinterpret_cast<const f32x4*>(afrag) + lane;
+#pragma unroll
+  for (int g = 0; g < NKS / 4; ++g) {
+    const f32x4 a = A[g * 64];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ks = 4 * g + c;
+      const int b = ks < 16 * FULL ? (ks >> 4) : FULL;
+      const int r = ks < 16 * FULL ? (ks & 15) : ks - 16 * FULL;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], in[b][r], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+// The same block on split-bf16 MFMA: x*w ~= xh*wh + xl*wh + xh*wl (fp32 accumulate); the dropped
+// xl*wl term is 2^-16 relative.  A fragments from LDS: [ks][hi|lo][lane][8].
+template <int NKS16, int FULL, int NIN>
+__device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
+                                                  const ActB (&in)[NIN], int lane) {
+  const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
+  // A fragments are fetched two K-steps ahead of the MFMAs that consume them (LDS latency is
+  // ~128 cycles, one K-step is 96 cycles of matrix pipe): hipcc does not pipeline this by itself
+  constexpr int PF = 2;
+  bf16x8 wh[NKS16], wl[NKS16];
+#pragma unroll
+  for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
+    wh[ks] = A[(2 * ks) * 64];
+    wl[ks] = A[(2 * ks + 1) * 64];
+  }
+#pragma unroll
+  for (int ks = 0; ks < NKS16; ++ks) {
+    if (ks + PF < NKS16) {
+      wh[ks + PF] = A[(2 * (ks + PF)) * 64];
+      wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);     // the reads above are issued HERE, ahead of the MFMAs
+    const int b = ks < 2 * FULL ? (ks >> 1) : FULL;
+    const int s = ks < 2 * FULL ? (ks & 1) : 0;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].hi[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].lo[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], in[b].hi[s], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+
+template <int MODE, int PREC>
+__global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
+  using WS = Streamer<PREC>;
+  __shared__ __attribute__((aligned(16))) char ring[RING * WS::SLOT_BYTES];
+  __shared__ unsigned int wg_mask[2];
+  __shared__ unsigned char wg_list[N_MEMBERS];
+
+  const int lane_inv = threadIdx.x & 63;
+  const int lane = lane_inv;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h_inv = lane >> 5;
+  const int h = h_inv;
+  const int j = lane & 31;
+  const bool upper = wave >= NW / 2;      // second wavefront of its SIMD (see the chunk loop)
+
+  // ---- locate this lane's query point ------------------------------------------------------
+  bool valid;
+  int64_t out_idx;
+  bool hack = false;
+  float qx, qy, qz;
+  int row = 0;
+  if (MODE == 0) {
+    row = blockIdx.y;
+    const int64_t i = (int64_t(blockIdx.x) * NW + wave) * 32 + j;
+    valid = i < p.n_points;
+    const int64_t ic = valid ? i : (p.n_points - 1);
+    const float* q = p.xyz + (int64_t(row) * p.n_points + ic) * 3;
+    qx = q[0]; qy = q[1]; qz = q[2];
+    out_idx = int64_t(row) * p.n_points + ic;
+    if (p.hack_chunk > 0) hack = ((ic + 1) % p.hack_chunk == 0) || (ic == p.n_points - 1);
+  } else {
+    // The hardware places block b on XCD b % 8: XCD x works on super-bricks x, x+8, x+16, ...
+    // (interleaved, so every XCD sees the same mix of near-surface and empty space) and its
+    // consecutive blocks are the bricks of ONE super-brick.
+    constexpr int SBN = SBX * SBY * SBZ;
+    const int local = blockIdx.x >> 3;
+    const int inner = local % SBN;
+    int bid = (local / SBN) * 8 + (blockIdx.x & 7);          // super-brick index
+    const int sz = bid % p.nsz; bid /= p.nsz;
+    const int sy = bid % p.nsy; bid /= p.nsy;
+    const int bx = bid * SBX + inner / (SBY * SBZ);
+    const int by = sy * SBY + (inner / SBZ) % SBY;
+    const int bz = sz * SBZ + inner % SBZ;
+    const int wx = NW == 8 ? (wave & 1) : 0, wy = NW == 8 ? ((wave >> 1) & 1) : 0;
+    const int wz = NW == 8 ? (wave >> 2) : wave;
+    const int ix = p.ix0 + bx * BRX + wx * 4 + (j >> 3);
+    const int iy = by * BRY + wy * 4 + ((j >> 1) & 3);
+    const int iz = bz * BRZ + wz * 2 + (j & 1);
+    valid = ix < p.ix1 && iy < p.ry && iz < p.rz;
+    const int cx_ = min(ix, p.ix1 - 1), cy_ = min(iy, p.ry - 1), cz_ = min(iz, p.rz - 1);
+    qx = p.ax[cx_]; qy = p.ay[cy_]; qz = p.az[cz_];
+    const int64_t gi = (int64_t(cx_) * p.ry + cy_) * p.rz + cz_;
+    out_idx = gi - int64_t(p.ix0) * p.ry * p.rz;
+    if (p.hack_chunk > 0)
+      hack = ((gi + 1) % p.hack_chunk == 0) || (gi == int64_t(p.rx) * p.ry * p.rz - 1);
+  }
+
+  const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
+  const float* anch = st + LS_OFF_ANCH;
+
+  // ---- blend normaliser and active-member mask (EnsembledDeepSDF.py:129-150) -----------------
+  float S = 0.f;
+#pragma unroll 1
+  for (int k = 0; k < N_LOC; ++k) {
+    const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
+    S += expf(-(d * d) / 0.01f);
+  }
+  const float w_bg = expf(-0.2f / 0.01f);
+  S += w_bg;
+  const float denom = S + 1e-6f;
+  const float thr = p.prune_tol * denom;
+  uint64_t wmask = 0;                    // members this wavefront evaluates (wave-uniform)
+  const bool any_valid = __ballot(valid) != 0ull;
+  if (p.prune_tol < 0.f) {
+    wmask = any_valid ? (1ull << N_MEMBERS) - 1 : 0ull;
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < N_MEMBERS; ++k) {
+      float w = w_bg;
+      if (k < N_LOC) {
+        const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
+        w = expf(-(d * d) / 0.01f);
+      }
+      if (__ballot(valid && !hack && w > thr) != 0ull) wmask |= 1ull << k;
+    }
+  }
+
+  const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
+  if (p.stats && lane == 0) {
+    atomicAdd(p.stats, nv * __popcll(wmask));
+    atomicAdd(p.stats + 1, nv);
+  }
+
+  // ---- union over the workgroup: the members whose weights get streamed ----------------------
+  if (threadIdx.x < 2) wg_mask[threadIdx.x] = 0u;
+  __syncthreads();
+  if (lane == 0) {
+    atomicOr(&wg_mask[0], (unsigned int)(wmask & 0xffffffffull));
+    atomicOr(&wg_mask[1], (unsigned int)(wmask >> 32));
+  }
+  __syncthreads();
+  const uint64_t gmask = (uint64_t(wg_mask[1]) << 32) | wg_mask[0];
+  const int n_active = __popcll(gmask);
+  if (threadIdx.x < N_MEMBERS) {
+    if ((gmask >> threadIdx.x) & 1ull)
+      wg_list[__popcll(gmask & ((1ull << threadIdx.x) - 1))] = (unsigned char)threadIdx.x;
+  }
+  __syncthreads();
+  WS ws{p, st, ring, wg_list, n_active, 0, wave, lane};
+  ws.load_ids();
+  ws.issue(false, 0);
+  ws.issue(false, 1);
+
+  float acc = 0.f;
+#if NPHM_PROF
+  long long prof[6] = {0, 0, 0, 0, 0, 0};   // L0 gemm, sync, gemm, epilogue, member total, kernel total
+  const long long t_kernel = clock64();
+#endif
+
+#pragma unroll 1
+  for (int mi = 0; mi < n_active; ++mi) {
+    const int k = wg_list[mi];
+    if (!((wmask >> k) & 1ull)) {
+      // this wavefront's 32 points do not need member k: keep the ring moving only
+      static_for<CHUNKS_PER_MEMBER>([&](auto cc) __attribute__((always_inline)) {
+        ws.template sync<decltype(cc)::value>();
+      });
+      ws.next_member();
+      continue;
+    }
+    // lane-derived values are re-materialised per member (opaque to LICM): hoisting the dozens of
+    // per-site lane offsets out of this loop costs more registers than recomputing them
+    int h = h_inv, lane = lane_inv;
+    asm volatile("" : "+v"(h), "+v"(lane));
+    PROF_T(t_m0);
+
+    // local coordinates (EnsembledDeepSDF.py:240-244): anchor-relative, odd member of a
+    // symmetric pair mirrored in x, background member uses global coordinates
+    float cx = qx, cy = qy, cz = qz;
+    float wk = w_bg;
+    if (k < N_LOC) {
+      const float ax = anch[3 * k], ay = anch[3 * k + 1], az = anch[3 * k + 2];
+      cx = qx - ax; cy = qy - ay; cz = qz - az;
+      const float dx = ax - qx, dy = ay - qy, dz = az - qz;
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
+      wk = expf(-(d * d) / 0.01f);
+    }
+    if (k < 2 * N_SYMM && (k & 1)) cx = -cx;
+    const float b4 = p.packed_f32[size_t(member_set(k)) * SET_STRIDE + OFF_L4B];
+    float part = 0.f;
+
+    // Activations of this wavefront's 32 points (registers): fp32 blocks or split-bf16 operands
+    using Act = typename std::conditional<PREC == 0, f32x16, ActB>::type;
+    Act H[7], G[4];
+    auto store_act = [&](const f32x16& v, Act& dst) __attribute__((always_inline)) {
+      if constexpr (PREC == 0) { dst = v; pin16(dst); } else { split_block(v, dst); }
+    };
+
+    // ---- 19 chunks: 0 = L0 (3 coords -> 200), 1..4 = L1, 5..11 = L2, 12..18 = L3; each = GEMM on
+    // the MFMA pipe + epilogue on the VALU.  The NW wavefronts of the workgroup meet at ONE barrier per
+    // chunk (weight ring), but the upper half (the second wave of every SIMD) places it one epilogue
+    // earlier: while the lower half runs GEMM(c) the upper half runs epilogue(c-1), then the roles
+    // swap - matrix and vector pipes of a SIMD stay busy together instead of alternating in lockstep.
+    f32x16 d;          // accumulator of the GEMM chunk in flight
+    f32x16 d0[7];      // the 7 accumulators of the L0 chunk
+    auto gemm = [&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      PROF_T(t_g0);
+      const char* buf = ws.slot(c);
+      if constexpr (c == 0) {
+        // L0: lin0 restricted to the coordinates, folded bias as an extra K column (prep_kernels.hip)
+        if constexpr (PREC == 0) {
+          const float* A = reinterpret_cast<const float*>(buf) + lane;
+          const float bk0 = h ? cy : cx, bk1 = h ? 1.f : cz;
+#pragma unroll
+          for (int ob = 0; ob < 7; ++ob) {
+            f32x16 z = {};
+            z = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob) * 64], bk0, z, 0, 0, 0);
+            d0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob + 1) * 64], bk1, z, 0, 0, 0);
+          }
+        } else {
+          const bf16x8* A = reinterpret_cast<const bf16x8*>(buf) + lane;
+          __bf16 xh[3], xl[3], xll[3];
+          const float cs[3] = {cx, cy, cz};
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            xh[i] = (__bf16)cs[i];
+            const float r1 = cs[i] - (float)xh[i];
+            xl[i] = (__bf16)r1;
+            xll[i] = (__bf16)(r1 - (float)xl[i]);
+          }
+          const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+          bf16x8 bv;
+          bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
+          bv[3] = h ? one : xl[0];
+          bv[4] = h ? xll[0] : xl[1];
+          bv[5] = h ? xll[1] : xl[2];
+          bv[6] = h ? xll[2] : one;
+          bv[7] = h ? zero : one;
+#pragma unroll
+          for (int ob = 0; ob < 7; ++ob) {
+            f32x16 z = {};
+            d0[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ob * 64], bv, z, 0, 0, 0);
+          }
+        }
+      } else {
+        d = load_frag16(WS::tail_of(buf) + h * 16);
+        constexpr int g = c - 1;
+        if constexpr (PREC == 0) {
+          if constexpr (g < L1_OB) d = gemm_block_f32<L1_KS, 6, 7>(buf, d, H, lane);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_block_f32<L2_KS, 3, 4>(buf, d, G, lane);
+          else d = gemm_block_f32<L3_KS, 6, 7>(buf, d, H, lane);
+        } else {
+          if constexpr (g < L1_OB) d = gemm_block_bf16<L1_KS16, 6, 7>(buf, d, H, lane);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_block_bf16<L2_KS16, 3, 4>(buf, d, G, lane);
+          else d = gemm_block_bf16<L3_KS16, 6, 7>(buf, d, H, lane);
+        }
+      }
+#if NPHM_PROF
+      if constexpr (c == 0) asm volatile("" : "+v"(d0[6][0])); else asm volatile("" : "+v"(d[0]));
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // let the last MFMA retire before the stamp
+#endif
+      PROF_T(t_g1);
+      PROF_ADD(c == 0 ? 0 : 2, t_g0, t_g1);
+    };
+    auto epilogue = [&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      PROF_T(t_e0);
+      if constexpr (c == 0) {
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+          f32x16 v;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = softplus2(d0[b][r]);
+          store_act(v, H[b]);
+        }
+      } else if constexpr (c - 1 < L1_OB + L2_OB) {
+        constexpr int g = c - 1;
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = softplus2(d[r]);
+        if constexpr (g == L1_OB - 1) {
+          // skip connection: features 101..103 of lin2's input are the local coords (block 3,
+          // regs 1..3 of the upper half-wave); 1/sqrt(2) and the activation scale live in the weights
+          v[1] = h ? cx : v[1];
+          v[2] = h ? cy : v[2];
+          v[3] = h ? cz : v[3];
+        }
+        if constexpr (g < L1_OB) store_act(v, G[g]); else store_act(v, H[g - L1_OB]);
+      } else {
+        // L3 block: lin4 (200 -> 1) fused; read its fragment AFTER the GEMM (hoisted above it, it
+        // only gets spilled)
+        unsigned int w4a = WS::lds_addr(reinterpret_cast<const char*>(WS::tail_of(ws.slot(c)) + 32 + h * 16));
+        asm volatile("" : "+v"(w4a) : "v"(d[15]));
+        const f32x16 w4 = load_frag16_lds(w4a);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = fmaf(softplus2(d[r]), w4[r], part);
+        asm volatile("" : "+v"(part));      // finish this block's epilogue here (see pin16)
+      }
+      PROF_T(t_e1);
+      PROF_ADD(3, t_e0, t_e1);
+    };
+    static_for<CHUNKS_PER_MEMBER>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      if constexpr (c > 1) {
+        if (upper) { PROF_T(t_s0); ws.template sync<c>(); PROF_T(t_s1); PROF_ADD(1, t_s0, t_s1); }
+        epilogue(std::integral_constant<int, (c > 0 ? c - 1 : 0)>{});
+        if (!upper) { PROF_T(t_s0); ws.template sync<c>(); PROF_T(t_s1); PROF_ADD(1, t_s0, t_s1); }
+      } else if constexpr (c == 1) {
+        // the L0 epilogue (7 blocks) is as long for both halves: enter the stagger after it
+        epilogue(std::integral_constant<int, 0>{});
+        PROF_T(t_s0); ws.template sync<c>(); PROF_T(t_s1); PROF_ADD(1, t_s0, t_s1);
+      } else {
+        PROF_T(t_s0); ws.template sync<c>(); PROF_T(t_s1); PROF_ADD(1, t_s0, t_s1);
+      }
+      gemm(cc);
+    });
+    epilogue(std::integral_constant<int, CHUNKS_PER_MEMBER - 1>{});
+
+    const float f = part + __shfl_xor(part, 32) + b4;
+
+    // ---- Gaussian blend (EnsembledDeepSDF.py:144-149) ------------------------------------------
+    acc = fmaf(wk / denom, f, acc);
+    ws.next_member();
+    PROF_T(t_m2);
+    PROF_ADD(4, t_m0, t_m2);
+  }
+#if NPHM_PROF
+  prof[5] = clock64() - t_kernel;
+  if (p.stats && lane == 0 && n_active > 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(p.stats + 2 + i, (unsigned long long)prof[i]);
+    for (int i = 0; i < 3; ++i) atomicAdd(p.stats + 8 + i, (unsigned long long)ws.sprof[i]);
+    atomicAdd(p.stats + 11, 1ull);
+  }
+#endif
+
+  // eval-mode overwrite (EnsembledDeepSDF.py:260-261): every member predicts 1 for this point
+  if (hack) acc = S / denom;
+  if (valid && h == 0) p.out[out_idx] = acc;
+}
+
+}  // namespace nphm
+
+// ============================================================================================
+// C ABI (include/nphm_amd.h)
+// ============================================================================================
+extern "C" {
+
+static int check_prec(int precision) {
+  if (precision != NPHM_PREC_F32 && precision != NPHM_PREC_BF16X3)
+    return nphm_fail_msg("nphm_identity_eval: unsupported precision mode");
+  return 0;
+}
+
+static void fill_common(nphm::EvalArgs& a, const void* packed, const void* latent_state, float* out,
+                        unsigned long long* stats, float prune_tol, int64_t hack_chunk) {
+  memset(&a, 0, sizeof(a));
+  a.packed_f32 = static_cast<const float*>(packed);
+  a.packed_bf16 = reinterpret_cast<const uint16_t*>(static_cast<const char*>(packed) + nphm::PACKED_F32_FLOATS * 4);
+  a.state = static_cast<const float*>(latent_state);
+  a.out = out;
+  a.stats = stats;
+  a.prune_tol = prune_tol;
+  a.hack_chunk = hack_chunk;
+}
+
+int nphm_identity_eval_points(const void* packed, const void* latent_state,
+                              const float* xyz, int n_rows, int64_t n_points,
+                              int64_t hack_chunk, float prune_tol, int precision,
+                              float* sdf_out, unsigned long long* stats, void* stream) {
+  if (!packed || !latent_state || !xyz || !sdf_out) return nphm_fail_msg("nphm_identity_eval_points: null pointer");
+  if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_identity_eval_points: empty input");
+  if (check_prec(precision)) return -2;
+  nphm::EvalArgs a;
+  fill_common(a, packed, latent_state, sdf_out, stats, prune_tol, hack_chunk);
+  a.xyz = xyz;
+  a.n_points = n_points;
+  const int64_t tiles = (n_points + 32 * nphm::NW - 1) / (32 * nphm::NW);
+  if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_identity_eval_points: too many points");
+  const dim3 grid((unsigned)tiles, n_rows), block(64 * nphm::NW);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((nphm::eval_kernel<0, 1>), grid, block, 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_eval_points launch", e);
+  return 0;
+}
+
+int nphm_identity_eval_grid(const void* packed, const void* latent_state,
+                            const float* axis_x, const float* axis_y, const float* axis_z,
+                            int rx, int ry, int rz, int ix0, int ix1,
+                            int64_t hack_chunk, float prune_tol, int precision,
+                            float* sdf_out, unsigned long long* stats, void* stream) {
+  if (!packed || !latent_state || !axis_x || !axis_y || !axis_z || !sdf_out)
+    return nphm_fail_msg("nphm_identity_eval_grid: null pointer");
+  if (rx <= 0 || ry <= 0 || rz <= 0 || ix0 < 0 || ix1 > rx || ix0 >= ix1)
+    return nphm_fail_msg("nphm_identity_eval_grid: bad grid / slab bounds");
+  if (check_prec(precision)) return -2;
+  nphm::EvalArgs a;
+  fill_common(a, packed, latent_state, sdf_out, stats, prune_tol, hack_chunk);
+  a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
+  a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
+  a.nbx = (ix1 - ix0 + nphm::BRX - 1) / nphm::BRX; a.nby = (ry + nphm::BRY - 1) / nphm::BRY;
+  a.nbz = (rz + nphm::BRZ - 1) / nphm::BRZ;
+  a.nsx = (a.nbx + nphm::SBX - 1) / nphm::SBX; a.nsy = (a.nby + nphm::SBY - 1) / nphm::SBY;
+  a.nsz = (a.nbz + nphm::SBZ - 1) / nphm::SBZ;
+  const int64_t supers = (int64_t(a.nsx) * a.nsy * a.nsz + 7) / 8 * 8;       // padded to the 8 XCDs
+  const int64_t bricks = supers * (nphm::SBX * nphm::SBY * nphm::SBZ);
+  if (bricks > 0x7fffffffLL) return nphm_fail_msg("nphm_identity_eval_grid: slab too large for one launch");
+  const dim3 grid((unsigned)bricks), block(64 * nphm::NW);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((nphm::eval_kernel<1, 1>), grid, block, 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_eval_grid launch", e);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,23 @@
+import torch, sys
+sys.path.insert(0,"tests"); sys.path.insert(0,".")
+import _util as U
+from nphm_amd import _lib, reconstruction as R
+dev=torch.device("cuda:0")
+for prec,code in (("bf16x3",1),("f32",0)):
+    net=U.build_identity(device=dev).eval(); net.precision=prec
+    lat=U.sample_latent(0).to(dev)
+    res=256
+    axes=R.grid_axes(U.MINI,U.MAXI,res)
+    ax=[torch.from_numpy(a).to(dev) for a in axes]
+    lib=_lib.load()
+    packed,state,_=net.prepare_latent(lat[None])
+    out=torch.empty(res**3,device=dev)
+    for it in range(2):
+        stats=torch.zeros(16,dtype=torch.int64,device=dev)
+        rc=lib.nphm_identity_eval_grid(packed.data_ptr(),state.data_ptr(),ax[0].data_ptr(),ax[1].data_ptr(),ax[2].data_ptr(),res,res,res,0,res,25000,1e-7,code,out.data_ptr(),stats.data_ptr(),None)
+        torch.cuda.synchronize()
+    s=stats.cpu().numpy().astype(float)
+    nw=s[11]; names=["L0_gemm","sync(active)","gemm","epilogue","member_total","kernel_total","vmcnt_wait(all)","barrier_wait(all)","dma_issue(all)"]
+    mw = s[0]/32  # member-waves
+    print(prec, "member-waves", mw, "active waves", nw)
+    for i,n in enumerate(names): print(f"  {n:14s} {s[2+i]:.4g} ticks  per member-wave {s[2+i]/mw:9.1f}  share of kernel_total {s[2+i]/s[7]:.3f}")
