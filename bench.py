@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--prune-tol", type=float, default=None)
-    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3"])
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
     ap.add_argument("--chunk", type=int, default=25000, help="get_logits chunk whose last voxel is overwritten (eval mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40000)
@@ -144,7 +144,9 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         active = stats.cpu().numpy()
         mean_active = float(active[0]) / max(1, args.steps) / n_local     # evaluated member-points / point
-        exec_flops = mean_active * FLOP_MEMBER_FOLDED * n_local
+        # executed matrix-pipe FLOPs: the split-bf16 path issues 3 bf16 MFMA products per fp32 product
+        passes = 3 if net.precision == "bf16x3" else 1
+        exec_flops = passes * mean_active * FLOP_MEMBER_FOLDED * n_local
         peak = PEAK_TFLOPS[net.precision]
         achieved = exec_flops / (k_ms * 1e-3) / 1e12
         out = {
@@ -162,7 +164,8 @@ def main():
                          "frac": achieved / peak, "traffic": None,
                          "kernel": "nphm::eval_kernel<1,%d>" % net._precision_code(),
                          "kernel_ms": k_ms, "points_per_launch": n_local,
-                         "executed_flops_per_point": mean_active * FLOP_MEMBER_FOLDED,
+                         "executed_flops_per_point": passes * mean_active * FLOP_MEMBER_FOLDED,
+                         "mfma_passes": passes,
                          "mean_active_members": mean_active,
                          "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12},
         }

@@ -181,7 +181,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         # ---- execution knobs (defaults keep reference numerics within 1e-4) -------------------
         self.backend = "hip"            # "hip" | "composite"
         self.prune_tol = float(os.environ.get("NPHM_AMD_PRUNE_TOL", "1e-7"))
-        self.precision = os.environ.get("NPHM_AMD_PRECISION", "f32")   # "f32" | "bf16x3"
+        self.precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3")   # "bf16x3" | "f32"
         self._pack_cache = None         # (key, packed tensor)
 
     # ------------------------------------------------------------------------------------------
