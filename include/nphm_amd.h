@@ -94,6 +94,56 @@ int nphm_identity_eval_grid(const void* packed, const void* latent_state,
                             int64_t hack_chunk, float prune_tol, int precision,
                             float* sdf_out, unsigned long long* stats, void* stream);
 
+/* Second stage of the two-stage evaluation get_logits_backward (src/NPHM/models/reconstruction.py:28-56):
+ * the identity field at displaced lattice points.  xyz_slab [(ix1-ix0)*ry*rz, 3] holds the canonical
+ * points x + F_ex(x) of the slab in flattened lattice order (nphm_mlp_eval_grid with add_input);
+ * traversal, output order and the chunk overwrite are those of nphm_identity_eval_grid. */
+int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
+                                   const float* xyz_slab, int rx, int ry, int rz, int ix0, int ix1,
+                                   int64_t hack_chunk, float prune_tol, int precision,
+                                   float* sdf_out, unsigned long long* stats, void* stream);
+
+/* ---- dense skip-MLP: DeepSDF (NPM global SDF, backbone of DeformationNetwork) ----------- */
+/* Architecture (src/NPHM/models/deepSDF.py:7-62): dims = [3 + lat_dim] + [hidden_dim]*nlayers + [out_dim],
+ * input re-injected (concat, / sqrt 2) before layer nlayers/2, Softplus(beta) activations.
+ * The fused kernel covers input_dim 3, beta 100, no positional encoding (num_freq_bands 0),
+ * 32 <= hidden_dim <= 1024, hidden_dim > 3 + lat_dim, 2 <= nlayers <= 11, out_dim <= 4 — i.e. the NPM
+ * net (npm.yaml: 512/1024/8/1) and the NPHM deformation backbone (nphm_def.yaml: 232/512/6/3).
+ * Returns 1 if covered. */
+int nphm_mlp_supported(int lat_dim, int hidden_dim, int nlayers, int out_dim, int input_dim, float beta,
+                       int num_freq_bands);
+size_t nphm_mlp_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim);
+size_t nphm_mlp_latent_state_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows);
+
+/* Re-lay the state_dict tensors lin{0..nlayers}.{weight,bias} (arrays of nlayers+1 device pointers)
+ * into split-bf16 MFMA fragment order (replaces the per-call nn.Linear GEMMs of deepSDF.py:76-88). */
+int nphm_mlp_pack(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                  const float* const* lin_weight, const float* const* lin_bias, void* packed, void* stream);
+
+/* Per conditioning vector (one per batch row; cond_rows [n_rows, lat_dim] = lat_rep[:, 0, :] of
+ * DeepSDF.forward, or [compressor(z_id, anchors) | z_ex] of DeformationNetwork mode 'compress',
+ * deepSDF.py:212-223): the latent columns of lin0 and of the skip layer folded into bias vectors
+ * (replaces torch.cat([xyz, lat_rep]) per point, deepSDF.py:75, :82). */
+int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                            const float* const* lin_weight, const float* const* lin_bias,
+                            const float* cond_rows, int n_rows, void* latent_state, void* stream);
+
+/* DeepSDF.forward (deepSDF.py:64-89) for row-constant latents: out[b,n,:out_dim] for xyz[b,n,:3].
+ * add_input != 0 adds xyz to the first 3 outputs: canonical points x + F_ex(x) of get_logits_backward
+ * (src/NPHM/models/reconstruction.py:44-46) / posed vertices of deform_mesh (:83-84). */
+int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                         const void* packed, const void* latent_state,
+                         const float* xyz, int n_rows, int64_t n_points, int add_input,
+                         float* out, void* stream);
+
+/* The same on the x-slab [ix0, ix1) of an [rx,ry,rz] 'ij' lattice (utils/reconstruction.py:5-20):
+ * out [(ix1-ix0)*ry*rz, out_dim] in flattened lattice order. */
+int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                       const void* packed, const void* latent_state,
+                       const float* axis_x, const float* axis_y, const float* axis_z,
+                       int rx, int ry, int rz, int ix0, int ix1, int add_input,
+                       float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

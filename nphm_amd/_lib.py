@@ -32,6 +32,17 @@ SYMBOLS = {
                                           c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_eval_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_int, c_int, c_int, c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_eval_grid_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                               c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "nphm_mlp_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_int]),
+    "nphm_mlp_packed_bytes": (c_size_t, [c_int] * 4),
+    "nphm_mlp_latent_state_bytes": (c_size_t, [c_int] * 5),
+    "nphm_mlp_pack": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_mlp_prepare_latent": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nphm_mlp_eval_points": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+                                                    c_void_p, c_void_p]),
+    "nphm_mlp_eval_grid": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -69,6 +80,11 @@ def check(rc: int, what: str):
 
 def ptr_array5(tensors):
     return _PtrArr5(*[t.data_ptr() for t in tensors])
+
+
+def ptr_array(tensors):
+    """ctypes array of device pointers (any length)."""
+    return (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 def ptr_array3(tensors):

@@ -8,7 +8,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["prep_kernels.hip", "eval_kernel.hip"]
+SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip"]
 OUT = os.path.join(HERE, "libnphm_amd.so")
 
 

@@ -12,8 +12,9 @@
 //   * per chunk: GEMM on the matrix pipe (fp32 MFMA, or 3 bf16 MFMAs per fp32 product), epilogue
 //     (bias is the accumulator init; base-2 softplus; re-split to bf16 hi/lo) on the vector pipe;
 //     the two wavefronts of a SIMD run half a phase apart so both pipes stay busy;
-//   * MODE 0 reads xyz[n,3]; MODE 1 generates the 'ij' lattice from three axis arrays, bricks are
-//     enumerated so that each XCD works on a compact region (L2 reuse of the streamed members).
+//   * MODE 0 reads xyz[n,3]; MODE 1 generates the 'ij' lattice from three axis arrays (or reads
+//     lattice-ordered displaced points: two-stage evaluation), bricks are enumerated so that each
+//     XCD works on a compact region (L2 reuse of the streamed members).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -389,9 +390,16 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     const int iz = bz * BRZ + wz * 2 + (j & 1);
     valid = ix < p.ix1 && iy < p.ry && iz < p.rz;
     const int cx_ = min(ix, p.ix1 - 1), cy_ = min(iy, p.ry - 1), cz_ = min(iz, p.rz - 1);
-    qx = p.ax[cx_]; qy = p.ay[cy_]; qz = p.az[cz_];
     const int64_t gi = (int64_t(cx_) * p.ry + cy_) * p.rz + cz_;
     out_idx = gi - int64_t(p.ix0) * p.ry * p.rz;
+    if (p.xyz) {
+      // lattice-ORDERED but displaced queries (canonical points x + F_ex(x) of the two-stage
+      // evaluation): same brick traversal, coordinates from the slab-local point array
+      const float* q = p.xyz + out_idx * 3;
+      qx = q[0]; qy = q[1]; qz = q[2];
+    } else {
+      qx = p.ax[cx_]; qy = p.ay[cy_]; qz = p.az[cz_];
+    }
     if (p.hack_chunk > 0)
       hack = ((gi + 1) % p.hack_chunk == 0) || (gi == int64_t(p.rx) * p.ry * p.rz - 1);
   }
@@ -667,6 +675,23 @@ static void fill_common(nphm::EvalArgs& a, const void* packed, const void* laten
   a.hack_chunk = hack_chunk;
 }
 
+static int launch_grid(nphm::EvalArgs& a, int precision, hipStream_t st, const char* who) {
+  const int nx = a.ix1 - a.ix0;
+  a.nbx = (nx + nphm::BRX - 1) / nphm::BRX; a.nby = (a.ry + nphm::BRY - 1) / nphm::BRY;
+  a.nbz = (a.rz + nphm::BRZ - 1) / nphm::BRZ;
+  a.nsx = (a.nbx + nphm::SBX - 1) / nphm::SBX; a.nsy = (a.nby + nphm::SBY - 1) / nphm::SBY;
+  a.nsz = (a.nbz + nphm::SBZ - 1) / nphm::SBZ;
+  const int64_t supers = (int64_t(a.nsx) * a.nsy * a.nsz + 7) / 8 * 8;       // padded to the 8 XCDs
+  const int64_t bricks = supers * (nphm::SBX * nphm::SBY * nphm::SBZ);
+  if (bricks > 0x7fffffffLL) return nphm_fail_msg("slab too large for one launch");
+  const dim3 grid((unsigned)bricks), block(64 * nphm::NW);
+  if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((nphm::eval_kernel<1, 1>), grid, block, 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail(who, e);
+  return 0;
+}
+
 int nphm_identity_eval_points(const void* packed, const void* latent_state,
                               const float* xyz, int n_rows, int64_t n_points,
                               int64_t hack_chunk, float prune_tol, int precision,
@@ -703,20 +728,26 @@ int nphm_identity_eval_grid(const void* packed, const void* latent_state,
   fill_common(a, packed, latent_state, sdf_out, stats, prune_tol, hack_chunk);
   a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
   a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
-  a.nbx = (ix1 - ix0 + nphm::BRX - 1) / nphm::BRX; a.nby = (ry + nphm::BRY - 1) / nphm::BRY;
-  a.nbz = (rz + nphm::BRZ - 1) / nphm::BRZ;
-  a.nsx = (a.nbx + nphm::SBX - 1) / nphm::SBX; a.nsy = (a.nby + nphm::SBY - 1) / nphm::SBY;
-  a.nsz = (a.nbz + nphm::SBZ - 1) / nphm::SBZ;
-  const int64_t supers = (int64_t(a.nsx) * a.nsy * a.nsz + 7) / 8 * 8;       // padded to the 8 XCDs
-  const int64_t bricks = supers * (nphm::SBX * nphm::SBY * nphm::SBZ);
-  if (bricks > 0x7fffffffLL) return nphm_fail_msg("nphm_identity_eval_grid: slab too large for one launch");
-  const dim3 grid((unsigned)bricks), block(64 * nphm::NW);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((nphm::eval_kernel<1, 1>), grid, block, 0, st, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return nphm_fail("nphm_identity_eval_grid launch", e);
-  return 0;
+  return launch_grid(a, precision, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid");
+}
+
+int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
+                                   const float* xyz_slab, int rx, int ry, int rz, int ix0, int ix1,
+                                   int64_t hack_chunk, float prune_tol, int precision,
+                                   float* sdf_out, unsigned long long* stats, void* stream) {
+  if (!xyz_slab) return nphm_fail_msg("nphm_identity_eval_grid_points: null pointer");
+  // the axis pointers are never dereferenced when xyz_slab is given
+  const float* dummy = xyz_slab;
+  if (!packed || !latent_state || !sdf_out) return nphm_fail_msg("nphm_identity_eval_grid_points: null pointer");
+  if (rx <= 0 || ry <= 0 || rz <= 0 || ix0 < 0 || ix1 > rx || ix0 >= ix1)
+    return nphm_fail_msg("nphm_identity_eval_grid_points: bad grid / slab bounds");
+  if (check_prec(precision)) return -2;
+  nphm::EvalArgs a;
+  fill_common(a, packed, latent_state, sdf_out, stats, prune_tol, hack_chunk);
+  a.xyz = xyz_slab;
+  a.ax = dummy; a.ay = dummy; a.az = dummy;
+  a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
+  return launch_grid(a, precision, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid_points");
 }
 
 }  // extern "C"

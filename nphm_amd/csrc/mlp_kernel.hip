@@ -1,0 +1,570 @@
+// mlp_kernel.hip — fused dense skip-MLP for the reference's DeepSDF (src/NPHM/models/deepSDF.py:6-89):
+// the NPM global SDF and the backbone of the forward-deformation network
+// (DeformationNetwork, deepSDF.py:118-239; chunked drivers get_logits_backward / deform_mesh,
+// src/NPHM/models/reconstruction.py:28-88).  One latent per batch row (mlp_layout.h).
+//
+// Structure (numbers in DESIGN.md):
+//   * one workgroup = 8 wavefronts = M points (64 at hidden <= 512, 32 at hidden <= 1024) for the
+//     WHOLE network; activations live in LDS as split-bf16 (hi | lo) K chunks, 128 KiB;
+//   * a layer is an output-stationary GEMM: wavefront w owns the 32-row output tiles w, w+8, ...
+//     for all M points (accumulators in registers), its A fragments (weights) stream L2 -> VGPR
+//     with no reuse inside the workgroup (every weight byte is fetched once per M points), B
+//     fragments (activations) come from LDS with conflict-free 16-byte reads;
+//   * x*w ~= xh*wh + xl*wh + xh*wl on v_mfma_f32_32x32x16_bf16 (fp32 accumulate);
+//   * the accumulators are initialised by one extra "coordinate K-step" per tile that carries the
+//     bias, the folded latent and - for lin0 and the skip layer - the xyz columns;
+//   * epilogue: base-2 softplus, re-split to bf16 hi/lo in registers; the LDS tile is overwritten
+//     in place between two workgroup barriers;
+//   * the last layer (out <= 4) splits K over the 8 wavefronts and combines the partial sums in a
+//     fixed order (bitwise reproducible).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "capi_common.h"
+#include "mlp_layout.h"
+
+namespace nphm {
+namespace mlp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline uint16_t f32_to_bf16_rn(float x) {
+  uint32_t u = __float_as_uint(x);
+  uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+  return uint16_t(r >> 16);
+}
+__device__ inline float bf16_to_f32(uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+
+// ---------------------------------------------------------------------------------------------
+// pack: nn.Linear weights -> split-bf16 MFMA A fragments (once per weight update)
+// ---------------------------------------------------------------------------------------------
+struct PtrTable {
+  const float* w[MAX_LINEAR];
+  const float* b[MAX_LINEAR];
+};
+
+struct PackArgs {
+  PtrTable t;
+  Plan plan;
+  uint16_t* out;
+};
+
+__global__ void mlp_pack_kernel(PackArgs a) {
+  const int l = blockIdx.y + 1;                       // layer 0 has no activation columns
+  const Layer& L = a.plan.layer[l];
+  const size_t total = size_t(L.n_tiles) * L.k_steps * 2 * 64 * 8;
+  for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total;
+       e += size_t(gridDim.x) * blockDim.x) {
+    const int i = e & 7, lane = (e >> 3) & 63, part = (e >> 9) & 1;
+    const size_t gg = e >> 10;
+    const int ks = int(gg % L.k_steps), n = int(gg / L.k_steps);
+    const int row = 32 * n + (lane & 31);
+    const int f = 32 * (ks >> 1) + feat_local(8 * (ks & 1) + i, lane >> 5);
+    float w = 0.f;
+    if (row < L.out_dim && f < L.k_act) w = a.t.w[l][size_t(row) * L.in_dim + f] * L.act_scale;
+    const uint16_t hi = f32_to_bf16_rn(w);
+    const uint16_t lo = f32_to_bf16_rn(w - bf16_to_f32(hi));
+    a.out[L.w_off / 2 + e] = part ? lo : hi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prepare: per latent row, the coordinate K-step fragments of every layer (folded latent + bias)
+// grid (n_linear, n_rows), 256 threads
+// ---------------------------------------------------------------------------------------------
+struct PrepArgs {
+  PtrTable t;
+  Plan plan;
+  const float* cond;   // [n_rows, lat_dim]
+  int lat_dim;
+  char* state;         // [n_rows, state_row_bytes]
+};
+
+__global__ __launch_bounds__(256) void mlp_prepare_kernel(PrepArgs a) {
+  __shared__ float bias[1024];
+  __shared__ float lat[1024];
+  const int l = blockIdx.x, row = blockIdx.y, t = threadIdx.x;
+  const Layer& L = a.plan.layer[l];
+  const float* W = a.t.w[l];
+  const float* cond = a.cond + size_t(row) * a.lat_dim;
+  for (int j = t; j < a.lat_dim; j += blockDim.x) lat[j] = cond[j];
+  __syncthreads();
+  for (int o = t; o < 32 * L.n_tiles; o += blockDim.x) {
+    float v = 0.f;
+    if (o < L.out_dim) {
+      if (L.lat_col >= 0) {
+        const float* wl = W + size_t(o) * L.in_dim + L.lat_col;
+        for (int j = 0; j < a.lat_dim; ++j) v = fmaf(wl[j], lat[j], v);
+        v *= L.in_scale;
+      }
+      v = (v + a.t.b[l][o]) * L.add_scale;
+    }
+    bias[o] = v;
+  }
+  __syncthreads();
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.state + size_t(row) * a.plan.state_row_bytes + L.c_off);
+  for (int e = t; e < L.n_tiles * 64 * 8; e += blockDim.x) {
+    const int i = e & 7, lane = (e >> 3) & 63, n = e >> 9;
+    const int o = 32 * n + (lane & 31), hh = lane >> 5;
+    uint16_t v = 0;
+    if (o < L.out_dim) {
+      const float b = bias[o];
+      const uint16_t bh = f32_to_bf16_rn(b);
+      const float r1 = b - bf16_to_f32(bh);
+      const uint16_t bm = f32_to_bf16_rn(r1);
+      const uint16_t bl = f32_to_bf16_rn(r1 - bf16_to_f32(bm));
+      auto wc = [&](int c) -> float {
+        return L.coord_col < 0 ? 0.f : W[size_t(o) * L.in_dim + L.coord_col + c] * L.in_scale * L.add_scale;
+      };
+      auto whi = [&](int c) { return f32_to_bf16_rn(wc(c)); };
+      auto wlo = [&](int c) { const float w = wc(c); return f32_to_bf16_rn(w - bf16_to_f32(f32_to_bf16_rn(w))); };
+      if (hh == 0) v = i < 3 ? whi(i) : i < 6 ? whi(i - 3) : i == 6 ? bh : bm;
+      else v = i < 3 ? wlo(i) : i == 3 ? bl : i < 7 ? whi(i - 4) : uint16_t(0);
+    }
+    out[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// evaluation
+// ---------------------------------------------------------------------------------------------
+struct LayerDev {
+  int n_tiles, k_steps;
+  uint32_t w_off, c_off;
+};
+
+struct EvalArgs {
+  const char* packed;
+  const char* state;
+  size_t state_row_bytes;
+  float* out;             // [n_rows, n_points, out_dim]
+  int out_dim;
+  int add_input;          // out[..., c] += xyz[..., c] (c < 3): canonical / posed points
+  int n_linear;
+  LayerDev layer[MAX_LINEAR];
+  // MODE 0
+  const float* xyz;       // [n_rows, n_points, 3]
+  int64_t n_points;
+  // MODE 1: x-slab [ix0, ix1) of an 'ij' lattice, points in flattened lattice order
+  const float* ax; const float* ay; const float* az;
+  int rx, ry, rz, ix0, ix1;
+};
+
+// k softplus(d / k) in base 2 (see mlp_layout.h); agrees with nn.Softplus(beta=100, threshold=20)
+// to < 1e-9 in unscaled units
+__device__ __forceinline__ float softplus2(float d) {
+  const float t = __builtin_amdgcn_exp2f(-fabsf(d));
+  return __builtin_amdgcn_fmed3f(d, 0.f, __builtin_inff()) + __builtin_amdgcn_logf(1.f + t);
+}
+
+struct Split8 { bf16x8 hi, lo; };
+
+__device__ __forceinline__ Split8 split8(const float* x) {
+  Split8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hb = (__bf16)x[i];
+    o.hi[i] = hb;
+    o.lo[i] = (__bf16)(x[i] - (float)hb);
+  }
+  return o;
+}
+
+// B operand of the coordinate K-step for one point (see mlp_layout.h)
+__device__ __forceinline__ bf16x8 coord_operand(float x, float y, float z, int h) {
+  const float cs[3] = {x, y, z};
+  __bf16 xh[3], xl[3], xll[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    xh[i] = (__bf16)cs[i];
+    const float r1 = cs[i] - (float)xh[i];
+    xl[i] = (__bf16)r1;
+    xll[i] = (__bf16)(r1 - (float)xl[i]);
+  }
+  const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+  bf16x8 bv;
+  bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
+  bv[3] = h ? one : xl[0];
+  bv[4] = h ? xll[0] : xl[1];
+  bv[5] = h ? xll[1] : xl[2];
+  bv[6] = h ? xll[2] : one;
+  bv[7] = h ? zero : one;
+  return bv;
+}
+
+template <int MT, int NTW, int MODE>
+__global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
+  constexpr int M = 32 * MT;               // points per workgroup
+  constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
+  constexpr int NCH = HMAX / 8;            // 16-byte K chunks per point
+  constexpr int PART_BYTES = NCH * M * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act_hi = smem;
+  char* act_lo = smem + PART_BYTES;
+  float* partial = reinterpret_cast<float*>(smem + 2 * PART_BYTES);   // [WAVES][M][4]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int row = blockIdx.y;
+  const int64_t base = int64_t(blockIdx.x) * M;
+  const int64_t n_pts = MODE == 0 ? p.n_points : int64_t(p.ix1 - p.ix0) * p.ry * p.rz;
+
+  auto point_coords = [&](int64_t i, float& x, float& y, float& z) {
+    const int64_t ic = i < n_pts ? i : n_pts - 1;
+    if (MODE == 0) {
+      const float* q = p.xyz + (int64_t(row) * n_pts + ic) * 3;
+      x = q[0]; y = q[1]; z = q[2];
+    } else {
+      const int64_t plane = int64_t(p.ry) * p.rz;
+      const int ix = p.ix0 + int(ic / plane);
+      const int rem = int(ic % plane);
+      x = p.ax[ix]; y = p.ay[rem / p.rz]; z = p.az[rem % p.rz];
+    }
+  };
+
+  bf16x8 bv[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    float x, y, z;
+    point_coords(base + 32 * t + j, x, y, z);
+    bv[t] = coord_operand(x, y, z, h);
+  }
+
+  const char* st = p.state + size_t(row) * p.state_row_bytes;
+  const f32x16 zero16 = {};
+  f32x16 acc[NTW][MT];
+  Split8 packed_out[NTW][MT][2];
+
+  // epilogue of the wavefront's tiles: softplus, re-split (registers only)
+  auto activate = [&](int ni) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (i < ni) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = softplus2(acc[i][t][r]);
+          packed_out[i][t][0] = split8(v);
+          packed_out[i][t][1] = split8(v + 8);
+        }
+      }
+    }
+  };
+  // D tile (n, t): registers 8*half .. 8*half+7 of lane (h, j) are K chunk 4n + 2*half + h of point 32t + j
+  auto store_tiles = [&](int ni) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (i < ni) {
+        const int n = wave + WAVES * i;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int off = ((4 * n + 2 * half + h) * M + 32 * t + j) * 16;
+            *reinterpret_cast<bf16x8*>(act_hi + off) = packed_out[i][t][half].hi;
+            *reinterpret_cast<bf16x8*>(act_lo + off) = packed_out[i][t][half].lo;
+          }
+        }
+      }
+    }
+  };
+  auto tiles_of = [&](int n_tiles) { return n_tiles > wave ? (n_tiles - wave + WAVES - 1) / WAVES : 0; };
+  // accumulator init: coordinate K-step (bias, folded latent, xyz columns)
+  auto coord_step = [&](const LayerDev& L, int ni) __attribute__((always_inline)) {
+    const bf16x8* C = reinterpret_cast<const bf16x8*>(st + L.c_off) + lane;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (i < ni) {
+        const bf16x8 a = C[(wave + WAVES * i) * 64];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv[t], zero16, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- layer 0: coordinates only ---------------------------------------------------------------
+  {
+    const LayerDev& L = p.layer[0];
+    const int ni = tiles_of(L.n_tiles);
+    coord_step(L, ni);
+    activate(ni);
+    store_tiles(ni);
+  }
+
+  // ---- hidden layers ---------------------------------------------------------------------------
+#pragma unroll 1
+  for (int l = 1; l < p.n_linear - 1; ++l) {
+    const LayerDev& L = p.layer[l];
+    const int ni = tiles_of(L.n_tiles);
+    const int ks = L.k_steps;
+    coord_step(L, ni);
+    __syncthreads();                                  // the previous layer's tile is complete
+    if (ni > 0) {
+      const bf16x8* W = reinterpret_cast<const bf16x8*>(p.packed + L.w_off) + lane;
+      const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
+      const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
+      bf16x8 ah[2][NTW], al[2][NTW], bh[2][MT], bl[2][MT];
+      auto load_a = [&](int slot, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+          if (i < ni) {
+            const size_t o = (size_t(wave + WAVES * i) * ks + s) * 128;
+            ah[slot][i] = W[o];
+            al[slot][i] = W[o + 64];
+          }
+        }
+      };
+      auto load_b = [&](int slot, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          bh[slot][t] = Bh[2 * s * M + 32 * t];
+          bl[slot][t] = Bl[2 * s * M + 32 * t];
+        }
+      };
+      auto mma = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+          if (i < ni) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot][i], bh[slot][t], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot][i], bl[slot][t], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot][i], bh[slot][t], acc[i][t], 0, 0, 0);
+            }
+          }
+        }
+      };
+      load_a(0, 0);
+      load_a(1, 1);
+      load_b(0, 0);
+#pragma unroll 1
+      for (int s = 0; s < ks; s += 2) {
+        load_b(1, s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < ks) { load_a(0, s + 2); load_b(0, s + 2); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < ks) load_a(1, s + 3);
+      }
+    }
+    activate(ni);
+    __syncthreads();                                  // every wavefront has read the old tile
+    store_tiles(ni);
+  }
+
+  // ---- last layer: K split over the wavefronts, one output tile --------------------------------
+  {
+    const LayerDev& L = p.layer[p.n_linear - 1];
+    const int ks = L.k_steps;
+    if (wave == 0) {
+      coord_step(L, 1);
+    } else {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[0][t] = zero16;
+    }
+    __syncthreads();
+    const bf16x8* W = reinterpret_cast<const bf16x8*>(p.packed + L.w_off) + lane;
+    const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
+    const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
+#pragma unroll 1
+    for (int s = wave; s < ks; s += WAVES) {
+      const bf16x8 wh = W[size_t(s) * 128], wl = W[size_t(s) * 128 + 64];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const bf16x8 xh = Bh[2 * s * M + 32 * t], xl = Bl[2 * s * M + 32 * t];
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[0][t], 0, 0, 0);
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[0][t], 0, 0, 0);
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[0][t], 0, 0, 0);
+      }
+    }
+    // rows 0..3 of the tile are registers 0..3 of the lanes with h == 0
+    if (h == 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        float* q = partial + (wave * M + 32 * t + j) * 4;
+        q[0] = acc[0][t][0]; q[1] = acc[0][t][1]; q[2] = acc[0][t][2]; q[3] = acc[0][t][3];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < M * p.out_dim; e += blockDim.x) {
+      const int m = e / p.out_dim, c = e % p.out_dim;
+      const int64_t i = base + m;
+      if (i < n_pts) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
+        if (p.add_input && c < 3) {
+          float x, y, z;
+          point_coords(i, x, y, z);
+          v += c == 0 ? x : (c == 1 ? y : z);
+        }
+        p.out[(int64_t(row) * n_pts + i) * p.out_dim + c] = v;
+      }
+    }
+  }
+}
+
+template <int MT, int NTW>
+constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) * 16 * 2 + WAVES * 32 * MT * 4 * 4; }
+
+}  // namespace mlp
+}  // namespace nphm
+
+// ============================================================================================
+// C ABI (include/nphm_amd.h)
+// ============================================================================================
+using nphm::mlp::Config;
+using nphm::mlp::Plan;
+
+template <int MODE>
+static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st) {
+  using namespace nphm::mlp;
+  for (int l = 0; l < plan.n_linear; ++l) {
+    a.layer[l].n_tiles = plan.layer[l].n_tiles;
+    a.layer[l].k_steps = plan.layer[l].k_steps;
+    a.layer[l].w_off = plan.layer[l].w_off;
+    a.layer[l].c_off = plan.layer[l].c_off;
+  }
+  a.n_linear = plan.n_linear;
+  a.state_row_bytes = plan.state_row_bytes;
+  const int M = plan.variant == 0 ? 64 : 32;
+  const int64_t tiles = (n_pts + M - 1) / M;
+  if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
+  const dim3 grid((unsigned)tiles, n_rows), block(64 * WAVES);
+  hipError_t e;
+  if (plan.variant == 0) {
+    auto k = mlp_eval_kernel<2, 2, MODE>;
+    constexpr size_t lds = lds_bytes<2, 2>();
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
+    hipLaunchKernelGGL(k, grid, block, lds, st, a);
+  } else {
+    auto k = mlp_eval_kernel<1, 4, MODE>;
+    constexpr size_t lds = lds_bytes<1, 4>();
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
+    hipLaunchKernelGGL(k, grid, block, lds, st, a);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_mlp_eval launch", e);
+  return 0;
+}
+
+extern "C" {
+
+static bool plan_of(int lat_dim, int hidden_dim, int nlayers, int out_dim, Plan& plan) {
+  Config c{lat_dim, hidden_dim, nlayers, out_dim};
+  return nphm::mlp::make_plan(c, plan);
+}
+
+int nphm_mlp_supported(int lat_dim, int hidden_dim, int nlayers, int out_dim, int input_dim, float beta,
+                       int num_freq_bands) {
+  Plan plan;
+  return input_dim == 3 && beta == 100.f && num_freq_bands == 0 && plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan);
+}
+
+size_t nphm_mlp_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim) {
+  Plan plan;
+  return plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) ? plan.packed_bytes : 0;
+}
+
+size_t nphm_mlp_latent_state_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows) {
+  Plan plan;
+  return plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) ? plan.state_row_bytes * size_t(n_rows > 0 ? n_rows : 0) : 0;
+}
+
+static int fill_table(nphm::mlp::PtrTable& t, const Plan& plan, const float* const* w, const float* const* b,
+                      const char* who) {
+  if (!w || !b) return nphm_fail_msg(who);
+  for (int l = 0; l < plan.n_linear; ++l) {
+    if (!w[l] || !b[l]) return nphm_fail_msg(who);
+    t.w[l] = w[l];
+    t.b[l] = b[l];
+  }
+  return 0;
+}
+
+int nphm_mlp_pack(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                  const float* const* lin_weight, const float* const* lin_bias, void* packed, void* stream) {
+  nphm::mlp::PackArgs a;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, a.plan)) return nphm_fail_msg("nphm_mlp_pack: unsupported architecture");
+  if (!packed) return nphm_fail_msg("nphm_mlp_pack: null packed buffer");
+  if (fill_table(a.t, a.plan, lin_weight, lin_bias, "nphm_mlp_pack: null weight/bias pointer")) return -2;
+  a.out = static_cast<uint16_t*>(packed);
+  hipLaunchKernelGGL(nphm::mlp::mlp_pack_kernel, dim3(1024, a.plan.n_linear - 1), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_mlp_pack launch", e);
+  return 0;
+}
+
+int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                            const float* const* lin_weight, const float* const* lin_bias,
+                            const float* cond_rows, int n_rows, void* latent_state, void* stream) {
+  nphm::mlp::PrepArgs a;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, a.plan))
+    return nphm_fail_msg("nphm_mlp_prepare_latent: unsupported architecture");
+  if (n_rows <= 0) return nphm_fail_msg("nphm_mlp_prepare_latent: n_rows must be > 0");
+  if ((!cond_rows && lat_dim > 0) || !latent_state) return nphm_fail_msg("nphm_mlp_prepare_latent: null pointer");
+  if (fill_table(a.t, a.plan, lin_weight, lin_bias, "nphm_mlp_prepare_latent: null weight/bias pointer")) return -2;
+  a.cond = cond_rows;
+  a.lat_dim = lat_dim;
+  a.state = static_cast<char*>(latent_state);
+  hipLaunchKernelGGL(nphm::mlp::mlp_prepare_kernel, dim3(a.plan.n_linear, n_rows), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_mlp_prepare_latent launch", e);
+  return 0;
+}
+
+int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                         const void* packed, const void* latent_state,
+                         const float* xyz, int n_rows, int64_t n_points, int add_input,
+                         float* out, void* stream) {
+  Plan plan;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points: unsupported architecture");
+  if (!packed || !latent_state || !xyz || !out) return nphm_fail_msg("nphm_mlp_eval_points: null pointer");
+  if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_mlp_eval_points: empty input");
+  nphm::mlp::EvalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const char*>(packed);
+  a.state = static_cast<const char*>(latent_state);
+  a.out = out;
+  a.out_dim = out_dim;
+  a.add_input = add_input;
+  a.xyz = xyz;
+  a.n_points = n_points;
+  return launch_eval<0>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+}
+
+int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                       const void* packed, const void* latent_state,
+                       const float* axis_x, const float* axis_y, const float* axis_z,
+                       int rx, int ry, int rz, int ix0, int ix1, int add_input,
+                       float* out, void* stream) {
+  Plan plan;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_grid: unsupported architecture");
+  if (!packed || !latent_state || !axis_x || !axis_y || !axis_z || !out) return nphm_fail_msg("nphm_mlp_eval_grid: null pointer");
+  if (rx <= 0 || ry <= 0 || rz <= 0 || ix0 < 0 || ix1 > rx || ix0 >= ix1)
+    return nphm_fail_msg("nphm_mlp_eval_grid: bad grid / slab bounds");
+  nphm::mlp::EvalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const char*>(packed);
+  a.state = static_cast<const char*>(latent_state);
+  a.out = out;
+  a.out_dim = out_dim;
+  a.add_input = add_input;
+  a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
+  a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
+  return launch_eval<1>(plan, a, int64_t(ix1 - ix0) * ry * rz, 1, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

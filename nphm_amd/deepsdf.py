@@ -3,9 +3,16 @@
 contracts and ``state_dict`` layout (``lin{i}.{weight,bias}``, ``compressor.0.*``,
 ``defDeepSDF.lin{i}.*``).
 
-The MLP body is evaluated by ``DeepSDF.evaluate``: the latent columns of the first layer and of
-the skip layer are applied once per latent row (``lat_rep.shape[1] == 1`` or a row-constant
-latent) instead of once per point.
+Execution tiers (same policy as the identity field, ensembled_deepsdf.py):
+
+* **HIP** (``libnphm_amd.so``, gfx950): whenever no autograd graph is needed, the tensors live on a
+  ROCm device, the architecture is covered (``nphm_mlp_supported``: the NPM net and the NPHM
+  deformation backbone are) and the conditioning is constant along the point axis.  One fused
+  kernel runs the whole skip-MLP; if the library is missing this tier raises.
+* **composite**: ``DeepSDF.evaluate`` — a differentiable PyTorch formulation in which the latent
+  columns of the first layer and of the skip layer are applied once per latent row.  Used when
+  gradients are required, for per-point conditioning (training-mode noise, 'interpolate') and for
+  other architectures.  Never chosen silently on a CPU tensor: that needs ``backend = "composite"``.
 """
 from __future__ import annotations
 
@@ -15,6 +22,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .ensembled_deepsdf import sample_point_feature  # noqa: F401  (re-exported like the reference)
 
 _SQRT2 = float(np.sqrt(2))
@@ -33,6 +41,12 @@ class DeepSDF(nn.Module):
         self.lat_dim = lat_dim
         self.input_dim = input_dim
         self.d_spatial = d_spatial
+        self.hidden_dim = hidden_dim
+        self.nlayers = nlayers
+        self.n_out = out_dim
+        self.beta = beta
+        self.backend = "hip"            # "hip" | "composite"
+        self._pack_cache = None         # (key, packed tensor)
         print(d_in)
         print(hidden_dim)
         dims = [d_in] + [hidden_dim] * nlayers + [out_dim]
@@ -81,7 +95,87 @@ class DeepSDF(nn.Module):
                 x = self.activation(x)
         return x
 
+    # ---- HIP tier ----------------------------------------------------------------------------
+    def _arch(self):
+        return (self.lat_dim, self.hidden_dim, self.nlayers, self.n_out)
+
+    def hip_supported(self) -> bool:
+        lib = _lib.load()
+        return bool(lib.nphm_mlp_supported(*self._arch(), self.input_dim, float(self.beta),
+                                           0 if self.num_freq_bands is None else int(self.num_freq_bands)))
+
+    def _lin_params(self):
+        lins = [getattr(self, f"lin{i}") for i in range(self.num_layers - 1)]
+        return [m.weight for m in lins], [m.bias for m in lins]
+
+    def _packed(self, device):
+        """Split-bf16 MFMA-fragment copy of the weights on ``device``; rebuilt when a parameter
+        changed (optimizer step, load_state_dict, .to())."""
+        ws, bs = self._lin_params()
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in ws + bs) + (str(device),)
+        if self._pack_cache is not None and self._pack_cache[0] == key:
+            return self._pack_cache[1]
+        lib = _lib.load()
+        for t in ws + bs:
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.NphmAmdError("DeepSDF parameters must be contiguous fp32 on the query device")
+        packed = torch.empty(lib.nphm_mlp_packed_bytes(*self._arch()), dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.nphm_mlp_pack(*self._arch(), _lib.ptr_array(ws), _lib.ptr_array(bs), packed.data_ptr(),
+                                     stream), "nphm_mlp_pack")
+        self._pack_cache = (key, packed)
+        return packed
+
+    def prepare_latent(self, cond_rows: torch.Tensor):
+        """cond_rows [B, lat_dim] -> (packed weights, per-row state) via the HIP prologue kernel."""
+        lib = _lib.load()
+        device = cond_rows.device
+        packed = self._packed(device)
+        cond_rows = cond_rows.contiguous().float()
+        B = cond_rows.shape[0]
+        state = torch.empty(lib.nphm_mlp_latent_state_bytes(*self._arch(), B), dtype=torch.uint8, device=device)
+        ws, bs = self._lin_params()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.nphm_mlp_prepare_latent(*self._arch(), _lib.ptr_array(ws), _lib.ptr_array(bs),
+                                               cond_rows.data_ptr(), B, state.data_ptr(), stream),
+                   "nphm_mlp_prepare_latent")
+        return packed, state
+
+    def forward_hip(self, xyz, cond_rows, add_input=False):
+        """xyz [B,N,3] fp32 on a ROCm device, cond_rows [B, lat_dim] -> [B,N,out_dim]
+        (+ xyz on the first three outputs if ``add_input``)."""
+        lib = _lib.load()
+        B, N, _ = xyz.shape
+        packed, state = self.prepare_latent(cond_rows)
+        xyz = xyz.contiguous().float()
+        out = torch.empty(B, N, self.n_out, dtype=torch.float32, device=xyz.device)
+        stream = torch.cuda.current_stream(xyz.device).cuda_stream
+        _lib.check(lib.nphm_mlp_eval_points(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(),
+                                            B, N, int(bool(add_input)), out.data_ptr(), stream),
+                   "nphm_mlp_eval_points")
+        return out
+
+    def _tier(self, xyz, cond):
+        """'hip' or 'composite' for this call; raises on a CPU tensor without the explicit opt-in."""
+        if self.backend == "composite":
+            return "composite"
+        if not xyz.is_cuda:
+            raise _lib.NphmAmdError(
+                "DeepSDF: tensors are on the CPU; the HIP path needs a ROCm device "
+                "(set module.backend = 'composite' explicitly for the PyTorch formulation)")
+        needs_graph = torch.is_grad_enabled() and (
+            xyz.requires_grad or cond.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_graph or xyz.dtype != torch.float32 or not self.hip_supported():
+            return "composite"
+        if cond.shape[1] != 1 and (cond.shape[1] != xyz.shape[1] or not bool((cond == cond[:, :1]).all())):
+            return "composite"
+        return "hip"
+
     def forward(self, xyz, lat_rep, anchors=None):
+        if self._tier(xyz if xyz.dim() == 3 else xyz.unsqueeze(0), lat_rep) == "hip":
+            squeeze = xyz.dim() < 3
+            out = self.forward_hip(xyz.unsqueeze(0) if squeeze else xyz, lat_rep[:, 0, :])
+            return (out.squeeze(0) if squeeze else out), None
         return self.evaluate(self._embed(xyz), lat_rep), None
 
 
@@ -169,5 +263,27 @@ class DeformationNetwork(nn.Module):
         if xyz.dim() < 3:
             xyz = xyz.unsqueeze(0)
         cond = self._condition(xyz, lat_rep, anchors)
-        pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
+        if self.defDeepSDF._tier(xyz, cond) == "hip":
+            pred = self.defDeepSDF.forward_hip(xyz, cond[:, 0, :])
+        else:
+            pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
         return pred[..., :3], pred[..., -1:]
+
+    @property
+    def backend(self):
+        return self.defDeepSDF.backend
+
+    @backend.setter
+    def backend(self, value):
+        self.defDeepSDF.backend = value
+
+    def canonical_points(self, xyz, lat_rep, anchors):
+        """x + F_ex(x) in one fused launch (HIP tier) — the canonicalisation step of
+        get_logits_backward / deform_mesh (models/reconstruction.py:44-46, :83-84)."""
+        if xyz.dim() < 3:
+            xyz = xyz.unsqueeze(0)
+        cond = self._condition(xyz, lat_rep, anchors)
+        if self.defDeepSDF._tier(xyz, cond) == "hip" and self.defDeepSDF.n_out >= 3:
+            return self.defDeepSDF.forward_hip(xyz, cond[:, 0, :], add_input=True)[..., :3]
+        pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
+        return xyz[..., :3] + pred[..., :3]

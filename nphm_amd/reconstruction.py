@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .deepsdf import DeepSDF, DeformationNetwork
 from .ensembled_deepsdf import FastEnsembleDeepSDFMirrored
 
 
@@ -124,6 +125,90 @@ def evaluate_grid(decoder: FastEnsembleDeepSDFMirrored, encoding: torch.Tensor, 
     return (out, anchors) if return_anchors else out
 
 
+def _mlp_hip_ready(decoder, device) -> bool:
+    return (isinstance(decoder, DeepSDF) and decoder.backend == "hip" and device.type == "cuda"
+            and decoder.hip_supported())
+
+
+def evaluate_grid_mlp(mlp: DeepSDF, cond_row: torch.Tensor, axes: Sequence, *, x_range=None,
+                      add_input: bool = False, out: Optional[torch.Tensor] = None):
+    """A DeepSDF skip-MLP (NPM SDF / deformation backbone) on the x-slab ``x_range`` of the 'ij'
+    lattice spanned by ``axes``: device tensor [(ix1-ix0)*ry*rz, out_dim] in flattened lattice
+    order, one fused launch.  ``cond_row`` [1, lat_dim] is the conditioning vector;
+    ``add_input`` adds the lattice coordinates to the first three outputs."""
+    lib = _lib.load()
+    device = cond_row.device
+    if not _mlp_hip_ready(mlp, device):
+        raise _lib.NphmAmdError("evaluate_grid_mlp needs a HIP-covered DeepSDF on a ROCm device")
+    ax, ay, az = [torch.as_tensor(a, dtype=torch.float32, device=device).contiguous() for a in axes]
+    rx, ry, rz = ax.numel(), ay.numel(), az.numel()
+    ix0, ix1 = (0, rx) if x_range is None else x_range
+    packed, state = mlp.prepare_latent(_as_lat_row(cond_row.to(device=device, dtype=torch.float32), mlp.lat_dim))
+    n = (ix1 - ix0) * ry * rz
+    if out is None:
+        out = torch.empty(n, mlp.n_out, dtype=torch.float32, device=device)
+    elif out.numel() != n * mlp.n_out or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous fp32 tensor with (ix1-ix0)*ry*rz*out_dim elements")
+    stream = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(lib.nphm_mlp_eval_grid(*mlp._arch(), packed.data_ptr(), state.data_ptr(), ax.data_ptr(),
+                                      ay.data_ptr(), az.data_ptr(), rx, ry, rz, ix0, ix1, int(bool(add_input)),
+                                      out.data_ptr(), stream), "nphm_mlp_eval_grid")
+    return out
+
+
+def _expr_condition(decoder_expr, encoding_expr, anchors, device):
+    """Conditioning row [1, lat_dim] of the expression decoder for a row-constant latent."""
+    enc = encoding_expr.reshape(1, 1, -1).to(device=device, dtype=torch.float32)
+    if isinstance(decoder_expr, DeformationNetwork):
+        dummy = torch.zeros(1, 1, 3, device=device)
+        was_training = decoder_expr.training
+        decoder_expr.eval()                      # no conditioning noise (deepSDF.py:220-221)
+        try:
+            with torch.no_grad():
+                cond = decoder_expr._condition(dummy, enc, anchors)
+        finally:
+            decoder_expr.train(was_training)
+        return decoder_expr.defDeepSDF, cond[:, 0, :]
+    return decoder_expr, enc[:, 0, :]
+
+
+def evaluate_grid_two_stage(decoder_shape: FastEnsembleDeepSDFMirrored, decoder_expr, encoding_shape,
+                            encoding_expr, axes: Sequence, *, anchors=None, hack_chunk: Optional[int] = None,
+                            x_range=None, out: Optional[torch.Tensor] = None, return_canonical: bool = False):
+    """Two-stage lattice evaluation (get_logits_backward, models/reconstruction.py:28-56) entirely on
+    the device: canonical points x + F_ex(x, z_ex) by the fused deformation kernel, then the identity
+    field at those points by the fused ensemble kernel (same brick traversal as evaluate_grid).
+    ``anchors`` [1,39,3] conditions an NPHM 'compress' deformation net (default: the identity
+    net's predicted anchors); ``encoding_expr`` is the expression decoder's full latent
+    ([z_id | z_ex] for DeformationNetwork)."""
+    lib = _lib.load()
+    device = encoding_shape.device
+    if not _hip_ready(decoder_shape, device):
+        raise _lib.NphmAmdError("evaluate_grid_two_stage needs the HIP-backed NPHM identity field on a ROCm device")
+    ax, ay, az = [torch.as_tensor(a, dtype=torch.float32, device=device).contiguous() for a in axes]
+    rx, ry, rz = ax.numel(), ay.numel(), az.numel()
+    ix0, ix1 = (0, rx) if x_range is None else x_range
+    if hack_chunk is None:
+        hack_chunk = 0 if decoder_shape.training else rx * ry * rz
+    lat = _as_lat_row(encoding_shape.to(device=device, dtype=torch.float32), decoder_shape.lat_dim)
+    packed, state, anchors_pred = decoder_shape.prepare_latent(lat)
+    if anchors is None:
+        anchors = anchors_pred
+    mlp, cond = _expr_condition(decoder_expr, encoding_expr, anchors, device)
+    canonical = evaluate_grid_mlp(mlp, cond, (ax, ay, az), x_range=(ix0, ix1), add_input=True)
+    if canonical.shape[1] != 3:
+        canonical = canonical[:, :3].contiguous()
+    n = (ix1 - ix0) * ry * rz
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(lib.nphm_identity_eval_grid_points(
+        packed.data_ptr(), state.data_ptr(), canonical.data_ptr(), rx, ry, rz, ix0, ix1, int(hack_chunk),
+        float(decoder_shape.prune_tol), decoder_shape._precision_code(), out.data_ptr(), None, stream),
+        "nphm_identity_eval_grid_points")
+    return (out, canonical) if return_canonical else out
+
+
 def slab_bounds(rx: int, world_size: int, rank: int):
     """Contiguous x-slab of rank ``rank``: ceil(rx/world) planes each, last ranks may be short."""
     per = (rx + world_size - 1) // world_size
@@ -182,6 +267,17 @@ def get_logits(decoder, encoding, grid_points, nbatch_points=100000, return_anch
         logits = vol.cpu().numpy()
         return (logits, anchors) if return_anchors else logits
 
+    if _mlp_hip_ready(decoder, device) and grid_points.dtype == torch.float32 and grid_points.shape[0] == 1:
+        # NPM global SDF: one fused launch over the whole point set (no eval-mode overwrite in DeepSDF)
+        lat = _as_lat_row(encoding.to(device), decoder.lat_dim)
+        lattice = _detect_lattice(grid_points)
+        if lattice is not None:
+            vol = evaluate_grid_mlp(decoder, lat, lattice)
+        else:
+            vol = decoder.forward_hip(grid_points, lat)
+        logits = vol.reshape(-1).cpu().numpy()
+        return (logits, None) if return_anchors else logits
+
     # generic decoders: the reference's chunk loop (latent broadcast instead of repeat)
     enc = encoding.reshape(1, 1, -1)
     chunks = []
@@ -195,24 +291,57 @@ def get_logits(decoder, encoding, grid_points, nbatch_points=100000, return_anch
 
 
 def get_logits_backward(decoder_shape, decoder_expr, encoding_shape, encoding_expr, grid_points,
-                        nbatch_points=100000, return_anchors=False):
+                        nbatch_points=100000, return_anchors=False, anchors=None):
     """models/reconstruction.py:28-56: canonicalise with the deformation field, then query the
-    identity field (two-stage evaluation)."""
+    identity field (two-stage evaluation).  ``anchors`` (extension, default None = the reference's
+    call) conditions an NPHM 'compress' deformation net, which the reference's own signature cannot
+    serve (it passes None, :44)."""
+    device = grid_points.device
+    expr_hip = encoding_expr is None or _mlp_hip_ready(
+        decoder_expr.defDeepSDF if isinstance(decoder_expr, DeformationNetwork) else decoder_expr, device)
+    expr_needs_anchors = isinstance(decoder_expr, DeformationNetwork) and decoder_expr.mode in (
+        "compress", "interpolate", "GNN")
+    if (_hip_ready(decoder_shape, device) and expr_hip and grid_points.dtype == torch.float32
+            and grid_points.shape[0] == 1 and not (expr_needs_anchors and anchors is None)
+            and not (isinstance(decoder_expr, DeformationNetwork) and decoder_expr.mode == "interpolate")):
+        lib = _lib.load()
+        lat = _as_lat_row(encoding_shape.to(device), decoder_shape.lat_dim)
+        hack = 0 if decoder_shape.training else int(nbatch_points)
+        lattice = _detect_lattice(grid_points)
+        if encoding_expr is None:
+            return get_logits(decoder_shape, encoding_shape, grid_points, nbatch_points, return_anchors)
+        if lattice is not None:
+            vol = evaluate_grid_two_stage(decoder_shape, decoder_expr, lat, encoding_expr, lattice,
+                                          anchors=anchors, hack_chunk=hack)
+            anchors_pred = decoder_shape.prepare_latent(lat)[2] if return_anchors else None
+        else:
+            mlp, cond = _expr_condition(decoder_expr, encoding_expr, anchors, device)
+            canonical = mlp.forward_hip(grid_points, cond, add_input=True)[..., :3].contiguous()
+            packed, state, anchors_pred = decoder_shape.prepare_latent(lat)
+            vol = torch.empty(canonical.shape[1], dtype=torch.float32, device=device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.nphm_identity_eval_points(
+                packed.data_ptr(), state.data_ptr(), canonical.data_ptr(), 1, canonical.shape[1], hack,
+                float(decoder_shape.prune_tol), decoder_shape._precision_code(), vol.data_ptr(), None, stream),
+                "nphm_identity_eval_points")
+        logits = vol.cpu().numpy()
+        return (logits, anchors_pred) if return_anchors else logits
+
     enc_s = encoding_shape.reshape(1, 1, -1)
     chunks = []
-    anchors = None
+    anchors_out = None
     for points in torch.split(grid_points, nbatch_points, dim=1):
         with torch.no_grad():
             if encoding_expr is not None:
                 enc_e = encoding_expr.reshape(1, 1, -1)
-                offsets, _ = decoder_expr(points, enc_e.expand(1, points.shape[1], -1), None)
+                offsets, _ = decoder_expr(points, enc_e.expand(1, points.shape[1], -1), anchors)
                 points_can = points + offsets
             else:
                 points_can = points
-            logits, anchors = decoder_shape(points_can, enc_s.expand(1, points.shape[1], -1), None)
+            logits, anchors_out = decoder_shape(points_can, enc_s.expand(1, points.shape[1], -1), None)
             chunks.append(logits.reshape(-1).detach().cpu())
     logits = torch.cat(chunks, dim=0).numpy()
-    return (logits, anchors) if return_anchors else logits
+    return (logits, anchors_out) if return_anchors else logits
 
 
 def deform_mesh(mesh, deformer, lat_rep, anchors, lat_rep_shape=None):
@@ -220,12 +349,15 @@ def deform_mesh(mesh, deformer, lat_rep, anchors, lat_rep_shape=None):
     verts = torch.from_numpy(np.asarray(mesh.vertices)).float().unsqueeze(0).to(lat_rep.device)
     cond = lat_rep if lat_rep_shape is None else torch.cat([lat_rep_shape, lat_rep], dim=-1)
     with torch.no_grad():
-        parts = []
-        for pts in torch.split(verts, 1 << 16, dim=1):
-            d, _ = deformer(pts, cond, anchors)
-            parts.append(d)
-        delta = torch.cat(parts, dim=1)
-    posed = (verts[:, :, :3] + delta).squeeze(0).cpu().numpy()
+        if isinstance(deformer, DeformationNetwork):
+            # one fused launch for all vertices (HIP tier; composite otherwise)
+            posed = deformer.canonical_points(verts, cond, anchors).squeeze(0).cpu().numpy()
+        else:
+            parts = []
+            for pts in torch.split(verts, 1 << 16, dim=1):
+                d, _ = deformer(pts, cond, anchors)
+                parts.append(d)
+            posed = (verts[:, :, :3] + torch.cat(parts, dim=1)).squeeze(0).cpu().numpy()
     try:
         import trimesh
         return trimesh.Trimesh(posed, mesh.faces, process=False)

@@ -1,0 +1,235 @@
+"""GPU parity tests of the fused dense skip-MLP kernel (libnphm_amd.so: nphm_mlp_*), i.e. the
+reference's DeepSDF / DeformationNetwork (src/NPHM/models/deepSDF.py) and the two-stage drivers
+get_logits_backward / deform_mesh (src/NPHM/models/reconstruction.py:28-88), against
+  * the golden fixtures produced by the reference's own PyTorch modules (tests/golden/make_golden.py),
+  * the numpy oracle (oracle/nphm_oracle.py) on seeded inputs.
+Tolerance: the north star's 1e-4 absolute (TOL_BAR); the split-bf16 path is expected ~1e-6."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import _util as U
+import nphm_amd
+from nphm_amd import reconstruction as R
+from oracle import nphm_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL_BAR = 1e-4
+TOL_TIGHT = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def dnet(dev):
+    return U.build_deformation(device=dev).eval()
+
+
+@pytest.fixture(scope="module")
+def npm(dev):
+    return U.build_npm(device=dev).eval()
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _spy(module, name):
+    called = {}
+    orig = getattr(module, name)
+
+    def wrapper(*a, **k):
+        called["n"] = called.get("n", 0) + 1
+        return orig(*a, **k)
+    setattr(module, name, wrapper)
+    return called, lambda: setattr(module, name, orig)
+
+
+def test_hip_tier_is_what_runs(dnet, npm, dev):
+    g = U.golden("deformation")
+    assert dnet.defDeepSDF.hip_supported() and npm.hip_supported()
+    called, restore = _spy(dnet.defDeepSDF, "forward_hip")
+    try:
+        with torch.no_grad():
+            dnet(_t(g["xyz"], dev), _t(g["lat"], dev), _t(g["anchors"], dev))
+    finally:
+        restore()
+    assert called.get("n") == 1
+    # training mode adds per-point conditioning noise (deepSDF.py:220-221) -> composite tier
+    dnet.train()
+    called, restore = _spy(dnet.defDeepSDF, "forward_hip")
+    try:
+        with torch.no_grad():
+            dnet(_t(g["xyz"], dev), _t(g["lat"], dev), _t(g["anchors"], dev))
+    finally:
+        restore()
+        dnet.eval()
+    assert not called
+
+
+def test_deformation_golden(dnet, dev):
+    g = U.golden("deformation")
+    xyz, lat, anc = _t(g["xyz"], dev), _t(g["lat"], dev), _t(g["anchors"], dev)
+    with torch.no_grad():
+        off, rest = dnet(xyz, lat, anc)
+        assert off.shape == (1, xyz.shape[1], 3) and rest.shape == (1, xyz.shape[1], 1)
+        e = U.maxdiff(off.cpu().numpy(), g["offsets"])
+        print(f"deformation max abs err vs reference: {e:.3e}")
+        assert e < TOL_TIGHT and U.maxdiff(rest.cpu().numpy(), g["rest"]) < TOL_TIGHT
+        # get_logits-style repeated latent / per-point anchors (row 0 is what counts)
+        n = xyz.shape[1]
+        off2, _ = dnet(xyz, lat.repeat(1, n, 1), anc.unsqueeze(1).repeat(1, n, 1, 1))
+        assert torch.equal(off, off2)
+        # canonical points = x + offsets, fused
+        can = dnet.canonical_points(xyz, lat, anc)
+        assert U.maxdiff(can.cpu().numpy(), g["xyz"] + g["offsets"]) < TOL_TIGHT
+
+
+def test_npm_golden(npm, dev):
+    g = U.golden("npm")
+    with torch.no_grad():
+        sdf, none = npm(_t(g["xyz"], dev), _t(g["lat"][None, None], dev))
+    e = U.maxdiff(sdf.cpu().numpy(), g["sdf"])
+    print(f"NPM max abs err vs reference: {e:.3e}")
+    assert none is None and sdf.shape == (1, g["xyz"].shape[1], 1) and e < 2e-5
+    res = int(g["grid_res"])
+    grid = torch.from_numpy(R.create_grid_points_from_bounds(U.MINI, U.MAXI, res)).to(dev, dtype=torch.float)[None]
+    called, restore = _spy(R, "evaluate_grid_mlp")
+    try:
+        vol = R.get_logits(npm, _t(g["lat"], dev), grid, nbatch_points=200)
+    finally:
+        restore()
+    assert called.get("n") == 1 and vol.dtype == np.float32
+    assert U.maxdiff(vol, g["grid_logits"]) < 2e-5
+
+
+@pytest.mark.parametrize("n", [1, 31, 64, 65, 1000])
+def test_ragged_sizes_and_batch_rows_vs_oracle(dnet, dev, n):
+    rng = np.random.default_rng(n)
+    B = 3
+    xyz = rng.uniform(-0.6, 0.6, size=(B, n, 3)).astype(np.float32)
+    lat = (0.3 * rng.standard_normal((B, 1, 1544))).astype(np.float32)
+    anc = (U.anchors_mean()[None] + 0.01 * rng.standard_normal((B, 39, 3))).astype(np.float32)
+    ref, _ = O.deformation_forward(U.np_state(dnet), xyz, lat, anc)
+    with torch.no_grad():
+        off, _ = dnet(_t(xyz, dev), _t(lat, dev), _t(anc, dev))
+    assert U.maxdiff(off.cpu().numpy(), ref) < TOL_TIGHT
+    # 2-D xyz is accepted (reference: no batch axis handling in DeepSDF, DeformationNetwork unsqueezes)
+    with torch.no_grad():
+        off1, _ = dnet(_t(xyz[0], dev), _t(lat[:1], dev), _t(anc[:1], dev))
+    assert U.maxdiff(off1.cpu().numpy(), ref[:1]) < TOL_TIGHT
+
+
+def test_grid_kernel_equals_points_kernel_bitwise(dnet, npm, dev):
+    axes = R.grid_axes(U.MINI, U.MAXI, (5, 7, 11))
+    pts = torch.from_numpy(np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(1, -1, 3)).to(dev)
+    g = U.golden("deformation")
+    mlp, cond = R._expr_condition(dnet, _t(g["lat"], dev), _t(g["anchors"], dev), dev)
+    a = R.evaluate_grid_mlp(mlp, cond, axes)
+    b = mlp.forward_hip(pts, cond)
+    assert torch.equal(a, b[0])
+    # x-slabs are slices of the full volume (multi-GPU sharding invariant)
+    s0 = R.evaluate_grid_mlp(mlp, cond, axes, x_range=(0, 2), add_input=True)
+    s1 = R.evaluate_grid_mlp(mlp, cond, axes, x_range=(2, 5), add_input=True)
+    full = R.evaluate_grid_mlp(mlp, cond, axes, add_input=True)
+    assert torch.equal(torch.cat([s0, s1]), full)
+    assert U.maxdiff((full - a).cpu().numpy(), pts[0].cpu().numpy()) < 1e-6
+    gn = U.golden("npm")
+    v = R.evaluate_grid_mlp(npm, _t(gn["lat"][None], dev), axes)
+    w = npm.forward_hip(pts, _t(gn["lat"][None], dev))
+    assert torch.equal(v, w[0])
+
+
+def test_two_stage_golden_and_oracle(dnet, dev):
+    g = U.golden("deformation")
+    inet = U.build_identity(device=dev).eval()
+    inet.prune_tol = -1.0
+    res, chunk = int(g["grid_res"]), int(g["grid_chunk"])
+    grid = torch.from_numpy(R.create_grid_points_from_bounds(U.MINI, U.MAXI, res)).to(dev, dtype=torch.float)[None]
+    lat_id = _t(g["lat"].reshape(-1)[:1344], dev)
+    lat_ex = _t(g["lat"].reshape(-1), dev)
+    anc = _t(g["anchors"], dev)
+    called, restore = _spy(R, "evaluate_grid_two_stage")
+    try:
+        vol = R.get_logits_backward(inet, dnet, lat_id, lat_ex, grid, nbatch_points=chunk, anchors=anc)
+    finally:
+        restore()
+    assert called.get("n") == 1
+    e = U.maxdiff(vol, g["two_stage_logits"])
+    print(f"two-stage (deformation -> identity) max abs err vs reference: {e:.3e}")
+    assert e < TOL_BAR
+    # non-lattice point set: points kernels, same chunk rule
+    perm = torch.randperm(res ** 3, generator=torch.Generator().manual_seed(5)).to(dev)
+    vol_p = R.get_logits_backward(inet, dnet, lat_id, lat_ex, grid[:, perm], nbatch_points=chunk, anchors=anc)
+    hacked = O.hack_indices(res ** 3, chunk)
+    keep = np.ones(res ** 3, bool); keep[hacked] = False
+    inv = np.empty(res ** 3, np.int64); inv[perm.cpu().numpy()] = np.arange(res ** 3)
+    keep_both = keep & keep[inv]
+    assert U.maxdiff(vol_p[inv][keep_both], g["two_stage_logits"][keep_both]) < TOL_BAR
+    # default anchors = the identity net's predicted anchors (config 3 of BASELINE.json)
+    vol_d, can = R.evaluate_grid_two_stage(inet, dnet, lat_id, lat_ex, R.grid_axes(U.MINI, U.MAXI, 12),
+                                           hack_chunk=0, return_canonical=True)
+    params, amean = U.np_state(inet), U.anchors_mean()
+    pts = O.create_grid_points_from_bounds(U.MINI, U.MAXI, 12).astype(np.float32)[None]
+    _, anc_pred = O.nphm_identity_forward(params, amean, pts[:, :1], g["lat"][:, :, :1344], training=True)
+    off, _ = O.deformation_forward(U.np_state(dnet), pts, g["lat"], anc_pred)
+    assert U.maxdiff(can.cpu().numpy(), pts[0] + off[0]) < TOL_TIGHT
+    ref, _ = O.nphm_identity_forward(params, amean, (pts + off).astype(np.float32), g["lat"][:, :, :1344], training=True)
+    assert U.maxdiff(vol_d.cpu().numpy(), ref.reshape(-1)) < TOL_BAR
+
+
+def test_deform_mesh_matches_oracle(dnet, dev):
+    g = U.golden("deformation")
+    rng = np.random.default_rng(2)
+    verts = rng.uniform(-0.4, 0.4, size=(7001, 3))
+    mesh = SimpleNamespace(vertices=verts, faces=np.zeros((1, 3), np.int64))
+    lat_id = _t(g["lat"][..., :1344], dev)
+    lat_ex = _t(g["lat"][..., 1344:], dev)
+    out = R.deform_mesh(mesh, dnet, lat_ex, _t(g["anchors"], dev), lat_rep_shape=lat_id)
+    off, _ = O.deformation_forward(U.np_state(dnet), verts.astype(np.float32)[None], g["lat"], g["anchors"])
+    assert U.maxdiff(np.asarray(out.vertices), verts.astype(np.float32) + off[0]) < TOL_TIGHT
+
+
+def test_weight_update_invalidates_pack_and_composite_agrees(dev):
+    d = U.build_deformation(device=dev).eval()
+    g = U.golden("deformation")
+    xyz, lat, anc = _t(g["xyz"][:, :200], dev), _t(g["lat"], dev), _t(g["anchors"], dev)
+    with torch.no_grad():
+        a, _ = d(xyz, lat, anc)
+        d.defDeepSDF.lin4.weight.mul_(1.5)
+        d.defDeepSDF.lin0.bias.add_(0.01)
+        b, _ = d(xyz, lat, anc)
+        assert not torch.equal(a, b)
+        d.backend = "composite"
+        c, _ = d(xyz, lat, anc)
+    assert U.maxdiff(b.cpu().numpy(), c.cpu().numpy()) < TOL_TIGHT
+
+
+def test_stress_weights_relative(dev):
+    """Sharper networks (weights x2): activations leave the softplus knee, outputs grow; compare
+    relatively against the fp32 oracle."""
+    d = U.build_deformation(device=dev).eval()
+    n = U.build_npm(device=dev).eval()
+    rng = np.random.default_rng(9)
+    xyz = rng.uniform(-0.6, 0.6, size=(1, 777, 3)).astype(np.float32)
+    g, gn = U.golden("deformation"), U.golden("npm")
+    with torch.no_grad():
+        for m in (d.defDeepSDF, n):
+            for i in range(m.num_layers - 1):
+                getattr(m, f"lin{i}").weight.mul_(2.0)
+        off, _ = d(_t(xyz, dev), _t(g["lat"], dev), _t(g["anchors"], dev))
+        sdf, _ = n(_t(xyz, dev), _t(gn["lat"][None, None], dev))
+    ref, _ = O.deformation_forward(U.np_state(d), xyz, g["lat"], g["anchors"])
+    rel = np.max(np.abs(off.cpu().numpy() - ref) / (1.0 + np.abs(ref)))
+    lat = np.repeat(gn["lat"][None, None], xyz.shape[1], axis=1)
+    refn = O.deepsdf_forward(U.np_state(n), "", xyz, lat, nlayers=8)
+    reln = np.max(np.abs(sdf.cpu().numpy() - refn) / (1.0 + np.abs(refn)))
+    print(f"stress x2: deformation max rel err {rel:.3e} (|ref| up to {np.abs(ref).max():.2f}), "
+          f"NPM {reln:.3e} (|ref| up to {np.abs(refn).max():.2f})")
+    assert rel < TOL_BAR and reln < TOL_BAR

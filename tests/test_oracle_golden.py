@@ -200,6 +200,10 @@ def test_composite_autograd_first_and_second_order():
 def test_composite_deformation_and_npm():
     g = U.golden("deformation")
     dnet = U.build_deformation().eval()
+    with pytest.raises(RuntimeError):                # CPU tensors: no silent non-HIP path
+        with torch.no_grad():
+            dnet(torch.from_numpy(g["xyz"]), torch.from_numpy(g["lat"]), torch.from_numpy(g["anchors"]))
+    dnet.backend = "composite"
     with torch.no_grad():
         off, rest = dnet(torch.from_numpy(g["xyz"]), torch.from_numpy(g["lat"]), torch.from_numpy(g["anchors"]))
         assert U.maxdiff(off.numpy(), g["offsets"]) < TOL and U.maxdiff(rest.numpy(), g["rest"]) < TOL
@@ -209,6 +213,7 @@ def test_composite_deformation_and_npm():
         assert U.maxdiff(off2.numpy(), g["offsets"]) < TOL
     gn = U.golden("npm")
     npm = U.build_npm()
+    npm.backend = "composite"
     with torch.no_grad():
         sdf, none = npm(torch.from_numpy(gn["xyz"]), torch.from_numpy(gn["lat"][None, None]))
         assert none is None and U.maxdiff(sdf.numpy(), gn["sdf"]) < 5e-6
