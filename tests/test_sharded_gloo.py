@@ -1,0 +1,70 @@
+"""Multi-process (gloo, world_size 2, CPU) tests of the x-slab sharding + all-gather reassembly used
+for multi-GPU lattice extraction.  The per-slab evaluator is injected (a CPU
+stand-in with the same contract as evaluate_grid: slab-local values in flattened lattice order), so
+what is tested is the partition, the padding of short slabs and the gather order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _util as U  # noqa: F401  (sys.path)
+from nphm_amd import reconstruction as R
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, shape, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rx, ry, rz = shape
+        axes = [np.arange(n, dtype=np.float32) for n in shape]
+        plane = ry * rz
+
+        def evaluate(xr):
+            i0, i1 = xr
+            # value = global flat index, as the kernel's slab-local output would hold for f(i) = i
+            return torch.arange(i0 * plane, i1 * plane, dtype=torch.float32)
+
+        full = R.evaluate_grid_sharded(None, torch.zeros(1), axes, evaluate=evaluate)
+        ok = torch.equal(full, torch.arange(rx * plane, dtype=torch.float32))
+        i0, i1 = R.slab_bounds(rx, world, rank)
+        q.put((rank, bool(ok), (i0, i1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", [(8, 3, 5), (5, 4, 3), (1, 2, 2)])
+def test_all_gather_reassembles_the_volume(shape):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    bounds = dict((r, b) for r, _, b in res)
+    assert bounds[0][0] == 0 and bounds[0][1] == bounds[1][0] and bounds[1][1] == shape[0]
+
+
+def test_slab_bounds_cover_without_overlap():
+    for rx in (1, 5, 8, 256, 257, 512):
+        for world in (1, 2, 4, 8):
+            spans = [R.slab_bounds(rx, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == rx
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0] and a[0] <= a[1]
