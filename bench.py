@@ -139,6 +139,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- mesh-extract wall-clock (second half of the BASELINE metric): latent -> SDF volume (all
+    # ranks) -> host -> marching cubes -> vertices/faces, measured once outside the timed region
+    mesh = None
+    barrier()
+    t_m0 = time.perf_counter()
+    step(False)
+    barrier()
+    t_m1 = time.perf_counter()
+    if rank == 0:
+        vol_dev = shard if world == 1 else full[: n_total]
+        vol_host = vol_dev.cpu().numpy()
+        t_m2 = time.perf_counter()
+        m = R.mesh_from_logits(vol_host, U.MINI, U.MAXI, args.res)
+        t_m3 = time.perf_counter()
+        mesh = {"wall_ms": (t_m3 - t_m0) * 1e3, "volume_ms": (t_m1 - t_m0) * 1e3, "d2h_ms": (t_m2 - t_m1) * 1e3,
+                "marching_cubes_ms": (t_m3 - t_m2) * 1e3, "n_vertices": int(len(m.vertices)),
+                "n_faces": int(len(m.faces)), "host_threads": os.cpu_count(),
+                "note": "native marching cubes (nphm_mc_extract) on the host cores; PyMCubes of the reference is absent"}
+
     if rank == 0:
         n_local = (i1 - i0) * plane
         k_ms = float(np.mean(kernel_ms))
@@ -169,6 +188,7 @@ def main():
                          "mean_active_members": mean_active,
                          "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12},
         }
+        out["mesh_extract"] = mesh
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(net, lat, axes, args.cpu_sample)
         else:

@@ -144,6 +144,18 @@ int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                        int rx, int ry, int rz, int ix0, int ix1, int add_input,
                        float* out, void* stream);
 
+/* ---- host side: iso-surface extraction for mesh_from_logits ------------------------------- */
+/* Marching cubes on a HOST fp32 volume [nx,ny,nz] ('ij' order) — the step the reference delegates to
+ * the third-party PyMCubes: mcubes.marching_cubes(-logits, 0.0) (src/NPHM/utils/reconstruction.py:25-30).
+ * negate != 0 extracts on -volume (the reference negates the SDF so that inside is positive);
+ * vertices come in index space (x,y,z) = (i,j,k) as float64, shared between triangles, normals
+ * pointing from field > iso to field < iso; n_threads <= 0 uses every host core; the output does
+ * not depend on the thread count.  Two-step: extract (sizes), fetch (copy out), free. */
+int nphm_mc_extract(const float* volume, int nx, int ny, int nz, double iso, int negate, int n_threads,
+                    void** handle, int64_t* n_verts, int64_t* n_faces);
+int nphm_mc_fetch(void* handle, double* verts, int64_t* faces);
+void nphm_mc_free(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,9 +4,9 @@ from .ensembled_deepsdf import (EnsembledDeepSDF, EnsembledLinear, FastEnsembleD
                                 sample_point_feature)
 from .deepsdf import DeepSDF, DeformationNetwork
 from .reconstruction import (create_grid_points_from_bounds, deform_mesh, get_logits,
-                             get_logits_backward, grid_axes)
+                             get_logits_backward, grid_axes, marching_cubes, mesh_from_logits)
 from ._lib import NphmAmdError
 
 __all__ = ["EnsembledDeepSDF", "EnsembledLinear", "FastEnsembleDeepSDFMirrored", "sample_point_feature",
            "DeepSDF", "DeformationNetwork", "create_grid_points_from_bounds", "deform_mesh", "get_logits",
-           "get_logits_backward", "grid_axes", "NphmAmdError"]
+           "get_logits_backward", "grid_axes", "marching_cubes", "mesh_from_logits", "NphmAmdError"]

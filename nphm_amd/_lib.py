@@ -43,6 +43,10 @@ SYMBOLS = {
                                                     c_void_p, c_void_p]),
     "nphm_mlp_eval_grid": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nphm_mc_extract": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_int, c_int,
+                                ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
+    "nphm_mc_fetch": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "nphm_mc_free": (None, [c_void_p]),
 }
 
 _lib = None

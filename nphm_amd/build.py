@@ -8,7 +8,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip"]
+SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip", "marching_cubes.cpp"]
 OUT = os.path.join(HERE, "libnphm_amd.so")
 
 
@@ -24,7 +24,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread",
            "-I", os.path.join(HERE, "..", "include")]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
     if verbose:

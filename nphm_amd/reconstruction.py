@@ -83,6 +83,48 @@ def _detect_lattice(points: torch.Tensor):
     return (ax, ay, az) if bool(ok) else None
 
 
+def marching_cubes(volume: np.ndarray, isovalue: float = 0.0, *, negate: bool = False, n_threads: int = 0):
+    """Iso-surface of a host fp32 volume [nx,ny,nz] -> (vertices float64 [nv,3] in index space,
+    triangles int64 [nf,3]); same contract as the third-party ``mcubes.marching_cubes`` the
+    reference calls (utils/reconstruction.py:30).  Native, slab-parallel over the host cores."""
+    import ctypes
+    lib = _lib.load()
+    vol = np.ascontiguousarray(volume, dtype=np.float32)
+    if vol.ndim != 3:
+        raise ValueError("marching_cubes expects a 3-D volume")
+    handle, nv, nf = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+    rc = lib.nphm_mc_extract(vol.ctypes.data, vol.shape[0], vol.shape[1], vol.shape[2], float(isovalue),
+                             int(bool(negate)), int(n_threads), ctypes.byref(handle), ctypes.byref(nv),
+                             ctypes.byref(nf))
+    if rc != 0:
+        raise _lib.NphmAmdError(f"nphm_mc_extract failed ({rc})")
+    try:
+        verts = np.empty((nv.value, 3), np.float64)
+        faces = np.empty((nf.value, 3), np.int64)
+        lib.nphm_mc_fetch(handle, verts.ctypes.data, faces.ctypes.data)
+    finally:
+        lib.nphm_mc_free(handle)
+    return verts, faces
+
+
+def mesh_from_logits(logits, mini, maxi, resolution, n_threads: int = 0):
+    """utils/reconstruction.py:22-37: SDF volume -> mesh in world coordinates.  Like the reference
+    it negates ``logits`` IN PLACE (``logits *= -1`` on a reshape view) and extracts the zero level
+    set; returns a ``trimesh.Trimesh`` when trimesh is installed, else a namespace with
+    ``vertices`` / ``faces``."""
+    logits = np.reshape(logits, (resolution,) * 3)
+    logits *= -1
+    vertices, triangles = marching_cubes(logits, 0.0, n_threads=n_threads)
+    step = (np.array(maxi) - np.array(mini)) / (resolution - 1)
+    vertices = vertices * np.expand_dims(step, axis=0)
+    vertices += [mini[0], mini[1], mini[2]]
+    try:
+        import trimesh
+        return trimesh.Trimesh(vertices, triangles)
+    except ImportError:
+        return SimpleNamespace(vertices=vertices, faces=triangles)
+
+
 # ----------------------------------------------------------------------------------------------
 # fused grid evaluation (NPHM identity field)
 # ----------------------------------------------------------------------------------------------
