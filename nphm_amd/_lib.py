@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnphm_amd.so")
+LIB_PATH = os.environ.get("NPHM_AMD_LIB") or os.path.join(_HERE, "libnphm_amd.so")   # override: dev builds
 
 NPHM_PREC_F32 = 0
 NPHM_PREC_BF16X3 = 1

@@ -155,10 +155,16 @@ class DeepSDF(nn.Module):
                    "nphm_mlp_eval_points")
         return out
 
-    def _tier(self, xyz, cond):
-        """'hip' or 'composite' for this call; raises on a CPU tensor without the explicit opt-in."""
+    def _hip_rows(self, xyz, cond):
+        """How the HIP tier can serve this call: returns (xyz_view [R,n,3], cond_rows [R,lat_dim]) or
+        None (-> composite tier).  Raises on a CPU tensor without the explicit opt-in.
+
+        Besides a row-constant conditioning ([B,1,L] or a ``repeat`` along the points) it recognises
+        the flattened batch the reference's root finder passes (iterative_root_finding.py:137-139):
+        xyz [1, S*n, 3] with a conditioning that is constant on S equal segments, which is re-viewed
+        as S batch rows."""
         if self.backend == "composite":
-            return "composite"
+            return None
         if not xyz.is_cuda:
             raise _lib.NphmAmdError(
                 "DeepSDF: tensors are on the CPU; the HIP path needs a ROCm device "
@@ -166,15 +172,32 @@ class DeepSDF(nn.Module):
         needs_graph = torch.is_grad_enabled() and (
             xyz.requires_grad or cond.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_graph or xyz.dtype != torch.float32 or not self.hip_supported():
-            return "composite"
-        if cond.shape[1] != 1 and (cond.shape[1] != xyz.shape[1] or not bool((cond == cond[:, :1]).all())):
-            return "composite"
-        return "hip"
+            return None
+        B, N = xyz.shape[0], xyz.shape[1]
+        if cond.shape[1] == 1:
+            return xyz, cond[:, 0, :]
+        if cond.shape[1] != N:
+            return None
+        change = (cond[:, 1:] != cond[:, :-1]).any(dim=-1)                 # [B, N-1]
+        if B > 1:
+            return (xyz, cond[:, 0, :]) if not bool(change.any()) else None
+        edges = change[0].nonzero().flatten()                             # one host sync
+        if edges.numel() == 0:
+            return xyz, cond[:, 0, :]
+        seg = int(edges[0]) + 1
+        if N % seg or edges.numel() != N // seg - 1:
+            return None
+        expect = torch.arange(seg - 1, N - 1, seg, device=edges.device)
+        if not torch.equal(edges, expect):
+            return None
+        return xyz.reshape(N // seg, seg, 3), cond[0, ::seg, :]
 
     def forward(self, xyz, lat_rep, anchors=None):
-        if self._tier(xyz if xyz.dim() == 3 else xyz.unsqueeze(0), lat_rep) == "hip":
-            squeeze = xyz.dim() < 3
-            out = self.forward_hip(xyz.unsqueeze(0) if squeeze else xyz, lat_rep[:, 0, :])
+        squeeze = xyz.dim() < 3
+        x3 = xyz.unsqueeze(0) if squeeze else xyz
+        plan = self._hip_rows(x3, lat_rep)
+        if plan is not None:
+            out = self.forward_hip(*plan).reshape(x3.shape[0], x3.shape[1], self.n_out)
             return (out.squeeze(0) if squeeze else out), None
         return self.evaluate(self._embed(xyz), lat_rep), None
 
@@ -263,8 +286,9 @@ class DeformationNetwork(nn.Module):
         if xyz.dim() < 3:
             xyz = xyz.unsqueeze(0)
         cond = self._condition(xyz, lat_rep, anchors)
-        if self.defDeepSDF._tier(xyz, cond) == "hip":
-            pred = self.defDeepSDF.forward_hip(xyz, cond[:, 0, :])
+        plan = self.defDeepSDF._hip_rows(xyz, cond)
+        if plan is not None:
+            pred = self.defDeepSDF.forward_hip(*plan).reshape(xyz.shape[0], xyz.shape[1], -1)
         else:
             pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
         return pred[..., :3], pred[..., -1:]
@@ -283,7 +307,9 @@ class DeformationNetwork(nn.Module):
         if xyz.dim() < 3:
             xyz = xyz.unsqueeze(0)
         cond = self._condition(xyz, lat_rep, anchors)
-        if self.defDeepSDF._tier(xyz, cond) == "hip" and self.defDeepSDF.n_out >= 3:
-            return self.defDeepSDF.forward_hip(xyz, cond[:, 0, :], add_input=True)[..., :3]
+        plan = self.defDeepSDF._hip_rows(xyz, cond) if self.defDeepSDF.n_out >= 3 else None
+        if plan is not None:
+            out = self.defDeepSDF.forward_hip(*plan, add_input=True)
+            return out.reshape(xyz.shape[0], xyz.shape[1], -1)[..., :3]
         pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
         return xyz[..., :3] + pred[..., :3]

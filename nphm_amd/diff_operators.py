@@ -1,0 +1,32 @@
+"""Autograd operators the fitting loop applies to the fields — host-side mirror of
+src/NPHM/models/diff_operators.py (``jac`` :26-54, ``gradient`` :69-79).  They are callers of the
+hot path: the fields' differentiable (composite) tier serves them."""
+from __future__ import annotations
+
+import torch
+
+
+def jac(decoder_expr, xc, cond, anchors):
+    """Jacobian of the posed position x_d = x_c + F_ex(x_c) w.r.t. the canonical point
+    (diff_operators.py:26-54): xc [B,N,3] -> [B,N,3,3] with [..., i, :] = d x_d[i] / d x_c.
+    Like the reference it switches ``requires_grad`` on for ``xc`` in place and issues one
+    vector-Jacobian product per output coordinate (graph kept, not extended)."""
+    xc.requires_grad_(True)
+    offsets, _ = decoder_expr(xc, cond, anchors)
+    xd = xc + offsets
+    rows = []
+    for i in range(xd.shape[-1]):
+        seed = torch.zeros_like(xd)
+        seed[..., i] = 1
+        rows.append(torch.autograd.grad(outputs=xd, inputs=xc, grad_outputs=seed, create_graph=False,
+                                        retain_graph=True, only_inputs=True)[0])
+    return torch.stack(rows, dim=-2)
+
+
+def gradient(outputs, inputs):
+    """d outputs / d inputs[..., -3:] with an all-ones cotangent, graph retained and extended
+    (diff_operators.py:69-79) — the SDF normal direction used by the losses."""
+    ones = torch.ones_like(outputs)
+    g = torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=ones, create_graph=True,
+                            retain_graph=True, only_inputs=True, allow_unused=True)[0]
+    return g[:, :, -3:]

@@ -1,0 +1,194 @@
+"""Latent-code fitting loops — host-side mirror of src/NPHM/models/fitting.py
+(``inference_iterative_root_finding_joint`` :14-177, ``inference_identity_space`` :180-288):
+Adam on the identity code (and one expression code per observation) so that the observed points lie
+on the zero level set of the posed SDF.  The loops are CALLERS of the hot path:
+per step they run one anchor forward, a Broyden correspondence search through the deformation field
+(no-grad forwards -> fused HIP kernel), two Jacobians of the deformation field and one
+forward/backward of the identity field (autograd -> composite tier).
+
+Same signatures, RNG consumption order, schedules and loss terms as the reference; additions are
+keyword-only (``verbose``, ``history``)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+from torch import optim
+
+from .iterative_root_finding import jac, nabla, search
+
+_UNOBSERVED = (30, 31, 39)          # local codes that the single-view scans never see (fitting.py:148)
+
+
+def _apply_schedule(j, step_scale, schedule_cfg, lambdas, optimizers, with_expr):
+    """Hand-tuned learning-rate / loss-weight schedule (fitting.py:40-52, :197-206)."""
+    key = int(j / step_scale)
+    if key in schedule_cfg["lr"]:
+        for o in optimizers:
+            for group in o.param_groups:
+                group["lr"] /= schedule_cfg["lr"][key]
+    if key in schedule_cfg["symm_dist"]:
+        lambdas["symm_dist"] /= schedule_cfg["symm_dist"][key]
+    if key in schedule_cfg["reg_glob"]:
+        lambdas["reg_global"] /= schedule_cfg["reg_glob"][key]
+    if key in schedule_cfg["reg_loc"]:
+        lambdas["reg_loc"] /= schedule_cfg["reg_loc"][key]
+    if with_expr and key in schedule_cfg["reg_expr"]:
+        lambdas["reg_expr"] /= schedule_cfg["reg_expr"][key]
+
+
+def _sample_observations(all_obs, n_batch, n_points):
+    """n_batch observations with replacement, <= n_points points each with replacement
+    (fitting.py:61-70); two torch.randint streams in the reference's order."""
+    obs_idx = torch.randint(0, len(all_obs), [n_batch])
+    picked = []
+    for i in range(n_batch):
+        cloud = all_obs[obs_idx[i]]
+        n = min(n_points, cloud.shape[0])
+        sub = torch.randint(0, cloud.shape[0], [n])
+        picked.append(cloud.clone()[sub, :])
+    return obs_idx, torch.stack(picked, dim=0)
+
+
+def _clamped_surface_loss(sdf, j, step_scale):
+    """mean |sdf| over the points below a shrinking threshold (fitting.py:119-132)."""
+    l = sdf.abs()
+    l = l[l < 0.1]
+    if j > int(250 * step_scale):
+        l = l[l < 0.05]
+    if j > int(500 * step_scale):
+        l = l[l < 0.0075]
+    return l.mean()
+
+
+def _shape_regularisers(decoder, lat_rep_shape, loss_dict):
+    """Identity-code regularisers (fitting.py:139-166)."""
+    if hasattr(decoder, "lat_dim_glob"):
+        loss_dict["reg_loc"] = (torch.norm(lat_rep_shape[..., 64:], dim=-1) ** 2).mean()
+        loss_dict["reg_global"] = (torch.norm(lat_rep_shape[..., :64], dim=-1) ** 2).mean()
+        loss_dict["reg_unobserved"] = 0
+        for idx in _UNOBSERVED:
+            loss_dict["reg_unobserved"] += torch.norm(
+                lat_rep_shape[..., 64 + idx * 32:64 + (idx + 1) * 32], dim=-1).square().mean()
+        g, s, d = decoder.lat_dim_glob, decoder.num_symm_pairs, decoder.lat_dim_loc
+        pairs = lat_rep_shape[:, :, g:g + 2 * s * d].view(lat_rep_shape.shape[0], 2 * s, d)
+        loss_dict["symm_dist"] = torch.norm(pairs[:, ::2, :] - pairs[:, 1::2, :], dim=-1).mean()
+    else:
+        loss_dict["symm_dist"] = 0
+        loss_dict["reg_unobserved"] = 0
+        loss_dict["reg_loc"] = 0
+        loss_dict["reg_global"] = (torch.norm(lat_rep_shape, dim=-1) ** 2).mean()
+
+
+def _report(j, lambdas, loss_dict, extra=None):
+    line = "Epoch: {:5d}".format(j)
+    for k in lambdas.keys():
+        line += " " + k + " {:02.8f} ".format(float(torch.as_tensor(loss_dict[k]).detach()))
+    print(line) if extra is None else print(line, extra)
+
+
+def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[torch.Tensor], lambdas, n_steps,
+                                           schedule_cfg: Dict, step_scale=1, lr_scale=1, *, verbose: bool = True,
+                                           history: Optional[list] = None):
+    """Joint fit of one identity code and one expression code per observation (fitting.py:14-177).
+    Returns (lat_rep [n_obs,1,lat_dim_expr], lat_rep_shape [1,1,lat_dim], anchors)."""
+    device = all_obs[0].device
+    n_obs = len(all_obs)
+    n_batch, n_points = 5, 1000
+    lat_dim_expr = decoder_expr.lat_dim_expr if hasattr(decoder_expr, "lat_dim_expr") else 200
+    lat_rep = torch.zeros([n_obs, 1, lat_dim_expr], device=device).float()
+    lat_rep.requires_grad = True
+    lat_rep_shape = torch.zeros([1, 1, decoder.lat_dim], device=device)
+    lat_rep_shape.requires_grad = True
+    opt = optim.Adam(params=[lat_rep_shape], lr=0.01 * lr_scale)
+    opt_expr = optim.Adam(params=[lat_rep], lr=0.01 * lr_scale)
+    local = hasattr(decoder, "lat_dim_loc")
+    anchors = None
+
+    for j in range(int(n_steps * step_scale)):
+        _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt, opt_expr), True)
+        opt.zero_grad()
+        opt_expr.zero_grad()
+
+        # anchors of the current identity code (N = 1 forward; only mlp_pos matters)
+        _, anchors = decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)
+
+        obs_idx, obs = _sample_observations(all_obs, n_batch, n_points)
+        obs_idx = obs_idx.long().to(device)
+        glob_cond = torch.cat([lat_rep_shape.repeat(n_batch, 1, 1), lat_rep[obs_idx, :, :]], dim=-1)
+
+        # canonical correspondences by Broyden root finding (no gradient flows through it)
+        anchors_rep = anchors.clone().unsqueeze(1).repeat(n_batch, obs.shape[1], 1, 1) if local else None
+        p_corresp, search_result = search(obs, glob_cond.repeat(1, obs.shape[1], 1), decoder_expr, anchors_rep,
+                                          multi_corresp=False)
+        p_corresp = p_corresp.detach()
+        _anchors = None
+        if anchors is not None:
+            _anchors = anchors.clone().unsqueeze(1).repeat(n_batch, p_corresp.shape[1], 1, 1)
+
+        # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
+        cond_rep = glob_cond.repeat(1, p_corresp.shape[1], 1)
+        preds_posed, _ = decoder_expr(p_corresp, cond_rep, _anchors)
+        preds_posed = preds_posed + p_corresp
+        grad_inv = jac(decoder_expr, p_corresp, cond_rep, _anchors).inverse()
+        correction = preds_posed - preds_posed.detach()
+        correction = torch.einsum("bnij,bnj->bni", -grad_inv.detach(), correction)
+        xc = p_corresp + correction
+
+        shape_cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
+        sdf, _ = decoder(xc, shape_cond, None)
+        _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)        # computed, unused (as in the reference)
+
+        sdf = sdf[search_result["valid_ids"], :]
+        loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale),
+                     "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
+        _shape_regularisers(decoder, lat_rep_shape, loss_dict)
+
+        loss = 0
+        for k in lambdas.keys():
+            loss = loss + loss_dict[k] * lambdas[k]
+        loss.backward()
+        opt.step()
+        opt_expr.step()
+        if history is not None:
+            history.append({k: float(torch.as_tensor(loss_dict[k]).detach()) for k in lambdas.keys()} |
+                           {"loss": float(loss.detach()), "n_valid": int(search_result["valid_ids"].sum())})
+        if verbose:
+            _report(j, lambdas, loss_dict, search_result["valid_ids"].sum().item())
+
+    return lat_rep, lat_rep_shape, anchors
+
+
+def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_steps, schedule_cfg: Dict,
+                             step_scale=1, lr_scale=1, *, verbose: bool = False, history: Optional[list] = None):
+    """Identity-only fit on neutral observations (fitting.py:180-288): no deformation field, the
+    observed points are canonical points.  Returns (lat_rep_shape, anchors)."""
+    device = all_obs[0].device
+    n_batch, n_points = 5, 1000
+    lat_rep_shape = torch.zeros([1, 1, decoder.lat_dim], device=device)
+    lat_rep_shape.requires_grad = True
+    opt = optim.Adam(params=[lat_rep_shape], lr=0.01 * lr_scale)
+    local = hasattr(decoder, "lat_dim_loc")
+    anchors = None
+
+    for j in range(int(n_steps * step_scale)):
+        _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt,), False)
+        opt.zero_grad()
+        _, anchors = decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)
+        _, obs = _sample_observations(all_obs, n_batch, n_points)
+        cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
+        sdf, _ = decoder(obs, cond, None)
+        loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale)}
+        _shape_regularisers(decoder, lat_rep_shape, loss_dict)
+        loss = 0
+        for k in lambdas.keys():
+            loss = loss + loss_dict[k] * lambdas[k]
+        loss.backward()
+        opt.step()
+        if history is not None:
+            history.append({k: float(torch.as_tensor(loss_dict[k]).detach()) for k in lambdas.keys()} |
+                           {"loss": float(loss.detach())})
+        if verbose:
+            _report(j, lambdas, loss_dict)
+
+    return lat_rep_shape, anchors

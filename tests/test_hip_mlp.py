@@ -233,3 +233,34 @@ def test_stress_weights_relative(dev):
     print(f"stress x2: deformation max rel err {rel:.3e} (|ref| up to {np.abs(ref).max():.2f}), "
           f"NPM {reln:.3e} (|ref| up to {np.abs(refn).max():.2f})")
     assert rel < TOL_BAR and reln < TOL_BAR
+
+
+def test_flattened_batch_with_segmented_conditioning(dnet, dev):
+    """The reference's root finder flattens a batch of observations into ONE row of points whose
+    conditioning is constant on equal segments (iterative_root_finding.py:137-139); the HIP tier
+    re-views it as batch rows."""
+    rng = np.random.default_rng(4)
+    S, n = 5, 333
+    xyz = rng.uniform(-0.5, 0.5, size=(S, n, 3)).astype(np.float32)
+    lat = (0.3 * rng.standard_normal((S, 1, 1544))).astype(np.float32)
+    lat[:, :, :1344] = lat[:1, :, :1344]                      # shared identity code, per-row expression
+    anc = np.repeat(U.anchors_mean()[None], S, 0).astype(np.float32)
+    called, restore = _spy(dnet.defDeepSDF, "forward_hip")
+    try:
+        with torch.no_grad():
+            a, _ = dnet(_t(xyz, dev), _t(lat, dev), _t(anc, dev))
+            flat_lat = _t(np.repeat(lat, n, 1).reshape(1, S * n, 1544), dev)
+            flat_anc = _t(np.repeat(anc[:, None], n, 1).reshape(1, S * n, 39, 3), dev)
+            b, _ = dnet(_t(xyz.reshape(1, S * n, 3), dev), flat_lat, flat_anc)
+            # irregular segments are not re-viewed: composite tier, same values
+            irregular = flat_lat.clone()
+            irregular[0, 7] = irregular[0, -1]
+            c, _ = dnet(_t(xyz.reshape(1, S * n, 3), dev), irregular, flat_anc)
+    finally:
+        restore()
+    assert called.get("n") == 2
+    assert torch.equal(a.reshape(1, S * n, 3), b)
+    ref, _ = O.deformation_forward(U.np_state(dnet), xyz, lat, anc)
+    assert U.maxdiff(b.cpu().numpy().reshape(S, n, 3), ref) < TOL_TIGHT
+    keep = np.ones(S * n, bool); keep[7] = False
+    assert U.maxdiff(c.cpu().numpy()[0, keep], ref.reshape(-1, 3)[keep]) < TOL_TIGHT

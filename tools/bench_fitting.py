@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Latent-code fitting (BASELINE.json configs[4]): steps/s of inference_iterative_root_finding_joint on
+one GPU with synthetic single-view observations (points near the zero level set of a seeded
+ground-truth latent; the NPHM dataset is not available).  Development tool."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _util as U  # noqa: E402
+from nphm_amd import fitting as F  # noqa: E402
+from nphm_amd import reconstruction as R  # noqa: E402
+
+LAMBDAS = {"surface": 2.0, "reg_expr": 0.01, "reg_global": 0.25, "reg_unobserved": 10, "reg_loc": 0.05,
+           "symm_dist": 5.0}
+SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 500: 9999}, "reg_glob": {200: 3, 600: 10},
+            "reg_loc": {500: 3, 600: 10}, "reg_expr": {600: 10}}
+
+
+def synthetic_observations(shape_net, dev, n_obs=3, n_pts=2500, res=96):
+    """Marching-cubes vertices of the ground-truth identity's zero level set, a random subset per
+    observation (the deformation is what the fit has to explain away: here the neutral pose)."""
+    lat = U.sample_latent(5).to(dev)
+    shape_net.eval()
+    axes = R.grid_axes(U.MINI, U.MAXI, res)
+    vol = R.evaluate_grid(shape_net, lat, axes, hack_chunk=0).cpu().numpy()
+    mesh = R.mesh_from_logits(vol, U.MINI, U.MAXI, res)
+    v = torch.from_numpy(np.asarray(mesh.vertices)).float()
+    g = torch.Generator().manual_seed(0)
+    return [v[torch.randperm(v.shape[0], generator=g)[:n_pts]].to(dev) for _ in range(n_obs)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--backend", default=None, choices=[None, "composite"])
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    shape_net = U.build_identity(device=dev)
+    expr_net = U.build_deformation(device=dev).eval()
+    obs = synthetic_observations(shape_net, dev)
+    shape_net.train()
+    if args.backend:
+        shape_net.backend = args.backend
+        expr_net.backend = args.backend
+    torch.manual_seed(0)
+    cfg = {k: dict(v) for k, v in SCHEDULE.items()}
+    F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), args.warmup, cfg, verbose=False)
+    torch.cuda.synchronize()
+    hist = []
+    t0 = time.perf_counter()
+    F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), args.steps, cfg, verbose=False,
+                                             history=hist)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"workload": "latent fitting, 3 observations x 2500 pts, 5x1000 pts/step", "steps": args.steps,
+                      "steps_per_s": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                      "backend": args.backend or "hip+composite", "first_loss": hist[0]["loss"],
+                      "last_loss": hist[-1]["loss"], "n_valid_last": hist[-1]["n_valid"]}))
+
+
+if __name__ == "__main__":
+    main()
