@@ -92,30 +92,34 @@ def main():
     axes_dev = [torch.from_numpy(a).to(dev) for a in axes]
     rx = ry = rz = args.res
     n_total = rx * ry * rz
-    i0, i1 = R.slab_bounds(rx, world, rank)
     plane = ry * rz
-    per = (rx + world - 1) // world
+    # N > 1: every rank takes the x-planes of every N-th 8-plane brick slab (work-balanced)
+    planes = R.cyclic_planes(rx, world, rank)
+    planes_dev = torch.from_numpy(planes).to(dev)
+    n_planes = len(planes)
 
     lib = _lib.load()
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
-    shard = torch.zeros(per * plane, dtype=torch.float32, device=dev)
-    full = torch.empty(world * per * plane, dtype=torch.float32, device=dev) if world > 1 else None
+    shard = torch.zeros(max(n_planes, 1) * plane, dtype=torch.float32, device=dev)
     ev_k0, ev_k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     kernel_ms = []
+    box = {"full": None}
 
     def step(timed):
         packed, state, _ = net.prepare_latent(lat[None])
         stream = torch.cuda.current_stream(dev).cuda_stream
         if timed:
             ev_k0.record()
-        _lib.check(lib.nphm_identity_eval_grid(
-            packed.data_ptr(), state.data_ptr(), axes_dev[0].data_ptr(), axes_dev[1].data_ptr(),
-            axes_dev[2].data_ptr(), rx, ry, rz, i0, i1, args.chunk, float(net.prune_tol),
-            net._precision_code(), shard.data_ptr(), stats.data_ptr() if timed else None, stream), "eval_grid")
+        if n_planes:
+            _lib.check(lib.nphm_identity_eval_grid_planes(
+                packed.data_ptr(), state.data_ptr(), axes_dev[0].data_ptr(), axes_dev[1].data_ptr(),
+                axes_dev[2].data_ptr(), rx, ry, rz, planes_dev.data_ptr(), n_planes, args.chunk,
+                float(net.prune_tol), net._precision_code(), shard.data_ptr(),
+                stats.data_ptr() if timed else None, stream), "eval_grid_planes")
         if timed:
             ev_k1.record()
         if world > 1:
-            dist.all_gather_into_tensor(full, shard)
+            box["full"] = R.gather_planes(shard[: n_planes * plane], rx, plane)
         return ev_k0, ev_k1
 
     def barrier():
@@ -148,7 +152,7 @@ def main():
     barrier()
     t_m1 = time.perf_counter()
     if rank == 0:
-        vol_dev = shard if world == 1 else full[: n_total]
+        vol_dev = shard if world == 1 else box["full"]
         vol_host = vol_dev.cpu().numpy()
         t_m2 = time.perf_counter()
         m = R.mesh_from_logits(vol_host, U.MINI, U.MAXI, args.res)
@@ -159,7 +163,7 @@ def main():
                 "note": "native marching cubes (nphm_mc_extract) on the host cores; PyMCubes of the reference is absent"}
 
     if rank == 0:
-        n_local = (i1 - i0) * plane
+        n_local = n_planes * plane
         k_ms = float(np.mean(kernel_ms))
         active = stats.cpu().numpy()
         mean_active = float(active[0]) / max(1, args.steps) / n_local     # evaluated member-points / point
@@ -178,10 +182,10 @@ def main():
             "config": {"workload": f"NPHM 39-anchor identity net, {args.res}^3 lattice extraction "
                                    f"(BASELINE.json configs[1]), eval-mode get_logits chunk {args.chunk}",
                        "res": args.res, "prune_tol": net.prune_tol, "precision": net.precision,
-                       "parallelism": f"x-slab x{world}" + (" + all_gather" if world > 1 else "")},
+                       "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather" if world > 1 else "single GPU")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
-                         "kernel": "nphm::eval_kernel<1,%d>" % net._precision_code(),
+                         "kernel": "nphm::eval_kernel<1,%d>" % net._precision_code(), "rank0_planes": n_planes,
                          "kernel_ms": k_ms, "points_per_launch": n_local,
                          "executed_flops_per_point": passes * mean_active * FLOP_MEMBER_FOLDED,
                          "mfma_passes": passes,

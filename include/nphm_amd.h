@@ -94,6 +94,16 @@ int nphm_identity_eval_grid(const void* packed, const void* latent_state,
                             int64_t hack_chunk, float prune_tol, int precision,
                             float* sdf_out, unsigned long long* stats, void* stream);
 
+/* The same for an arbitrary ascending set of x-planes (device array x_planes[n_planes]): the
+ * multi-GPU partition hands every rank the planes of every world_size-th 8-plane brick slab, which
+ * balances the (spatially varying) ensemble work.  sdf_out [n_planes*ry*rz] in list order; the chunk
+ * overwrite uses GLOBAL flat indices, so the union of all ranks' outputs is the single-GPU volume. */
+int nphm_identity_eval_grid_planes(const void* packed, const void* latent_state,
+                                   const float* axis_x, const float* axis_y, const float* axis_z,
+                                   int rx, int ry, int rz, const int* x_planes, int n_planes,
+                                   int64_t hack_chunk, float prune_tol, int precision,
+                                   float* sdf_out, unsigned long long* stats, void* stream);
+
 /* Second stage of the two-stage evaluation get_logits_backward (src/NPHM/models/reconstruction.py:28-56):
  * the identity field at displaced lattice points.  xyz_slab [(ix1-ix0)*ry*rz, 3] holds the canonical
  * points x + F_ex(x) of the slab in flattened lattice order (nphm_mlp_eval_grid with add_input);

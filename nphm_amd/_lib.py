@@ -32,6 +32,9 @@ SYMBOLS = {
                                           c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_eval_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_int, c_int, c_int, c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_eval_grid_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                               c_int, c_void_p, c_int, c_int64, c_float, c_int, c_void_p, c_void_p,
+                                               c_void_p]),
     "nphm_identity_eval_grid_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_mlp_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_int]),

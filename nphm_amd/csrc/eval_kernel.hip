@@ -42,6 +42,7 @@ struct EvalArgs {
   // MODE 1 (grid)
   const float* ax; const float* ay; const float* az;
   int rx, ry, rz, ix0, ix1;
+  const int* xplanes;       // optional: local x index -> global x plane (non-contiguous plane sets)
   int nbx, nby, nbz;        // bricks per axis
   int nsx, nsy, nsz;        // super-bricks (2x4x4 bricks) per axis
   int64_t hack_chunk;
@@ -385,13 +386,16 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     const int bz = sz * SBZ + inner % SBZ;
     const int wx = NW == 8 ? (wave & 1) : 0, wy = NW == 8 ? ((wave >> 1) & 1) : 0;
     const int wz = NW == 8 ? (wave >> 2) : wave;
-    const int ix = p.ix0 + bx * BRX + wx * 4 + (j >> 3);
+    // local x index (position inside the slab / the plane list) and the global plane it denotes
+    const int lx = bx * BRX + wx * 4 + (j >> 3);
     const int iy = by * BRY + wy * 4 + ((j >> 1) & 3);
     const int iz = bz * BRZ + wz * 2 + (j & 1);
-    valid = ix < p.ix1 && iy < p.ry && iz < p.rz;
-    const int cx_ = min(ix, p.ix1 - 1), cy_ = min(iy, p.ry - 1), cz_ = min(iz, p.rz - 1);
+    const int nlx = p.ix1 - p.ix0;
+    valid = lx < nlx && iy < p.ry && iz < p.rz;
+    const int clx = min(lx, nlx - 1), cy_ = min(iy, p.ry - 1), cz_ = min(iz, p.rz - 1);
+    const int cx_ = p.xplanes ? p.xplanes[clx] : p.ix0 + clx;
     const int64_t gi = (int64_t(cx_) * p.ry + cy_) * p.rz + cz_;
-    out_idx = gi - int64_t(p.ix0) * p.ry * p.rz;
+    out_idx = (int64_t(clx) * p.ry + cy_) * p.rz + cz_;
     if (p.xyz) {
       // lattice-ORDERED but displaced queries (canonical points x + F_ex(x) of the two-stage
       // evaluation): same brick traversal, coordinates from the slab-local point array
@@ -729,6 +733,24 @@ int nphm_identity_eval_grid(const void* packed, const void* latent_state,
   a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
   a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
   return launch_grid(a, precision, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid");
+}
+
+int nphm_identity_eval_grid_planes(const void* packed, const void* latent_state,
+                                   const float* axis_x, const float* axis_y, const float* axis_z,
+                                   int rx, int ry, int rz, const int* x_planes, int n_planes,
+                                   int64_t hack_chunk, float prune_tol, int precision,
+                                   float* sdf_out, unsigned long long* stats, void* stream) {
+  if (!packed || !latent_state || !axis_x || !axis_y || !axis_z || !sdf_out || !x_planes)
+    return nphm_fail_msg("nphm_identity_eval_grid_planes: null pointer");
+  if (rx <= 0 || ry <= 0 || rz <= 0 || n_planes <= 0 || n_planes > rx)
+    return nphm_fail_msg("nphm_identity_eval_grid_planes: bad grid / plane count");
+  if (check_prec(precision)) return -2;
+  nphm::EvalArgs a;
+  fill_common(a, packed, latent_state, sdf_out, stats, prune_tol, hack_chunk);
+  a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
+  a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = 0; a.ix1 = n_planes;
+  a.xplanes = x_planes;
+  return launch_grid(a, precision, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid_planes");
 }
 
 int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,

@@ -185,7 +185,7 @@ class DeepSDF(nn.Module):
         if edges.numel() == 0:
             return xyz, cond[:, 0, :]
         seg = int(edges[0]) + 1
-        if N % seg or edges.numel() != N // seg - 1:
+        if seg < 64 or N % seg or edges.numel() != N // seg - 1:      # per-point conditioning: composite
             return None
         expect = torch.arange(seg - 1, N - 1, seg, device=edges.device)
         if not torch.equal(edges, expect):

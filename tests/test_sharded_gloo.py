@@ -1,4 +1,4 @@
-"""Multi-process (gloo, world_size 2, CPU) tests of the x-slab sharding + all-gather reassembly used
+"""Multi-process (gloo, world_size 2, CPU) tests of the cyclic x-plane sharding + all-gather reassembly used
 for multi-GPU lattice extraction.  The per-slab evaluator is injected (a CPU
 stand-in with the same contract as evaluate_grid: slab-local values in flattened lattice order), so
 what is tested is the partition, the padding of short slabs and the gather order."""
@@ -30,20 +30,21 @@ def _worker(rank, world, port, shape, q):
         axes = [np.arange(n, dtype=np.float32) for n in shape]
         plane = ry * rz
 
-        def evaluate(xr):
-            i0, i1 = xr
-            # value = global flat index, as the kernel's slab-local output would hold for f(i) = i
-            return torch.arange(i0 * plane, i1 * plane, dtype=torch.float32)
+        def evaluate(planes):
+            # value = global flat index, as the kernel's plane-list output would hold for f(i) = i
+            p = torch.from_numpy(planes.astype(np.int64))
+            return (p[:, None] * plane + torch.arange(plane)[None, :]).reshape(-1).float()
 
-        full = R.evaluate_grid_sharded(None, torch.zeros(1), axes, evaluate=evaluate)
-        ok = torch.equal(full, torch.arange(rx * plane, dtype=torch.float32))
-        i0, i1 = R.slab_bounds(rx, world, rank)
-        q.put((rank, bool(ok), (i0, i1)))
+        ok = True
+        for unit in (8, 2):
+            full = R.evaluate_grid_sharded(None, torch.zeros(1), axes, evaluate=evaluate, unit=unit)
+            ok = ok and torch.equal(full, torch.arange(rx * plane, dtype=torch.float32))
+        q.put((rank, bool(ok), R.cyclic_planes(rx, world, rank, 2).tolist()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape", [(8, 3, 5), (5, 4, 3), (1, 2, 2)])
+@pytest.mark.parametrize("shape", [(40, 3, 5), (21, 4, 3), (5, 4, 3), (1, 2, 2)])
 def test_all_gather_reassembles_the_volume(shape):
     world = 2
     port = _free_port()
@@ -57,14 +58,19 @@ def test_all_gather_reassembles_the_volume(shape):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
-    bounds = dict((r, b) for r, _, b in res)
-    assert bounds[0][0] == 0 and bounds[0][1] == bounds[1][0] and bounds[1][1] == shape[0]
+    planes = dict((r, b) for r, _, b in res)
+    assert sorted(planes[0] + planes[1]) == list(range(shape[0]))
 
 
-def test_slab_bounds_cover_without_overlap():
+def test_partitions_cover_without_overlap():
     for rx in (1, 5, 8, 256, 257, 512):
         for world in (1, 2, 4, 8):
             spans = [R.slab_bounds(rx, world, r) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == rx
             for a, b in zip(spans, spans[1:]):
                 assert a[1] == b[0] and a[0] <= a[1]
+            sets = [R.cyclic_planes(rx, world, r) for r in range(world)]
+            assert sorted(np.concatenate(sets).tolist()) == list(range(rx))
+            assert all(np.all(np.diff(s) > 0) for s in sets if len(s) > 1)
+            if rx % (8 * world) == 0:
+                assert len({len(s) for s in sets}) == 1

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backend", default=None, choices=[None, "composite"])
+    ap.add_argument("--profile", action="store_true", help="synchronising per-phase timers (slower)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     shape_net = U.build_identity(device=dev)
@@ -51,6 +52,29 @@ def main():
     if args.backend:
         shape_net.backend = args.backend
         expr_net.backend = args.backend
+    phases = {}
+    if args.profile:
+        import nphm_amd.fitting as FM
+        import nphm_amd.iterative_root_finding as IRF
+
+        def timed(name, fn):
+            def wrapper(*a, **k):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                out = fn(*a, **k)
+                torch.cuda.synchronize()
+                phases[name] = phases.get(name, 0.0) + time.perf_counter() - t
+                return out
+            return wrapper
+        FM.search = timed("search(total)", FM.search)
+        IRF.jac = timed("search.jac+inverse-input", IRF.jac)
+        IRF.broyden = timed("search.broyden", IRF.broyden)
+        FM.jac = timed("jac(implicit diff)", FM.jac)
+        FM.nabla = timed("nabla(unused result)", FM.nabla)
+        shape_net.forward = timed("identity forward (composite, all calls)", shape_net.forward)
+        expr_net.forward = timed("deformation forward (all calls)", expr_net.forward)
+        orig_backward = torch.Tensor.backward
+        torch.Tensor.backward = timed("loss.backward", orig_backward)
     torch.manual_seed(0)
     cfg = {k: dict(v) for k, v in SCHEDULE.items()}
     F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), args.warmup, cfg, verbose=False)
@@ -61,6 +85,9 @@ def main():
                                              history=hist)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.profile:
+        for k, v in sorted(phases.items(), key=lambda kv: -kv[1]):
+            print(f"  {k:45s} {v / (args.steps + args.warmup) * 1e3:8.2f} ms/step")
     print(json.dumps({"workload": "latent fitting, 3 observations x 2500 pts, 5x1000 pts/step", "steps": args.steps,
                       "steps_per_s": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                       "backend": args.backend or "hip+composite", "first_loss": hist[0]["loss"],
