@@ -44,6 +44,17 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel, n_points):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    (profiles/traffic.json; the counters cannot be read live from inside the process), scaled to this
+    launch's point count.  None if no profile covers the kernel."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
+        return t["traffic_bytes"] * n_points / t["points_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(net, lat, axes, n_sample):
     """The oracle (numpy port of the reference arithmetic) on the host cores, on the first
     n_sample lattice points of the same workload."""
@@ -55,10 +66,17 @@ def cpu_baseline(net, lat, axes, n_sample):
     idx = np.linspace(0, g.shape[0] - 1, n_sample).astype(np.int64)
     pts = g[idx][None].astype(np.float32)
     latn = lat.cpu().numpy()[None, None]
+    threads = 1
+    try:                                         # numpy's BLAS pool is what the oracle's GEMMs run on
+        from threadpoolctl import threadpool_info
+        threads = max([1] + [int(i.get("num_threads", 1)) for i in threadpool_info()])
+    except Exception:
+        pass
     t0 = time.perf_counter()
     O.nphm_identity_forward(params, amean, pts, latn, training=False)
     dt = time.perf_counter() - t0
-    return {"value": n_sample / dt / 1e6, "unit": "Mpoints/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": n_sample / dt / 1e6, "unit": "Mpoints/s", "cores": threads, "host_cores": os.cpu_count(),
+            "kind": "port",
             "sample": f"{n_sample} lattice points (uniform stride over the {len(axes[0])}^3 volume), "
                       f"oracle/nphm_oracle.py numpy fp32, dense 40-member evaluation, {dt:.1f} s"}
 
@@ -184,7 +202,9 @@ def main():
                        "res": args.res, "prune_tol": net.prune_tol, "precision": net.precision,
                        "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather" if world > 1 else "single GPU")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak,
+                         "traffic": measured_traffic("nphm::eval_kernel<1,%d>" % net._precision_code(), n_local),
+                         "algorithmic_bytes": 4 * n_local,
                          "kernel": "nphm::eval_kernel<1,%d>" % net._precision_code(), "rank0_planes": n_planes,
                          "kernel_ms": k_ms, "points_per_launch": n_local,
                          "executed_flops_per_point": passes * mean_active * FLOP_MEMBER_FOLDED,
