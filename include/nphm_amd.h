@@ -146,6 +146,17 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                          const float* xyz, int n_rows, int64_t n_points, int add_input,
                          float* out, void* stream);
 
+/* Value AND spatial Jacobian in one launch (forward-mode, tangents carried through the same GEMMs):
+ * out[b,n,0,:] = f(x), out[b,n,1+c,i] = d f_i / d x_c.  With add_input the identity is added too:
+ * out[:,:,0,:] = x + F(x), out[:,:,1+c,:] = d (x + F) / d x_c — the analytic form of
+ * jac(decoder_expr, xc, ...) (src/NPHM/models/diff_operators.py:26-54: 1 forward + 3 autograd VJPs),
+ * used twice per fitting step (iterative_root_finding.py:123, fitting.py:101).
+ * out [n_rows, n_points, 4, out_dim]. */
+int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                             const void* packed, const void* latent_state,
+                             const float* xyz, int n_rows, int64_t n_points, int add_input,
+                             float* out, void* stream);
+
 /* The same on the x-slab [ix0, ix1) of an [rx,ry,rz] 'ij' lattice (utils/reconstruction.py:5-20):
  * out [(ix1-ix0)*ry*rz, out_dim] in flattened lattice order. */
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,

@@ -194,9 +194,33 @@ __device__ __forceinline__ bf16x8 coord_operand(float x, float y, float z, int h
   return bv;
 }
 
-template <int MT, int NTW, int MODE>
+// d softplus / d d in the scaled domain: 1 / (1 + 2^-d)
+__device__ __forceinline__ float sigmoid2(float d) {
+  const float t = __builtin_amdgcn_exp2f(-fabsf(d));
+  return (d >= 0.f ? 1.f : t) * __builtin_amdgcn_rcpf(1.f + t);
+}
+
+// B operand of the coordinate K-step for the tangent stream d/dx_c: the unit vector e_c in the xh
+// slots (exact in bf16), zeros in the xl / xll / bias slots
+__device__ __forceinline__ bf16x8 unit_operand(int c) {
+  const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+  bf16x8 bv;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bv[i] = zero;
+  bv[0] = c == 0 ? one : zero;
+  bv[1] = c == 1 ? one : zero;
+  bv[2] = c == 2 ? one : zero;
+  return bv;
+}
+
+// JVP = forward-mode derivative w.r.t. xyz carried along: the M columns of a workgroup are 4 streams
+// (value, d/dx, d/dy, d/dz) of M/4 points; the tangent streams go through the SAME GEMMs (their
+// coordinate K-step sees the unit vectors, no bias) and their epilogue multiplies by the value
+// stream's sigmoid instead of applying softplus.  Output [n, 4, out_dim].
+template <int MT, int NTW, int MODE, bool JVP>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
-  constexpr int M = 32 * MT;               // points per workgroup
+  constexpr int M = 32 * MT;               // columns per workgroup
+  constexpr int PTS = JVP ? M / 4 : M;     // points per workgroup
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
   constexpr int NCH = HMAX / 8;            // 16-byte K chunks per point
   constexpr int PART_BYTES = NCH * M * 16;
@@ -209,7 +233,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, j = lane & 31;
   const int row = blockIdx.y;
-  const int64_t base = int64_t(blockIdx.x) * M;
+  const int64_t base = int64_t(blockIdx.x) * PTS;
   const int64_t n_pts = MODE == 0 ? p.n_points : int64_t(p.ix1 - p.ix0) * p.ry * p.rz;
 
   auto point_coords = [&](int64_t i, float& x, float& y, float& z) {
@@ -228,10 +252,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   bf16x8 bv[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
+    const int col = 32 * t + j;
     float x, y, z;
-    point_coords(base + 32 * t + j, x, y, z);
+    point_coords(base + col % PTS, x, y, z);
     bv[t] = coord_operand(x, y, z, h);
+    if (JVP && col >= PTS) bv[t] = unit_operand(col / PTS - 1);
   }
+  // lane that holds the value stream of this lane's point in m-tile 0 (JVP epilogue)
+  int value_lane[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) value_lane[t] = (lane & 32) | ((32 * t + j) % PTS);
 
   const char* st = p.state + size_t(row) * p.state_row_bytes;
   const f32x16 zero16 = {};
@@ -247,7 +277,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
         for (int t = 0; t < MT; ++t) {
           float v[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = softplus2(acc[i][t][r]);
+          for (int r = 0; r < 16; ++r) {
+            if (JVP) {
+              const float sig = __shfl(sigmoid2(acc[i][0][r]), value_lane[t]);
+              const bool is_value = 32 * t + j < PTS;
+              v[r] = is_value ? softplus2(acc[i][t][r]) : sig * acc[i][t][r];
+            } else {
+              v[r] = softplus2(acc[i][t][r]);
+            }
+          }
           packed_out[i][t][0] = split8(v);
           packed_out[i][t][1] = split8(v + 8);
         }
@@ -396,17 +434,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     __syncthreads();
     for (int e = threadIdx.x; e < M * p.out_dim; e += blockDim.x) {
       const int m = e / p.out_dim, c = e % p.out_dim;
-      const int64_t i = base + m;
+      const int stream = m / PTS;                       // 0 unless JVP
+      const int64_t i = base + m % PTS;
       if (i < n_pts) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
         if (p.add_input && c < 3) {
-          float x, y, z;
-          point_coords(i, x, y, z);
-          v += c == 0 ? x : (c == 1 ? y : z);
+          if (stream == 0) {
+            float x, y, z;
+            point_coords(i, x, y, z);
+            v += c == 0 ? x : (c == 1 ? y : z);
+          } else if (c == stream - 1) {
+            v += 1.f;                                   // d (x + F) / d x_c
+          }
         }
-        p.out[(int64_t(row) * n_pts + i) * p.out_dim + c] = v;
+        if (JVP) p.out[((int64_t(row) * n_pts + i) * 4 + stream) * p.out_dim + c] = v;
+        else p.out[(int64_t(row) * n_pts + i) * p.out_dim + c] = v;
       }
     }
   }
@@ -424,7 +468,7 @@ constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) *
 using nphm::mlp::Config;
 using nphm::mlp::Plan;
 
-template <int MODE>
+template <int MODE, bool JVP = false>
 static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st) {
   using namespace nphm::mlp;
   for (int l = 0; l < plan.n_linear; ++l) {
@@ -435,19 +479,19 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   }
   a.n_linear = plan.n_linear;
   a.state_row_bytes = plan.state_row_bytes;
-  const int M = plan.variant == 0 ? 64 : 32;
+  const int M = (plan.variant == 0 ? 64 : 32) / (JVP ? 4 : 1);      // points per workgroup
   const int64_t tiles = (n_pts + M - 1) / M;
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * WAVES);
   hipError_t e;
   if (plan.variant == 0) {
-    auto k = mlp_eval_kernel<2, 2, MODE>;
+    auto k = mlp_eval_kernel<2, 2, MODE, JVP>;
     constexpr size_t lds = lds_bytes<2, 2>();
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
   } else {
-    auto k = mlp_eval_kernel<1, 4, MODE>;
+    auto k = mlp_eval_kernel<1, 4, MODE, JVP>;
     constexpr size_t lds = lds_bytes<1, 4>();
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
@@ -543,6 +587,26 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   a.xyz = xyz;
   a.n_points = n_points;
   return launch_eval<0>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+}
+
+int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                             const void* packed, const void* latent_state,
+                             const float* xyz, int n_rows, int64_t n_points, int add_input,
+                             float* out, void* stream) {
+  Plan plan;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points_jvp: unsupported architecture");
+  if (!packed || !latent_state || !xyz || !out) return nphm_fail_msg("nphm_mlp_eval_points_jvp: null pointer");
+  if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_mlp_eval_points_jvp: empty input");
+  nphm::mlp::EvalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const char*>(packed);
+  a.state = static_cast<const char*>(latent_state);
+  a.out = out;
+  a.out_dim = out_dim;
+  a.add_input = add_input;
+  a.xyz = xyz;
+  a.n_points = n_points;
+  return launch_eval<0, true>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
 }
 
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,

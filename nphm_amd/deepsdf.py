@@ -155,6 +155,21 @@ class DeepSDF(nn.Module):
                    "nphm_mlp_eval_points")
         return out
 
+    def forward_hip_jvp(self, xyz, cond_rows, add_input=False):
+        """Value and spatial Jacobian in one fused launch (forward-mode tangents carried through the
+        same GEMMs): xyz [B,N,3], cond_rows [B,lat_dim] -> [B,N,4,out_dim] with [:,:,0] = f(x)
+        (+ x if ``add_input``) and [:,:,1+c,i] = d f_i / d x_c (+ identity if ``add_input``)."""
+        lib = _lib.load()
+        B, N, _ = xyz.shape
+        packed, state = self.prepare_latent(cond_rows)
+        xyz = xyz.contiguous().float()
+        out = torch.empty(B, N, 4, self.n_out, dtype=torch.float32, device=xyz.device)
+        stream = torch.cuda.current_stream(xyz.device).cuda_stream
+        _lib.check(lib.nphm_mlp_eval_points_jvp(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(),
+                                                B, N, int(bool(add_input)), out.data_ptr(), stream),
+                   "nphm_mlp_eval_points_jvp")
+        return out
+
     def _hip_rows(self, xyz, cond):
         """How the HIP tier can serve this call: returns (xyz_view [R,n,3], cond_rows [R,lat_dim]) or
         None (-> composite tier).  Raises on a CPU tensor without the explicit opt-in.
@@ -300,6 +315,25 @@ class DeformationNetwork(nn.Module):
     @backend.setter
     def backend(self, value):
         self.defDeepSDF.backend = value
+
+    def jacobian(self, xyz, lat_rep, anchors):
+        """Posed points x + F_ex(x) [B,N,3] and the Jacobian d (x + F_ex) / d x [B,N,3,3]
+        ([..., i, c] = d posed_i / d x_c — the layout of diff_operators.jac) in ONE fused launch
+        instead of one forward + three autograd VJPs.  Detached results; returns None when the HIP
+        tier cannot serve the call (CPU / composite backend / per-point conditioning / training-mode
+        noise), so callers fall back to autograd."""
+        if xyz.dim() < 3:
+            xyz = xyz.unsqueeze(0)
+        if self.backend == "composite" or not xyz.is_cuda or self.defDeepSDF.n_out < 3:
+            return None
+        with torch.no_grad():
+            x = xyz.detach()
+            cond = self._condition(x, lat_rep.detach(), None if anchors is None else anchors.detach())
+            plan = self.defDeepSDF._hip_rows(x, cond)
+            if plan is None:
+                return None
+            out = self.defDeepSDF.forward_hip_jvp(*plan, add_input=True).reshape(x.shape[0], x.shape[1], 4, -1)
+        return out[:, :, 0, :3], out[:, :, 1:, :3].transpose(-1, -2)
 
     def canonical_points(self, xyz, lat_rep, anchors):
         """x + F_ex(x) in one fused launch (HIP tier) — the canonicalisation step of

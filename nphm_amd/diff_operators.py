@@ -9,9 +9,14 @@ import torch
 def jac(decoder_expr, xc, cond, anchors):
     """Jacobian of the posed position x_d = x_c + F_ex(x_c) w.r.t. the canonical point
     (diff_operators.py:26-54): xc [B,N,3] -> [B,N,3,3] with [..., i, :] = d x_d[i] / d x_c.
-    Like the reference it switches ``requires_grad`` on for ``xc`` in place and issues one
-    vector-Jacobian product per output coordinate (graph kept, not extended)."""
+    Like the reference it switches ``requires_grad`` on for ``xc`` in place; the result carries no
+    graph (the reference's VJPs use create_graph=False).  On a ROCm device the deformation field's
+    fused value+Jacobian kernel serves it; otherwise one vector-Jacobian product per output
+    coordinate."""
     xc.requires_grad_(True)
+    fused = decoder_expr.jacobian(xc, cond, anchors) if hasattr(decoder_expr, "jacobian") else None
+    if fused is not None:                       # analytic forward-mode Jacobian, one HIP launch
+        return fused[1]
     offsets, _ = decoder_expr(xc, cond, anchors)
     xd = xc + offsets
     rows = []

@@ -264,3 +264,51 @@ def test_flattened_batch_with_segmented_conditioning(dnet, dev):
     assert U.maxdiff(b.cpu().numpy().reshape(S, n, 3), ref) < TOL_TIGHT
     keep = np.ones(S * n, bool); keep[7] = False
     assert U.maxdiff(c.cpu().numpy()[0, keep], ref.reshape(-1, 3)[keep]) < TOL_TIGHT
+
+
+def test_fused_jacobian_matches_autograd(dnet, npm, dev):
+    """nphm_mlp_eval_points_jvp (forward-mode tangents through the same GEMMs) vs the reference's
+    definition of jac: one forward + three autograd VJPs (diff_operators.py:26-54) on the composite
+    tier, and the flattened-batch form the root finder uses."""
+    from nphm_amd import diff_operators as D
+    rng = np.random.default_rng(12)
+    S, n = 5, 213
+    xyz = rng.uniform(-0.5, 0.5, size=(S, n, 3)).astype(np.float32)
+    lat = (0.3 * rng.standard_normal((S, 1, 1544))).astype(np.float32)
+    lat[:, :, :1344] = lat[:1, :, :1344]
+    anc = np.repeat(U.anchors_mean()[None], S, 0).astype(np.float32)
+    x = _t(xyz, dev)
+    posed, J = dnet.jacobian(x, _t(lat, dev), _t(anc, dev))
+    assert posed.shape == (S, n, 3) and J.shape == (S, n, 3, 3) and not J.requires_grad
+    with torch.no_grad():
+        off, _ = dnet(x, _t(lat, dev), _t(anc, dev))
+    assert U.maxdiff((x + off).cpu().numpy(), posed.cpu().numpy()) < 1e-6
+    dnet.backend = "composite"
+    try:
+        J_ref = D.jac(dnet, x.clone(), _t(lat, dev).repeat(1, n, 1), _t(anc, dev).unsqueeze(1).repeat(1, n, 1, 1))
+    finally:
+        dnet.backend = "hip"
+    e = U.maxdiff(J.cpu().numpy(), J_ref.cpu().numpy())
+    print(f"fused Jacobian vs autograd: max abs err {e:.3e} (|J - I| up to {float((J_ref - torch.eye(3, device=dev)).abs().max()):.3f})")
+    assert e < 2e-5
+    # through jac() itself, in the flattened-batch form (segment-constant conditioning)
+    called, restore = _spy(dnet.defDeepSDF, "forward_hip_jvp")
+    try:
+        J_flat = D.jac(dnet, x.reshape(1, S * n, 3).clone(), _t(np.repeat(lat, n, 1).reshape(1, S * n, 1544), dev),
+                       _t(np.repeat(anc[:, None], n, 1).reshape(1, S * n, 39, 3), dev))
+    finally:
+        restore()
+    assert called.get("n") == 1 and torch.equal(J_flat.reshape(S, n, 3, 3), J)
+    # NPM SDF: the spatial gradient (surface normal direction)
+    gn = U.golden("npm")
+    q = _t(gn["xyz"], dev)
+    out = npm.forward_hip_jvp(q, _t(gn["lat"][None], dev))
+    npm.backend = "composite"
+    try:
+        qg = q.clone().requires_grad_(True)
+        sdf, _ = npm(qg, _t(gn["lat"][None, None], dev))
+        (g_ref,) = torch.autograd.grad(sdf.sum(), qg)
+    finally:
+        npm.backend = "hip"
+    assert U.maxdiff(out[:, :, 0, 0].cpu().numpy(), sdf[..., 0].detach().cpu().numpy()) < 2e-5
+    assert U.maxdiff(out[:, :, 1:, 0].cpu().numpy(), g_ref.cpu().numpy()) < 5e-5
