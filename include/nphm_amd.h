@@ -157,6 +157,20 @@ int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_d
                              const float* xyz, int n_rows, int64_t n_points, int add_input,
                              float* out, void* stream);
 
+/* Correspondence search of the fitting loop in ONE launch: Broyden root finding of
+ * x + F(x) = obs per point (src/NPHM/models/iterative_root_finding.py:5-71 broyden as called by
+ * search :152-156 — there <= 16 forwards of the field with a host sync each).  Same per-point state
+ * machine: every point takes the first update, then moves while its best residual norm is > cvg_thresh
+ * and its current one < dvg_thresh; the inverse Jacobian gets the rank-one ("good Broyden") update with
+ * the +-eps guard on the denominator; x_out is the final iterate, diff_out the smallest residual norm
+ * seen, valid_out = diff_out < cvg_thresh.  x_init / obs / x_out [n_rows, n_points, 3], jinv_init
+ * [n_rows, n_points, 3, 3] (inverse of nphm_mlp_eval_points_jvp's Jacobian), out_dim >= 3. */
+int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                     const void* packed, const void* latent_state,
+                     const float* obs, const float* x_init, const float* jinv_init, int n_rows, int64_t n_points,
+                     int max_steps, float cvg_thresh, float dvg_thresh, float eps,
+                     float* x_out, float* diff_out, unsigned char* valid_out, void* stream);
+
 /* The same on the x-slab [ix0, ix1) of an [rx,ry,rz] 'ij' lattice (utils/reconstruction.py:5-20):
  * out [(ix1-ix0)*ry*rz, out_dim] in flattened lattice order. */
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,

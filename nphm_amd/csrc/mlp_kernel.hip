@@ -147,6 +147,13 @@ struct EvalArgs {
   // MODE 0
   const float* xyz;       // [n_rows, n_points, 3]
   int64_t n_points;
+  // KIND 2 (Broyden): xyz = initial iterates, out = final iterates [n_rows, n_points, 3]
+  const float* obs;       // [n_rows, n_points, 3] observed (posed) points
+  const float* jinv;      // [n_rows, n_points, 3, 3] initial inverse Jacobians
+  float* diff_out;        // [n_rows, n_points] smallest residual norm seen
+  unsigned char* valid_out;   // [n_rows, n_points] converged
+  int max_steps;
+  float cvg, dvg, eps;
   // MODE 1: x-slab [ix0, ix1) of an 'ij' lattice, points in flattened lattice order
   const float* ax; const float* ay; const float* az;
   int rx, ry, rz, ix0, ix1;
@@ -217,8 +224,15 @@ __device__ __forceinline__ bf16x8 unit_operand(int c) {
 // (value, d/dx, d/dy, d/dz) of M/4 points; the tangent streams go through the SAME GEMMs (their
 // coordinate K-step sees the unit vectors, no bias) and their epilogue multiplies by the value
 // stream's sigmoid instead of applying softplus.  Output [n, 4, out_dim].
-template <int MT, int NTW, int MODE, bool JVP>
+//
+// KIND 2 = Broyden root finding x + F(x) = obs fused around the network (the reference's
+// iterative_root_finding.broyden, one launch instead of <= 16 forwards + host syncs): the workgroup
+// keeps its M points for up to max_steps + 1 evaluations, thread m < M owns point m's solver state
+// (x, g, dx, dg, 3x3 inverse Jacobian, best residual) in registers, the iterate travels to the
+// wavefronts through LDS; a workgroup leaves as soon as none of its points is active.
+template <int MT, int NTW, int MODE, int KIND>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
+  constexpr bool JVP = KIND == 1, BROY = KIND == 2;
   constexpr int M = 32 * MT;               // columns per workgroup
   constexpr int PTS = JVP ? M / 4 : M;     // points per workgroup
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   char* act_hi = smem;
   char* act_lo = smem + PART_BYTES;
   float* partial = reinterpret_cast<float*>(smem + 2 * PART_BYTES);   // [WAVES][M][4]
+  float* xs = partial + WAVES * M * 4;                                // [M][4] current iterate (KIND 2)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -249,12 +264,34 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     }
   };
 
+  // ---- KIND 2: solver state of point threadIdx.x (threads < M) -----------------------------------
+  float bx[3] = {0, 0, 0}, bobs[3] = {0, 0, 0}, bgx[3] = {0, 0, 0}, bdx[3] = {0, 0, 0}, bdgx[3] = {0, 0, 0};
+  float bJ[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bbest = 0.f;
+  bool bactive = false, bowner = false;
+  if (BROY && threadIdx.x < M) {
+    const int64_t i = base + threadIdx.x;
+    bowner = i < n_pts;
+    const int64_t ic = (int64_t(row) * n_pts + (bowner ? i : n_pts - 1));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { bx[c] = p.xyz[ic * 3 + c]; bobs[c] = p.obs[ic * 3 + c]; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) bJ[c] = p.jinv[ic * 9 + c];
+    xs[threadIdx.x * 4 + 0] = bx[0]; xs[threadIdx.x * 4 + 1] = bx[1]; xs[threadIdx.x * 4 + 2] = bx[2];
+  }
+
+#pragma unroll 1
+  for (int it = 0;; ++it) {                 // one pass unless KIND 2
   bf16x8 bv[MT];
+  if (BROY) __syncthreads();                // the iterate written by the owners is visible
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int col = 32 * t + j;
     float x, y, z;
-    point_coords(base + col % PTS, x, y, z);
+    if (BROY) {
+      x = xs[col * 4]; y = xs[col * 4 + 1]; z = xs[col * 4 + 2];
+    } else {
+      point_coords(base + col % PTS, x, y, z);
+    }
     bv[t] = coord_operand(x, y, z, h);
     if (JVP && col >= PTS) bv[t] = unit_operand(col / PTS - 1);
   }
@@ -432,32 +469,100 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < M * p.out_dim; e += blockDim.x) {
-      const int m = e / p.out_dim, c = e % p.out_dim;
-      const int stream = m / PTS;                       // 0 unless JVP
-      const int64_t i = base + m % PTS;
-      if (i < n_pts) {
-        float v = 0.f;
+    if (!BROY) {
+      for (int e = threadIdx.x; e < M * p.out_dim; e += blockDim.x) {
+        const int m = e / p.out_dim, c = e % p.out_dim;
+        const int stream = m / PTS;                       // 0 unless JVP
+        const int64_t i = base + m % PTS;
+        if (i < n_pts) {
+          float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
-        if (p.add_input && c < 3) {
-          if (stream == 0) {
-            float x, y, z;
-            point_coords(i, x, y, z);
-            v += c == 0 ? x : (c == 1 ? y : z);
-          } else if (c == stream - 1) {
-            v += 1.f;                                   // d (x + F) / d x_c
+          for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
+          if (p.add_input && c < 3) {
+            if (stream == 0) {
+              float x, y, z;
+              point_coords(i, x, y, z);
+              v += c == 0 ? x : (c == 1 ? y : z);
+            } else if (c == stream - 1) {
+              v += 1.f;                                   // d (x + F) / d x_c
+            }
           }
+          if (JVP) p.out[((int64_t(row) * n_pts + i) * 4 + stream) * p.out_dim + c] = v;
+          else p.out[(int64_t(row) * n_pts + i) * p.out_dim + c] = v;
         }
-        if (JVP) p.out[((int64_t(row) * n_pts + i) * 4 + stream) * p.out_dim + c] = v;
-        else p.out[(int64_t(row) * n_pts + i) * p.out_dim + c] = v;
       }
     }
+  }
+  if (!BROY) break;
+
+  // ---- KIND 2: one Broyden step per evaluation (iterative_root_finding.py:24-69) ------------------
+  int flag = 0;
+  if (threadIdx.x < M) {
+    const int m = threadIdx.x;
+    float gnew[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
+      gnew[c] = (v + bx[c]) - bobs[c];                    // residual (x + F(x)) - obs
+    }
+    if (it == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) bgx[c] = gnew[c];
+      bbest = sqrtf(bgx[0] * bgx[0] + bgx[1] * bgx[1] + bgx[2] * bgx[2]);
+      bactive = bowner;                                   // the first update is applied to every point
+    } else {
+      if (bactive) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { bdgx[c] = gnew[c] - bgx[c]; bgx[c] += bdgx[c]; }
+      }
+      const float nrm = sqrtf(bgx[0] * bgx[0] + bgx[1] * bgx[1] + bgx[2] * bgx[2]);
+      if (nrm < bbest) bbest = nrm;
+      bactive = bowner && bbest > p.cvg && nrm < p.dvg;   // converged and diverged points stop moving
+    }
+    flag = bactive;
+  }
+  const int any_active = __syncthreads_or(flag);
+  if ((it > 0 && !any_active) || it == p.max_steps) break;
+  if (threadIdx.x < M && bactive) {
+    if (it > 0) {
+      // rank-one update of the inverse Jacobian: J += (dx - J dg) (dx^T J) / (dx^T J dg)
+      float vT[3], a[3], b = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) vT[jj] = bdx[0] * bJ[jj] + bdx[1] * bJ[3 + jj] + bdx[2] * bJ[6 + jj];
+#pragma unroll
+      for (int i2 = 0; i2 < 3; ++i2)
+        a[i2] = bdx[i2] - (bJ[3 * i2] * bdgx[0] + bJ[3 * i2 + 1] * bdgx[1] + bJ[3 * i2 + 2] * bdgx[2]);
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) b += vT[jj] * bdgx[jj];
+      b += b >= 0.f ? p.eps : -p.eps;
+#pragma unroll
+      for (int i2 = 0; i2 < 3; ++i2) {
+        const float u = a[i2] / b;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) bJ[3 * i2 + jj] += u * vT[jj];
+      }
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < 3; ++i2) {
+      bdx[i2] = -(bJ[3 * i2] * bgx[0] + bJ[3 * i2 + 1] * bgx[1] + bJ[3 * i2 + 2] * bgx[2]);
+      bx[i2] += bdx[i2];
+      xs[threadIdx.x * 4 + i2] = bx[i2];
+    }
+  }
+  }  // evaluation loop
+
+  if (BROY && threadIdx.x < M && bowner) {
+    const int64_t i = int64_t(row) * n_pts + base + threadIdx.x;
+    p.out[i * 3] = bx[0]; p.out[i * 3 + 1] = bx[1]; p.out[i * 3 + 2] = bx[2];
+    p.diff_out[i] = bbest;
+    p.valid_out[i] = bbest < p.cvg ? 1 : 0;
   }
 }
 
 template <int MT, int NTW>
-constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) * 16 * 2 + WAVES * 32 * MT * 4 * 4; }
+constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) * 16 * 2 + (WAVES + 1) * 32 * MT * 4 * 4; }
 
 }  // namespace mlp
 }  // namespace nphm
@@ -468,7 +573,7 @@ constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) *
 using nphm::mlp::Config;
 using nphm::mlp::Plan;
 
-template <int MODE, bool JVP = false>
+template <int MODE, int KIND = 0>
 static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st) {
   using namespace nphm::mlp;
   for (int l = 0; l < plan.n_linear; ++l) {
@@ -479,19 +584,19 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   }
   a.n_linear = plan.n_linear;
   a.state_row_bytes = plan.state_row_bytes;
-  const int M = (plan.variant == 0 ? 64 : 32) / (JVP ? 4 : 1);      // points per workgroup
+  const int M = (plan.variant == 0 ? 64 : 32) / (KIND == 1 ? 4 : 1);      // points per workgroup
   const int64_t tiles = (n_pts + M - 1) / M;
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * WAVES);
   hipError_t e;
   if (plan.variant == 0) {
-    auto k = mlp_eval_kernel<2, 2, MODE, JVP>;
+    auto k = mlp_eval_kernel<2, 2, MODE, KIND>;
     constexpr size_t lds = lds_bytes<2, 2>();
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
   } else {
-    auto k = mlp_eval_kernel<1, 4, MODE, JVP>;
+    auto k = mlp_eval_kernel<1, 4, MODE, KIND>;
     constexpr size_t lds = lds_bytes<1, 4>();
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
@@ -606,7 +711,35 @@ int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_d
   a.add_input = add_input;
   a.xyz = xyz;
   a.n_points = n_points;
-  return launch_eval<0, true>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+  return launch_eval<0, 1>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+}
+
+int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                     const void* packed, const void* latent_state,
+                     const float* obs, const float* x_init, const float* jinv_init, int n_rows, int64_t n_points,
+                     int max_steps, float cvg_thresh, float dvg_thresh, float eps,
+                     float* x_out, float* diff_out, unsigned char* valid_out, void* stream) {
+  Plan plan;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) || out_dim < 3)
+    return nphm_fail_msg("nphm_mlp_broyden: unsupported architecture (needs a 3-vector field)");
+  if (!packed || !latent_state || !obs || !x_init || !jinv_init || !x_out || !diff_out || !valid_out)
+    return nphm_fail_msg("nphm_mlp_broyden: null pointer");
+  if (n_rows <= 0 || n_points <= 0 || max_steps < 0) return nphm_fail_msg("nphm_mlp_broyden: empty input");
+  nphm::mlp::EvalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const char*>(packed);
+  a.state = static_cast<const char*>(latent_state);
+  a.out = x_out;
+  a.out_dim = out_dim;
+  a.xyz = x_init;
+  a.n_points = n_points;
+  a.obs = obs;
+  a.jinv = jinv_init;
+  a.diff_out = diff_out;
+  a.valid_out = valid_out;
+  a.max_steps = max_steps;
+  a.cvg = cvg_thresh; a.dvg = dvg_thresh; a.eps = eps;
+  return launch_eval<0, 2>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
 }
 
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,

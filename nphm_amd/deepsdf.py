@@ -16,6 +16,7 @@ Execution tiers (same policy as the identity field, ensembled_deepsdf.py):
 """
 from __future__ import annotations
 
+import math
 from typing import Optional
 
 import numpy as np
@@ -170,6 +171,25 @@ class DeepSDF(nn.Module):
                    "nphm_mlp_eval_points_jvp")
         return out
 
+    def broyden_hip(self, obs, x_init, jinv_init, cond_rows, max_steps, cvg_thresh, dvg_thresh, eps=1e-6):
+        """Roots of x + f(x) = obs by Broyden's method, fused around the network in one launch
+        (nphm_mlp_broyden).  obs / x_init [B,N,3], jinv_init [B,N,3,3], cond_rows [B,lat_dim] ->
+        (x [B,N,3], smallest residual norm [B,N], converged [B,N] bool)."""
+        lib = _lib.load()
+        B, N, _ = x_init.shape
+        packed, state = self.prepare_latent(cond_rows)
+        dev = x_init.device
+        obs, x_init, jinv_init = obs.contiguous().float(), x_init.contiguous().float(), jinv_init.contiguous().float()
+        x = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        diff = torch.empty(B, N, dtype=torch.float32, device=dev)
+        valid = torch.empty(B, N, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.nphm_mlp_broyden(*self._arch(), packed.data_ptr(), state.data_ptr(), obs.data_ptr(),
+                                        x_init.data_ptr(), jinv_init.data_ptr(), B, N, int(max_steps),
+                                        float(cvg_thresh), float(dvg_thresh), float(eps), x.data_ptr(),
+                                        diff.data_ptr(), valid.data_ptr(), stream), "nphm_mlp_broyden")
+        return x, diff, valid.bool()
+
     def _hip_rows(self, xyz, cond):
         """How the HIP tier can serve this call: returns (xyz_view [R,n,3], cond_rows [R,lat_dim]) or
         None (-> composite tier).  Raises on a CPU tensor without the explicit opt-in.
@@ -199,11 +219,14 @@ class DeepSDF(nn.Module):
         edges = change[0].nonzero().flatten()                             # one host sync
         if edges.numel() == 0:
             return xyz, cond[:, 0, :]
-        seg = int(edges[0]) + 1
-        if seg < 64 or N % seg or edges.numel() != N // seg - 1:      # per-point conditioning: composite
+        if edges.numel() > 64:                                            # per-point conditioning
             return None
-        expect = torch.arange(seg - 1, N - 1, seg, device=edges.device)
-        if not torch.equal(edges, expect):
+        # segment length = gcd of the run boundaries (runs may merge when neighbouring segments
+        # carry the same code, e.g. an observation sampled twice in a fitting batch)
+        seg = N
+        for e in (edges + 1).tolist():
+            seg = math.gcd(seg, int(e))
+        if seg < 64:
             return None
         return xyz.reshape(N // seg, seg, 3), cond[0, ::seg, :]
 
@@ -334,6 +357,28 @@ class DeformationNetwork(nn.Module):
                 return None
             out = self.defDeepSDF.forward_hip_jvp(*plan, add_input=True).reshape(x.shape[0], x.shape[1], 4, -1)
         return out[:, :, 0, :3], out[:, :, 1:, :3].transpose(-1, -2)
+
+    def broyden(self, obs, x_init, jinv_init, lat_rep, anchors, max_steps=15, cvg_thresh=1e-6, dvg_thresh=0.2,
+                eps=1e-6):
+        """Canonical correspondences x_c with x_c + F_ex(x_c) = obs for all points in ONE fused launch
+        (the reference iterates <= max_steps + 1 forwards with a host sync each,
+        iterative_root_finding.py:5-71).  obs / x_init [B,N,3], jinv_init [B,N,3,3], lat_rep / anchors as
+        for ``forward``.  Returns {'result' [B*N,3,1], 'diff' [B*N], 'valid_ids' [B*N]} like the
+        reference's broyden, or None when the HIP tier cannot serve the call."""
+        if self.backend == "composite" or not x_init.is_cuda or self.defDeepSDF.n_out < 3:
+            return None
+        with torch.no_grad():
+            x0 = x_init.detach()
+            cond = self._condition(x0, lat_rep.detach(), None if anchors is None else anchors.detach())
+            plan = self.defDeepSDF._hip_rows(x0, cond)
+            if plan is None:
+                return None
+            xv, rows = plan
+            R, n = xv.shape[0], xv.shape[1]
+            x, diff, valid = self.defDeepSDF.broyden_hip(obs.detach().reshape(R, n, 3), xv,
+                                                         jinv_init.detach().reshape(R, n, 3, 3), rows, max_steps,
+                                                         cvg_thresh, dvg_thresh, eps)
+        return {"result": x.reshape(-1, 3, 1), "diff": diff.reshape(-1), "valid_ids": valid.reshape(-1)}
 
     def canonical_points(self, xyz, lat_rep, anchors):
         """x + F_ex(x) in one fused launch (HIP tier) — the canonicalisation step of

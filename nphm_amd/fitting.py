@@ -89,9 +89,13 @@ def _report(j, lambdas, loss_dict, extra=None):
 
 def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[torch.Tensor], lambdas, n_steps,
                                            schedule_cfg: Dict, step_scale=1, lr_scale=1, *, verbose: bool = True,
-                                           history: Optional[list] = None):
+                                           history: Optional[list] = None, compute_unused_sdf_grad: bool = False):
     """Joint fit of one identity code and one expression code per observation (fitting.py:14-177).
-    Returns (lat_rep [n_obs,1,lat_dim_expr], lat_rep_shape [1,1,lat_dim], anchors)."""
+    Returns (lat_rep [n_obs,1,lat_dim_expr], lat_rep_shape [1,1,lat_dim], anchors).
+
+    The reference also evaluates ``nabla(decoder, p_corresp, ...)`` every step (:112) and never uses
+    the result; it has no side effect on the fit (no RNG, no parameter, no in-place update), so it is
+    skipped unless ``compute_unused_sdf_grad`` — the fitted latents are identical either way."""
     device = all_obs[0].device
     n_obs = len(all_obs)
     n_batch, n_points = 5, 1000
@@ -137,7 +141,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
 
         shape_cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
         sdf, _ = decoder(xc, shape_cond, None)
-        _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)        # computed, unused (as in the reference)
+        if compute_unused_sdf_grad:
+            _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
 
         sdf = sdf[search_result["valid_ids"], :]
         loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale),

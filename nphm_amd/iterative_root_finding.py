@@ -100,8 +100,20 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
         err = xd - (obs.reshape(1, -1, 3) if obs.shape[0] != 1 else obs)
         return err.flatten(0, 1)[mask].unsqueeze(-1)
 
-    with torch.no_grad():
-        result = broyden(residual, x0, J_inv_init, cvg_thresh=1e-6, dvg_thresh=0.2, max_steps=15)
+    result = None
+    if hasattr(decoder_expr, "broyden"):
+        # fused solver: same per-point state machine, one launch, no host syncs (None: not applicable)
+        if multi_corresp or cond.shape[0] == 1:
+            result = decoder_expr.broyden(obs, xc_init, J_inv_init, cond, anchors, max_steps=15, cvg_thresh=1e-6,
+                                          dvg_thresh=0.2)
+        else:      # the reference flattens the batch into one row of points (:137-139)
+            result = decoder_expr.broyden(obs.reshape(1, -1, 3), xc_init.reshape(1, -1, 3), J_inv_init,
+                                          cond.reshape(1, -1, cond.shape[2]),
+                                          None if anchors is None else anchors.reshape(1, -1, anchors.shape[2], 3),
+                                          max_steps=15, cvg_thresh=1e-6, dvg_thresh=0.2)
+    if result is None:
+        with torch.no_grad():
+            result = broyden(residual, x0, J_inv_init, cvg_thresh=1e-6, dvg_thresh=0.2, max_steps=15)
 
     if multi_corresp:
         xc_opt = result["result"].reshape(B, N, -1, 3)

@@ -17,7 +17,7 @@ LAMBDAS = {"surface": 2.0, "reg_expr": 0.01, "reg_global": 0.25, "reg_unobserved
 SCHEDULE = {"lr": {2: 2}, "symm_dist": {1: 10, 3: 9999}, "reg_glob": {1: 3}, "reg_loc": {2: 3}, "reg_expr": {3: 10}}
 
 
-def _run_joint(device, backend):
+def _run_joint(device, backend, **kw):
     g = U.golden("fitting")
     shape_net = U.build_identity(device=device).train()
     expr_net = U.build_deformation(device=device).eval()
@@ -30,7 +30,7 @@ def _run_joint(device, backend):
     torch.manual_seed(0)
     lat_e, lat_s, anc = F.inference_iterative_root_finding_joint(
         shape_net, expr_net, obs, dict(LAMBDAS), int(g["n_steps"]), {k: dict(v) for k, v in SCHEDULE.items()},
-        verbose=False, history=hist)
+        verbose=False, history=hist, **kw)
     keys = [str(k) for k in g["keys"]]
     table = np.array([[h[k] for k in keys] + [h["n_valid"]] for h in hist])
     return g, table, lat_e.detach().cpu().numpy(), lat_s.detach().cpu().numpy(), anc.detach().cpu().numpy()
@@ -58,6 +58,14 @@ def test_joint_fit_matches_reference_loop_cpu():
     assert np.array_equal(table[:, -1], g["history"][:, -1])                       # converged correspondences
     _check_trace(table, g, tight=2e-6, loose=1e-4)
     _check_latents(lat_s, lat_e, anc, g, typical=1e-6, worst=2e-3)
+
+
+def test_unused_sdf_gradient_has_no_effect_cpu():
+    """The reference computes nabla(decoder, p_corresp) every step and drops it (fitting.py:112); the
+    mirror skips it by default — bit-identical fit either way."""
+    _, t0, e0, s0, a0 = _run_joint("cpu", "composite")
+    _, t1, e1, s1, a1 = _run_joint("cpu", "composite", compute_unused_sdf_grad=True)
+    assert np.array_equal(t0, t1) and np.array_equal(e0, e1) and np.array_equal(s0, s1) and np.array_equal(a0, a1)
 
 
 def test_identity_space_fit_matches_reference_loop_cpu():

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backend", default=None, choices=[None, "composite"])
     ap.add_argument("--profile", action="store_true", help="synchronising per-phase timers (slower)")
+    ap.add_argument("--with-unused-nabla", action="store_true", help="also evaluate the reference's dead nabla() call")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     shape_net = U.build_identity(device=dev)
@@ -68,7 +69,9 @@ def main():
             return wrapper
         FM.search = timed("search(total)", FM.search)
         IRF.jac = timed("search.jac+inverse-input", IRF.jac)
-        IRF.broyden = timed("search.broyden", IRF.broyden)
+        IRF.broyden = timed("search.broyden(python)", IRF.broyden)
+        if hasattr(expr_net, "broyden"):
+            expr_net.broyden = timed("search.broyden(fused)", expr_net.broyden)
         FM.jac = timed("jac(implicit diff)", FM.jac)
         FM.nabla = timed("nabla(unused result)", FM.nabla)
         shape_net.forward = timed("identity forward (composite, all calls)", shape_net.forward)
@@ -77,12 +80,13 @@ def main():
         torch.Tensor.backward = timed("loss.backward", orig_backward)
     torch.manual_seed(0)
     cfg = {k: dict(v) for k, v in SCHEDULE.items()}
-    F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), args.warmup, cfg, verbose=False)
+    kw = {"compute_unused_sdf_grad": args.with_unused_nabla}
+    F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), args.warmup, cfg, verbose=False, **kw)
     torch.cuda.synchronize()
     hist = []
     t0 = time.perf_counter()
     F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), args.steps, cfg, verbose=False,
-                                             history=hist)
+                                             history=hist, **kw)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if args.profile:
@@ -90,7 +94,7 @@ def main():
             print(f"  {k:45s} {v / (args.steps + args.warmup) * 1e3:8.2f} ms/step")
     print(json.dumps({"workload": "latent fitting, 3 observations x 2500 pts, 5x1000 pts/step", "steps": args.steps,
                       "steps_per_s": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                      "backend": args.backend or "hip+composite", "first_loss": hist[0]["loss"],
+                      "backend": args.backend or "hip+composite", "unused_nabla": args.with_unused_nabla, "first_loss": hist[0]["loss"],
                       "last_loss": hist[-1]["loss"], "n_valid_last": hist[-1]["n_valid"]}))
 
 
