@@ -119,15 +119,14 @@ def main():
     lib = _lib.load()
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
     shard = torch.zeros(max(n_planes, 1) * plane, dtype=torch.float32, device=dev)
-    ev_k0, ev_k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    kernel_ms = []
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     box = {"full": None}
 
-    def step(timed):
+    def step(timed, ev=None):
         packed, state, _ = net.prepare_latent(lat[None])
         stream = torch.cuda.current_stream(dev).cuda_stream
         if timed:
-            ev_k0.record()
+            ev[0].record()                     # HIP events on the launch stream bracket the dominant kernel
         if n_planes:
             _lib.check(lib.nphm_identity_eval_grid_planes(
                 packed.data_ptr(), state.data_ptr(), axes_dev[0].data_ptr(), axes_dev[1].data_ptr(),
@@ -135,10 +134,9 @@ def main():
                 float(net.prune_tol), net._precision_code(), shard.data_ptr(),
                 stats.data_ptr() if timed else None, stream), "eval_grid_planes")
         if timed:
-            ev_k1.record()
+            ev[1].record()
         if world > 1:
             box["full"] = R.gather_planes(shard[: n_planes * plane], rx, plane)
-        return ev_k0, ev_k1
 
     def barrier():
         if world > 1:
@@ -149,13 +147,11 @@ def main():
         step(False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-        # HIP events on the launch stream bracket only the dominant kernel
-        ev_k1.synchronize()
-        kernel_ms.append(ev_k0.elapsed_time(ev_k1))
+    for i in range(args.steps):
+        step(True, events[i])
     barrier()
     dt = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
