@@ -104,6 +104,31 @@ int nphm_identity_eval_grid_planes(const void* packed, const void* latent_state,
                                    int64_t hack_chunk, float prune_tol, int precision,
                                    float* sdf_out, unsigned long long* stats, void* stream);
 
+/* First-order backward of FastEnsembleDeepSDFMirrored.forward for the latent-fitting loop
+ * (src/NPHM/models/fitting.py:111, :167: loss.backward() through decoder(xc, z_id); what autograd
+ * computes through EnsembledDeepSDF.py:101-150).  Train-mode forward only (no chunk overwrite).
+ *   nphm_identity_pack_bwd : transposed split-bf16 pack of lin0..lin3 (once per weight update)
+ *   nphm_identity_backward : the caller lists, per (batch row, member), the points whose normalised
+ *     blend weight exceeds its pruning tolerance: tiles [n_tiles][4] = (row, member, offset into
+ *     point_list, count <= 64), point_list = point indices inside the row.  sdf = forward values,
+ *     grad_sdf = dL/dsdf, both [n_rows, n_points].  ACCUMULATES (+=) into
+ *       grad_xyz [n_rows,n_points,3], grad_anchors [n_rows,39,3] (anchors = second forward output),
+ *       grad_b0 / grad_b2 [n_rows,40,200] = dL/d(b0 + W0[:,3:] cond_k), dL/d(b2 + W2[:,104:] cond_k / sqrt2),
+ *     which the host chains through mlp_pos and the latent columns.  No weight gradients.
+ *   nphm_identity_member_forward : the forward half on the same (row, member) point lists: the member
+ *     predictions f_k into member_sdf [n_rows, n_points, 40] (entries of unlisted pairs are left
+ *     untouched); the host blends them.  Serves the forward of the autograd tier, whose query points are
+ *     scattered surface samples (a brick-coherent wavefront of eval_points would touch most members). */
+size_t nphm_identity_bwd_packed_bytes(void);
+int nphm_identity_member_forward(const void* packed, const void* packed_bwd, const void* latent_state,
+                                 const float* xyz, int64_t n_points, const int* tiles, int n_tiles,
+                                 const int* point_list, float* member_sdf, void* stream);
+int nphm_identity_pack_bwd(const float* const lin_weight[5], void* packed_bwd, void* stream);
+int nphm_identity_backward(const void* packed, const void* packed_bwd, const void* latent_state,
+                           const float* xyz, const float* sdf, const float* grad_sdf, int64_t n_points,
+                           const int* tiles, int n_tiles, const int* point_list,
+                           float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2, void* stream);
+
 /* Second stage of the two-stage evaluation get_logits_backward (src/NPHM/models/reconstruction.py:28-56):
  * the identity field at displaced lattice points.  xyz_slab [(ix1-ix0)*ry*rz, 3] holds the canonical
  * points x + F_ex(x) of the slab in flattened lattice order (nphm_mlp_eval_grid with add_input);

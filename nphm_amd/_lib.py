@@ -35,6 +35,12 @@ SYMBOLS = {
     "nphm_identity_eval_grid_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                c_int, c_void_p, c_int, c_int64, c_float, c_int, c_void_p, c_void_p,
                                                c_void_p]),
+    "nphm_identity_bwd_packed_bytes": (c_size_t, []),
+    "nphm_identity_pack_bwd": (c_int, [_PtrArr5, c_void_p, c_void_p]),
+    "nphm_identity_member_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
+                                             c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_eval_grid_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_mlp_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_int]),

@@ -1,0 +1,575 @@
+// ident_bwd_kernel.hip — first-order backward of the NPHM identity field
+// (FastEnsembleDeepSDFMirrored.forward, src/NPHM/models/EnsembledDeepSDF.py:203-267) for the latent
+// fitting loop (src/NPHM/models/fitting.py:111-167: loss.backward() through decoder(xc, z_id)), i.e.
+// what torch.autograd computes there through 5 bmm's, 4 softplus and the blend per member.
+//
+// Gradients returned: d L / d xyz [B,N,3], d L / d anchors [B,39,3] and d L / d (folded biases of
+// lin0 and of the skip layer) [B,40,200] each; the host module chains the last three through
+// mlp_pos / the latent columns of lin0 and lin2 with ordinary autograd (tiny).  Weight gradients are
+// NOT produced (the fitting loop never uses them): the host picks this tier only when no parameter
+// requires grad.
+//
+// Decomposition: member-centric.  The host lists, per (batch row, member), the points whose
+// normalised blend weight exceeds prune_tol; one workgroup = 8 wavefronts = one member x 64 listed
+// points.  It recomputes the member's forward (activations in LDS as split-bf16 K chunks, every
+// wavefront owns one 32-row output tile of every layer, weights stream L2 -> VGPR from the forward
+// pack), keeps sigma'(d_l) of its own tiles in registers, then runs the transposed chain
+//   G3 = g w_k/denom * w4 * s3,  G2 = (W3^T G3) s2,  G1 = (W2a^T G2 / sqrt2) s1,  G0 = (W1^T G1) s0,
+//   d c = W0c^T G0 + W2c^T G2 / sqrt2
+// on the same MFMA path (split-bf16 x3, transposed pack), reduces the bias gradients over its points
+// and adds the blend-weight terms (f_k - sdf) d w_k / d q.  All in the scaled domain of layout.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "capi_common.h"
+#include "layout.h"
+
+namespace nphm {
+namespace bwd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WAVES = 8;
+constexpr int M = 64;                    // points per workgroup (2 m-tiles)
+constexpr int MT = 2;
+constexpr int NCH = 28;                  // 7 blocks x 4 K chunks of 8 features
+constexpr int PLANE_BYTES = NCH * M * 16;
+
+// transposed pack, per weight set (uint16 units): stage A = lin3^T, B = lin2^T (104 rows: h1 | coords),
+// C = lin1^T, D = lin0[:, :3]^T; fragments [ob][ks][hi|lo][lane][8] like the forward pack
+constexpr int A_OB = 7, A_KS = 13, B_OB = 4, B_KS = 13, C_OB = 7, C_KS = 7, D_OB = 1, D_KS = 13;
+constexpr int OFF_A = 0;
+constexpr int OFF_B = OFF_A + A_OB * A_KS * 1024;
+constexpr int OFF_C = OFF_B + B_OB * B_KS * 1024;
+constexpr int OFF_D = OFF_C + C_OB * C_KS * 1024;
+constexpr int BWD_SET_STRIDE = OFF_D + D_OB * D_KS * 1024;
+
+__device__ inline uint16_t f32_to_bf16_rn(float x) {
+  uint32_t u = __float_as_uint(x);
+  uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+  return uint16_t(r >> 16);
+}
+__device__ inline float bf16_to_f32(uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+
+struct PackArgs {
+  const float* w[5];
+  uint16_t* out;
+};
+
+// k-slot 8*h + i of K-step ks <-> feature feat_of(ks >> 1, 8*(ks & 1) + i, h) of the producing tile
+__global__ void pack_bwd_kernel(PackArgs a) {
+  const int s = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= BWD_SET_STRIDE) return;
+  int stage, x, nks;
+  if (e < OFF_B) { stage = 0; x = e - OFF_A; nks = A_KS; }
+  else if (e < OFF_C) { stage = 1; x = e - OFF_B; nks = B_KS; }
+  else if (e < OFF_D) { stage = 2; x = e - OFF_C; nks = C_KS; }
+  else { stage = 3; x = e - OFF_D; nks = D_KS; }
+  const int i = x & 7, lane = (x >> 3) & 63, part = (x >> 9) & 1, gg = x >> 10;
+  const int ks = gg % nks, ob = gg / nks;
+  const int row = 32 * ob + (lane & 31);                         // output row of the transposed stage
+  const int kf = feat_of(ks >> 1, 8 * (ks & 1) + i, lane >> 5);  // its K feature = output feature of the forward layer
+  float w = 0.f;
+  if (stage == 0) {                       // lin3^T: rows = lin3 inputs, K = lin3 outputs
+    if (row < HID && kf < HID) w = a.w[3][(size_t(s) * HID + kf) * HID + row];
+  } else if (stage == 1) {                // lin2^T: rows 0..100 h1 (1/sqrt2), rows 101..103 coords (k/sqrt2)
+    if (row < L2_IN && kf < HID) {
+      w = a.w[2][(size_t(s) * HID + kf) * HID + row] / INV_SQRT2_DIV;
+      if (row >= L1_OUT) w *= SP_SCALE;
+    }
+  } else if (stage == 2) {                // lin1^T: rows = lin1 inputs (200), K = lin1 outputs (101)
+    if (row < HID && kf < L1_OUT) w = a.w[1][(size_t(s) * L1_OUT + kf) * HID + row];
+  } else {                                // lin0[:, :3]^T: rows = coordinates, K = lin0 outputs
+    if (row < 3 && kf < HID) w = a.w[0][(size_t(s) * HID + kf) * D_IN + row] * SP_SCALE;
+  }
+  const uint16_t hi = f32_to_bf16_rn(w);
+  const uint16_t lo = f32_to_bf16_rn(w - bf16_to_f32(hi));
+  a.out[size_t(s) * BWD_SET_STRIDE + e] = part ? lo : hi;
+}
+
+struct BwdArgs {
+  const uint16_t* packed_bf16;    // forward pack (layout.h, bf16 half of the packed buffer)
+  const float* packed_f32;        // for lin4's bias
+  const uint16_t* packed_bwd;
+  const float* state;             // [n_rows, LS_ROW_STRIDE]
+  const float* xyz;               // [n_rows, n_points, 3]
+  const float* sdf;               // [n_rows, n_points] blended forward value
+  const float* gout;              // [n_rows, n_points] d L / d sdf
+  const int* tiles;               // [n_tiles][4] = row, member, offset into list, count (<= 64)
+  const int* list;                // point indices (within their row)
+  int64_t n_points;
+  float* gxyz;                    // [n_rows, n_points, 3]   (+=)
+  float* ganch;                   // [n_rows, 39, 3]         (+=)
+  float* gb0;                     // [n_rows, 40, 200]       (+=)
+  float* gb2;                     // [n_rows, 40, 200]       (+=)
+  float* fmem;                    // forward-only kernel: [n_rows, n_points, 40] member predictions
+};
+
+__device__ __forceinline__ float softplus2(float d) {
+  const float t = __builtin_amdgcn_exp2f(-fabsf(d));
+  return __builtin_amdgcn_fmed3f(d, 0.f, __builtin_inff()) + __builtin_amdgcn_logf(1.f + t);
+}
+__device__ __forceinline__ float sigmoid2(float d) {
+  const float t = __builtin_amdgcn_exp2f(-fabsf(d));
+  return (d >= 0.f ? 1.f : t) * __builtin_amdgcn_rcpf(1.f + t);
+}
+
+struct Split8 { bf16x8 hi, lo; };
+__device__ __forceinline__ Split8 split8(const float* x) {
+  Split8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hb = (__bf16)x[i];
+    o.hi[i] = hb;
+    o.lo[i] = (__bf16)(x[i] - (float)hb);
+  }
+  return o;
+}
+
+// B operand of the coordinate K-step (prep_kernels.hip, L0 block): h=0: xh | xl | 1 1; h=1: xh | 1 | xll | 0
+__device__ __forceinline__ bf16x8 coord_operand(float x, float y, float z, int h) {
+  const float cs[3] = {x, y, z};
+  __bf16 xh[3], xl[3], xll[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    xh[i] = (__bf16)cs[i];
+    const float r1 = cs[i] - (float)xh[i];
+    xl[i] = (__bf16)r1;
+    xll[i] = (__bf16)(r1 - (float)xl[i]);
+  }
+  const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+  bf16x8 bv;
+  bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
+  bv[3] = h ? one : xl[0];
+  bv[4] = h ? xll[0] : xl[1];
+  bv[5] = h ? xll[1] : xl[2];
+  bv[6] = h ? xll[2] : one;
+  bv[7] = h ? zero : one;
+  return bv;
+}
+
+__device__ __forceinline__ f32x16 load_frag16(const float* p) {
+  const f32x4* q = reinterpret_cast<const f32x4*>(p);
+  f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+  f32x16 o;
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+  o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  o[8] = c[0]; o[9] = c[1]; o[10] = c[2]; o[11] = c[3];
+  o[12] = d[0]; o[13] = d[1]; o[14] = d[2]; o[15] = d[3];
+  return o;
+}
+
+// sum over the 32 lanes of a half-wave (all lanes of the half end up with the total)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// BWD = false: the forward half only — per-member predictions f_k of the listed points into
+// fmem[row, point, member] (the host blends them); used by the autograd tier's forward, where the
+// query points are scattered surface samples for which the brick-coherent kernel of eval_kernel.hip
+// prunes poorly (a wavefront of 32 unrelated points touches most members).
+template <bool BWD>
+__global__ __launch_bounds__(64 * WAVES, 2) void ident_member_kernel(BwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char act_hi[PLANE_BYTES];
+  __shared__ __attribute__((aligned(16))) char act_lo[PLANE_BYTES];
+  __shared__ float part[WAVES][M];          // per-wave partial of lin4 / of the coordinate gradient
+  __shared__ float pt_q[M][4];              // query point, validity
+  __shared__ float pt_c[M][4];              // local coordinates of the member
+  __shared__ float pt_g[M][4];              // df (= g w_k / denom), blend coefficient, denominators
+  __shared__ float pt_dc[M][4];             // d L / d local coords from the skip layer
+  __shared__ int pt_idx[M];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int* tile = p.tiles + 4 * blockIdx.x;
+  const int row = tile[0], k = tile[1], off = tile[2], cnt = tile[3];
+  const int set = member_set(k);
+  const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
+  const float* anch = st + LS_OFF_ANCH;
+  const float sign_x = (k < 2 * N_SYMM && (k & 1)) ? -1.f : 1.f;
+  const float w_bg = expf(-0.2f / 0.01f);
+
+  // ---- per point (threads < M): coordinates, blend weights --------------------------------------
+  if (threadIdx.x < M) {
+    const int m = threadIdx.x;
+    const bool ok = m < cnt;
+    const int n = p.list[off + (ok ? m : cnt - 1)];
+    const float* q = p.xyz + (int64_t(row) * p.n_points + n) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    float S = w_bg, wk = w_bg, dk = 0.f, nk = 1.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll 1
+    for (int a = 0; a < N_LOC; ++a) {
+      const float dx = anch[3 * a] - qx, dy = anch[3 * a + 1] - qy, dz = anch[3 * a + 2] - qz;
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float d = nrm + 1e-5f;
+      const float w = expf(-(d * d) / 0.01f);
+      S += w;
+      if (a == k) { wk = w; dk = d; nk = nrm; ax = anch[3 * a]; ay = anch[3 * a + 1]; az = anch[3 * a + 2]; }
+    }
+    const float denom = S + 1e-6f;
+    const float g = ok ? p.gout[int64_t(row) * p.n_points + n] : 0.f;
+    pt_idx[m] = ok ? n : -1;
+    pt_q[m][0] = qx; pt_q[m][1] = qy; pt_q[m][2] = qz; pt_q[m][3] = nk;
+    pt_c[m][0] = sign_x * (qx - ax); pt_c[m][1] = qy - ay; pt_c[m][2] = qz - az; pt_c[m][3] = 0.f;
+    pt_g[m][0] = g * wk / denom;                                       // d L / d f_k
+    // d L / d w_k * d w_k / d d  (without the (f_k - sdf) factor, which needs the forward value)
+    pt_g[m][1] = (k < N_LOC) ? g / denom * wk * (-2.f * dk / 0.01f) : 0.f;
+    pt_g[m][2] = ok ? p.sdf[int64_t(row) * p.n_points + n] : 0.f;
+    pt_g[m][3] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- this lane's two points (m-tiles) ---------------------------------------------------------
+  float cx[MT], cy[MT], cz[MT];
+  bf16x8 bv[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = 32 * t + j;
+    cx[t] = pt_c[m][0]; cy[t] = pt_c[m][1]; cz[t] = pt_c[m][2];
+    bv[t] = coord_operand(cx[t], cy[t], cz[t], h);
+  }
+
+  const uint16_t* fw = p.packed_bf16 + size_t(set) * BF_SET_STRIDE;
+  const uint16_t* bw = p.packed_bwd + size_t(set) * BWD_SET_STRIDE;
+  const float* tails = st + LS_OFF_TAIL + size_t(k) * GEMM_CHUNKS * TAIL_FLOATS;
+  const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
+  const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
+  const f32x16 zero16 = {};
+
+  // out tile `n` of a stage: acc[t] += sum over ks K-steps of A(n, s) x act(s)   (split-bf16 x3)
+  auto gemm_tile = [&](f32x16 (&acc)[MT], const uint16_t* frag_base, int n, int ks) __attribute__((always_inline)) {
+    const bf16x8* W = reinterpret_cast<const bf16x8*>(frag_base) + size_t(n) * ks * 128 + lane;
+    bf16x8 ah[2], al[2], bh[2][MT], bl[2][MT];
+    auto load = [&](int slot, int s) __attribute__((always_inline)) {
+      ah[slot] = W[s * 128];
+      al[slot] = W[s * 128 + 64];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        bh[slot][t] = Bh[2 * s * M + 32 * t];
+        bl[slot][t] = Bl[2 * s * M + 32 * t];
+      }
+    };
+    auto mma = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot], bh[slot][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot], bl[slot][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot], bh[slot][t], acc[t], 0, 0, 0);
+      }
+    };
+    load(0, 0);
+#pragma unroll 1
+    for (int s = 0; s < ks; s += 2) {
+      if (s + 1 < ks) load(1, s + 1);
+      mma(0);
+      if (s + 2 < ks) load(0, s + 2);
+      if (s + 1 < ks) mma(1);
+    }
+  };
+  // D tile n -> LDS K chunks 4n + 2*half + h of the points
+  auto store_tile = [&](int n, const f32x16 (&v)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      float tmp[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmp[r] = v[t][r];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const Split8 s8 = split8(tmp + 8 * half);
+        const int o = ((4 * n + 2 * half + h) * M + 32 * t + j) * 16;
+        *reinterpret_cast<bf16x8*>(act_hi + o) = s8.hi;
+        *reinterpret_cast<bf16x8*>(act_lo + o) = s8.lo;
+      }
+    }
+  };
+
+  f32x16 acc[MT], s0[MT], s1[MT], s2[MT], s3[MT], val[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) { s0[t] = zero16; s1[t] = zero16; s2[t] = zero16; s3[t] = zero16; }
+
+  // ================================ forward (recompute) ==========================================
+  // L0: lin0 on the local coordinates, folded bias inside the block (per-latent state)
+  if (wave < 7) {
+    const bf16x8* A0 = reinterpret_cast<const bf16x8*>(st + LS_OFF_L0B + size_t(k) * L0_BLOCK_FLOATS) + lane;
+    const bf16x8 a = A0[wave * 64];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv[t], zero16, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[t][r] = sigmoid2(acc[t][r]); val[t][r] = softplus2(acc[t][r]); }
+    }
+    store_tile(wave, val);
+  }
+  __syncthreads();
+  // L1: 200 -> 101 (4 tiles); the skip coordinates join tile 3 as features 101..103
+  if (wave < L1_OB) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = load_frag16(tails + wave * TAIL_FLOATS + h * 16);
+    gemm_tile(acc, fw + BF_OFF_L1A, wave, L1_KS16);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1[t][r] = sigmoid2(acc[t][r]); val[t][r] = softplus2(acc[t][r]); }
+      if (wave == L1_OB - 1) {
+        val[t][1] = h ? cx[t] : val[t][1];
+        val[t][2] = h ? cy[t] : val[t][2];
+        val[t][3] = h ? cz[t] : val[t][3];
+      }
+    }
+  }
+  __syncthreads();                       // every wavefront has read a0
+  if (wave < L1_OB) store_tile(wave, val);
+  __syncthreads();
+  // L2: 104 -> 200
+  if (wave < 7) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = load_frag16(tails + (L1_OB + wave) * TAIL_FLOATS + h * 16);
+    gemm_tile(acc, fw + BF_OFF_L2A, wave, L2_KS16);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s2[t][r] = sigmoid2(acc[t][r]); val[t][r] = softplus2(acc[t][r]); }
+  }
+  __syncthreads();
+  if (wave < 7) store_tile(wave, val);
+  __syncthreads();
+  // L3: 200 -> 200, lin4 fused: f = sum a3 * w4 / k + b4
+  f32x16 w4v = zero16;
+  if (wave < 7) {
+    const float* tl = tails + (L1_OB + L2_OB + wave) * TAIL_FLOATS;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = load_frag16(tl + h * 16);
+    gemm_tile(acc, fw + BF_OFF_L3A, wave, L3_KS16);
+    w4v = load_frag16(tl + 32 + h * 16);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      float partial = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s3[t][r] = sigmoid2(acc[t][r]);
+        partial = fmaf(softplus2(acc[t][r]), w4v[r], partial);
+      }
+      partial += __shfl_xor(partial, 32);
+      if (h == 0) part[wave][32 * t + j] = partial;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < M) {
+    const int m = threadIdx.x;
+    float f = p.packed_f32[size_t(set) * SET_STRIDE + OFF_L4B];
+#pragma unroll
+    for (int w = 0; w < 7; ++w) f += part[w][m];
+    if (!BWD) {
+      if (pt_idx[m] >= 0) p.fmem[(int64_t(row) * p.n_points + pt_idx[m]) * N_MEMBERS + k] = f;
+    }
+    // blend-weight term: d L / d q += g (f_k - sdf) / denom * d w_k / d d * (q - a_k) / |q - a_k|
+    pt_g[m][3] = pt_g[m][1] * (f - pt_g[m][2]);
+  }
+  if (!BWD) return;
+  __syncthreads();
+
+  // ================================ backward =====================================================
+  // G3 = df * (w4 / k) * s3   (gradient w.r.t. the SCALED pre-activation of lin3)
+  if (wave < 7) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const float df = pt_g[32 * t + j][0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) val[t][r] = df * w4v[r] * s3[t][r];
+    }
+    store_tile(wave, val);               // a2 is no longer needed (every wavefront passed the barriers above)
+  }
+  __syncthreads();
+  // stage A: G2 = (lin3^T G3) * s2 ; bias gradient of the skip layer
+  if (wave < 7) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = zero16;
+    gemm_tile(acc, bw + OFF_A, wave, A_KS);
+    float* gb = p.gb2 + (size_t(row) * N_MEMBERS + k) * HID;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) { val[t][r] = acc[t][r] * s2[t][r]; sum += val[t][r]; }
+      sum = half_wave_sum(sum);
+      const int f = feat_of(wave, r, h);
+      if (j == 0 && f < HID) atomicAdd(gb + f, sum * SP_SCALE);
+    }
+  }
+  __syncthreads();
+  if (wave < 7) store_tile(wave, val);
+  __syncthreads();
+  // stage B: rows 0..100: G1 = (lin2a^T G2 / sqrt2) * s1 ; rows 101..103: d L / d coords (skip path)
+  if (wave < B_OB) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = zero16;
+    gemm_tile(acc, bw + OFF_B, wave, B_KS);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) val[t][r] = acc[t][r] * s1[t][r];
+      if (wave == B_OB - 1) {
+        if (h) {                          // features 101..103 = registers 1..3 of the upper half-wave
+          pt_dc[32 * t + j][0] = acc[t][1]; pt_dc[32 * t + j][1] = acc[t][2]; pt_dc[32 * t + j][2] = acc[t][3];
+          val[t][1] = 0.f; val[t][2] = 0.f; val[t][3] = 0.f;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < B_OB) store_tile(wave, val);
+  __syncthreads();
+  // stage C: G0 = (lin1^T G1) * s0 ; bias gradient of lin0
+  if (wave < 7) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = zero16;
+    gemm_tile(acc, bw + OFF_C, wave, C_KS);
+    float* gb = p.gb0 + (size_t(row) * N_MEMBERS + k) * HID;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) { val[t][r] = acc[t][r] * s0[t][r]; sum += val[t][r]; }
+      sum = half_wave_sum(sum);
+      const int f = feat_of(wave, r, h);
+      if (j == 0 && f < HID) atomicAdd(gb + f, sum * SP_SCALE);
+    }
+  }
+  __syncthreads();
+  if (wave < 7) store_tile(wave, val);
+  __syncthreads();
+  // stage D: d L / d coords (lin0 path) = (k lin0[:, :3])^T G0 ; one tile, wavefront 0
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = zero16;
+    gemm_tile(acc, bw + OFF_D, 0, D_KS);
+    if (h == 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        float* o = pt_dc[32 * t + j];
+        // rows 0..2 of the tile = registers 0..2 of the lower half-wave
+        o[0] += acc[t][0]; o[1] += acc[t][1]; o[2] += acc[t][2];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- per point: chain to the query point and to the anchor --------------------------------------
+  if (threadIdx.x < M) {
+    const int m = threadIdx.x;
+    const int n = pt_idx[m];
+    float gq[3] = {0.f, 0.f, 0.f};
+    if (n >= 0) {
+      gq[0] = sign_x * pt_dc[m][0]; gq[1] = pt_dc[m][1]; gq[2] = pt_dc[m][2];      // through c = s (q - a)
+      float ga[3] = {0.f, 0.f, 0.f};
+      if (k < N_LOC) {
+        ga[0] = -gq[0]; ga[1] = -gq[1]; ga[2] = -gq[2];
+        const float nk = pt_q[m][3];
+        if (nk > 0.f) {                                                            // through w_k(|q - a_k|)
+          const float cb = pt_g[m][3] / nk;
+          const float ex = sign_x * pt_c[m][0], ey = pt_c[m][1], ez = pt_c[m][2];   // q - a_k
+          gq[0] += cb * ex; gq[1] += cb * ey; gq[2] += cb * ez;
+          ga[0] -= cb * ex; ga[1] -= cb * ey; ga[2] -= cb * ez;
+        }
+      } else {
+        gq[0] = pt_dc[m][0];      // the background member sees global coordinates (no anchor)
+      }
+      float* o = p.gxyz + (int64_t(row) * p.n_points + n) * 3;
+      atomicAdd(o, gq[0]); atomicAdd(o + 1, gq[1]); atomicAdd(o + 2, gq[2]);
+      pt_q[m][0] = ga[0]; pt_q[m][1] = ga[1]; pt_q[m][2] = ga[2];
+    } else {
+      pt_q[m][0] = 0.f; pt_q[m][1] = 0.f; pt_q[m][2] = 0.f;
+    }
+    // anchor gradient: sum over the workgroup's points (one wavefront holds all 64)
+    float sx = pt_q[m][0], sy = pt_q[m][1], sz = pt_q[m][2];
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) { sx += __shfl_xor(sx, o2); sy += __shfl_xor(sy, o2); sz += __shfl_xor(sz, o2); }
+    if (m == 0 && k < N_LOC) {
+      float* o = p.ganch + (size_t(row) * N_LOC + k) * 3;
+      atomicAdd(o, sx); atomicAdd(o + 1, sy); atomicAdd(o + 2, sz);
+    }
+  }
+}
+
+}  // namespace bwd
+}  // namespace nphm
+
+// ============================================================================================
+// C ABI (include/nphm_amd.h)
+// ============================================================================================
+extern "C" {
+
+size_t nphm_identity_bwd_packed_bytes(void) { return size_t(nphm::N_SETS) * nphm::bwd::BWD_SET_STRIDE * 2; }
+
+int nphm_identity_pack_bwd(const float* const lin_weight[5], void* packed_bwd, void* stream) {
+  if (!packed_bwd) return nphm_fail_msg("nphm_identity_pack_bwd: null packed buffer");
+  nphm::bwd::PackArgs a;
+  for (int i = 0; i < 5; ++i) {
+    if (!lin_weight[i]) return nphm_fail_msg("nphm_identity_pack_bwd: null weight pointer");
+    a.w[i] = lin_weight[i];
+  }
+  a.out = static_cast<uint16_t*>(packed_bwd);
+  dim3 g((nphm::bwd::BWD_SET_STRIDE + 255) / 256, nphm::N_SETS);
+  hipLaunchKernelGGL(nphm::bwd::pack_bwd_kernel, g, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_pack_bwd launch", e);
+  return 0;
+}
+
+int nphm_identity_backward(const void* packed, const void* packed_bwd, const void* latent_state,
+                           const float* xyz, const float* sdf, const float* grad_sdf, int64_t n_points,
+                           const int* tiles, int n_tiles, const int* point_list,
+                           float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2, void* stream) {
+  if (!packed || !packed_bwd || !latent_state || !xyz || !sdf || !grad_sdf || !tiles || !point_list || !grad_xyz ||
+      !grad_anchors || !grad_b0 || !grad_b2)
+    return nphm_fail_msg("nphm_identity_backward: null pointer");
+  if (n_points <= 0 || n_tiles < 0) return nphm_fail_msg("nphm_identity_backward: bad sizes");
+  if (n_tiles == 0) return 0;
+  nphm::bwd::BwdArgs a;
+  a.packed_f32 = static_cast<const float*>(packed);
+  a.packed_bf16 = reinterpret_cast<const uint16_t*>(static_cast<const char*>(packed) + nphm::PACKED_F32_FLOATS * 4);
+  a.packed_bwd = static_cast<const uint16_t*>(packed_bwd);
+  a.state = static_cast<const float*>(latent_state);
+  a.xyz = xyz; a.sdf = sdf; a.gout = grad_sdf;
+  a.tiles = tiles; a.list = point_list; a.n_points = n_points;
+  a.gxyz = grad_xyz; a.ganch = grad_anchors; a.gb0 = grad_b0; a.gb2 = grad_b2;
+  a.fmem = nullptr;
+  hipLaunchKernelGGL(nphm::bwd::ident_member_kernel<true>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_backward launch", e);
+  return 0;
+}
+
+int nphm_identity_member_forward(const void* packed, const void* packed_bwd, const void* latent_state,
+                                 const float* xyz, int64_t n_points, const int* tiles, int n_tiles,
+                                 const int* point_list, float* member_sdf, void* stream) {
+  if (!packed || !latent_state || !xyz || !tiles || !point_list || !member_sdf)
+    return nphm_fail_msg("nphm_identity_member_forward: null pointer");
+  if (n_points <= 0 || n_tiles < 0) return nphm_fail_msg("nphm_identity_member_forward: bad sizes");
+  if (n_tiles == 0) return 0;
+  nphm::bwd::BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed_f32 = static_cast<const float*>(packed);
+  a.packed_bf16 = reinterpret_cast<const uint16_t*>(static_cast<const char*>(packed) + nphm::PACKED_F32_FLOATS * 4);
+  a.packed_bwd = static_cast<const uint16_t*>(packed_bwd);      // unused by the forward half
+  a.state = static_cast<const float*>(latent_state);
+  a.xyz = xyz;
+  a.sdf = xyz; a.gout = xyz;                                      // read but ignored (valid memory)
+  a.tiles = tiles; a.list = point_list; a.n_points = n_points;
+  a.fmem = member_sdf;
+  hipLaunchKernelGGL(nphm::bwd::ident_member_kernel<false>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_member_forward launch", e);
+  return 0;
+}
+
+}  // extern "C"

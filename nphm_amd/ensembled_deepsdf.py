@@ -9,6 +9,11 @@ Execution tiers of ``FastEnsembleDeepSDFMirrored.forward``:
   live on a ROCm device, the architecture is the NPHM one (nphm.yaml) and the latent is constant
   along the point axis (what get_logits / the fitting loop pass).  One fused kernel evaluates the
   40-member ensemble and the Gaussian blend; if the library is missing this tier raises.
+* **HIP autograd** (first order): when a graph IS needed but no parameter requires grad (latent
+  fitting: only xyz / the latent are optimised), in training mode: forward = the same fused kernel,
+  backward = ``nphm_identity_backward`` (member-centric MFMA kernel) for d/dxyz, d/danchors and
+  d/d(folded biases), chained through ``mlp_pos`` and the latent columns by ordinary autograd.  Not
+  double-differentiable (training needs the composite tier, which it gets: its parameters require grad).
 * **composite**: a differentiable PyTorch formulation (latent columns of lin0 / the skip layer are
   applied once per latent instead of once per point).  Used when gradients are required
   (fitting / training, incl. double backward), for per-point latents and for other architectures.
@@ -147,6 +152,80 @@ def sample_point_feature(q, p, fea, var=0.1 ** 2, background=False):
     return (w.unsqueeze(-1) * fea).sum(dim=2)
 
 
+def _member_point_lists(anchors, xyz, prune_tol, n_members):
+    """(row, member) -> points whose normalised blend weight exceeds ``prune_tol`` (all points if
+    negative): blend weights [B,N,A] (zero where pruned), tile table int32 [T,4] = (row, member,
+    offset into the point list, count <= 64) and the point list int32 [P] (sorted by row, member,
+    point).  One host sync (the per-pair counts size the launch)."""
+    B, N, _ = xyz.shape
+    A = n_members
+    d = (anchors[:, None, :, :] - xyz[:, :, None, :]).norm(dim=3) + 1e-5
+    w = torch.exp(-(d * d) / 0.01)
+    w_bg = float(np.exp(-20.0))
+    denom = w.sum(dim=2, keepdim=True) + w_bg + 1e-6
+    what = torch.cat([w, torch.full_like(w[:, :, :1], w_bg)], dim=2) / denom
+    mask = what > float(prune_tol) if prune_tol >= 0 else torch.ones_like(what, dtype=torch.bool)
+    idx = mask.permute(0, 2, 1).nonzero()                      # sorted by (row, member, point)
+    counts = torch.bincount(idx[:, 0] * A + idx[:, 1], minlength=B * A).cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    n_t = (counts + 63) // 64                                  # 64-point tiles per (row, member)
+    bk = np.repeat(np.arange(B * A), n_t)
+    within = np.arange(int(n_t.sum())) - np.repeat(np.cumsum(n_t) - n_t, n_t)
+    tiles = np.stack([bk // A, bk % A, offs[bk] + 64 * within, np.minimum(64, counts[bk] - 64 * within)],
+                     axis=1).astype(np.int32)
+    return what * mask, torch.from_numpy(tiles).to(xyz.device), idx[:, 2].to(torch.int32).contiguous()
+
+
+class _IdentityFieldFn(torch.autograd.Function):
+    """sdf = field(xyz; anchors, folded biases) with hand-written forward and first-order backward
+    kernels (member-centric: one workgroup = one member x 64 of the points that member matters for).
+    The kernels work on the HIP prologue's state (built from the detached latent rows); ``anchors`` /
+    ``b0f`` / ``b2f`` are the same quantities as differentiable torch tensors and only receive
+    gradients."""
+
+    @staticmethod
+    def forward(ctx, module, xyz, lat_rows, anchors, b0f, b2f):
+        lib = _lib.load()
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        A = module.num_kps + 1
+        packed, state, anchors_hip = module.prepare_latent(lat_rows)
+        xyz_c = xyz.detach().contiguous().float()
+        what, tiles, plist = _member_point_lists(anchors_hip, xyz_c, module.prune_tol, A)
+        fmem = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if tiles.shape[0]:
+            _lib.check(lib.nphm_identity_member_forward(
+                packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N,
+                tiles.data_ptr(), tiles.shape[0], plist.data_ptr(), fmem.data_ptr(), stream),
+                "nphm_identity_member_forward")
+        out = (what * fmem).sum(dim=2, keepdim=True)
+        ctx.module = module
+        ctx.save_for_backward(xyz_c, out, packed, state, tiles, plist)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        module = ctx.module
+        xyz, out, packed, state, tiles, plist = ctx.saved_tensors
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        A = module.num_kps + 1
+        gx = torch.zeros(B, N, 3, dtype=torch.float32, device=dev)
+        ga = torch.zeros(B, module.num_kps, 3, dtype=torch.float32, device=dev)
+        gb0 = torch.zeros(B, A, module.hidden_dim, dtype=torch.float32, device=dev)
+        gb2 = torch.zeros_like(gb0)
+        if tiles.shape[0]:
+            g = grad_out.detach().reshape(B, N).contiguous().float()
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.nphm_identity_backward(
+                packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz.data_ptr(),
+                out.data_ptr(), g.data_ptr(), N, tiles.data_ptr(), tiles.shape[0], plist.data_ptr(), gx.data_ptr(),
+                ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_backward")
+        return None, gx, None, ga, gb0, gb2
+
+
 class FastEnsembleDeepSDFMirrored(nn.Module):
     """NPHM identity SDF: one small MLP per facial anchor (+ one background MLP), evaluated in
     anchor-local coordinates (odd member of each symmetric pair mirrored in x) and blended by a
@@ -183,6 +262,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         self.prune_tol = float(os.environ.get("NPHM_AMD_PRUNE_TOL", "1e-7"))
         self.precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3")   # "bf16x3" | "f32"
         self._pack_cache = None         # (key, packed tensor)
+        self._pack_bwd_cache = None     # (key, transposed pack for the backward kernel)
 
     # ------------------------------------------------------------------------------------------
     def hip_supported(self) -> bool:
@@ -213,6 +293,19 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         _lib.check(lib.nphm_identity_pack(_lib.ptr_array5(ws), _lib.ptr_array5(bs), packed.data_ptr(), stream),
                    "nphm_identity_pack")
         self._pack_cache = (key, packed)
+        return packed
+
+    def _packed_bwd(self, device):
+        """Transposed split-bf16 pack of lin0..lin3 for nphm_identity_backward (cached like _packed)."""
+        ws, _ = self._lin_params()
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in ws) + (str(device),)
+        if self._pack_bwd_cache is not None and self._pack_bwd_cache[0] == key:
+            return self._pack_bwd_cache[1]
+        lib = _lib.load()
+        packed = torch.empty(lib.nphm_identity_bwd_packed_bytes(), dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.nphm_identity_pack_bwd(_lib.ptr_array5(ws), packed.data_ptr(), stream), "nphm_identity_pack_bwd")
+        self._pack_bwd_cache = (key, packed)
         return packed
 
     def prepare_latent(self, lat_rows: torch.Tensor):
@@ -250,6 +343,23 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             float(self.prune_tol), self._precision_code(), out.data_ptr(), None, stream),
             "nphm_identity_eval_points")
         return out, anchors
+
+    def _forward_hip_autograd(self, xyz, lat_rows):
+        """Differentiable (first order) w.r.t. xyz and the latent rows; values from the fused kernel."""
+        B = xyz.shape[0]
+        g, A = self.lat_dim_glob, self.num_kps + 1
+        anchors = self.mlp_pos(lat_rows[:, :g]).view(B, self.num_kps, 3)
+        anchors = anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
+        cond = torch.cat([lat_rows[:, None, :g].expand(B, A, g), lat_rows[:, g:].reshape(B, A, self.lat_dim_loc)], dim=-1)
+        e = self.ensembled_deep_sdf
+        d_in = self.input_dim
+        n1 = e.lin1.out_features                          # width of the skip layer's hidden part
+        W0 = e.lin0.member_weight()[:, :, d_in:]          # [A, H, 96] latent columns of lin0
+        W2 = e.lin2.member_weight()[:, :, n1 + d_in:]     # [A, H, 96] latent columns of the skip layer
+        b0f = torch.einsum("bkc,kfc->bkf", cond, W0) + e.lin0.member_bias()[None]
+        b2f = torch.einsum("bkc,kfc->bkf", cond, W2) / _SQRT2 + e.lin2.member_bias()[None]
+        sdf = _IdentityFieldFn.apply(self, xyz, lat_rows.detach(), anchors, b0f, b2f)
+        return sdf, anchors
 
     def _forward_composite(self, xyz, lat_rep):
         B, N, _ = xyz.shape
@@ -294,10 +404,16 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             raise _lib.NphmAmdError(
                 "FastEnsembleDeepSDFMirrored: tensors are on the CPU; the HIP path needs a ROCm device "
                 "(set module.backend = 'composite' explicitly for the PyTorch formulation)")
-        if needs_graph or not self.hip_supported() or xyz.dtype != torch.float32:
+        if not self.hip_supported() or xyz.dtype != torch.float32:
             return self._forward_composite(xyz, lat_rep)
         if lat_rep.shape[1] != 1:
             # get_logits passes encoding.repeat(1, N, 1): constant along the point axis
             if lat_rep.shape[1] != N or not bool((lat_rep == lat_rep[:, :1]).all()):
                 return self._forward_composite(xyz, lat_rep)
+        if needs_graph:
+            # first-order HIP autograd tier: latent fitting (no parameter requires grad, train mode, no
+            # chunk overwrite to differentiate around); everything else builds the composite graph
+            if self.training and not any(p.requires_grad for p in self.parameters()):
+                return self._forward_hip_autograd(xyz, lat_rep[:, 0, :])
+            return self._forward_composite(xyz, lat_rep)
         return self._forward_hip(xyz, lat_rep[:, 0, :])

@@ -10,6 +10,7 @@ Same signatures, RNG consumption order, schedules and loss terms as the referenc
 keyword-only (``verbose``, ``history``)."""
 from __future__ import annotations
 
+from contextlib import contextmanager
 from typing import Dict, List, Optional
 
 import torch
@@ -18,6 +19,22 @@ from torch import optim
 from .iterative_root_finding import jac, nabla, search
 
 _UNOBSERVED = (30, 31, 39)          # local codes that the single-view scans never see (fitting.py:148)
+
+
+@contextmanager
+def _frozen(*modules):
+    """The fitting loops optimise latent codes only; the reference leaves the decoders' parameters
+    trainable and lets autograd fill their .grad, which nothing reads.  Freezing them
+    for the duration of the loop skips that work and lets the identity field use its hand-written
+    first-order backward; the flags are restored afterwards.  The fitted latents do not change."""
+    saved = [(p, p.requires_grad) for m in modules if m is not None for p in m.parameters()]
+    for p, _ in saved:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p, flag in saved:
+            p.requires_grad_(flag)
 
 
 def _apply_schedule(j, step_scale, schedule_cfg, lambdas, optimizers, with_expr):
@@ -109,57 +126,58 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     local = hasattr(decoder, "lat_dim_loc")
     anchors = None
 
-    for j in range(int(n_steps * step_scale)):
-        _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt, opt_expr), True)
-        opt.zero_grad()
-        opt_expr.zero_grad()
+    with _frozen(decoder, decoder_expr):
+        for j in range(int(n_steps * step_scale)):
+            _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt, opt_expr), True)
+            opt.zero_grad()
+            opt_expr.zero_grad()
 
-        # anchors of the current identity code (N = 1 forward; only mlp_pos matters)
-        _, anchors = decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)
+            # anchors of the current identity code (N = 1 forward; only mlp_pos matters)
+            _, anchors = decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)
 
-        obs_idx, obs = _sample_observations(all_obs, n_batch, n_points)
-        obs_idx = obs_idx.long().to(device)
-        glob_cond = torch.cat([lat_rep_shape.repeat(n_batch, 1, 1), lat_rep[obs_idx, :, :]], dim=-1)
+            obs_idx, obs = _sample_observations(all_obs, n_batch, n_points)
+            obs_idx = obs_idx.long().to(device)
+            glob_cond = torch.cat([lat_rep_shape.repeat(n_batch, 1, 1), lat_rep[obs_idx, :, :]], dim=-1)
 
-        # canonical correspondences by Broyden root finding (no gradient flows through it)
-        anchors_rep = anchors.clone().unsqueeze(1).repeat(n_batch, obs.shape[1], 1, 1) if local else None
-        p_corresp, search_result = search(obs, glob_cond.repeat(1, obs.shape[1], 1), decoder_expr, anchors_rep,
-                                          multi_corresp=False)
-        p_corresp = p_corresp.detach()
-        _anchors = None
-        if anchors is not None:
-            _anchors = anchors.clone().unsqueeze(1).repeat(n_batch, p_corresp.shape[1], 1, 1)
+            # canonical correspondences by Broyden root finding (no gradient flows through it)
+            anchors_rep = anchors.clone().unsqueeze(1).repeat(n_batch, obs.shape[1], 1, 1) if local else None
+            p_corresp, search_result = search(obs, glob_cond.repeat(1, obs.shape[1], 1), decoder_expr, anchors_rep,
+                                              multi_corresp=False)
+            p_corresp = p_corresp.detach()
+            _anchors = None
+            if anchors is not None:
+                _anchors = anchors.clone().unsqueeze(1).repeat(n_batch, p_corresp.shape[1], 1, 1)
 
-        # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
-        cond_rep = glob_cond.repeat(1, p_corresp.shape[1], 1)
-        preds_posed, _ = decoder_expr(p_corresp, cond_rep, _anchors)
-        preds_posed = preds_posed + p_corresp
-        grad_inv = jac(decoder_expr, p_corresp, cond_rep, _anchors).inverse()
-        correction = preds_posed - preds_posed.detach()
-        correction = torch.einsum("bnij,bnj->bni", -grad_inv.detach(), correction)
-        xc = p_corresp + correction
+            # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
+            cond_rep = glob_cond.repeat(1, p_corresp.shape[1], 1)
+            preds_posed, _ = decoder_expr(p_corresp, cond_rep, _anchors)
+            preds_posed = preds_posed + p_corresp
+            grad_inv = jac(decoder_expr, p_corresp, cond_rep, _anchors).inverse()
+            correction = preds_posed - preds_posed.detach()
+            correction = torch.einsum("bnij,bnj->bni", -grad_inv.detach(), correction)
+            xc = p_corresp + correction
 
-        shape_cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
-        sdf, _ = decoder(xc, shape_cond, None)
-        if compute_unused_sdf_grad:
-            _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
+            shape_cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
+            sdf, _ = decoder(xc, shape_cond, None)
+            if compute_unused_sdf_grad:
+                _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
 
-        sdf = sdf[search_result["valid_ids"], :]
-        loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale),
-                     "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
-        _shape_regularisers(decoder, lat_rep_shape, loss_dict)
+            sdf = sdf[search_result["valid_ids"], :]
+            loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale),
+                         "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
+            _shape_regularisers(decoder, lat_rep_shape, loss_dict)
 
-        loss = 0
-        for k in lambdas.keys():
-            loss = loss + loss_dict[k] * lambdas[k]
-        loss.backward()
-        opt.step()
-        opt_expr.step()
-        if history is not None:
-            history.append({k: float(torch.as_tensor(loss_dict[k]).detach()) for k in lambdas.keys()} |
-                           {"loss": float(loss.detach()), "n_valid": int(search_result["valid_ids"].sum())})
-        if verbose:
-            _report(j, lambdas, loss_dict, search_result["valid_ids"].sum().item())
+            loss = 0
+            for k in lambdas.keys():
+                loss = loss + loss_dict[k] * lambdas[k]
+            loss.backward()
+            opt.step()
+            opt_expr.step()
+            if history is not None:
+                history.append({k: float(torch.as_tensor(loss_dict[k]).detach()) for k in lambdas.keys()} |
+                               {"loss": float(loss.detach()), "n_valid": int(search_result["valid_ids"].sum())})
+            if verbose:
+                _report(j, lambdas, loss_dict, search_result["valid_ids"].sum().item())
 
     return lat_rep, lat_rep_shape, anchors
 
@@ -176,24 +194,25 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
     local = hasattr(decoder, "lat_dim_loc")
     anchors = None
 
-    for j in range(int(n_steps * step_scale)):
-        _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt,), False)
-        opt.zero_grad()
-        _, anchors = decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)
-        _, obs = _sample_observations(all_obs, n_batch, n_points)
-        cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
-        sdf, _ = decoder(obs, cond, None)
-        loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale)}
-        _shape_regularisers(decoder, lat_rep_shape, loss_dict)
-        loss = 0
-        for k in lambdas.keys():
-            loss = loss + loss_dict[k] * lambdas[k]
-        loss.backward()
-        opt.step()
-        if history is not None:
-            history.append({k: float(torch.as_tensor(loss_dict[k]).detach()) for k in lambdas.keys()} |
-                           {"loss": float(loss.detach())})
-        if verbose:
-            _report(j, lambdas, loss_dict)
+    with _frozen(decoder):
+        for j in range(int(n_steps * step_scale)):
+            _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt,), False)
+            opt.zero_grad()
+            _, anchors = decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)
+            _, obs = _sample_observations(all_obs, n_batch, n_points)
+            cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
+            sdf, _ = decoder(obs, cond, None)
+            loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale)}
+            _shape_regularisers(decoder, lat_rep_shape, loss_dict)
+            loss = 0
+            for k in lambdas.keys():
+                loss = loss + loss_dict[k] * lambdas[k]
+            loss.backward()
+            opt.step()
+            if history is not None:
+                history.append({k: float(torch.as_tensor(loss_dict[k]).detach()) for k in lambdas.keys()} |
+                               {"loss": float(loss.detach())})
+            if verbose:
+                _report(j, lambdas, loss_dict)
 
     return lat_rep_shape, anchors

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backend", default=None, choices=[None, "composite"])
     ap.add_argument("--profile", action="store_true", help="synchronising per-phase timers (slower)")
+    ap.add_argument("--torch-profile", action="store_true", help="torch.profiler table of 5 steps")
     ap.add_argument("--with-unused-nabla", action="store_true", help="also evaluate the reference's dead nabla() call")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -83,6 +84,13 @@ def main():
     kw = {"compute_unused_sdf_grad": args.with_unused_nabla}
     F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), args.warmup, cfg, verbose=False, **kw)
     torch.cuda.synchronize()
+    if args.torch_profile:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), 5, cfg, verbose=False, **kw)
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=28, max_name_column_width=48))
+        print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=14, max_name_column_width=60))
     hist = []
     t0 = time.perf_counter()
     F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), args.steps, cfg, verbose=False,
