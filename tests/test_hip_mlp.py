@@ -361,3 +361,32 @@ def test_fused_broyden_matches_the_python_solver(dev):
         with torch.no_grad():
             off, _ = d(xc_f, cond, anc)
         assert float((xc_f + off - obs)[vf].norm(dim=-1).max()) < 5e-6
+
+
+def test_two_stage_full_size_256_cubed_properties(dnet, dev):
+    """BASELINE.json configs[2] at full size: deformation -> identity on 256^3, checked through
+    determinism, slab invariance and a random subsample against the points kernels / the oracle."""
+    res = 256
+    inet = U.build_identity(device=dev).eval()
+    g = U.golden("deformation")
+    lat_id = _t(g["lat"].reshape(-1)[:1344], dev)
+    lat_ex = _t(g["lat"].reshape(-1), dev)
+    axes = R.grid_axes(U.MINI, U.MAXI, res)
+    vol, can = R.evaluate_grid_two_stage(inet, dnet, lat_id, lat_ex, axes, hack_chunk=0, return_canonical=True)
+    assert vol.shape == (res ** 3,) and can.shape == (res ** 3, 3) and bool(torch.isfinite(vol).all())
+    slab = R.evaluate_grid_two_stage(inet, dnet, lat_id, lat_ex, axes, hack_chunk=0, x_range=(96, 104))
+    assert torch.equal(slab, vol.view(res, -1)[96:104].reshape(-1))
+    rng = np.random.default_rng(1)
+    keep = rng.choice(res ** 3, 2048, replace=False)
+    ax, ay, az = axes
+    pts = np.stack([ax[keep // (res * res)], ay[(keep // res) % res], az[keep % res]], -1).astype(np.float32)
+    anchors = inet.prepare_latent(lat_id[None])[2]
+    with torch.no_grad():
+        off, _ = dnet(_t(pts[None], dev), lat_ex[None, None], anchors)
+    k = torch.from_numpy(keep).to(dev)
+    assert U.maxdiff(can[k].cpu().numpy(), pts + off[0].cpu().numpy()) < 1e-6
+    sub = slice(0, 128)
+    off_o, _ = O.deformation_forward(U.np_state(dnet), pts[None, sub], g["lat"], anchors.cpu().numpy())
+    ref, _ = O.nphm_identity_forward(U.np_state(inet), U.anchors_mean(), (pts[None, sub] + off_o).astype(np.float32),
+                                     g["lat"][:, :, :1344], training=True)
+    assert U.maxdiff(vol[k][sub].cpu().numpy(), ref.reshape(-1)) < TOL_BAR
