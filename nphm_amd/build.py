@@ -24,7 +24,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-fno-honor-nans",
            "-I", os.path.join(HERE, "..", "include")]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
     if verbose:

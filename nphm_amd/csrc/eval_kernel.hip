@@ -64,9 +64,16 @@ struct EvalArgs {
 // here the log term is already 0 in fp32 for 100 d > 16.7, so the two agree to < 1e-9 in d units.
 __device__ __forceinline__ float softplus2(float d) {
   const float t = __builtin_amdgcn_exp2f(-fabsf(d));                 // raw v_exp_f32
-  return __builtin_amdgcn_fmed3f(d, 0.f, __builtin_inff()) +         // relu without a canonicalize
-         __builtin_amdgcn_logf(1.f + t);                             // raw v_log_f32, arg in [1,2]
+  // relu: built with -fno-honor-nans so that it is ONE v_max_f32 (otherwise a canonicalising
+  // v_max(x, x) is put in front; inline asm is not an option - it would read MFMA results without
+  // the hazard wait states the compiler inserts for its own instructions)
+  return fmaxf(d, 0.f) + __builtin_amdgcn_logf(1.f + t);             // raw v_log_f32, arg in [1,2]
 }
+
+// registers of the LAST 32-row block of a layer that hold real features: 200 = 6*32 + 8 and
+// 101 + 3 = 3*32 + 8 -> features 32b .. 32b+7 = registers 0..3 of both half-waves; the other 12
+// registers are padding (zero weights downstream) and skip the epilogue arithmetic
+constexpr int LAST_BLOCK_REGS = 4;
 
 // Pin values at this program point.  Without a use in the producing basic block LLVM sinks the
 // (pure) softplus arithmetic across the next workgroup barrier, next to the MFMAs that consume it,
@@ -584,16 +591,17 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       if constexpr (c == 0) {
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
-          f32x16 v;
+          f32x16 v = {};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = softplus2(d0[b][r]);
+          for (int r = 0; r < (b == 6 ? LAST_BLOCK_REGS : 16); ++r) v[r] = softplus2(d0[b][r]);
           store_act(v, H[b]);
         }
       } else if constexpr (c - 1 < L1_OB + L2_OB) {
         constexpr int g = c - 1;
-        f32x16 v;
+        constexpr bool last_block = g == L1_OB - 1 || g == L1_OB + L2_OB - 1;
+        f32x16 v = {};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = softplus2(d[r]);
+        for (int r = 0; r < (last_block ? LAST_BLOCK_REGS : 16); ++r) v[r] = softplus2(d[r]);
         if constexpr (g == L1_OB - 1) {
           // skip connection: features 101..103 of lin2's input are the local coords (block 3,
           // regs 1..3 of the upper half-wave); 1/sqrt(2) and the activation scale live in the weights
@@ -609,7 +617,8 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         asm volatile("" : "+v"(w4a) : "v"(d[15]));
         const f32x16 w4 = load_frag16_lds(w4a);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part = fmaf(softplus2(d[r]), w4[r], part);
+        for (int r = 0; r < (c == CHUNKS_PER_MEMBER - 1 ? LAST_BLOCK_REGS : 16); ++r)
+          part = fmaf(softplus2(d[r]), w4[r], part);
         asm volatile("" : "+v"(part));      // finish this block's epilogue here (see pin16)
       }
       PROF_T(t_e1);
