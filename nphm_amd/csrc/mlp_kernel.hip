@@ -163,7 +163,7 @@ struct EvalArgs {
 // to < 1e-9 in unscaled units
 __device__ __forceinline__ float softplus2(float d) {
   const float t = __builtin_amdgcn_exp2f(-fabsf(d));
-  return __builtin_amdgcn_fmed3f(d, 0.f, __builtin_inff()) + __builtin_amdgcn_logf(1.f + t);
+  return fmaxf(d, 0.f) + __builtin_amdgcn_logf(1.f + t);   // one v_max_f32 under -fno-honor-nans
 }
 
 struct Split8 { bf16x8 hi, lo; };
