@@ -209,12 +209,23 @@ int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
  * the third-party PyMCubes: mcubes.marching_cubes(-logits, 0.0) (src/NPHM/utils/reconstruction.py:25-30).
  * negate != 0 extracts on -volume (the reference negates the SDF so that inside is positive);
  * vertices come in index space (x,y,z) = (i,j,k) as float64, shared between triangles, normals
- * pointing from field > iso to field < iso; n_threads <= 0 uses every host core; the output does
+ * pointing from field > iso to field < iso; n_threads <= 0 = min(16, host cores); the output does
  * not depend on the thread count.  Two-step: extract (sizes), fetch (copy out), free. */
 int nphm_mc_extract(const float* volume, int nx, int ny, int nz, double iso, int negate, int n_threads,
                     void** handle, int64_t* n_verts, int64_t* n_faces);
 int nphm_mc_fetch(void* handle, double* verts, int64_t* faces);
 void nphm_mc_free(void* handle);
+
+/* The same extraction on the GPU for a DEVICE-resident volume (no 4 B/voxel device->host copy, no host
+ * pass): bit-identical vertices, triangles and ordering.  workspace: nphm_mc_device_workspace_bytes()
+ * device bytes.  nphm_mc_device_count classifies, scans and returns the mesh size (it synchronises
+ * `stream` once: the caller allocates verts [n_verts,3] float64 and faces [n_faces,3] int64 on the
+ * device), nphm_mc_device_emit fills them (stream-ordered). */
+size_t nphm_mc_device_workspace_bytes(int nx, int ny, int nz);
+int nphm_mc_device_count(const float* volume, int nx, int ny, int nz, double iso, int negate, void* workspace,
+                         int64_t* n_verts, int64_t* n_faces, void* stream);
+int nphm_mc_device_emit(const float* volume, int nx, int ny, int nz, double iso, int negate, void* workspace,
+                        double* verts, int64_t* faces, void* stream);
 
 #ifdef __cplusplus
 }

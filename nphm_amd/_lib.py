@@ -60,6 +60,11 @@ SYMBOLS = {
                                 ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "nphm_mc_fetch": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nphm_mc_free": (None, [c_void_p]),
+    "nphm_mc_device_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "nphm_mc_device_count": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_int, c_void_p,
+                                     ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_void_p]),
+    "nphm_mc_device_emit": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
 }
 
 _lib = None

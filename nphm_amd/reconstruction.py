@@ -107,6 +107,50 @@ def marching_cubes(volume: np.ndarray, isovalue: float = 0.0, *, negate: bool = 
     return verts, faces
 
 
+def marching_cubes_device(volume: torch.Tensor, isovalue: float = 0.0, *, negate: bool = False):
+    """The same extraction for a DEVICE-resident fp32 volume [nx,ny,nz], on the GPU (count, hipCUB
+    scan, emit): (vertices float64 [nv,3], triangles int64 [nf,3]) as device tensors, bit-identical to
+    ``marching_cubes`` of the same volume.  One host sync (the mesh size)."""
+    import ctypes
+    lib = _lib.load()
+    if not volume.is_cuda or volume.dtype != torch.float32 or volume.dim() != 3:
+        raise ValueError("marching_cubes_device expects a 3-D fp32 tensor on a ROCm device")
+    vol = volume.contiguous()
+    nx, ny, nz = vol.shape
+    dev = vol.device
+    ws = torch.empty(lib.nphm_mc_device_workspace_bytes(nx, ny, nz), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    nv, nf = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(lib.nphm_mc_device_count(vol.data_ptr(), nx, ny, nz, float(isovalue), int(bool(negate)), ws.data_ptr(),
+                                        ctypes.byref(nv), ctypes.byref(nf), stream), "nphm_mc_device_count")
+    verts = torch.empty(nv.value, 3, dtype=torch.float64, device=dev)
+    faces = torch.empty(nf.value, 3, dtype=torch.int64, device=dev)
+    _lib.check(lib.nphm_mc_device_emit(vol.data_ptr(), nx, ny, nz, float(isovalue), int(bool(negate)), ws.data_ptr(),
+                                       verts.data_ptr() if nv.value else None, faces.data_ptr() if nf.value else None,
+                                       stream), "nphm_mc_device_emit")
+    return verts, faces
+
+
+def extract_mesh(decoder, encoding, mini, maxi, resolution, nbatch_points=25000):
+    """latent -> mesh without leaving the device until the mesh exists: the NPHM identity SDF on the
+    reference lattice (= get_logits, incl. the eval-mode chunk overwrite) followed by the GPU marching
+    cubes (= mesh_from_logits); only vertices / triangles travel to the host.  Same mesh as
+    ``mesh_from_logits(get_logits(decoder, encoding, grid, nbatch_points), mini, maxi, resolution)``."""
+    axes = grid_axes(mini, maxi, resolution)
+    hack = 0 if decoder.training else int(nbatch_points)
+    vol = evaluate_grid(decoder, encoding, axes, hack_chunk=hack)
+    verts, faces = marching_cubes_device(vol.view(resolution, resolution, resolution), 0.0, negate=True)
+    step = (np.array(maxi) - np.array(mini)) / (resolution - 1)
+    vertices = verts.cpu().numpy() * np.expand_dims(step, axis=0)
+    vertices += [mini[0], mini[1], mini[2]]
+    triangles = faces.cpu().numpy()
+    try:
+        import trimesh
+        return trimesh.Trimesh(vertices, triangles)
+    except ImportError:
+        return SimpleNamespace(vertices=vertices, faces=triangles)
+
+
 def mesh_from_logits(logits, mini, maxi, resolution, n_threads: int = 0):
     """utils/reconstruction.py:22-37: SDF volume -> mesh in world coordinates.  Like the reference
     it negates ``logits`` IN PLACE (``logits *= -1`` on a reshape view) and extracts the zero level
