@@ -17,6 +17,7 @@ import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 import numpy as np
 import torch
@@ -169,8 +170,9 @@ def main():
         vol_dev = shard if world == 1 else box["full"]
         vol_host = vol_dev.cpu().numpy()
         t_m2 = time.perf_counter()
-        m = R.mesh_from_logits(vol_host, U.MINI, U.MAXI, args.res)
+        vh, fh = R.marching_cubes(vol_host.reshape(rx, ry, rz), 0.0, negate=True)     # host extractor
         t_m3 = time.perf_counter()
+        m = SimpleNamespace(vertices=vh, faces=fh)
         # the same mesh without the volume leaving the device: GPU marching cubes, only the mesh travels
         torch.cuda.synchronize()
         t_d0 = time.perf_counter()
