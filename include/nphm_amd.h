@@ -72,8 +72,9 @@ int nphm_identity_prepare_latent(const void* packed,
  *   point of every forward() call when the n_points of a row are evaluated in chunks of
  *   hack_chunk points: indices i with (i+1) % hack_chunk == 0 or i == n_points-1 get
  *   sum(w)/(sum(w)+1e-6).  hack_chunk = n_points is a single eval-mode forward(); 0 = train mode.
- *   prune_tol: members whose normalised blend weight is <= prune_tol for all 32 points of a
- *   wavefront are skipped (|error| <= 40*prune_tol*max|f_k|); < 0 evaluates all 40 members.
+ *   prune_tol: per point the smallest-weight members are dropped as long as their normalised blend
+ *   weights sum to <= 40*prune_tol (so |error| <= 40*prune_tol*max|f_k|); a wavefront skips a member
+ *   that all of its 32 points drop; < 0 evaluates all 40 members.
  *   stats (nullable, device): stats[0] += evaluated (point, member) pairs, stats[1] += points —
  *   the executed-work counter behind bench.py's roofline figure. */
 int nphm_identity_eval_points(const void* packed, const void* latent_state,

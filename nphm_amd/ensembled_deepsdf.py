@@ -153,8 +153,9 @@ def sample_point_feature(q, p, fea, var=0.1 ** 2, background=False):
 
 
 def _member_point_lists(anchors, xyz, prune_tol, n_members):
-    """(row, member) -> points whose normalised blend weight exceeds ``prune_tol`` (all points if
-    negative): blend weights [B,N,A] (zero where pruned), tile table int32 [T,4] = (row, member,
+    """(row, member) -> points that keep the member under the pruning rule of the fused kernel (per
+    point the smallest normalised blend weights are dropped while they sum to <= 40 * prune_tol; all
+    points if negative): blend weights [B,N,A] (zero where pruned), tile table int32 [T,4] = (row, member,
     offset into the point list, count <= 64) and the point list int32 [P] (sorted by row, member,
     point).  One host sync (the per-pair counts size the launch)."""
     B, N, _ = xyz.shape
@@ -164,7 +165,16 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
     w_bg = float(np.exp(-20.0))
     denom = w.sum(dim=2, keepdim=True) + w_bg + 1e-6
     what = torch.cat([w, torch.full_like(w[:, :, :1], w_bg)], dim=2) / denom
-    mask = what > float(prune_tol) if prune_tol >= 0 else torch.ones_like(what, dtype=torch.bool)
+    if prune_tol >= 0:
+        # same rule as the fused kernel: per point, drop the smallest weights while they sum to <= A * tol
+        tol = float(prune_tol)
+        cut = torch.full_like(what[..., :1], tol)
+        for mult in (2.0, 4.0, 8.0, 16.0, 40.0):
+            below = (what * (what <= mult * tol)).sum(dim=2, keepdim=True)
+            cut = torch.where(below <= A * tol, torch.full_like(cut, mult * tol), cut)
+        mask = what > cut
+    else:
+        mask = torch.ones_like(what, dtype=torch.bool)
     idx = mask.permute(0, 2, 1).nonzero()                      # sorted by (row, member, point)
     counts = torch.bincount(idx[:, 0] * A + idx[:, 1], minlength=B * A).cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(counts)])
