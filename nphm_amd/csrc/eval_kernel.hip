@@ -419,19 +419,23 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   const float* anch = st + LS_OFF_ANCH;
 
   // ---- blend normaliser and active-member mask (EnsembledDeepSDF.py:129-150) -----------------
+  // the 39 anchor weights of this lane's point are computed ONCE and kept in registers (the member
+  // loop's registers are not live yet): the three passes below index them statically (unrolled)
+  float wv[N_LOC];
   float S = 0.f;
-#pragma unroll 1
+#pragma unroll
   for (int k = 0; k < N_LOC; ++k) {
     const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
     const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
-    S += expf(-(d * d) / 0.01f);
+    wv[k] = expf(-(d * d) / 0.01f);
+    S += wv[k];
   }
   const float w_bg = expf(-0.2f / 0.01f);
   S += w_bg;
   const float denom = S + 1e-6f;
   // Pruning rule, per point: drop the smallest-weight members as long as their normalised weights sum
   // to <= 40 * prune_tol (|error| <= 40 * prune_tol * max|f_k|, the bound of dropping every member
-  // below prune_tol - but it is spent where it buys most: 6.6 instead of 8.1 members per wavefront).
+  // below prune_tol - but it is spent where it buys most: 6.2 instead of 7.6 members per wavefront).
   // The cut is the largest of 6 candidate thresholds whose cumulated weight stays within the budget.
   float thr = p.prune_tol * denom;
   uint64_t wmask = 0;                    // members this wavefront evaluates (wave-uniform)
@@ -441,33 +445,24 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   } else {
     constexpr int NT = 6;
     const float mult[NT] = {1.f, 2.f, 4.f, 8.f, 16.f, 40.f};
-    float below[NT] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int k = 0; k < N_MEMBERS; ++k) {
-      float w = w_bg;
-      if (k < N_LOC) {
-        const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
-        w = expf(-(d * d) / 0.01f);
-      }
+    float below[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) below[t] += w <= mult[t] * thr ? w : 0.f;
+    for (int t = 0; t < NT; ++t) below[t] = w_bg <= mult[t] * thr ? w_bg : 0.f;
+#pragma unroll
+    for (int k = 0; k < N_LOC; ++k) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) below[t] += wv[k] <= mult[t] * thr ? wv[k] : 0.f;
     }
     const float budget = float(N_MEMBERS) * thr;
     float cut = thr;                     // the first candidate always fits: <= 40 members below prune_tol
 #pragma unroll
     for (int t = 1; t < NT; ++t) cut = below[t] <= budget ? mult[t] * thr : cut;
     thr = cut;
-#pragma unroll 1
-    for (int k = 0; k < N_MEMBERS; ++k) {
-      float w = w_bg;
-      if (k < N_LOC) {
-        const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
-        w = expf(-(d * d) / 0.01f);
-      }
-      if (__ballot(valid && !hack && w > thr) != 0ull) wmask |= 1ull << k;
-    }
+    const bool live = valid && !hack;
+#pragma unroll
+    for (int k = 0; k < N_LOC; ++k)
+      if (__ballot(live && wv[k] > thr) != 0ull) wmask |= 1ull << k;
+    if (__ballot(live && w_bg > thr) != 0ull) wmask |= 1ull << N_LOC;
   }
 
   const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
