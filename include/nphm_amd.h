@@ -41,6 +41,11 @@ int nphm_identity_supported(int lat_dim_glob, int lat_dim_loc, int n_loc, int n_
 /* Precision of the per-member MLP GEMMs. */
 #define NPHM_PREC_F32     0   /* v_mfma_f32_32x32x2_f32: exact fp32 products            */
 #define NPHM_PREC_BF16X3  1   /* split-bf16 (hi*hi + hi*lo + lo*hi) on 32x32x16 bf16 MFMA */
+#define NPHM_PREC_BF16X3_ADAPTIVE 2  /* the same for every member whose normalised blend weight reaches
+                                        NPHM_LIGHT_TOL somewhere in the wavefront; single-pass bf16
+                                        (hi*hi) for the others: their error enters the blend scaled by
+                                        a weight < NPHM_LIGHT_TOL */
+#define NPHM_LIGHT_TOL 1e-3f
 
 size_t nphm_identity_packed_bytes(void);
 size_t nphm_identity_latent_state_bytes(int n_rows);
@@ -75,8 +80,9 @@ int nphm_identity_prepare_latent(const void* packed,
  *   prune_tol: per point the smallest-weight members are dropped as long as their normalised blend
  *   weights sum to <= 40*prune_tol (so |error| <= 40*prune_tol*max|f_k|); a wavefront skips a member
  *   that all of its 32 points drop; < 0 evaluates all 40 members.
- *   stats (nullable, device): stats[0] += evaluated (point, member) pairs, stats[1] += points —
- *   the executed-work counter behind bench.py's roofline figure. */
+ *   stats (nullable, device, 16 x u64): stats[0] += evaluated (point, member) pairs, stats[1] +=
+ *   points, stats[15] += the pairs evaluated single-pass (adaptive mode) — the executed-work counters
+ *   behind bench.py's roofline figure. */
 int nphm_identity_eval_points(const void* packed, const void* latent_state,
                               const float* xyz, int n_rows, int64_t n_points,
                               int64_t hack_chunk, float prune_tol, int precision,

@@ -36,6 +36,7 @@ struct EvalArgs {
   float* out;
   unsigned long long* stats;
   float prune_tol;
+  float light_tol;          // bf16 path: members below this normalised weight in a wavefront run single-pass
   // MODE 0 (points)
   const float* xyz;         // [n_rows, n_points, 3]
   int64_t n_points;
@@ -89,16 +90,26 @@ struct ActB {
   bf16x8 hi[2], lo[2];
 };
 
-__device__ __forceinline__ void split_block(const f32x16& v, ActB& o) {
+// light (wave-uniform): the member's blend weight is small at every point of the wavefront - its
+// GEMMs run single-pass (hi x hi only, see gemm_block_bf16) and the lo parts are not computed
+__device__ __forceinline__ void split_block(const f32x16& v, ActB& o, const bool light) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float x = v[8 * s + i];
-      const __bf16 hb = (__bf16)x;
-      o.hi[s][i] = hb;
-      o.lo[s][i] = (__bf16)(x - (float)hb);
+    for (int i = 0; i < 8; ++i) o.hi[s][i] = (__bf16)v[8 * s + i];
+  }
+  if (!light) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = v[8 * s + i];
+        o.lo[s][i] = (__bf16)(x - (float)o.hi[s][i]);
+      }
     }
+  } else {
+    const bf16x8 z = {};
+    o.lo[0] = z; o.lo[1] = z;
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {            // pin the packed operands (same reason as pin16)
@@ -320,7 +331,7 @@ __device__ __forceinline__ f32x16 gemm_block_f32(const char* afrag, f32x16 acc,
 // xl*wl term is 2^-16 relative.  A fragments from LDS: [ks][hi|lo][lane][8].
 template <int NKS16, int FULL, int NIN>
 __device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
-                                                  const ActB (&in)[NIN], int lane) {
+                                                  const ActB (&in)[NIN], int lane, const bool light) {
   const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
   // A fragments are fetched two K-steps ahead of the MFMAs that consume them (LDS latency is
   // ~128 cycles, one K-step is 96 cycles of matrix pipe): hipcc does not pipeline this by itself
@@ -329,20 +340,22 @@ __device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
 #pragma unroll
   for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
     wh[ks] = A[(2 * ks) * 64];
-    wl[ks] = A[(2 * ks + 1) * 64];
+    if (!light) wl[ks] = A[(2 * ks + 1) * 64];
   }
 #pragma unroll
   for (int ks = 0; ks < NKS16; ++ks) {
     if (ks + PF < NKS16) {
       wh[ks + PF] = A[(2 * (ks + PF)) * 64];
-      wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
+      if (!light) wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
     }
     __builtin_amdgcn_sched_barrier(0);     // the reads above are issued HERE, ahead of the MFMAs
     const int b = ks < 2 * FULL ? (ks >> 1) : FULL;
     const int s = ks < 2 * FULL ? (ks & 1) : 0;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].hi[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].lo[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], in[b].hi[s], acc, 0, 0, 0);
+    if (!light) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].lo[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], in[b].hi[s], acc, 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   return acc;
@@ -439,10 +452,12 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   // The cut is the largest of 6 candidate thresholds whose cumulated weight stays within the budget.
   float thr = p.prune_tol * denom;
   uint64_t wmask = 0;                    // members this wavefront evaluates (wave-uniform)
+  uint64_t hmask = ~0ull;                // ... of which with the full split-bf16 product ("heavy")
   const bool any_valid = __ballot(valid) != 0ull;
   if (p.prune_tol < 0.f) {
     wmask = any_valid ? (1ull << N_MEMBERS) - 1 : 0ull;
   } else {
+    hmask = 0;
     constexpr int NT = 6;
     const float mult[NT] = {1.f, 2.f, 4.f, 8.f, 16.f, 40.f};
     float below[NT];
@@ -463,12 +478,19 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     for (int k = 0; k < N_LOC; ++k)
       if (__ballot(live && wv[k] > thr) != 0ull) wmask |= 1ull << k;
     if (__ballot(live && w_bg > thr) != 0ull) wmask |= 1ull << N_LOC;
+    // members that weigh >= light_tol somewhere in the wavefront keep the 3-pass product
+    const float heavy_thr = p.light_tol * denom;
+#pragma unroll
+    for (int k = 0; k < N_LOC; ++k)
+      if (__ballot(live && wv[k] >= heavy_thr) != 0ull) hmask |= 1ull << k;
+    if (__ballot(live && w_bg >= heavy_thr) != 0ull) hmask |= 1ull << N_LOC;
   }
 
   const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
   if (p.stats && lane == 0) {
     atomicAdd(p.stats, nv * __popcll(wmask));
     atomicAdd(p.stats + 1, nv);
+    atomicAdd(p.stats + 15, nv * __popcll(wmask & ~hmask));      // single-pass ("light") pairs
   }
 
   // ---- union over the workgroup: the members whose weights get streamed ----------------------
@@ -513,6 +535,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     int h = h_inv, lane = lane_inv;
     asm volatile("" : "+v"(h), "+v"(lane));
     PROF_T(t_m0);
+    // adaptive precision (bf16 path): single-pass products for a member that weighs < light_tol at
+    // every point of this wavefront (its error enters the blend scaled by that weight)
+    const bool light = PREC == 1 && !((hmask >> k) & 1ull);
 
     // local coordinates (EnsembledDeepSDF.py:240-244): anchor-relative, odd member of a
     // symmetric pair mirrored in x, background member uses global coordinates
@@ -533,7 +558,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     using Act = typename std::conditional<PREC == 0, f32x16, ActB>::type;
     Act H[7], G[4];
     auto store_act = [&](const f32x16& v, Act& dst) __attribute__((always_inline)) {
-      if constexpr (PREC == 0) { dst = v; pin16(dst); } else { split_block(v, dst); }
+      if constexpr (PREC == 0) { dst = v; pin16(dst); } else { split_block(v, dst, light); }
     };
 
     // ---- 19 chunks: 0 = L0 (3 coords -> 200), 1..4 = L1, 5..11 = L2, 12..18 = L3; each = GEMM on
@@ -591,9 +616,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           else if constexpr (g < L1_OB + L2_OB) d = gemm_block_f32<L2_KS, 3, 4>(buf, d, G, lane);
           else d = gemm_block_f32<L3_KS, 6, 7>(buf, d, H, lane);
         } else {
-          if constexpr (g < L1_OB) d = gemm_block_bf16<L1_KS16, 6, 7>(buf, d, H, lane);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_block_bf16<L2_KS16, 3, 4>(buf, d, G, lane);
-          else d = gemm_block_bf16<L3_KS16, 6, 7>(buf, d, H, lane);
+          if constexpr (g < L1_OB) d = gemm_block_bf16<L1_KS16, 6, 7>(buf, d, H, lane, light);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_block_bf16<L2_KS16, 3, 4>(buf, d, G, lane, light);
+          else d = gemm_block_bf16<L3_KS16, 6, 7>(buf, d, H, lane, light);
         }
       }
 #if NPHM_PROF
@@ -689,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
 extern "C" {
 
 static int check_prec(int precision) {
-  if (precision != NPHM_PREC_F32 && precision != NPHM_PREC_BF16X3)
+  if (precision != NPHM_PREC_F32 && precision != NPHM_PREC_BF16X3 && precision != NPHM_PREC_BF16X3_ADAPTIVE)
     return nphm_fail_msg("nphm_identity_eval: unsupported precision mode");
   return 0;
 }
@@ -703,10 +728,12 @@ static void fill_common(nphm::EvalArgs& a, const void* packed, const void* laten
   a.out = out;
   a.stats = stats;
   a.prune_tol = prune_tol;
+  a.light_tol = -1.f;                    // set per precision mode by the callers
   a.hack_chunk = hack_chunk;
 }
 
 static int launch_grid(nphm::EvalArgs& a, int precision, hipStream_t st, const char* who) {
+  a.light_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE ? NPHM_LIGHT_TOL : -1.f;
   const int nx = a.ix1 - a.ix0;
   a.nbx = (nx + nphm::BRX - 1) / nphm::BRX; a.nby = (a.ry + nphm::BRY - 1) / nphm::BRY;
   a.nbz = (a.rz + nphm::BRZ - 1) / nphm::BRZ;
@@ -738,6 +765,7 @@ int nphm_identity_eval_points(const void* packed, const void* latent_state,
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_identity_eval_points: too many points");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * nphm::NW);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  a.light_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE ? NPHM_LIGHT_TOL : -1.f;
   if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((nphm::eval_kernel<0, 1>), grid, block, 0, st, a);
   hipError_t e = hipGetLastError();

@@ -270,7 +270,9 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         # ---- execution knobs (defaults keep reference numerics within 1e-4) -------------------
         self.backend = "hip"            # "hip" | "composite"
         self.prune_tol = float(os.environ.get("NPHM_AMD_PRUNE_TOL", "1e-7"))
-        self.precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3")   # "bf16x3" | "f32"
+        # "bf16x3a" (default): split-bf16 products for members that weigh >= 1e-3 somewhere in the
+        # wavefront, single-pass bf16 for the rest | "bf16x3": split-bf16 everywhere | "f32": exact products
+        self.precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3a")
         self._pack_cache = None         # (key, packed tensor)
         self._pack_bwd_cache = None     # (key, transposed pack for the backward kernel)
 
@@ -339,7 +341,8 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         return packed, state, anchors
 
     def _precision_code(self):
-        return {"f32": _lib.NPHM_PREC_F32, "bf16x3": _lib.NPHM_PREC_BF16X3}[self.precision]
+        return {"f32": _lib.NPHM_PREC_F32, "bf16x3": _lib.NPHM_PREC_BF16X3,
+                "bf16x3a": _lib.NPHM_PREC_BF16X3_ADAPTIVE}[self.precision]
 
     def _forward_hip(self, xyz, lat_rows):
         lib = _lib.load()
