@@ -214,9 +214,9 @@ def main():
                        "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather" if world > 1 else "single GPU")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
-                         "traffic": measured_traffic("nphm::eval_kernel<1,%d>" % net._precision_code(), n_local),
+                         "traffic": measured_traffic("nphm::eval_kernel<1,%d>" % min(net._precision_code(), 1), n_local),
                          "algorithmic_bytes": 4 * n_local,
-                         "kernel": "nphm::eval_kernel<1,%d>" % net._precision_code(), "rank0_planes": n_planes,
+                         "kernel": "nphm::eval_kernel<1,%d>" % min(net._precision_code(), 1), "rank0_planes": n_planes,
                          "kernel_ms": k_ms, "points_per_launch": n_local,
                          "executed_flops_per_point": exec_flops / n_local, "mean_single_pass_members": mean_light,
                          "mfma_passes": passes,
