@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--prune-tol", type=float, default=None)
     ap.add_argument("--precision", default="bf16x3a", choices=["f32", "bf16x3", "bf16x3a"])
     ap.add_argument("--chunk", type=int, default=25000, help="get_logits chunk whose last voxel is overwritten (eval mode)")
+    ap.add_argument("--workload", default="identity", choices=["identity", "two_stage", "npm", "fitting"],
+                    help="identity = BASELINE.json configs[1] (the contract line); the others are the remaining "
+                         "configs (two_stage = configs[2], npm = configs[0], fitting = configs[4]), single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40000)
     return ap.parse_args()
@@ -82,8 +85,114 @@ def cpu_baseline(net, lat, axes, n_sample):
                       f"oracle/nphm_oracle.py numpy fp32, dense 40-member evaluation, {dt:.1f} s"}
 
 
+def _timed(fn, steps, warmup):
+    """wall seconds of `steps` calls after `warmup` (synchronised on both sides) + per-call HIP events"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, [a.elapsed_time(b) for a, b in ev]
+
+
+def other_workloads(args):
+    """BASELINE.json configs other than the contract line, one GPU, same JSON shape."""
+    import _util as U
+    from nphm_amd import reconstruction as R
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    base = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "data": "synthetic (seeded random-init weights, latents ~ shipped statistics)"}
+    if args.workload == "two_stage":
+        g = U.golden("deformation")
+        inet = U.build_identity(device=dev).eval()
+        dnet = U.build_deformation(device=dev).eval()
+        lat_id = torch.from_numpy(g["lat"].reshape(-1)[:1344]).to(dev)
+        lat_ex = torch.from_numpy(g["lat"].reshape(-1)).to(dev)
+        axes = [torch.from_numpy(a).to(dev) for a in R.grid_axes(U.MINI, U.MAXI, args.res)]
+        n = args.res ** 3
+        anchors = inet.prepare_latent(lat_id[None])[2]
+        mlp, cond = R._expr_condition(dnet, lat_ex, anchors, dev)
+        dt, _ = _timed(lambda: R.evaluate_grid_two_stage(inet, dnet, lat_id, lat_ex, axes, hack_chunk=args.chunk),
+                       args.steps, args.warmup)
+        _, k_ms = _timed(lambda: R.evaluate_grid_mlp(mlp, cond, axes, add_input=True), args.steps, 1)
+        flops = 3 * 2 * 1_074_688
+        ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
+        out = dict(base, metric="SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice",
+                   value=n * args.steps / dt / 1e6, unit="Mpoints/s", ms_per_step=dt / args.steps * 1e3,
+                   dtype="bf16x3(split-bf16 MFMA) deformation + " + inet.precision + " identity",
+                   config={"workload": f"NPHM identity + forward-deformation field, {args.res}^3 (BASELINE.json configs[2])",
+                           "res": args.res},
+                   roofline={"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                             "traffic": None, "kernel": "nphm::mlp::mlp_eval_kernel<2,2,1,0> (deformation stage, "
+                                                        "the longer of the two kernels)", "kernel_ms": float(np.mean(k_ms)),
+                             "executed_flops_per_point": flops}, cpu_baseline=None)
+    elif args.workload == "npm":
+        from oracle import nphm_oracle as O
+        gn = U.golden("npm")
+        npm = U.build_npm(device=dev).eval()
+        res = 64
+        axes = R.grid_axes(U.MINI, U.MAXI, res)
+        axes_dev = [torch.from_numpy(a).to(dev) for a in axes]
+        lat = torch.from_numpy(gn["lat"][None]).to(dev)
+        n = res ** 3
+        dt, k_ms = _timed(lambda: R.evaluate_grid_mlp(npm, lat, axes_dev), args.steps, args.warmup)
+        flops = 3 * 2 * 6_292_480
+        ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
+        cpu = None
+        if not args.no_cpu_baseline:
+            pts = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)[:, :20000]
+            latn = np.repeat(gn["lat"][None, None], pts.shape[1], axis=1)
+            t0 = time.perf_counter()
+            O.deepsdf_forward(U.np_state(npm), "", pts, latn, nlayers=8)
+            tc = time.perf_counter() - t0
+            cpu = {"value": pts.shape[1] / tc / 1e6, "unit": "Mpoints/s", "cores": os.cpu_count(), "kind": "port",
+                   "sample": f"first {pts.shape[1]} lattice points, oracle numpy fp32, {tc:.1f} s"}
+        out = dict(base, metric="SDF query throughput, NPM global DeepSDF, dense lattice", value=n * args.steps / dt / 1e6,
+                   unit="Mpoints/s", ms_per_step=dt / args.steps * 1e3, dtype="bf16x3(split-bf16 MFMA, fp32 accumulate)",
+                   config={"workload": "NPM global DeepSDF (lat 512, hidden 1024, 8 layers), 64^3 lattice "
+                                       "(BASELINE.json configs[0])", "res": res},
+                   roofline={"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                             "traffic": None, "kernel": "nphm::mlp::mlp_eval_kernel<1,4,1,0>", "kernel_ms": float(np.mean(k_ms)),
+                             "executed_flops_per_point": flops}, cpu_baseline=cpu)
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_fitting as BF
+        from nphm_amd import fitting as F
+        shape_net = U.build_identity(device=dev)
+        expr_net = U.build_deformation(device=dev).eval()
+        obs = BF.synthetic_observations(shape_net, dev)
+        shape_net.train()
+        cfg = {k: dict(v) for k, v in BF.SCHEDULE.items()}
+        torch.manual_seed(0)
+        F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(BF.LAMBDAS), args.warmup, cfg, verbose=False)
+        torch.cuda.synchronize()
+        steps = max(args.steps, 20)
+        t0 = time.perf_counter()
+        F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(BF.LAMBDAS), steps, cfg, verbose=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = dict(base, steps=steps, metric="latent-code fitting steps/s (inference_iterative_root_finding_joint)",
+                   value=steps / dt, unit="steps/s", ms_per_step=dt / steps * 1e3,
+                   dtype="bf16x3 kernels + fp32 PyTorch ops",
+                   config={"workload": "latent fitting, 3 synthetic observations x 2500 points, 5 x 1000 points per step, "
+                                       "Adam on identity + expression codes (BASELINE.json configs[4])"},
+                   roofline=None, cpu_baseline=None,
+                   note="host-latency bound: ~8 ms of Python/launch overhead per step against ~2 ms of kernels")
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.workload != "identity":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--workload other than identity runs on one GPU")
+        return other_workloads(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
