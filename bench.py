@@ -330,7 +330,11 @@ def main():
                          "executed_flops_per_point": exec_flops / n_local, "mean_single_pass_members": mean_light,
                          "mfma_passes": passes,
                          "mean_active_members": mean_active,
-                         "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12},
+                         "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12,
+                         "note": "achieved counts EXECUTED matrix FLOPs: the adaptive default issues one pass instead "
+                                 "of three for ~46% of the evaluated members, so it is faster at a lower FLOP rate "
+                                 "(--precision bf16x3: 3 passes everywhere, ~270 Mpoints/s at frac ~0.33); the kernel is "
+                                 "co-bound by its VALU epilogue (2 transcendentals per activation), DESIGN.md section 10"},
         }
         out["mesh_extract"] = mesh
         if not args.no_cpu_baseline and world == 1:
