@@ -230,3 +230,33 @@ def test_reference_attribute_surface():
     with pytest.raises(ValueError):
         import nphm_amd
         nphm_amd.DeformationNetwork("nope", 200, 32, 64, 32, 39, None, 512)
+
+
+def test_member_point_lists_cover_exactly_the_kept_pairs():
+    """Host logic of the autograd tier: the (row, member) tile table handed to the member-centric
+    kernels lists every (point, member) pair the pruning rule keeps exactly once, in tiles of <= 64
+    points of one (row, member), and the dropped weights respect the budget 40 * prune_tol."""
+    from nphm_amd.ensembled_deepsdf import _member_point_lists
+    rng = np.random.default_rng(3)
+    B, N, A = 2, 300, 40
+    anchors = torch.from_numpy(np.repeat(U.anchors_mean()[None], B, 0) + 0.01 * rng.standard_normal((B, 39, 3))).float()
+    xyz = torch.from_numpy(rng.uniform(U.MINI, U.MAXI, size=(B, N, 3))).float()
+    for tol in (1e-7, 1e-4, -1.0):
+        what, tiles, plist = _member_point_lists(anchors, xyz, tol, A)
+        kept = what > 0
+        seen = torch.zeros(B, N, A, dtype=torch.int32)
+        for b, k, off, cnt in tiles.tolist():
+            assert 0 < cnt <= 64
+            pts = plist[off:off + cnt].long()
+            seen[b, pts, k] += 1
+        if tol < 0:
+            assert bool((seen == 1).all())
+        else:
+            assert torch.equal(seen > 0, kept) and int(seen.max()) == 1
+            # what the rule dropped sums to <= 40 * tol per point (full weights recomputed here)
+            d = (anchors[:, None] - xyz[:, :, None]).norm(dim=3) + 1e-5
+            w = torch.exp(-(d * d) / 0.01)
+            w_bg = float(np.exp(-20.0))
+            full = torch.cat([w, torch.full_like(w[..., :1], w_bg)], 2) / (w.sum(2, keepdim=True) + w_bg + 1e-6)
+            dropped = (full * (~kept)).sum(2)
+            assert float(dropped.max()) <= 40 * tol * (1 + 1e-5)
