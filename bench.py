@@ -187,6 +187,37 @@ def other_workloads(args):
     print(json.dumps(out))
 
 
+def pytorch_rocm_line(net, lat, axes_dev, chunk, n_chunks=20):
+    """The same extraction the way the reference runs it on a GPU: chunked get_logits loop over
+    PyTorch-ROCm ops (this repo's composite formulation of the module = the reference arithmetic; the
+    reference checkout itself is not on the GPU box), on the first n_chunks chunks of the lattice."""
+    ax, ay, az = axes_dev
+    ry, rz = ay.numel(), az.numel()
+    n = n_chunks * chunk
+    idx = torch.arange(n, device=ax.device)
+    pts = torch.stack([ax[idx // (ry * rz)], ay[(idx // rz) % ry], az[idx % rz]], dim=-1)[None]
+    net.backend = "composite"
+    try:
+        def run():
+            out = []
+            for p in torch.split(pts, chunk, dim=1):
+                with torch.no_grad():
+                    sdf, _ = net(p, lat.reshape(1, 1, -1).repeat(1, p.shape[1], 1), None)
+                out.append(sdf.squeeze().detach().cpu())
+            return torch.cat(out)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        net.backend = "hip"
+    return {"value": n / dt / 1e6, "unit": "Mpoints/s",
+            "sample": f"first {n_chunks} chunks of {chunk} lattice points, eager PyTorch-ROCm fp32 on the same GPU, "
+                      f"per-chunk latent repeat and device->host copy as in get_logits, {dt * 1e3:.0f} ms"}
+
+
 def main():
     args = parse()
     if args.workload != "identity":
@@ -338,6 +369,7 @@ def main():
         }
         out["mesh_extract"] = mesh
         if not args.no_cpu_baseline and world == 1:
+            out["pytorch_rocm_baseline"] = pytorch_rocm_line(net, lat, axes_dev, args.chunk)
             out["cpu_baseline"] = cpu_baseline(net, lat, axes, args.cpu_sample)
         else:
             out["cpu_baseline"] = None
