@@ -16,6 +16,7 @@
 //     lattice-ordered displaced points: two-stage evaluation), bricks are enumerated so that each
 //     XCD works on a compact region (L2 reuse of the streamed members).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include <type_traits>
@@ -69,6 +70,35 @@ __device__ __forceinline__ float softplus2(float d) {
   // v_max(x, x) is put in front; inline asm is not an option - it would read MFMA results without
   // the hazard wait states the compiler inserts for its own instructions)
   return fmaxf(d, 0.f) + __builtin_amdgcn_logf(1.f + t);             // raw v_log_f32, arg in [1,2]
+}
+
+// Softplus for "light" members (adaptive precision, see split_block): the correction term
+// g(u) = log2(1 + 2^-u), u = |d'|, as (a0 - a1 min(u, .))^8 - max abs error 4.2e-3 in the scaled
+// domain (2.9e-5 in activation units, the size of the single-pass bf16 rounding these members already
+// carry; it enters the blend scaled by a weight < light_tol).  Plain multiply-adds in place of the
+// two quarter-rate transcendentals: a light chunk becomes MFMA-bound instead of VALU-bound.
+__device__ __forceinline__ float softplus2_light(float d) {
+  float q = fmaxf(fmaf(fabsf(d), -0.06564446f, 1.00028698f), 0.f);
+  q *= q;
+  q *= q;
+  return fmaf(q, q, fmaxf(d, 0.f));
+}
+
+#ifndef NPHM_LIGHT_POLY
+#define NPHM_LIGHT_POLY 1
+#endif
+// softplus of the first NR registers of an accumulator block (the rest stay 0)
+template <int NR>
+__device__ __forceinline__ f32x16 softplus_block(const f32x16& d, const bool light) {
+  f32x16 v = {};
+  if (NPHM_LIGHT_POLY && light) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = softplus2_light(d[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = softplus2(d[r]);
+  }
+  return v;
 }
 
 // registers of the LAST 32-row block of a layer that hold real features: 200 = 6*32 + 8 and
@@ -329,36 +359,49 @@ __device__ __forceinline__ f32x16 gemm_block_f32(const char* afrag, f32x16 acc,
 
 // The same block on split-bf16 MFMA: x*w ~= xh*wh + xl*wh + xh*wl (fp32 accumulate); the dropped
 // xl*wl term is 2^-16 relative.  A fragments from LDS: [ks][hi|lo][lane][8].
-template <int NKS16, int FULL, int NIN>
-__device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
-                                                  const ActB (&in)[NIN], int lane, const bool light) {
+template <int NKS16, int FULL, int NIN, bool LIGHT, int PF>
+__device__ __forceinline__ f32x16 gemm_block_bf16_impl(const char* afrag, f32x16 acc,
+                                                       const ActB (&in)[NIN], int lane) {
   const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
-  // A fragments are fetched two K-steps ahead of the MFMAs that consume them (LDS latency is
-  // ~128 cycles, one K-step is 96 cycles of matrix pipe): hipcc does not pipeline this by itself
-  constexpr int PF = 2;
+  // A fragments are fetched PF K-steps ahead of the MFMAs that consume them (LDS latency is
+  // ~128 cycles and more under load; one K-step is 96 cycles of matrix pipe, 32 for a single-pass
+  // member): hipcc does not pipeline this by itself
   bf16x8 wh[NKS16], wl[NKS16];
 #pragma unroll
   for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
     wh[ks] = A[(2 * ks) * 64];
-    if (!light) wl[ks] = A[(2 * ks + 1) * 64];
+    if (!LIGHT) wl[ks] = A[(2 * ks + 1) * 64];
   }
 #pragma unroll
   for (int ks = 0; ks < NKS16; ++ks) {
     if (ks + PF < NKS16) {
       wh[ks + PF] = A[(2 * (ks + PF)) * 64];
-      if (!light) wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
+      if (!LIGHT) wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
     }
     __builtin_amdgcn_sched_barrier(0);     // the reads above are issued HERE, ahead of the MFMAs
     const int b = ks < 2 * FULL ? (ks >> 1) : FULL;
     const int s = ks < 2 * FULL ? (ks & 1) : 0;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].hi[s], acc, 0, 0, 0);
-    if (!light) {
+    if (!LIGHT) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].lo[s], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], in[b].hi[s], acc, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   return acc;
+}
+
+#ifndef NPHM_PF_HEAVY
+#define NPHM_PF_HEAVY 2
+#endif
+#ifndef NPHM_PF_LIGHT
+#define NPHM_PF_LIGHT 5
+#endif
+template <int NKS16, int FULL, int NIN>
+__device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
+                                                  const ActB (&in)[NIN], int lane, const bool light) {
+  if (light) return gemm_block_bf16_impl<NKS16, FULL, NIN, true, NPHM_PF_LIGHT>(afrag, acc, in, lane);
+  return gemm_block_bf16_impl<NKS16, FULL, NIN, false, NPHM_PF_HEAVY>(afrag, acc, in, lane);
 }
 
 template <int MODE, int PREC>
@@ -634,17 +677,14 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       if constexpr (c == 0) {
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
-          f32x16 v = {};
-#pragma unroll
-          for (int r = 0; r < (b == 6 ? LAST_BLOCK_REGS : 16); ++r) v[r] = softplus2(d0[b][r]);
+          constexpr int NR0 = 16, NR1 = LAST_BLOCK_REGS;
+          f32x16 v = b == 6 ? softplus_block<NR1>(d0[b], light) : softplus_block<NR0>(d0[b], light);
           store_act(v, H[b]);
         }
       } else if constexpr (c - 1 < L1_OB + L2_OB) {
         constexpr int g = c - 1;
         constexpr bool last_block = g == L1_OB - 1 || g == L1_OB + L2_OB - 1;
-        f32x16 v = {};
-#pragma unroll
-        for (int r = 0; r < (last_block ? LAST_BLOCK_REGS : 16); ++r) v[r] = softplus2(d[r]);
+        f32x16 v = softplus_block<(last_block ? LAST_BLOCK_REGS : 16)>(d, light);
         if constexpr (g == L1_OB - 1) {
           // skip connection: features 101..103 of lin2's input are the local coords (block 3,
           // regs 1..3 of the upper half-wave); 1/sqrt(2) and the activation scale live in the weights
@@ -659,9 +699,10 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         unsigned int w4a = WS::lds_addr(reinterpret_cast<const char*>(WS::tail_of(ws.slot(c)) + 32 + h * 16));
         asm volatile("" : "+v"(w4a) : "v"(d[15]));
         const f32x16 w4 = load_frag16_lds(w4a);
+        const f32x16 v = softplus_block<(c == CHUNKS_PER_MEMBER - 1 ? LAST_BLOCK_REGS : 16)>(d, light);
 #pragma unroll
         for (int r = 0; r < (c == CHUNKS_PER_MEMBER - 1 ? LAST_BLOCK_REGS : 16); ++r)
-          part = fmaf(softplus2(d[r]), w4[r], part);
+          part = fmaf(v[r], w4[r], part);
         asm volatile("" : "+v"(part));      // finish this block's epilogue here (see pin16)
       }
       PROF_T(t_e1);
@@ -734,6 +775,9 @@ static void fill_common(nphm::EvalArgs& a, const void* packed, const void* laten
 
 static int launch_grid(nphm::EvalArgs& a, int precision, hipStream_t st, const char* who) {
   a.light_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE ? NPHM_LIGHT_TOL : -1.f;
+#if NPHM_PROF
+  if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
+#endif
   const int nx = a.ix1 - a.ix0;
   a.nbx = (nx + nphm::BRX - 1) / nphm::BRX; a.nby = (a.ry + nphm::BRY - 1) / nphm::BRY;
   a.nbz = (a.rz + nphm::BRZ - 1) / nphm::BRZ;
@@ -766,6 +810,9 @@ int nphm_identity_eval_points(const void* packed, const void* latent_state,
   const dim3 grid((unsigned)tiles, n_rows), block(64 * nphm::NW);
   hipStream_t st = static_cast<hipStream_t>(stream);
   a.light_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE ? NPHM_LIGHT_TOL : -1.f;
+#if NPHM_PROF
+  if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
+#endif
   if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((nphm::eval_kernel<0, 1>), grid, block, 0, st, a);
   hipError_t e = hipGetLastError();

@@ -1,10 +1,15 @@
-import torch, sys
+"""Per-phase cycle accounting of the identity kernel.  Needs a timing build of the library:
+  hipcc ... -DNPHM_PROF=1 (see nphm_amd/build.py for the flags) -o /tmp/libprof.so ; NPHM_AMD_LIB=/tmp/libprof.so python tools/phase_profile.py
+Modes: bf16x3 (all members 3-pass), all-light (NPHM_PROF_LIGHT_TOL=10: every member single-pass), adaptive, f32."""
+import os, torch, sys
 sys.path.insert(0,"tests"); sys.path.insert(0,".")
 import _util as U
 from nphm_amd import _lib, reconstruction as R
 dev=torch.device("cuda:0")
-for prec,code in (("bf16x3",1),("f32",0)):
-    net=U.build_identity(device=dev).eval(); net.precision=prec
+for prec,code,tol in (("bf16x3",1,None),("all-light",2,"10"),("adaptive",2,None),("f32",0,None)):
+    os.environ.pop("NPHM_PROF_LIGHT_TOL",None)
+    if tol: os.environ["NPHM_PROF_LIGHT_TOL"]=tol
+    net=U.build_identity(device=dev).eval(); net.precision={"all-light":"bf16x3a","adaptive":"bf16x3a"}.get(prec,prec)
     lat=U.sample_latent(0).to(dev)
     res=256
     axes=R.grid_axes(U.MINI,U.MAXI,res)
