@@ -44,6 +44,7 @@ def parse():
                     help="identity = BASELINE.json configs[1] (the contract line); the others are the remaining "
                          "configs (two_stage = configs[2], npm = configs[0], fitting = configs[4]), single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mesh", action="store_true", help="skip the mesh-extract leg (kernel timing experiments)")
     ap.add_argument("--cpu-sample", type=int, default=40000)
     return ap.parse_args()
 

@@ -50,6 +50,19 @@ struct EvalArgs {
   int64_t hack_chunk;
 };
 
+// 1: the LDS-DMA pieces of the prefetched chunk are issued between the K-steps of the GEMM in flight,
+// 0: all of them right behind the chunk's barrier
+#ifndef NPHM_DMA_INSTREAM
+#define NPHM_DMA_INSTREAM 1
+#endif
+#ifndef NPHM_AHEAD
+#define NPHM_AHEAD 2   // chunks the weight ring runs ahead of the GEMMs (2 or 3)
+#endif
+// timing ablations (results are garbage): 1 = no weight streaming, 2 = no workgroup barrier, 4 = no epilogue arithmetic,
+// 8 = no MFMA
+#ifndef NPHM_ABLATE
+#define NPHM_ABLATE 0
+#endif
 #ifndef NPHM_PROF
 #define NPHM_PROF 0  // 1: per-phase s_memtime accounting into stats[2..8] (timing builds only)
 #endif
@@ -65,6 +78,7 @@ struct EvalArgs {
 // d' = k d, returns k softplus(d) = max(d',0) + log2(1 + 2^-|d'|).  For 100 d > 20 PyTorch returns d;
 // here the log term is already 0 in fp32 for 100 d > 16.7, so the two agree to < 1e-9 in d units.
 __device__ __forceinline__ float softplus2(float d) {
+  if (NPHM_ABLATE & 4) return d;
   const float t = __builtin_amdgcn_exp2f(-fabsf(d));                 // raw v_exp_f32
   // relu: built with -fno-honor-nans so that it is ONE v_max_f32 (otherwise a canonicalising
   // v_max(x, x) is put in front; inline asm is not an option - it would read MFMA results without
@@ -78,6 +92,7 @@ __device__ __forceinline__ float softplus2(float d) {
 // carry; it enters the blend scaled by a weight < light_tol).  Plain multiply-adds in place of the
 // two quarter-rate transcendentals: a light chunk becomes MFMA-bound instead of VALU-bound.
 __device__ __forceinline__ float softplus2_light(float d) {
+  if (NPHM_ABLATE & 4) return d;
   float q = fmaxf(fmaf(fabsf(d), -0.06564446f, 1.00028698f), 0.f);
   q *= q;
   q *= q;
@@ -181,6 +196,39 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// compile-time loop over [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_range(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_range<B + 1, E>(f);
+  }
+}
+
+// NU epilogue units spread evenly over NS issue slots: unit u runs in slot floor(u * NS / NU), i.e.
+// slot s runs the units [unit_begin(s), unit_begin(s + 1))
+__host__ __device__ constexpr int unit_begin(int s, int ns, int nu) { return (s * nu + ns - 1) / ns; }
+
+// registers R, R+1 of an activation block -> their split-bf16 operand slots (one packed convert each
+// for hi and lo); LIGHT members carry no lo part
+template <int R, bool LIGHT>
+__device__ __forceinline__ void pack_pair(const f32x16& a, ActB& o) {
+  constexpr int s = R >> 3, i = R & 7;
+  const __bf16 h0 = (__bf16)a[R], h1 = (__bf16)a[R + 1];
+  o.hi[s][i] = h0;
+  o.hi[s][i + 1] = h1;
+  if constexpr (!LIGHT) {
+    o.lo[s][i] = (__bf16)(a[R] - (float)h0);
+    o.lo[s][i + 1] = (__bf16)(a[R + 1] - (float)h1);
+  }
+  // pin the finished operand registers here (see pin16): LLVM otherwise sinks the pure epilogue
+  // arithmetic to its use in the next layer's GEMM and keeps the accumulator alive until then
+  if constexpr (i == 6) {
+    asm volatile("" : "+v"(o.hi[s]));
+    if constexpr (!LIGHT) asm volatile("" : "+v"(o.lo[s]));
+  }
+}
+
 // ---- workgroup geometry ----------------------------------------------------------------------
 // NW = wavefronts per workgroup (all of them share one LDS ring): 8 -> 256 points per weight pass
 #ifndef NPHM_NW
@@ -210,6 +258,7 @@ template <> struct Stream<0> {
     return reinterpret_cast<const char*>(p.packed_f32 + size_t(s) * SET_STRIDE);
   }
   static constexpr int LS_OFF_L0 = LS_OFF_L0F;
+  static constexpr unsigned SET_BYTES = SET_STRIDE * 4u;
   __host__ __device__ static constexpr int offset(int g) {   // bytes inside a weight set, g = GEMM chunk
     return 4 * (g < L1_OB ? OFF_L1A + g * (L1_KS / 4) * 256
               : g < L1_OB + L2_OB ? OFF_L2A + (g - L1_OB) * (L2_KS / 4) * 256
@@ -225,6 +274,7 @@ template <> struct Stream<1> {
     return reinterpret_cast<const char*>(p.packed_bf16 + size_t(s) * BF_SET_STRIDE);
   }
   static constexpr int LS_OFF_L0 = LS_OFF_L0B;
+  static constexpr unsigned SET_BYTES = BF_SET_STRIDE * 2u;
   __host__ __device__ static constexpr int offset(int g) {
     return 2 * (g < L1_OB ? BF_OFF_L1A + g * L1_KS16 * 1024
               : g < L1_OB + L2_OB ? BF_OFF_L2A + (g - L1_OB) * L2_KS16 * 1024
@@ -249,16 +299,41 @@ struct Streamer {
   // LDS-DMA through inline asm: hipcc does not see these loads, so it neither drains them with a
   // vmcnt(0) in front of every later ds_read (which it does for the builtin: the DMA is a pending
   // LDS write it cannot disambiguate) nor counts them - sync() waits for exactly the chunk it
-  // needs.  M0 (DMA destination base) is saved/restored inside the statement.
-  __device__ static __forceinline__ void dma16(const char* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  // needs.  The loads are MUBUF (buffer_load ... offen lds): resource = base of the stream, the VGPR
+  // offset is the lane's constant 16 (4) bytes, chunk / group offsets are SGPRs and consecutive 1 KiB
+  // groups share ONE M0 (LDS destination) through the instruction offset, which moves both the memory
+  // and the LDS address.  Measured next to an MFMA stream (tools/micro/dma.hip): 35 cycles of
+  // wave-time per 1 KiB piece against 229 for global_load_lds with per-piece 64-bit VGPR addresses.
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i rs_w, rs_s;              // buffer resources: packed weight sets, per-latent state row
+  __device__ static __forceinline__ v4i make_rsrc(const void* base) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    v4i r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));   // stride 0: raw buffer
+    r[2] = 0x7fffffff;         // bytes addressable from base
+    r[3] = 0x00020000;         // gfx950 raw-buffer descriptor word
+    return r;
   }
-  __device__ static __forceinline__ void dma4(const float* gsrc, unsigned lds_dst) {
+  // M0 is a reserved register for hipcc: it is saved and restored inside the statement
+  template <int N> __device__ static __forceinline__ void dma16(const v4i& rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    static_assert(N >= 1 && N <= 4, "instruction offsets 0 .. 3072");
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#define NPHM_DMA_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+#define NPHM_DMA_MORE(off) "buffer_load_dwordx4 %1, %2, %4 offen offset:" #off " lds\n\t"
+#define NPHM_DMA_ARGS : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory"
+    if constexpr (N == 1) asm volatile(NPHM_DMA_HEAD "s_mov_b32 m0, %0" NPHM_DMA_ARGS);
+    else if constexpr (N == 2) asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) "s_mov_b32 m0, %0" NPHM_DMA_ARGS);
+    else if constexpr (N == 3) asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) NPHM_DMA_MORE(2048) "s_mov_b32 m0, %0" NPHM_DMA_ARGS);
+    else asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) NPHM_DMA_MORE(2048) NPHM_DMA_MORE(3072) "s_mov_b32 m0, %0" NPHM_DMA_ARGS);
+#undef NPHM_DMA_HEAD
+#undef NPHM_DMA_MORE
+#undef NPHM_DMA_ARGS
+  }
+  __device__ static __forceinline__ void dma4(const v4i& rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
   }
   __device__ static __forceinline__ unsigned lds_addr(const char* q) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)q;
@@ -270,53 +345,115 @@ struct Streamer {
     k_cur = mi < n_active ? __builtin_amdgcn_readfirstlane(int(list[mi])) : -1;
     k_nxt = mi + 1 < n_active ? __builtin_amdgcn_readfirstlane(int(list[mi + 1])) : -1;
   }
-  // fetch chunk `ci` (compile-time) of the current (next = false) or the next member into its slot
-  __device__ __forceinline__ void issue(const bool next, const int ci) const {
+  // Fetch of chunk `ci` of the current (next = false) or the next member into its ring slot, in pieces.
+  // A chunk of ng 1 KiB groups: piece 0 = Q = ng / NW consecutive groups per wavefront (one M0),
+  // piece 1 = the ng % NW left-over groups, one each for the first wavefronts, piece 2 = the 256-byte
+  // tail (one wavefront).  Every wavefront issues at least Q loads per chunk (sync() counts on it).
+  static constexpr int PIECES = 3;
+  __device__ __forceinline__ void issue_piece(const bool next, const int ci, const int i) const {
     const int k = next ? k_nxt : k_cur;
-    if (k < 0) return;
+    if (k < 0 || (NPHM_ABLATE & 1)) return;
     int l = lane;
-    asm volatile("" : "+v"(l));           // per-site addresses are recomputed, not hoisted (VGPRs)
-    const char* src = ci == 0
-        ? reinterpret_cast<const char*>(st + Stream<PREC>::LS_OFF_L0 + k * L0_BLOCK_FLOATS) + l * 16
-        : Stream<PREC>::set_base(p, member_set(k)) + Stream<PREC>::offset(ci - 1) + l * 16;
+    asm volatile("" : "+v"(l));           // the lane offset is recomputed per site, not kept live
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(ring + (ci % RING) * SLOT_BYTES));
-    constexpr int MAXG = 32;
     const int ng = Stream<PREC>::groups(ci);
-#pragma unroll
-    for (int i = 0; i < (MAXG + NW - 1) / NW; ++i) {
-      const int g = wave + i * NW;
-      if (i * NW < ng && g < ng) dma16(src + g * 1024, dst + g * 1024);
+    const int q = ng / NW, rem = ng - q * NW;
+    const unsigned base = ci == 0 ? unsigned(Stream<PREC>::LS_OFF_L0 + k * L0_BLOCK_FLOATS) * 4u
+                                  : unsigned(member_set(k)) * Stream<PREC>::SET_BYTES + unsigned(Stream<PREC>::offset(ci - 1));
+    const v4i& rs = ci == 0 ? rs_s : rs_w;
+    if (i == 0) {
+      const unsigned g = unsigned(q * wave) * 1024u;
+      const unsigned soff = __builtin_amdgcn_readfirstlane(base + g), d = __builtin_amdgcn_readfirstlane(dst + g);
+      if (q == 1) dma16<1>(rs, l * 16, soff, d);
+      else if (q == 2) dma16<2>(rs, l * 16, soff, d);
+      else if (q == 3) dma16<3>(rs, l * 16, soff, d);
+      else dma16<4>(rs, l * 16, soff, d);
+    } else if (i == 1) {
+      if (wave < rem) {
+        const unsigned g = unsigned(q * NW + wave) * 1024u;
+        dma16<1>(rs, l * 16, __builtin_amdgcn_readfirstlane(base + g), __builtin_amdgcn_readfirstlane(dst + g));
+      }
+    } else if (ci > 0 && wave == (ci & (NW - 1))) {
+      const unsigned soff = unsigned(LS_OFF_TAIL + (k * GEMM_CHUNKS + ci - 1) * TAIL_FLOATS) * 4u;
+      dma4(rs_s, l * 4, __builtin_amdgcn_readfirstlane(soff), dst + Stream<PREC>::MAIN_BYTES);
     }
-    if (ci > 0 && wave == (ci & (NW - 1)))
-      dma4(st + LS_OFF_TAIL + (k * GEMM_CHUNKS + ci - 1) * TAIL_FLOATS + l, dst + Stream<PREC>::MAIN_BYTES);
+  }
+  __device__ __forceinline__ void issue(const bool next, const int ci) const {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) issue_piece(next, ci, i);
+  }
+  // The ring runs AHEAD chunks in front of the GEMMs.  Ring positions: chunk ci of the member being
+  // consumed sits at position ci, position 19 is the phantom that keeps slots static, chunk ci of the
+  // NEXT member sits at 20 + ci.  During step CI (between the barriers of chunks CI and CI + 1) the
+  // pieces of position CI + AHEAD go out: that slot held position CI - 2, which every wavefront left
+  // before the barrier of chunk CI; the slot of position CI - 1 stays intact, its tail is still read
+  // by a fused lin3 epilogue.  Because of the phantom the next member's chunks 0, 1 go out in steps
+  // 17, 18 and its chunk 2 only in its own step 0 (together with chunk 3).
+  static constexpr int AHEAD = NPHM_AHEAD;
+  static constexpr int POS_NEXT = CHUNKS_PER_MEMBER + 1;
+  static_assert(AHEAD == 2 || AHEAD == 3, "the slot of position CI - 1 must survive step CI");
+  // AHEAD == 2: steps 17, 18 also fetch the next member's chunks 0, 1 (three ring positions ahead,
+  // across the phantom) and every step fetches exactly one chunk.
+  template <int CI> __device__ __forceinline__ void prefetch_piece(const int i) const {
+    if constexpr (AHEAD == 3 && CI == 0) {
+      if (i < PIECES) issue_piece(false, 2, i); else issue_piece(false, 3, i - PIECES);
+    } else if constexpr (AHEAD == 3) {
+      constexpr int Q = CI + AHEAD;
+      if constexpr (Q < CHUNKS_PER_MEMBER) issue_piece(false, Q, i);
+      else if constexpr (Q >= POS_NEXT) issue_piece(true, Q - POS_NEXT, i);
+    } else {
+      constexpr int T = CI + AHEAD;
+      if constexpr (T < CHUNKS_PER_MEMBER) issue_piece(false, T, i);
+      else issue_piece(true, T - CHUNKS_PER_MEMBER, i);
+    }
+  }
+  template <int CI> static constexpr int prefetch_pieces() { return (AHEAD == 3 && CI == 0) ? 2 * PIECES : PIECES; }
+  template <int CI> __device__ __forceinline__ void prefetch() const {
+#pragma unroll
+    for (int i = 0; i < prefetch_pieces<CI>(); ++i) prefetch_piece<CI>(i);
   }
   template <int N> __device__ static __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
   }
+  // lower bound of the DMAs a wavefront has in flight for the D-th fetch after chunk CI's when it
+  // reaches the barrier of chunk CI (D = 1 .. AHEAD - 1)
+  template <int CI, int D> static constexpr int younger(const bool has_next) {
+    if (D >= AHEAD) return 0;
+    if (AHEAD == 3) {
+      constexpr int Q = CI + D;
+      if (Q < CHUNKS_PER_MEMBER) return (CI == 0 && Q == 2) ? 0 : Stream<PREC>::groups(Q) / NW;
+      if (Q < POS_NEXT) return 0;
+      return has_next ? Stream<PREC>::groups(Q - POS_NEXT) / NW : 0;
+    }
+    constexpr int T = CI + D;
+    if (T < CHUNKS_PER_MEMBER) return Stream<PREC>::groups(T) / NW;
+    return has_next ? Stream<PREC>::groups(T - CHUNKS_PER_MEMBER) / NW : 0;
+  }
   // Every wavefront of the workgroup calls sync<CI>() exactly once per chunk, in the same order.
   template <int CI> __device__ __forceinline__ void sync() {
-    // chunk CI (issued two syncs ago) must have landed.  The only younger DMAs of this wavefront are
-    // those of the next chunk: at least groups/NW of them.  VMEM completes in order, so waiting until
-    // at most that many operations are outstanding retires every load of chunk CI.
-    constexpr int NXT = (CI + 1) % CHUNKS_PER_MEMBER;
-    constexpr int YOUNGER = Stream<PREC>::groups(NXT) / NW;
-    const bool has_next = CI + 1 < CHUNKS_PER_MEMBER || k_nxt >= 0;
+    // chunk CI must have landed.  The only younger DMAs of this wavefront are those of positions CI + 1
+    // and CI + 2.  VMEM completes in order, so waiting until at most that many operations are
+    // outstanding retires every load of chunk CI.
+    constexpr int YN = younger<CI, 1>(true) + younger<CI, 2>(true);     // a next member exists
+    constexpr int YL = younger<CI, 1>(false) + younger<CI, 2>(false);   // this is the last member
 #if NPHM_PROF
     const long long ta = clock64();
 #endif
-    if (has_next) wait_vm<YOUNGER>(); else wait_vm<0>();
+    if constexpr (YN == YL) {
+      wait_vm<YN>();
+    } else {
+      if (k_nxt >= 0) wait_vm<YN>(); else wait_vm<YL>();
+    }
 #if NPHM_PROF
     const long long tb = clock64();
 #endif
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(NPHM_ABLATE & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #if NPHM_PROF
     const long long tc = clock64();
 #endif
-    // every wavefront is past chunk CI-3 (its epilogue included), whose slot chunk CI+2 reuses
-    if constexpr (CI + 2 < CHUNKS_PER_MEMBER) issue(false, CI + 2);
-    else issue(true, CI + 2 - CHUNKS_PER_MEMBER);
+    if constexpr (!NPHM_DMA_INSTREAM) prefetch<CI>();
 #if NPHM_PROF
     const long long td = clock64();
     sprof[0] += tb - ta; sprof[1] += tc - tb; sprof[2] += td - tc;
@@ -404,6 +541,87 @@ __device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
   return gemm_block_bf16_impl<NKS16, FULL, NIN, false, NPHM_PF_HEAVY>(afrag, acc, in, lane);
 }
 
+// Epilogue bookkeeping of the chunk pipeline: number of accumulator registers of chunk P that hold
+// real features, and the chunks whose epilogue runs "exposed" right behind their own GEMM instead of
+// inside the next chunk's: the member's last chunk, and the next-to-last chunk of lin1 and of lin2 -
+// fusing those two would hold 13 live 16-register blocks + 2 accumulators + the A fragments (> 256 VGPRs)
+__host__ __device__ constexpr int epilogue_units(int P) {
+  return (P == L1_OB || P == L1_OB + L2_OB || P == CHUNKS_PER_MEMBER - 1) ? LAST_BLOCK_REGS : 16;
+}
+#ifndef NPHM_EXPOSE_A
+#define NPHM_EXPOSE_A -1
+#endif
+#ifndef NPHM_EXPOSE_B
+#define NPHM_EXPOSE_B -1
+#endif
+__host__ __device__ constexpr bool epilogue_exposed(int P) {
+  return P == NPHM_EXPOSE_A || P == NPHM_EXPOSE_B || P == CHUNKS_PER_MEMBER - 1;
+}
+
+// ---- GEMM of chunk c fused with the epilogue of chunk c-1 ----------------------------------------
+// A wavefront issues in order: the VALU epilogue of the previous chunk is cut into NU units and one
+// slice is placed behind every MFMA of this chunk's (dependent) accumulation chain, where it executes
+// in the shadow of that MFMA (32 cycles of matrix pipe, 4 of issue) - measured in
+// tools/micro/overlap.hip: MFMA + softplus interleaved in one wavefront cost max(...) + ~15 %, not the sum.
+// sched_barrier(0) after every slot keeps hipcc from regrouping the stream.
+template <int NKS16, int FULL, int NIN, bool LIGHT, int PF, int NU, class Epi, class Pre>
+__device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc, const ActB (&in)[NIN],
+                                                  int lane, Epi&& epi, Pre&& pre) {
+  const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
+  bf16x8 wh[NKS16], wl[NKS16];
+#pragma unroll
+  for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
+    wh[ks] = A[(2 * ks) * 64];
+    if (!LIGHT) wl[ks] = A[(2 * ks + 1) * 64];
+  }
+  constexpr int NM = LIGHT ? 1 : 3;        // MFMAs per K-step
+  constexpr int NS = NKS16 * NM;           // issue slots
+  static_for<NKS16>([&](auto kk) __attribute__((always_inline)) {
+    constexpr int ks = decltype(kk)::value;
+    if constexpr (ks + PF < NKS16) {
+      wh[ks + PF] = A[(2 * (ks + PF)) * 64];
+      if (!LIGHT) wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
+    }
+    pre(kk);                               // one piece of the weight prefetch (LDS-DMA issue) per K-step
+    __builtin_amdgcn_sched_barrier(0);     // the reads above are issued HERE, ahead of the MFMAs
+    constexpr int b = ks < 2 * FULL ? (ks >> 1) : FULL;
+    constexpr int sb = ks < 2 * FULL ? (ks & 1) : 0;
+    static_for<NM>([&](auto mm) __attribute__((always_inline)) {
+      constexpr int m = decltype(mm)::value;
+      if constexpr (m == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].hi[sb], acc, 0, 0, 0);
+      else if constexpr (m == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].lo[sb], acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], in[b].hi[sb], acc, 0, 0, 0);
+      constexpr int slot = ks * NM + m;
+      static_range<unit_begin(slot, NS, NU), unit_begin(slot + 1, NS, NU)>(epi);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+  return acc;
+}
+
+// fp32 MFMA flavour: one slot per group of 4 K-steps (4 x v_mfma_f32_32x32x2f32 = 256 cycles of matrix pipe)
+template <int NKS, int FULL, int NIN, int NU, class Epi, class Pre>
+__device__ __forceinline__ f32x16 gemm_fused_f32(const char* afrag, f32x16 acc, const f32x16 (&in)[NIN],
+                                                 int lane, Epi&& epi, Pre&& pre) {
+  const f32x4* A = reinterpret_cast<const f32x4*>(afrag) + lane;
+  constexpr int NS = NKS / 4;
+  static_for<NS>([&](auto gg) __attribute__((always_inline)) {
+    constexpr int g = decltype(gg)::value;
+    const f32x4 a = A[g * 64];
+    pre(gg);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ks = 4 * g + c;
+      const int b = ks < 16 * FULL ? (ks >> 4) : FULL;
+      const int r = ks < 16 * FULL ? (ks & 15) : ks - 16 * FULL;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], in[b][r], acc, 0, 0, 0);
+    }
+    static_range<unit_begin(g, NS, NU), unit_begin(g + 1, NS, NU)>(epi);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  return acc;
+}
+
 template <int MODE, int PREC>
 __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   using WS = Streamer<PREC>;
@@ -417,7 +635,6 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   const int h_inv = lane >> 5;
   const int h = h_inv;
   const int j = lane & 31;
-  const bool upper = wave >= NW / 2;      // second wavefront of its SIMD (see the chunk loop)
 
   // ---- locate this lane's query point ------------------------------------------------------
   bool valid;
@@ -551,10 +768,10 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       wg_list[__popcll(gmask & ((1ull << threadIdx.x) - 1))] = (unsigned char)threadIdx.x;
   }
   __syncthreads();
-  WS ws{p, st, ring, wg_list, n_active, 0, wave, lane};
+  WS ws{p, st, ring, wg_list, n_active, 0, wave, lane, WS::make_rsrc(Stream<PREC>::set_base(p, 0)), WS::make_rsrc(st)};
   ws.load_ids();
   ws.issue(false, 0);
-  ws.issue(false, 1);
+  ws.issue(false, 1);   // (AHEAD == 3: chunk 2 goes out in step 0)
 
   float acc = 0.f;
 #if NPHM_PROF
@@ -569,6 +786,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       // this wavefront's 32 points do not need member k: keep the ring moving only
       static_for<CHUNKS_PER_MEMBER>([&](auto cc) __attribute__((always_inline)) {
         ws.template sync<decltype(cc)::value>();
+        if constexpr (NPHM_DMA_INSTREAM) ws.template prefetch<decltype(cc)::value>();
       });
       ws.next_member();
       continue;
@@ -600,130 +818,197 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     // Activations of this wavefront's 32 points (registers): fp32 blocks or split-bf16 operands
     using Act = typename std::conditional<PREC == 0, f32x16, ActB>::type;
     Act H[7], G[4];
-    auto store_act = [&](const f32x16& v, Act& dst) __attribute__((always_inline)) {
-      if constexpr (PREC == 0) { dst = v; pin16(dst); } else { split_block(v, dst, light); }
-    };
+    f32x16 accs[2];    // accumulators of two consecutive chunks: GEMM(c) fills one while the epilogue of c-1 drains the other
+    const float coords[3] = {cx, cy, cz};
 
-    // ---- 19 chunks: 0 = L0 (3 coords -> 200), 1..4 = L1, 5..11 = L2, 12..18 = L3; each = GEMM on
-    // the MFMA pipe + epilogue on the VALU.  The NW wavefronts of the workgroup meet at ONE barrier per
-    // chunk (weight ring), but the upper half (the second wave of every SIMD) places it one epilogue
-    // earlier: while the lower half runs GEMM(c) the upper half runs epilogue(c-1), then the roles
-    // swap - matrix and vector pipes of a SIMD stay busy together instead of alternating in lockstep.
-    f32x16 d;          // accumulator of the GEMM chunk in flight
-    f32x16 d0[7];      // the 7 accumulators of the L0 chunk
-    auto gemm = [&](auto cc) __attribute__((always_inline)) {
-      constexpr int c = decltype(cc)::value;
-      PROF_T(t_g0);
-      const char* buf = ws.slot(c);
-      if constexpr (c == 0) {
-        // L0: lin0 restricted to the coordinates, folded bias as an extra K column (prep_kernels.hip)
-        if constexpr (PREC == 0) {
-          const float* A = reinterpret_cast<const float*>(buf) + lane;
-          const float bk0 = h ? cy : cx, bk1 = h ? 1.f : cz;
-#pragma unroll
-          for (int ob = 0; ob < 7; ++ob) {
-            f32x16 z = {};
-            z = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob) * 64], bk0, z, 0, 0, 0);
-            d0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob + 1) * 64], bk1, z, 0, 0, 0);
-          }
-        } else {
-          const bf16x8* A = reinterpret_cast<const bf16x8*>(buf) + lane;
-          __bf16 xh[3], xl[3], xll[3];
-          const float cs[3] = {cx, cy, cz};
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            xh[i] = (__bf16)cs[i];
-            const float r1 = cs[i] - (float)xh[i];
-            xl[i] = (__bf16)r1;
-            xll[i] = (__bf16)(r1 - (float)xl[i]);
-          }
-          const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-          bf16x8 bv;
-          bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
-          bv[3] = h ? one : xl[0];
-          bv[4] = h ? xll[0] : xl[1];
-          bv[5] = h ? xll[1] : xl[2];
-          bv[6] = h ? xll[2] : one;
-          bv[7] = h ? zero : one;
-#pragma unroll
-          for (int ob = 0; ob < 7; ++ob) {
-            f32x16 z = {};
-            d0[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ob * 64], bv, z, 0, 0, 0);
-          }
+    // ---- 19 chunks: 0 = L0 (3 coords -> 200), 1..4 = L1, 5..11 = L2, 12..18 = L3.  The NW wavefronts of
+    // the workgroup meet at ONE barrier per chunk (weight ring).  Between two barriers a wavefront runs
+    // GEMM(c) on the matrix pipe with the VALU epilogue of chunk c-1 threaded through it (gemm_fused_*):
+    // the epilogue of the last block of a layer is short (8 real features) and its block is consumed by
+    // the LAST K-step of the next layer's chunks, so the fusion also runs across layer boundaries.
+
+    // unit r (one accumulator register) of the epilogue of chunk P: softplus, then into the operand
+    // layout of the next layer (P <= 11) or, for lin3's blocks, straight into lin4's dot product
+    f32x4 w4q = {};
+    auto epi_unit = [&](auto PP, auto LL, auto uu) __attribute__((always_inline)) {
+      constexpr int P = decltype(PP)::value, r = decltype(uu)::value;
+      constexpr bool LIGHT = decltype(LL)::value;
+      f32x16& a = accs[P & 1];
+      constexpr int g = P - 1;
+      constexpr bool last_block = P == 0 || g == L1_OB - 1 || g == L1_OB + L2_OB - 1 || P == CHUNKS_PER_MEMBER - 1;
+      (void)last_block;
+      float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
+      if constexpr (P >= 1 + L1_OB + L2_OB) {
+        // lin3 block: lin4 (200 -> 1) fused; its 16 weights sit in the chunk's ring-slot tail
+        if constexpr (r % 4 == 0) {
+          typedef __attribute__((address_space(3))) const f32x4* lds_v4;
+          const unsigned int w4a = WS::lds_addr(reinterpret_cast<const char*>(WS::tail_of(ws.slot(P)) + 32 + h * 16 + r));
+          w4q = *(lds_v4)(size_t)w4a;
         }
+        part = fmaf(x, w4q[r % 4], part);
+        asm volatile("" : "+v"(part));      // finish this unit here (see pack_pair)
       } else {
-        d = load_frag16(WS::tail_of(buf) + h * 16);
-        constexpr int g = c - 1;
-        if constexpr (PREC == 0) {
-          if constexpr (g < L1_OB) d = gemm_block_f32<L1_KS, 6, 7>(buf, d, H, lane);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_block_f32<L2_KS, 3, 4>(buf, d, G, lane);
-          else d = gemm_block_f32<L3_KS, 6, 7>(buf, d, H, lane);
-        } else {
-          if constexpr (g < L1_OB) d = gemm_block_bf16<L1_KS16, 6, 7>(buf, d, H, lane, light);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_block_bf16<L2_KS16, 3, 4>(buf, d, G, lane, light);
-          else d = gemm_block_bf16<L3_KS16, 6, 7>(buf, d, H, lane, light);
-        }
-      }
-#if NPHM_PROF
-      if constexpr (c == 0) asm volatile("" : "+v"(d0[6][0])); else asm volatile("" : "+v"(d[0]));
-      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // let the last MFMA retire before the stamp
-#endif
-      PROF_T(t_g1);
-      PROF_ADD(c == 0 ? 0 : 2, t_g0, t_g1);
-    };
-    auto epilogue = [&](auto cc) __attribute__((always_inline)) {
-      constexpr int c = decltype(cc)::value;
-      PROF_T(t_e0);
-      if constexpr (c == 0) {
-#pragma unroll
-        for (int b = 0; b < 7; ++b) {
-          constexpr int NR0 = 16, NR1 = LAST_BLOCK_REGS;
-          f32x16 v = b == 6 ? softplus_block<NR1>(d0[b], light) : softplus_block<NR0>(d0[b], light);
-          store_act(v, H[b]);
-        }
-      } else if constexpr (c - 1 < L1_OB + L2_OB) {
-        constexpr int g = c - 1;
-        constexpr bool last_block = g == L1_OB - 1 || g == L1_OB + L2_OB - 1;
-        f32x16 v = softplus_block<(last_block ? LAST_BLOCK_REGS : 16)>(d, light);
-        if constexpr (g == L1_OB - 1) {
+        static_assert(P >= 1, "the L0 blocks have their own epilogue");
+        if constexpr (g == L1_OB - 1 && r >= 1 && r <= 3) {
           // skip connection: features 101..103 of lin2's input are the local coords (block 3,
           // regs 1..3 of the upper half-wave); 1/sqrt(2) and the activation scale live in the weights
-          v[1] = h ? cx : v[1];
-          v[2] = h ? cy : v[2];
-          v[3] = h ? cz : v[3];
+          x = h ? coords[r - 1] : x;
         }
-        if constexpr (g < L1_OB) store_act(v, G[g]); else store_act(v, H[g - L1_OB]);
-      } else {
-        // L3 block: lin4 (200 -> 1) fused; read its fragment AFTER the GEMM (hoisted above it, it
-        // only gets spilled)
-        unsigned int w4a = WS::lds_addr(reinterpret_cast<const char*>(WS::tail_of(ws.slot(c)) + 32 + h * 16));
-        asm volatile("" : "+v"(w4a) : "v"(d[15]));
-        const f32x16 w4 = load_frag16_lds(w4a);
-        const f32x16 v = softplus_block<(c == CHUNKS_PER_MEMBER - 1 ? LAST_BLOCK_REGS : 16)>(d, light);
+        Act& dst = g < L1_OB ? G[g < L1_OB ? g : 0] : H[g >= L1_OB ? g - L1_OB : 0];
+        constexpr int NR = (g == L1_OB - 1 || g == L1_OB + L2_OB - 1) ? LAST_BLOCK_REGS : 16;
+        if constexpr (PREC == 0) {
+          dst[r] = x;
+          asm volatile("" : "+v"(dst[r]));
+          if constexpr (r == NR - 1) {
 #pragma unroll
-        for (int r = 0; r < (c == CHUNKS_PER_MEMBER - 1 ? LAST_BLOCK_REGS : 16); ++r)
-          part = fmaf(v[r], w4[r], part);
-        asm volatile("" : "+v"(part));      // finish this block's epilogue here (see pin16)
+            for (int q = NR; q < 16; ++q) dst[q] = 0.f;
+          }
+        } else {
+          a[r] = x;
+          if constexpr (r & 1) pack_pair<r - 1, LIGHT>(a, dst);
+          if constexpr (r == NR - 1 && NR < 16) {
+            // padding features of a layer's last block: zero operands (their weights are zero too,
+            // but 0 x garbage could be NaN)
+            const __bf16 z = (__bf16)0.f;
+#pragma unroll
+            for (int q = NR; q < 8; ++q) { dst.hi[0][q] = z; dst.lo[0][q] = z; }
+            asm volatile("" : "+v"(dst.hi[0]));
+            asm volatile("" : "+v"(dst.lo[0]));
+          }
+        }
       }
-      PROF_T(t_e1);
-      PROF_ADD(3, t_e0, t_e1);
     };
-    static_for<CHUNKS_PER_MEMBER>([&](auto cc) __attribute__((always_inline)) {
-      constexpr int c = decltype(cc)::value;
-      if constexpr (c > 1) {
-        if (upper) { PROF_T(t_s0); ws.template sync<c>(); PROF_T(t_s1); PROF_ADD(1, t_s0, t_s1); }
-        epilogue(std::integral_constant<int, (c > 0 ? c - 1 : 0)>{});
-        if (!upper) { PROF_T(t_s0); ws.template sync<c>(); PROF_T(t_s1); PROF_ADD(1, t_s0, t_s1); }
-      } else if constexpr (c == 1) {
-        // the L0 epilogue (7 blocks) is as long for both halves: enter the stagger after it
-        epilogue(std::integral_constant<int, 0>{});
-        PROF_T(t_s0); ws.template sync<c>(); PROF_T(t_s1); PROF_ADD(1, t_s0, t_s1);
+    // unit r of the epilogue of L0 block B (accumulator accs[B & 1]) -> H[B]
+    auto epi_l0 = [&](auto BB, auto LL, auto uu) __attribute__((always_inline)) {
+      constexpr int B = decltype(BB)::value, r = decltype(uu)::value;
+      constexpr bool LIGHT = decltype(LL)::value;
+      constexpr int NR = B == 6 ? LAST_BLOCK_REGS : 16;
+      f32x16& a = accs[B & 1];
+      const float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
+      if constexpr (PREC == 0) {
+        H[B][r] = x;
+        asm volatile("" : "+v"(H[B][r]));
+        if constexpr (r == NR - 1) {
+#pragma unroll
+          for (int q = NR; q < 16; ++q) H[B][q] = 0.f;
+        }
       } else {
-        PROF_T(t_s0); ws.template sync<c>(); PROF_T(t_s1); PROF_ADD(1, t_s0, t_s1);
+        a[r] = x;
+        if constexpr (r & 1) pack_pair<r - 1, LIGHT>(a, H[B]);
+        if constexpr (r == NR - 1 && NR < 16) {
+          const __bf16 z = (__bf16)0.f;
+#pragma unroll
+          for (int q = NR; q < 8; ++q) { H[B].hi[0][q] = z; H[B].lo[0][q] = z; }
+          asm volatile("" : "+v"(H[B].hi[0]));
+          asm volatile("" : "+v"(H[B].lo[0]));
+        }
       }
-      gemm(cc);
-    });
-    epilogue(std::integral_constant<int, CHUNKS_PER_MEMBER - 1>{});
+    };
+
+    // one chunk between two barriers (LIGHT: this member runs single-pass for this wavefront)
+    auto step = [&](auto cc, auto LL) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      constexpr bool LIGHT = decltype(LL)::value;
+      const char* buf = ws.slot(c);
+      if constexpr (c == 0) {
+        // L0: lin0 restricted to the coordinates, folded bias as an extra K column (prep_kernels.hip);
+        // one MFMA (two on the fp32 path) per 32-feature block, the next block's issued ahead of
+        // this block's epilogue
+        auto l0_mfma = [&](auto BB) __attribute__((always_inline)) {
+          constexpr int ob = decltype(BB)::value;
+          f32x16 z = {};
+          if constexpr (PREC == 0) {
+            const float* A = reinterpret_cast<const float*>(buf) + lane;
+            const float bk0 = h ? cy : cx, bk1 = h ? 1.f : cz;
+            z = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob) * 64], bk0, z, 0, 0, 0);
+            accs[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob + 1) * 64], bk1, z, 0, 0, 0);
+          } else {
+            const bf16x8* A = reinterpret_cast<const bf16x8*>(buf) + lane;
+            __bf16 xh[3], xl[3], xll[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              xh[i] = (__bf16)coords[i];
+              const float r1 = coords[i] - (float)xh[i];
+              xl[i] = (__bf16)r1;
+              xll[i] = (__bf16)(r1 - (float)xl[i]);
+            }
+            const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+            bf16x8 bv;
+            bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
+            bv[3] = h ? one : xl[0];
+            bv[4] = h ? xll[0] : xl[1];
+            bv[5] = h ? xll[1] : xl[2];
+            bv[6] = h ? xll[2] : one;
+            bv[7] = h ? zero : one;
+            accs[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ob * 64], bv, z, 0, 0, 0);
+          }
+        };
+        l0_mfma(std::integral_constant<int, 0>{});
+        static_for<7>([&](auto BB) __attribute__((always_inline)) {
+          constexpr int ob = decltype(BB)::value;
+          if constexpr (ob + 1 < 7) l0_mfma(std::integral_constant<int, ob + 1>{});
+          if constexpr (NPHM_DMA_INSTREAM && 2 * ob < WS::template prefetch_pieces<0>()) {
+            ws.template prefetch_piece<0>(2 * ob);
+            ws.template prefetch_piece<0>(2 * ob + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          static_range<0, (ob == 6 ? LAST_BLOCK_REGS : 16)>([&](auto uu) __attribute__((always_inline)) { epi_l0(BB, LL, uu); });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+        constexpr int g = c - 1;
+        constexpr int P = c - 1;                       // chunk whose epilogue rides along
+        constexpr int NU = (P == 0 || epilogue_exposed(P)) ? 0 : epilogue_units(P);
+        auto epi = [&](auto uu) __attribute__((always_inline)) {
+          if constexpr (P >= 1) epi_unit(std::integral_constant<int, P>{}, LL, uu);
+        };
+        // the pieces of the chunk AHEAD of this one go out between the first K-steps, in MFMA shadow
+        auto pre = [&](auto kk) __attribute__((always_inline)) {
+          if constexpr (NPHM_DMA_INSTREAM && decltype(kk)::value < WS::template prefetch_pieces<c>())
+            ws.template prefetch_piece<c>(decltype(kk)::value);
+        };
+        f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
+        if constexpr (PREC == 0) {
+          if constexpr (g < L1_OB) d = gemm_fused_f32<L1_KS, 6, 7, NU>(buf, d, H, lane, epi, pre);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_f32<L2_KS, 3, 4, NU>(buf, d, G, lane, epi, pre);
+          else d = gemm_fused_f32<L3_KS, 6, 7, NU>(buf, d, H, lane, epi, pre);
+        } else {
+          constexpr int PF = LIGHT ? NPHM_PF_LIGHT : NPHM_PF_HEAVY;
+          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, LIGHT, PF, NU>(buf, d, H, lane, epi, pre);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, LIGHT, PF, NU>(buf, d, G, lane, epi, pre);
+          else d = gemm_fused_bf16<L3_KS16, 6, 7, LIGHT, PF, NU>(buf, d, H, lane, epi, pre);
+        }
+        accs[c & 1] = d;
+        if constexpr (epilogue_exposed(c)) {
+          static_range<0, epilogue_units(c)>([&](auto uu) __attribute__((always_inline)) {
+            epi_unit(std::integral_constant<int, c>{}, LL, uu);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    // the whole member under ONE branch on the (wave-uniform) precision class: two straight-line bodies
+    auto run_member = [&](auto LL) __attribute__((always_inline)) {
+      static_for<CHUNKS_PER_MEMBER>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        PROF_T(t_s0);
+        ws.template sync<c>();
+        PROF_T(t_s1);
+        PROF_ADD(1, t_s0, t_s1);
+        step(cc, LL);
+#if NPHM_PROF
+        asm volatile("" : "+v"(accs[c & 1][0]));
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // let the last MFMA retire before the stamp
+#endif
+        PROF_T(t_s2);
+        PROF_ADD(c == 0 ? 0 : 2, t_s1, t_s2);
+      });
+    };
+    if constexpr (PREC == 0) {
+      run_member(std::false_type{});
+    } else {
+      if (light) run_member(std::true_type{}); else run_member(std::false_type{});
+    }
 
     const float f = part + __shfl_xor(part, 32) + b4;
 
