@@ -304,10 +304,11 @@ def main():
     mesh = None
     barrier()
     t_m0 = time.perf_counter()
-    step(False)
+    if not args.no_mesh:
+        step(False)
     barrier()
     t_m1 = time.perf_counter()
-    if rank == 0:
+    if rank == 0 and not args.no_mesh:
         vol_dev = shard if world == 1 else box["full"]
         vol_host = vol_dev.cpu().numpy()
         t_m2 = time.perf_counter()
@@ -365,8 +366,8 @@ def main():
                          "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12,
                          "note": "achieved counts EXECUTED matrix FLOPs: the adaptive default issues one pass instead "
                                  "of three for ~46% of the evaluated members, so it is faster at a lower FLOP rate "
-                                 "(--precision bf16x3: 3 passes everywhere, ~270 Mpoints/s at frac ~0.33); the kernel is "
-                                 "co-bound by its VALU epilogue (2 transcendentals per activation), DESIGN.md section 10"},
+                                 "(--precision bf16x3: 3 passes everywhere, ~281 Mpoints/s at frac ~0.34); the kernel is "
+                                 "held back by the per-chunk weight streaming / barrier and the VALU epilogue threaded through the MFMA chain (ablations in DESIGN.md section 4.1)"},
         }
         out["mesh_extract"] = mesh
         if not args.no_cpu_baseline and world == 1:

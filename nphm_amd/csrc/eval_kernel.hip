@@ -59,7 +59,7 @@ struct EvalArgs {
 #define NPHM_AHEAD 2   // chunks the weight ring runs ahead of the GEMMs (2 or 3)
 #endif
 // timing ablations (results are garbage): 1 = no weight streaming, 2 = no workgroup barrier, 4 = no epilogue arithmetic,
-// 8 = no MFMA
+// 16 = no wait for the weight DMA
 #ifndef NPHM_ABLATE
 #define NPHM_ABLATE 0
 #endif
@@ -439,7 +439,8 @@ struct Streamer {
 #if NPHM_PROF
     const long long ta = clock64();
 #endif
-    if constexpr (YN == YL) {
+    if constexpr ((NPHM_ABLATE & 16) != 0) {
+    } else if constexpr (YN == YL) {
       wait_vm<YN>();
     } else {
       if (k_nxt >= 0) wait_vm<YN>(); else wait_vm<YL>();
@@ -529,10 +530,10 @@ __device__ __forceinline__ f32x16 gemm_block_bf16_impl(const char* afrag, f32x16
 }
 
 #ifndef NPHM_PF_HEAVY
-#define NPHM_PF_HEAVY 2
+#define NPHM_PF_HEAVY 1
 #endif
 #ifndef NPHM_PF_LIGHT
-#define NPHM_PF_LIGHT 5
+#define NPHM_PF_LIGHT 3
 #endif
 template <int NKS16, int FULL, int NIN>
 __device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
