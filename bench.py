@@ -44,6 +44,7 @@ def parse():
                     help="identity = BASELINE.json configs[1] (the contract line); the others are the remaining "
                          "configs (two_stage = configs[2], npm = configs[0], fitting = configs[4]), single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-binning", action="store_true", help="brick-order traversal instead of tiles binned by member set")
     ap.add_argument("--no-mesh", action="store_true", help="skip the mesh-extract leg (kernel timing experiments)")
     ap.add_argument("--cpu-sample", type=int, default=40000)
     return ap.parse_args()
@@ -263,6 +264,8 @@ def main():
     shard = torch.zeros(max(n_planes, 1) * plane, dtype=torch.float32, device=dev)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     box = {"full": None}
+    ws = None if args.no_binning or not n_planes else R.grid_workspace(dev, n_planes, ry, rz)
+    ws_ptr, ws_bytes = (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
 
     def step(timed, ev=None):
         packed, state, _ = net.prepare_latent(lat[None])
@@ -274,7 +277,7 @@ def main():
                 packed.data_ptr(), state.data_ptr(), axes_dev[0].data_ptr(), axes_dev[1].data_ptr(),
                 axes_dev[2].data_ptr(), rx, ry, rz, planes_dev.data_ptr(), n_planes, args.chunk,
                 float(net.prune_tol), net._precision_code(), shard.data_ptr(),
-                stats.data_ptr() if timed else None, stream), "eval_grid_planes")
+                stats.data_ptr() if timed else None, ws_ptr, ws_bytes, stream), "eval_grid_planes")
         if timed:
             ev[1].record()
         if world > 1:
@@ -342,6 +345,9 @@ def main():
         exec_flops = (passes * (mean_active - mean_light) + mean_light) * FLOP_MEMBER_FOLDED * n_local
         peak = PEAK_TFLOPS[net.precision]
         achieved = exec_flops / (k_ms * 1e-3) / 1e12
+        # the events bracket the whole grid call: with binning that is the tile pre-pass + radix sort
+        # (together ~1 % of it) + the dominant kernel
+        kname = "nphm::eval_kernel<%d,%d>" % (1 if ws is None else 2, min(net._precision_code(), 1))
         out = {
             "metric": "SDF query throughput, NPHM 39-anchor identity field, dense lattice extraction",
             "value": n_total * args.steps / dt / 1e6, "unit": "Mpoints/s", "n_gpus": world,
@@ -356,9 +362,9 @@ def main():
                        "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather" if world > 1 else "single GPU")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
-                         "traffic": measured_traffic("nphm::eval_kernel<1,%d>" % min(net._precision_code(), 1), n_local),
+                         "traffic": measured_traffic(kname, n_local),
                          "algorithmic_bytes": 4 * n_local,
-                         "kernel": "nphm::eval_kernel<1,%d>" % min(net._precision_code(), 1), "rank0_planes": n_planes,
+                         "kernel": kname, "rank0_planes": n_planes, "binned_tiles": ws is not None,
                          "kernel_ms": k_ms, "points_per_launch": n_local,
                          "executed_flops_per_point": exec_flops / n_local, "mean_single_pass_members": mean_light,
                          "mfma_passes": passes,

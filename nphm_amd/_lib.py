@@ -32,10 +32,12 @@ SYMBOLS = {
     "nphm_identity_eval_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_float,
                                           c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_eval_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                        c_int, c_int, c_int, c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+                                        c_int, c_int, c_int, c_int64, c_float, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_size_t, c_void_p]),
+    "nphm_identity_grid_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nphm_identity_eval_grid_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                c_int, c_void_p, c_int, c_int64, c_float, c_int, c_void_p, c_void_p,
-                                               c_void_p]),
+                                               c_void_p, c_size_t, c_void_p]),
     "nphm_identity_bwd_packed_bytes": (c_size_t, []),
     "nphm_identity_pack_bwd": (c_int, [_PtrArr5, c_void_p, c_void_p]),
     "nphm_identity_member_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
@@ -43,7 +45,8 @@ SYMBOLS = {
     "nphm_identity_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_eval_grid_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                               c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+                                               c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                               c_void_p]),
     "nphm_mlp_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_int]),
     "nphm_mlp_packed_bytes": (c_size_t, [c_int] * 4),
     "nphm_mlp_latent_state_bytes": (c_size_t, [c_int] * 5),
@@ -89,7 +92,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 1:
+    if lib.nphm_abi_version() != 2:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

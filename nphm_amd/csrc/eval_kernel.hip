@@ -16,6 +16,7 @@
 //     lattice-ordered displaced points: two-stage evaluation), bricks are enumerated so that each
 //     XCD works on a compact region (L2 reuse of the streamed members).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
@@ -48,6 +49,14 @@ struct EvalArgs {
   int nbx, nby, nbz;        // bricks per axis
   int nsx, nsy, nsz;        // super-bricks (2x4x4 bricks) per axis
   int64_t hack_chunk;
+  // MODE 2 (grid, tiles binned by member mask; written by tile_prepass_kernel + a radix sort)
+  const unsigned* tile_order;   // slot -> tile id, tiles of equal member masks adjacent
+  uint64_t* tile_masks;         // [tile][2]: members evaluated by the tile's wavefront, ... with 3 passes
+  float2* tile_sd;              // [tile][32]: (sum of blend weights, normaliser) of every point
+  uint64_t* tile_keys;          // sort keys (pre-pass output)
+  unsigned* tile_ids;           // identity permutation (pre-pass output)
+  int ntx, nty, ntz;            // 4x4x2-voxel tiles per axis of the slab
+  int n_tiles;
 };
 
 // 1: the LDS-DMA pieces of the prefetched chunk are issued between the K-steps of the GEMM in flight,
@@ -623,6 +632,148 @@ __device__ __forceinline__ f32x16 gemm_fused_f32(const char* afrag, f32x16 acc, 
   return acc;
 }
 
+// ---- query point of a lattice slab ---------------------------------------------------------------
+struct GridPoint {
+  bool valid, hack;
+  int64_t out_idx;
+  float qx, qy, qz;
+};
+// lx = position inside the slab / the plane list; (iy, iz) lattice indices
+__device__ __forceinline__ GridPoint grid_point(const EvalArgs& p, int lx, int iy, int iz, bool in_tile) {
+  GridPoint g;
+  const int nlx = p.ix1 - p.ix0;
+  g.valid = in_tile && lx < nlx && iy < p.ry && iz < p.rz;
+  const int clx = min(lx, nlx - 1), cy_ = min(iy, p.ry - 1), cz_ = min(iz, p.rz - 1);
+  const int cx_ = p.xplanes ? p.xplanes[clx] : p.ix0 + clx;
+  const int64_t gi = (int64_t(cx_) * p.ry + cy_) * p.rz + cz_;
+  g.out_idx = (int64_t(clx) * p.ry + cy_) * p.rz + cz_;
+  if (p.xyz) {
+    // lattice-ORDERED but displaced queries (canonical points x + F_ex(x) of the two-stage
+    // evaluation): same traversal, coordinates from the slab-local point array
+    const float* q = p.xyz + g.out_idx * 3;
+    g.qx = q[0]; g.qy = q[1]; g.qz = q[2];
+  } else {
+    g.qx = p.ax[cx_]; g.qy = p.ay[cy_]; g.qz = p.az[cz_];
+  }
+  g.hack = false;
+  if (p.hack_chunk > 0)
+    g.hack = ((gi + 1) % p.hack_chunk == 0) || (gi == int64_t(p.rx) * p.ry * p.rz - 1);
+  return g;
+}
+
+// ---- blend normaliser and active-member masks (EnsembledDeepSDF.py:129-150) ------------------------
+// Per lane: S = sum of the 40 blend weights, denom = S + 1e-6.  Per GROUP of lanes (the whole
+// wavefront, or with SPLIT its two 32-lane halves = two tiles of the binning pre-pass):
+//   wmask: members the group's wavefront evaluates, hmask: ... of which with the 3-pass product.
+// Pruning rule, per point: drop the smallest-weight members as long as their normalised weights sum
+// to <= 40 * prune_tol (|error| <= 40 * prune_tol * max|f_k|, the bound of dropping every member
+// below prune_tol - but it is spent where it buys most: 6.2 instead of 7.6 members per wavefront).
+// The cut is the largest of 6 candidate thresholds whose cumulated weight stays within the budget.
+template <bool SPLIT>
+__device__ __forceinline__ void blend_masks(const float* anch, float qx, float qy, float qz, bool valid, bool hack,
+                                            float prune_tol, float light_tol, float& S_out, float& denom_out,
+                                            uint64_t (&wmask)[2], uint64_t (&hmask)[2]) {
+  // the 39 anchor weights of this lane's point are computed ONCE and kept in registers: the three
+  // passes below index them statically (unrolled)
+  float wv[N_LOC];
+  float S = 0.f;
+#pragma unroll
+  for (int k = 0; k < N_LOC; ++k) {
+    const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
+    wv[k] = expf(-(d * d) / 0.01f);
+    S += wv[k];
+  }
+  const float w_bg = expf(-0.2f / 0.01f);
+  S += w_bg;
+  const float denom = S + 1e-6f;
+  S_out = S;
+  denom_out = denom;
+  auto any = [&](bool c, uint64_t bit, uint64_t (&m)[2]) __attribute__((always_inline)) {
+    const uint64_t b = __ballot(c);
+    if (SPLIT) {
+      if (b & 0xffffffffull) m[0] |= bit;
+      if (b >> 32) m[1] |= bit;
+    } else if (b) {
+      m[0] |= bit;
+    }
+  };
+  float thr = prune_tol * denom;
+  wmask[0] = wmask[1] = 0;                 // members this wavefront evaluates (wave-uniform)
+  hmask[0] = hmask[1] = ~0ull;             // ... of which with the full split-bf16 product ("heavy")
+  if (prune_tol < 0.f) {
+    const uint64_t b = __ballot(valid);
+    const uint64_t all = (1ull << N_MEMBERS) - 1;
+    if (SPLIT) { wmask[0] = (b & 0xffffffffull) ? all : 0ull; wmask[1] = (b >> 32) ? all : 0ull; }
+    else wmask[0] = b ? all : 0ull;
+  } else {
+    hmask[0] = hmask[1] = 0;
+    constexpr int NT = 6;
+    const float mult[NT] = {1.f, 2.f, 4.f, 8.f, 16.f, 40.f};
+    float below[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) below[t] = w_bg <= mult[t] * thr ? w_bg : 0.f;
+#pragma unroll
+    for (int k = 0; k < N_LOC; ++k) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) below[t] += wv[k] <= mult[t] * thr ? wv[k] : 0.f;
+    }
+    const float budget = float(N_MEMBERS) * thr;
+    float cut = thr;                     // the first candidate always fits: <= 40 members below prune_tol
+#pragma unroll
+    for (int t = 1; t < NT; ++t) cut = below[t] <= budget ? mult[t] * thr : cut;
+    thr = cut;
+    const bool live = valid && !hack;
+#pragma unroll
+    for (int k = 0; k < N_LOC; ++k) any(live && wv[k] > thr, 1ull << k, wmask);
+    any(live && w_bg > thr, 1ull << N_LOC, wmask);
+    // members that weigh >= light_tol somewhere in the group keep the 3-pass product
+    const float heavy_thr = light_tol * denom;
+#pragma unroll
+    for (int k = 0; k < N_LOC; ++k) any(live && wv[k] >= heavy_thr, 1ull << k, hmask);
+    any(live && w_bg >= heavy_thr, 1ull << N_LOC, hmask);
+  }
+}
+
+// ---- binning pre-pass ---------------------------------------------------------------------------------
+// Tiles = the 4x4x2-voxel blocks a wavefront of eval_kernel works on (tile t = ((tlx * nty) + ty) * ntz + tz).
+// One wavefront handles two tiles (its 32-lane halves): per point (S, denom), per tile the member
+// masks and a sort key = (wmask, hash(hmask)) - equal masks end up adjacent after the radix sort, so
+// the 8 wavefronts of a workgroup stream (nearly) the same members: no idle passes for members that
+// only a neighbouring tile needs, and the workgroups running together on an XCD share their weights.
+__device__ __forceinline__ void tile_lane(const EvalArgs& p, unsigned t, int j, int& lx, int& iy, int& iz) {
+  const int tz = int(t % unsigned(p.ntz));
+  const unsigned r = t / unsigned(p.ntz);
+  const int ty = int(r % unsigned(p.nty)), tlx = int(r / unsigned(p.nty));
+  lx = tlx * 4 + (j >> 3);
+  iy = ty * 4 + ((j >> 1) & 3);
+  iz = tz * 2 + (j & 1);
+}
+
+__global__ __launch_bounds__(256) void tile_prepass_kernel(EvalArgs p) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+  const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const unsigned t = wave_id * 2 + half;
+  const bool in_tile = t < unsigned(p.n_tiles);
+  int lx, iy, iz;
+  tile_lane(p, in_tile ? t : 0u, j, lx, iy, iz);
+  const GridPoint g = grid_point(p, lx, iy, iz, in_tile);
+  float S, denom;
+  uint64_t wmask[2], hmask[2];
+  blend_masks<true>(p.state + LS_OFF_ANCH, g.qx, g.qy, g.qz, g.valid, g.hack, p.prune_tol, p.light_tol, S, denom, wmask, hmask);
+  if (!in_tile) return;
+  p.tile_sd[size_t(t) * 32 + j] = make_float2(S, denom);
+  if (j == 0) {
+    const uint64_t w = wmask[half], h = hmask[half] & w;
+    p.tile_masks[2 * size_t(t)] = w;
+    p.tile_masks[2 * size_t(t) + 1] = hmask[half];
+    // 40 mask bits + 24 bits that tell different heavy sets of one mask apart
+    const uint64_t hh = (h * 0x9E3779B97F4A7C15ull) >> 40;
+    p.tile_keys[t] = (w << 24) | hh;
+    p.tile_ids[t] = t;
+  }
+}
+
 template <int MODE, int PREC>
 __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   using WS = Streamer<PREC>;
@@ -643,6 +794,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   bool hack = false;
   float qx, qy, qz;
   int row = 0;
+  unsigned tile = 0;
   if (MODE == 0) {
     row = blockIdx.y;
     const int64_t i = (int64_t(blockIdx.x) * NW + wave) * 32 + j;
@@ -652,7 +804,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     qx = q[0]; qy = q[1]; qz = q[2];
     out_idx = int64_t(row) * p.n_points + ic;
     if (p.hack_chunk > 0) hack = ((ic + 1) % p.hack_chunk == 0) || (ic == p.n_points - 1);
-  } else {
+  } else if (MODE == 1) {
     // The hardware places block b on XCD b % 8: XCD x works on super-bricks x, x+8, x+16, ...
     // (interleaved, so every XCD sees the same mix of near-surface and empty space) and its
     // consecutive blocks are the bricks of ONE super-brick.
@@ -667,84 +819,38 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     const int bz = sz * SBZ + inner % SBZ;
     const int wx = NW == 8 ? (wave & 1) : 0, wy = NW == 8 ? ((wave >> 1) & 1) : 0;
     const int wz = NW == 8 ? (wave >> 2) : wave;
-    // local x index (position inside the slab / the plane list) and the global plane it denotes
-    const int lx = bx * BRX + wx * 4 + (j >> 3);
-    const int iy = by * BRY + wy * 4 + ((j >> 1) & 3);
-    const int iz = bz * BRZ + wz * 2 + (j & 1);
-    const int nlx = p.ix1 - p.ix0;
-    valid = lx < nlx && iy < p.ry && iz < p.rz;
-    const int clx = min(lx, nlx - 1), cy_ = min(iy, p.ry - 1), cz_ = min(iz, p.rz - 1);
-    const int cx_ = p.xplanes ? p.xplanes[clx] : p.ix0 + clx;
-    const int64_t gi = (int64_t(cx_) * p.ry + cy_) * p.rz + cz_;
-    out_idx = (int64_t(clx) * p.ry + cy_) * p.rz + cz_;
-    if (p.xyz) {
-      // lattice-ORDERED but displaced queries (canonical points x + F_ex(x) of the two-stage
-      // evaluation): same brick traversal, coordinates from the slab-local point array
-      const float* q = p.xyz + out_idx * 3;
-      qx = q[0]; qy = q[1]; qz = q[2];
-    } else {
-      qx = p.ax[cx_]; qy = p.ay[cy_]; qz = p.az[cz_];
-    }
-    if (p.hack_chunk > 0)
-      hack = ((gi + 1) % p.hack_chunk == 0) || (gi == int64_t(p.rx) * p.ry * p.rz - 1);
+    const GridPoint g = grid_point(p, bx * BRX + wx * 4 + (j >> 3), by * BRY + wy * 4 + ((j >> 1) & 3),
+                                   bz * BRZ + wz * 2 + (j & 1), true);
+    valid = g.valid; hack = g.hack; out_idx = g.out_idx; qx = g.qx; qy = g.qy; qz = g.qz;
+  } else {
+    // binned tiles: slot -> tile through the sorted order of tile_prepass_kernel
+    const unsigned slot = blockIdx.x * NW + wave;
+    const bool in_tile = slot < unsigned(p.n_tiles);
+    tile = in_tile ? p.tile_order[in_tile ? slot : 0u] : 0u;
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    int lx, iy, iz;
+    tile_lane(p, tile, j, lx, iy, iz);
+    const GridPoint g = grid_point(p, lx, iy, iz, in_tile);
+    valid = g.valid; hack = g.hack; out_idx = g.out_idx; qx = g.qx; qy = g.qy; qz = g.qz;
   }
 
   const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
   const float* anch = st + LS_OFF_ANCH;
 
-  // ---- blend normaliser and active-member mask (EnsembledDeepSDF.py:129-150) -----------------
-  // the 39 anchor weights of this lane's point are computed ONCE and kept in registers (the member
-  // loop's registers are not live yet): the three passes below index them statically (unrolled)
-  float wv[N_LOC];
-  float S = 0.f;
-#pragma unroll
-  for (int k = 0; k < N_LOC; ++k) {
-    const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
-    wv[k] = expf(-(d * d) / 0.01f);
-    S += wv[k];
-  }
+  // ---- blend normaliser and active-member mask: computed here, or read from the binning pre-pass ----
+  float S, denom;
+  uint64_t wmask, hmask;
   const float w_bg = expf(-0.2f / 0.01f);
-  S += w_bg;
-  const float denom = S + 1e-6f;
-  // Pruning rule, per point: drop the smallest-weight members as long as their normalised weights sum
-  // to <= 40 * prune_tol (|error| <= 40 * prune_tol * max|f_k|, the bound of dropping every member
-  // below prune_tol - but it is spent where it buys most: 6.2 instead of 7.6 members per wavefront).
-  // The cut is the largest of 6 candidate thresholds whose cumulated weight stays within the budget.
-  float thr = p.prune_tol * denom;
-  uint64_t wmask = 0;                    // members this wavefront evaluates (wave-uniform)
-  uint64_t hmask = ~0ull;                // ... of which with the full split-bf16 product ("heavy")
-  const bool any_valid = __ballot(valid) != 0ull;
-  if (p.prune_tol < 0.f) {
-    wmask = any_valid ? (1ull << N_MEMBERS) - 1 : 0ull;
+  if (MODE == 2) {
+    const float2 sd = p.tile_sd[size_t(tile) * 32 + j];
+    S = sd.x; denom = sd.y;
+    const bool in_tile = blockIdx.x * NW + wave < unsigned(p.n_tiles);
+    wmask = in_tile ? p.tile_masks[2 * size_t(tile)] : 0ull;
+    hmask = in_tile ? p.tile_masks[2 * size_t(tile) + 1] : 0ull;
   } else {
-    hmask = 0;
-    constexpr int NT = 6;
-    const float mult[NT] = {1.f, 2.f, 4.f, 8.f, 16.f, 40.f};
-    float below[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) below[t] = w_bg <= mult[t] * thr ? w_bg : 0.f;
-#pragma unroll
-    for (int k = 0; k < N_LOC; ++k) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) below[t] += wv[k] <= mult[t] * thr ? wv[k] : 0.f;
-    }
-    const float budget = float(N_MEMBERS) * thr;
-    float cut = thr;                     // the first candidate always fits: <= 40 members below prune_tol
-#pragma unroll
-    for (int t = 1; t < NT; ++t) cut = below[t] <= budget ? mult[t] * thr : cut;
-    thr = cut;
-    const bool live = valid && !hack;
-#pragma unroll
-    for (int k = 0; k < N_LOC; ++k)
-      if (__ballot(live && wv[k] > thr) != 0ull) wmask |= 1ull << k;
-    if (__ballot(live && w_bg > thr) != 0ull) wmask |= 1ull << N_LOC;
-    // members that weigh >= light_tol somewhere in the wavefront keep the 3-pass product
-    const float heavy_thr = p.light_tol * denom;
-#pragma unroll
-    for (int k = 0; k < N_LOC; ++k)
-      if (__ballot(live && wv[k] >= heavy_thr) != 0ull) hmask |= 1ull << k;
-    if (__ballot(live && w_bg >= heavy_thr) != 0ull) hmask |= 1ull << N_LOC;
+    uint64_t wm[2], hm[2];
+    blend_masks<false>(anch, qx, qy, qz, valid, hack, p.prune_tol, p.light_tol, S, denom, wm, hm);
+    wmask = wm[0]; hmask = hm[0];
   }
 
   const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
@@ -1059,12 +1165,70 @@ static void fill_common(nphm::EvalArgs& a, const void* packed, const void* laten
   a.hack_chunk = hack_chunk;
 }
 
-static int launch_grid(nphm::EvalArgs& a, int precision, hipStream_t st, const char* who) {
+// workspace of the binned grid evaluation: [order][ids][keys in][keys out][masks][S, denom][sort temp]
+namespace {
+struct BinLayout {
+  int ntx, nty, ntz;
+  int64_t n_tiles;
+  size_t order, ids, keys_in, keys_out, masks, sd, temp, temp_bytes, bytes;
+};
+bool bin_layout(int nlx, int ry, int rz, BinLayout& l) {
+  l.ntx = (nlx + 3) / 4; l.nty = (ry + 3) / 4; l.ntz = (rz + 1) / 2;
+  l.n_tiles = int64_t(l.ntx) * l.nty * l.ntz;
+  if (l.n_tiles <= 0 || l.n_tiles > 0x3fffffffLL) return false;
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t r = o; o += (b + 255) / 256 * 256; return r; };
+  const size_t n = size_t(l.n_tiles);
+  l.order = take(n * 4); l.ids = take(n * 4); l.keys_in = take(n * 8); l.keys_out = take(n * 8);
+  l.masks = take(n * 16); l.sd = take(n * 32 * 8);
+  size_t tb = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, static_cast<const uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr),
+                                           static_cast<const unsigned*>(nullptr), static_cast<unsigned*>(nullptr), int(n));
+  l.temp_bytes = tb;
+  l.temp = take(tb);
+  l.bytes = o;
+  return true;
+}
+}  // namespace
+
+size_t nphm_identity_grid_workspace_bytes(int n_x_local, int ry, int rz) {
+  BinLayout l;
+  if (n_x_local <= 0 || ry <= 0 || rz <= 0 || !bin_layout(n_x_local, ry, rz, l)) return 0;
+  return l.bytes;
+}
+
+static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t workspace_bytes, hipStream_t st,
+                       const char* who) {
   a.light_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE ? NPHM_LIGHT_TOL : -1.f;
 #if NPHM_PROF
   if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
 #endif
   const int nx = a.ix1 - a.ix0;
+  if (workspace) {
+    // binned: tiles sorted by member mask (tile_prepass_kernel), one wavefront per tile in that order
+    BinLayout l;
+    if (!bin_layout(nx, a.ry, a.rz, l)) return nphm_fail_msg("slab too large for one launch");
+    if (workspace_bytes < l.bytes) return nphm_fail_msg("workspace smaller than nphm_identity_grid_workspace_bytes()");
+    char* ws = static_cast<char*>(workspace);
+    a.ntx = l.ntx; a.nty = l.nty; a.ntz = l.ntz; a.n_tiles = int(l.n_tiles);
+    a.tile_order = reinterpret_cast<const unsigned*>(ws + l.order);
+    a.tile_ids = reinterpret_cast<unsigned*>(ws + l.ids);
+    a.tile_keys = reinterpret_cast<uint64_t*>(ws + l.keys_in);
+    a.tile_masks = reinterpret_cast<uint64_t*>(ws + l.masks);
+    a.tile_sd = reinterpret_cast<float2*>(ws + l.sd);
+    const unsigned pre_blocks = unsigned((l.n_tiles + 7) / 8);                 // 4 wavefronts x 2 tiles
+    hipLaunchKernelGGL(nphm::tile_prepass_kernel, dim3(pre_blocks), dim3(256), 0, st, a);
+    size_t tb = l.temp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + l.temp, tb, a.tile_keys, reinterpret_cast<uint64_t*>(ws + l.keys_out),
+                                                      a.tile_ids, reinterpret_cast<unsigned*>(ws + l.order), int(l.n_tiles), 0, 64, st);
+    if (e != hipSuccess) return nphm_fail(who, e);
+    const dim3 grid(unsigned((l.n_tiles + nphm::NW - 1) / nphm::NW)), block(64 * nphm::NW);
+    if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<2, 0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((nphm::eval_kernel<2, 1>), grid, block, 0, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return nphm_fail(who, e);
+    return 0;
+  }
   a.nbx = (nx + nphm::BRX - 1) / nphm::BRX; a.nby = (a.ry + nphm::BRY - 1) / nphm::BRY;
   a.nbz = (a.rz + nphm::BRZ - 1) / nphm::BRZ;
   a.nsx = (a.nbx + nphm::SBX - 1) / nphm::SBX; a.nsy = (a.nby + nphm::SBY - 1) / nphm::SBY;
@@ -1110,7 +1274,8 @@ int nphm_identity_eval_grid(const void* packed, const void* latent_state,
                             const float* axis_x, const float* axis_y, const float* axis_z,
                             int rx, int ry, int rz, int ix0, int ix1,
                             int64_t hack_chunk, float prune_tol, int precision,
-                            float* sdf_out, unsigned long long* stats, void* stream) {
+                            float* sdf_out, unsigned long long* stats, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   if (!packed || !latent_state || !axis_x || !axis_y || !axis_z || !sdf_out)
     return nphm_fail_msg("nphm_identity_eval_grid: null pointer");
   if (rx <= 0 || ry <= 0 || rz <= 0 || ix0 < 0 || ix1 > rx || ix0 >= ix1)
@@ -1120,14 +1285,15 @@ int nphm_identity_eval_grid(const void* packed, const void* latent_state,
   fill_common(a, packed, latent_state, sdf_out, stats, prune_tol, hack_chunk);
   a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
   a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
-  return launch_grid(a, precision, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid");
+  return launch_grid(a, precision, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid");
 }
 
 int nphm_identity_eval_grid_planes(const void* packed, const void* latent_state,
                                    const float* axis_x, const float* axis_y, const float* axis_z,
                                    int rx, int ry, int rz, const int* x_planes, int n_planes,
                                    int64_t hack_chunk, float prune_tol, int precision,
-                                   float* sdf_out, unsigned long long* stats, void* stream) {
+                                   float* sdf_out, unsigned long long* stats, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   if (!packed || !latent_state || !axis_x || !axis_y || !axis_z || !sdf_out || !x_planes)
     return nphm_fail_msg("nphm_identity_eval_grid_planes: null pointer");
   if (rx <= 0 || ry <= 0 || rz <= 0 || n_planes <= 0 || n_planes > rx)
@@ -1138,13 +1304,14 @@ int nphm_identity_eval_grid_planes(const void* packed, const void* latent_state,
   a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
   a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = 0; a.ix1 = n_planes;
   a.xplanes = x_planes;
-  return launch_grid(a, precision, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid_planes");
+  return launch_grid(a, precision, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid_planes");
 }
 
 int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
                                    const float* xyz_slab, int rx, int ry, int rz, int ix0, int ix1,
                                    int64_t hack_chunk, float prune_tol, int precision,
-                                   float* sdf_out, unsigned long long* stats, void* stream) {
+                                   float* sdf_out, unsigned long long* stats, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   if (!xyz_slab) return nphm_fail_msg("nphm_identity_eval_grid_points: null pointer");
   // the axis pointers are never dereferenced when xyz_slab is given
   const float* dummy = xyz_slab;
@@ -1157,7 +1324,7 @@ int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
   a.xyz = xyz_slab;
   a.ax = dummy; a.ay = dummy; a.az = dummy;
   a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
-  return launch_grid(a, precision, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid_points");
+  return launch_grid(a, precision, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "nphm_identity_eval_grid_points");
 }
 
 }  // extern "C"

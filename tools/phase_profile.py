@@ -19,7 +19,7 @@ for prec,code,tol in (("bf16x3",1,None),("all-light",2,"10"),("adaptive",2,None)
     out=torch.empty(res**3,device=dev)
     for it in range(2):
         stats=torch.zeros(16,dtype=torch.int64,device=dev)
-        rc=lib.nphm_identity_eval_grid(packed.data_ptr(),state.data_ptr(),ax[0].data_ptr(),ax[1].data_ptr(),ax[2].data_ptr(),res,res,res,0,res,25000,1e-7,code,out.data_ptr(),stats.data_ptr(),None)
+        rc=lib.nphm_identity_eval_grid(packed.data_ptr(),state.data_ptr(),ax[0].data_ptr(),ax[1].data_ptr(),ax[2].data_ptr(),res,res,res,0,res,25000,1e-7,code,out.data_ptr(),stats.data_ptr(),None,0,None)
         torch.cuda.synchronize()
     s=stats.cpu().numpy().astype(float)
     nw=s[11]; names=["L0_gemm","sync(active)","gemm","epilogue","member_total","kernel_total","vmcnt_wait(all)","barrier_wait(all)","dma_issue(all)"]
