@@ -64,9 +64,6 @@ struct EvalArgs {
 #ifndef NPHM_DMA_INSTREAM
 #define NPHM_DMA_INSTREAM 1
 #endif
-#ifndef NPHM_AHEAD
-#define NPHM_AHEAD 2   // chunks the weight ring runs ahead of the GEMMs (2 or 3)
-#endif
 // timing ablations (results are garbage): 1 = no weight streaming, 2 = no workgroup barrier, 4 = no epilogue arithmetic,
 // 16 = no wait for the weight DMA
 #ifndef NPHM_ABLATE
@@ -391,68 +388,38 @@ struct Streamer {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) issue_piece(next, ci, i);
   }
-  // The ring runs AHEAD chunks in front of the GEMMs.  Ring positions: chunk ci of the member being
-  // consumed sits at position ci, position 19 is the phantom that keeps slots static, chunk ci of the
-  // NEXT member sits at 20 + ci.  During step CI (between the barriers of chunks CI and CI + 1) the
-  // pieces of position CI + AHEAD go out: that slot held position CI - 2, which every wavefront left
-  // before the barrier of chunk CI; the slot of position CI - 1 stays intact, its tail is still read
-  // by a fused lin3 epilogue.  Because of the phantom the next member's chunks 0, 1 go out in steps
-  // 17, 18 and its chunk 2 only in its own step 0 (together with chunk 3).
-  static constexpr int AHEAD = NPHM_AHEAD;
-  static constexpr int POS_NEXT = CHUNKS_PER_MEMBER + 1;
-  static_assert(AHEAD == 2 || AHEAD == 3, "the slot of position CI - 1 must survive step CI");
-  // AHEAD == 2: steps 17, 18 also fetch the next member's chunks 0, 1 (three ring positions ahead,
-  // across the phantom) and every step fetches exactly one chunk.
+  // The ring runs two chunks ahead of the GEMMs: during step CI (between the barriers of chunks CI and
+  // CI + 1) the pieces of chunk CI + 2 go out - its slot held chunk CI - 3 (chunk CI - 2 across the
+  // member boundary, where the phantom position 19 keeps the slots static): every wavefront left that one
+  // before the barrier of chunk CI, and the slot of chunk CI - 1 stays intact, its tail is still read by a
+  // fused lin3 epilogue.  Steps 17, 18 fetch the next member's chunks 0, 1.  (Three chunks ahead: no gain.)
+  static constexpr int AHEAD = 2;
   template <int CI> __device__ __forceinline__ void prefetch_piece(const int i) const {
-    if constexpr (AHEAD == 3 && CI == 0) {
-      if (i < PIECES) issue_piece(false, 2, i); else issue_piece(false, 3, i - PIECES);
-    } else if constexpr (AHEAD == 3) {
-      constexpr int Q = CI + AHEAD;
-      if constexpr (Q < CHUNKS_PER_MEMBER) issue_piece(false, Q, i);
-      else if constexpr (Q >= POS_NEXT) issue_piece(true, Q - POS_NEXT, i);
-    } else {
-      constexpr int T = CI + AHEAD;
-      if constexpr (T < CHUNKS_PER_MEMBER) issue_piece(false, T, i);
-      else issue_piece(true, T - CHUNKS_PER_MEMBER, i);
-    }
+    constexpr int T = CI + AHEAD;
+    if constexpr (T < CHUNKS_PER_MEMBER) issue_piece(false, T, i);
+    else issue_piece(true, T - CHUNKS_PER_MEMBER, i);
   }
-  template <int CI> static constexpr int prefetch_pieces() { return (AHEAD == 3 && CI == 0) ? 2 * PIECES : PIECES; }
   template <int CI> __device__ __forceinline__ void prefetch() const {
 #pragma unroll
-    for (int i = 0; i < prefetch_pieces<CI>(); ++i) prefetch_piece<CI>(i);
+    for (int i = 0; i < PIECES; ++i) prefetch_piece<CI>(i);
   }
   template <int N> __device__ static __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
   }
-  // lower bound of the DMAs a wavefront has in flight for the D-th fetch after chunk CI's when it
-  // reaches the barrier of chunk CI (D = 1 .. AHEAD - 1)
-  template <int CI, int D> static constexpr int younger(const bool has_next) {
-    if (D >= AHEAD) return 0;
-    if (AHEAD == 3) {
-      constexpr int Q = CI + D;
-      if (Q < CHUNKS_PER_MEMBER) return (CI == 0 && Q == 2) ? 0 : Stream<PREC>::groups(Q) / NW;
-      if (Q < POS_NEXT) return 0;
-      return has_next ? Stream<PREC>::groups(Q - POS_NEXT) / NW : 0;
-    }
-    constexpr int T = CI + D;
-    if (T < CHUNKS_PER_MEMBER) return Stream<PREC>::groups(T) / NW;
-    return has_next ? Stream<PREC>::groups(T - CHUNKS_PER_MEMBER) / NW : 0;
-  }
   // Every wavefront of the workgroup calls sync<CI>() exactly once per chunk, in the same order.
   template <int CI> __device__ __forceinline__ void sync() {
-    // chunk CI must have landed.  The only younger DMAs of this wavefront are those of positions CI + 1
-    // and CI + 2.  VMEM completes in order, so waiting until at most that many operations are
-    // outstanding retires every load of chunk CI.
-    constexpr int YN = younger<CI, 1>(true) + younger<CI, 2>(true);     // a next member exists
-    constexpr int YL = younger<CI, 1>(false) + younger<CI, 2>(false);   // this is the last member
+    // chunk CI must have landed.  The only younger DMAs of this wavefront are those of chunk CI + 1: at
+    // least groups / NW of them.  VMEM completes in order, so waiting until at most that many operations
+    // are outstanding retires every load of chunk CI.
+    constexpr int T = CI + 1;
 #if NPHM_PROF
     const long long ta = clock64();
 #endif
     if constexpr ((NPHM_ABLATE & 16) != 0) {
-    } else if constexpr (YN == YL) {
-      wait_vm<YN>();
+    } else if constexpr (T < CHUNKS_PER_MEMBER) {
+      wait_vm<Stream<PREC>::groups(T) / NW>();
     } else {
-      if (k_nxt >= 0) wait_vm<YN>(); else wait_vm<YL>();
+      if (k_nxt >= 0) wait_vm<Stream<PREC>::groups(0) / NW>(); else wait_vm<0>();
     }
 #if NPHM_PROF
     const long long tb = clock64();
@@ -878,7 +845,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   WS ws{p, st, ring, wg_list, n_active, 0, wave, lane, WS::make_rsrc(Stream<PREC>::set_base(p, 0)), WS::make_rsrc(st)};
   ws.load_ids();
   ws.issue(false, 0);
-  ws.issue(false, 1);   // (AHEAD == 3: chunk 2 goes out in step 0)
+  ws.issue(false, 1);
 
   float acc = 0.f;
 #if NPHM_PROF
@@ -1054,10 +1021,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         static_for<7>([&](auto BB) __attribute__((always_inline)) {
           constexpr int ob = decltype(BB)::value;
           if constexpr (ob + 1 < 7) l0_mfma(std::integral_constant<int, ob + 1>{});
-          if constexpr (NPHM_DMA_INSTREAM && 2 * ob < WS::template prefetch_pieces<0>()) {
-            ws.template prefetch_piece<0>(2 * ob);
-            ws.template prefetch_piece<0>(2 * ob + 1);
-          }
+          if constexpr (NPHM_DMA_INSTREAM && ob < WS::PIECES) ws.template prefetch_piece<0>(ob);
           __builtin_amdgcn_sched_barrier(0);
           static_range<0, (ob == 6 ? LAST_BLOCK_REGS : 16)>([&](auto uu) __attribute__((always_inline)) { epi_l0(BB, LL, uu); });
           __builtin_amdgcn_sched_barrier(0);
@@ -1071,7 +1035,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         };
         // the pieces of the chunk AHEAD of this one go out between the first K-steps, in MFMA shadow
         auto pre = [&](auto kk) __attribute__((always_inline)) {
-          if constexpr (NPHM_DMA_INSTREAM && decltype(kk)::value < WS::template prefetch_pieces<c>())
+          if constexpr (NPHM_DMA_INSTREAM && decltype(kk)::value < WS::PIECES)
             ws.template prefetch_piece<c>(decltype(kk)::value);
         };
         f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
