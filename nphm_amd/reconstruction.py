@@ -131,6 +131,18 @@ def marching_cubes_device(volume: torch.Tensor, isovalue: float = 0.0, *, negate
     return verts, faces
 
 
+def to_host(t: torch.Tensor) -> np.ndarray:
+    """Device tensor -> numpy through page-locked memory of torch's caching host allocator: one DMA at
+    link speed and no first-touch page faults (``tensor.cpu()`` lands in fresh pageable memory: 1-3 ms for
+    the 18 MB of a 256^3 mesh, with 25 ms outliers).  The array keeps the pinned block alive."""
+    if not t.is_cuda:
+        return t.numpy()
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy()
+
+
 def extract_mesh(decoder, encoding, mini, maxi, resolution, nbatch_points=25000):
     """latent -> mesh without leaving the device until the mesh exists: the NPHM identity SDF on the
     reference lattice (= get_logits, incl. the eval-mode chunk overwrite) followed by the GPU marching
@@ -141,9 +153,9 @@ def extract_mesh(decoder, encoding, mini, maxi, resolution, nbatch_points=25000)
     vol = evaluate_grid(decoder, encoding, axes, hack_chunk=hack)
     verts, faces = marching_cubes_device(vol.view(resolution, resolution, resolution), 0.0, negate=True)
     step = (np.array(maxi) - np.array(mini)) / (resolution - 1)
-    vertices = verts.cpu().numpy() * np.expand_dims(step, axis=0)
+    vertices = to_host(verts) * np.expand_dims(step, axis=0)
     vertices += [mini[0], mini[1], mini[2]]
-    triangles = faces.cpu().numpy()
+    triangles = to_host(faces)
     try:
         import trimesh
         return trimesh.Trimesh(vertices, triangles)
@@ -162,7 +174,7 @@ def mesh_from_logits(logits, mini, maxi, resolution, n_threads: int = 0):
         # a ROCm device is there: upload (4 B/voxel) + GPU extraction beats the host pass ~8x at 256^3;
         # the two extractors return bit-identical meshes
         v, f = marching_cubes_device(torch.from_numpy(np.ascontiguousarray(logits)).cuda(), 0.0)
-        vertices, triangles = v.cpu().numpy(), f.cpu().numpy()
+        vertices, triangles = to_host(v), to_host(f)
     else:
         vertices, triangles = marching_cubes(logits, 0.0, n_threads=n_threads)
     step = (np.array(maxi) - np.array(mini)) / (resolution - 1)
@@ -434,7 +446,7 @@ def get_logits(decoder, encoding, grid_points, nbatch_points=100000, return_anch
                 packed.data_ptr(), state.data_ptr(), pts.data_ptr(), 1, pts.shape[1], hack,
                 float(decoder.prune_tol), decoder._precision_code(), vol.data_ptr(), None, stream),
                 "nphm_identity_eval_points")
-        logits = vol.cpu().numpy()
+        logits = to_host(vol)
         return (logits, anchors) if return_anchors else logits
 
     if _mlp_hip_ready(decoder, device) and grid_points.dtype == torch.float32 and grid_points.shape[0] == 1:
@@ -445,7 +457,7 @@ def get_logits(decoder, encoding, grid_points, nbatch_points=100000, return_anch
             vol = evaluate_grid_mlp(decoder, lat, lattice)
         else:
             vol = decoder.forward_hip(grid_points, lat)
-        logits = vol.reshape(-1).cpu().numpy()
+        logits = to_host(vol.reshape(-1))
         return (logits, None) if return_anchors else logits
 
     # generic decoders: the reference's chunk loop (latent broadcast instead of repeat)
@@ -494,7 +506,7 @@ def get_logits_backward(decoder_shape, decoder_expr, encoding_shape, encoding_ex
                 packed.data_ptr(), state.data_ptr(), canonical.data_ptr(), 1, canonical.shape[1], hack,
                 float(decoder_shape.prune_tol), decoder_shape._precision_code(), vol.data_ptr(), None, stream),
                 "nphm_identity_eval_points")
-        logits = vol.cpu().numpy()
+        logits = to_host(vol)
         return (logits, anchors_pred) if return_anchors else logits
 
     enc_s = encoding_shape.reshape(1, 1, -1)
