@@ -7,14 +7,16 @@
 //     (layout.h); one workgroup = NW wavefronts = a compact brick of 32*NW points;
 //   * members whose normalised blend weight is <= prune_tol for every point of a wavefront are
 //     skipped; the workgroup streams the union of its wavefronts' members;
-//   * weights are streamed HBM/L2 -> LDS by LDS-DMA (global_load_lds) into a 5-slot ring shared by
-//     the workgroup, one 32-row output block ("chunk") at a time, two chunks ahead of their use;
-//   * per chunk: GEMM on the matrix pipe (fp32 MFMA, or 3 bf16 MFMAs per fp32 product), epilogue
-//     (bias is the accumulator init; base-2 softplus; re-split to bf16 hi/lo) on the vector pipe;
-//     the two wavefronts of a SIMD run half a phase apart so both pipes stay busy;
+//   * weights are streamed HBM/L2 -> LDS by LDS-DMA (MUBUF buffer_load ... lds) into a 5-slot ring shared
+//     by the workgroup, one 32-row output block ("chunk") at a time, two chunks ahead of their use;
+//   * per chunk: GEMM on the matrix pipe (fp32 MFMA, or 3 bf16 MFMAs per fp32 product; 1 for members
+//     whose blend weight stays below 1e-3 in the wavefront) with the VALU epilogue of the PREVIOUS chunk
+//     (base-2 softplus, re-split to bf16 hi/lo; bias is the accumulator init) threaded through its
+//     dependent MFMA chain - one wavefront keeps both pipes busy;
 //   * MODE 0 reads xyz[n,3]; MODE 1 generates the 'ij' lattice from three axis arrays (or reads
-//     lattice-ordered displaced points: two-stage evaluation), bricks are enumerated so that each
-//     XCD works on a compact region (L2 reuse of the streamed members).
+//     lattice-ordered displaced points: two-stage evaluation), bricks enumerated so that each XCD works
+//     on a compact region; MODE 2 is the same lattice traversed tile by tile (4x4x2 voxels = one
+//     wavefront) in the order of the tiles' active-member sets (tile_prepass_kernel + radix sort).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
@@ -92,7 +94,7 @@ __device__ __forceinline__ float softplus2(float d) {
   return fmaxf(d, 0.f) + __builtin_amdgcn_logf(1.f + t);             // raw v_log_f32, arg in [1,2]
 }
 
-// Softplus for "light" members (adaptive precision, see split_block): the correction term
+// Softplus for "light" members (adaptive precision: their GEMMs run single-pass, hi x hi only): the correction term
 // g(u) = log2(1 + 2^-u), u = |d'|, as (a0 - a1 min(u, .))^8 - max abs error 4.2e-3 in the scaled
 // domain (2.9e-5 in activation units, the size of the single-pass bf16 rounding these members already
 // carry; it enters the blend scaled by a weight < light_tol).  Plain multiply-adds in place of the
@@ -108,32 +110,10 @@ __device__ __forceinline__ float softplus2_light(float d) {
 #ifndef NPHM_LIGHT_POLY
 #define NPHM_LIGHT_POLY 1
 #endif
-// softplus of the first NR registers of an accumulator block (the rest stay 0)
-template <int NR>
-__device__ __forceinline__ f32x16 softplus_block(const f32x16& d, const bool light) {
-  f32x16 v = {};
-  if (NPHM_LIGHT_POLY && light) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) v[r] = softplus2_light(d[r]);
-  } else {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) v[r] = softplus2(d[r]);
-  }
-  return v;
-}
-
 // registers of the LAST 32-row block of a layer that hold real features: 200 = 6*32 + 8 and
 // 101 + 3 = 3*32 + 8 -> features 32b .. 32b+7 = registers 0..3 of both half-waves; the other 12
 // registers are padding (zero weights downstream) and skip the epilogue arithmetic
 constexpr int LAST_BLOCK_REGS = 4;
-
-// Pin values at this program point.  Without a use in the producing basic block LLVM sinks the
-// (pure) softplus arithmetic across the next workgroup barrier, next to the MFMAs that consume it,
-// which keeps pre- AND post-activation values live and spills.
-__device__ __forceinline__ void pin16(f32x16& v) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[r]));
-}
 
 // one 32-feature block of activations as split-bf16 B operands of v_mfma_f32_32x32x16_bf16:
 // K-step s consumes registers 8s..8s+7 of the block (k-slot 8h+i <-> register 8s+i)
@@ -141,49 +121,9 @@ struct ActB {
   bf16x8 hi[2], lo[2];
 };
 
-// light (wave-uniform): the member's blend weight is small at every point of the wavefront - its
-// GEMMs run single-pass (hi x hi only, see gemm_block_bf16) and the lo parts are not computed
-__device__ __forceinline__ void split_block(const f32x16& v, ActB& o, const bool light) {
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o.hi[s][i] = (__bf16)v[8 * s + i];
-  }
-  if (!light) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float x = v[8 * s + i];
-        o.lo[s][i] = (__bf16)(x - (float)o.hi[s][i]);
-      }
-    }
-  } else {
-    const bf16x8 z = {};
-    o.lo[0] = z; o.lo[1] = z;
-  }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {            // pin the packed operands (same reason as pin16)
-    asm volatile("" : "+v"(o.hi[s]));
-    asm volatile("" : "+v"(o.lo[s]));
-  }
-}
-
 __device__ __forceinline__ f32x16 load_frag16(const float* p) {
   // 16 consecutive floats (64-byte aligned) -> f32x16
   const f32x4* q = reinterpret_cast<const f32x4*>(p);
-  f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
-  f32x16 o;
-  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
-  o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-  o[8] = c[0]; o[9] = c[1]; o[10] = c[2]; o[11] = c[3];
-  o[12] = d[0]; o[13] = d[1]; o[14] = d[2]; o[15] = d[3];
-  return o;
-}
-
-__device__ __forceinline__ f32x16 load_frag16_lds(unsigned int lds_byte_addr) {
-  typedef __attribute__((address_space(3))) const f32x4* lds_v4;
-  lds_v4 q = (lds_v4)(size_t)lds_byte_addr;
   f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
   f32x16 o;
   o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
@@ -227,7 +167,7 @@ __device__ __forceinline__ void pack_pair(const f32x16& a, ActB& o) {
     o.lo[s][i] = (__bf16)(a[R] - (float)h0);
     o.lo[s][i + 1] = (__bf16)(a[R + 1] - (float)h1);
   }
-  // pin the finished operand registers here (see pin16): LLVM otherwise sinks the pure epilogue
+  // pin the finished operand registers here: LLVM otherwise sinks the pure epilogue
   // arithmetic to its use in the next layer's GEMM and keeps the accumulator alive until then
   if constexpr (i == 6) {
     asm volatile("" : "+v"(o.hi[s]));
@@ -451,73 +391,12 @@ struct Streamer {
   }
 };
 
-// One 32-row output block on fp32 MFMA: acc += sum_ks A(ks) x IN(block(ks))[reg(ks)].
-// A fragments come from LDS: [ks/4][lane][4].
-template <int NKS, int FULL, int NIN>
-__device__ __forceinline__ f32x16 gemm_block_f32(const char* afrag, f32x16 acc,
-                                                 const f32x16 (&in)[NIN], int lane) {
-  const f32x4* A = reinterpret_cast<const f32x4*>(afrag) + lane;
-#pragma unroll
-  for (int g = 0; g < NKS / 4; ++g) {
-    const f32x4 a = A[g * 64];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int ks = 4 * g + c;
-      const int b = ks < 16 * FULL ? (ks >> 4) : FULL;
-      const int r = ks < 16 * FULL ? (ks & 15) : ks - 16 * FULL;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], in[b][r], acc, 0, 0, 0);
-    }
-  }
-  return acc;
-}
-
-// The same block on split-bf16 MFMA: x*w ~= xh*wh + xl*wh + xh*wl (fp32 accumulate); the dropped
-// xl*wl term is 2^-16 relative.  A fragments from LDS: [ks][hi|lo][lane][8].
-template <int NKS16, int FULL, int NIN, bool LIGHT, int PF>
-__device__ __forceinline__ f32x16 gemm_block_bf16_impl(const char* afrag, f32x16 acc,
-                                                       const ActB (&in)[NIN], int lane) {
-  const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
-  // A fragments are fetched PF K-steps ahead of the MFMAs that consume them (LDS latency is
-  // ~128 cycles and more under load; one K-step is 96 cycles of matrix pipe, 32 for a single-pass
-  // member): hipcc does not pipeline this by itself
-  bf16x8 wh[NKS16], wl[NKS16];
-#pragma unroll
-  for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
-    wh[ks] = A[(2 * ks) * 64];
-    if (!LIGHT) wl[ks] = A[(2 * ks + 1) * 64];
-  }
-#pragma unroll
-  for (int ks = 0; ks < NKS16; ++ks) {
-    if (ks + PF < NKS16) {
-      wh[ks + PF] = A[(2 * (ks + PF)) * 64];
-      if (!LIGHT) wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
-    }
-    __builtin_amdgcn_sched_barrier(0);     // the reads above are issued HERE, ahead of the MFMAs
-    const int b = ks < 2 * FULL ? (ks >> 1) : FULL;
-    const int s = ks < 2 * FULL ? (ks & 1) : 0;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].hi[s], acc, 0, 0, 0);
-    if (!LIGHT) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].lo[s], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], in[b].hi[s], acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return acc;
-}
-
 #ifndef NPHM_PF_HEAVY
 #define NPHM_PF_HEAVY 1
 #endif
 #ifndef NPHM_PF_LIGHT
 #define NPHM_PF_LIGHT 3
 #endif
-template <int NKS16, int FULL, int NIN>
-__device__ __forceinline__ f32x16 gemm_block_bf16(const char* afrag, f32x16 acc,
-                                                  const ActB (&in)[NIN], int lane, const bool light) {
-  if (light) return gemm_block_bf16_impl<NKS16, FULL, NIN, true, NPHM_PF_LIGHT>(afrag, acc, in, lane);
-  return gemm_block_bf16_impl<NKS16, FULL, NIN, false, NPHM_PF_HEAVY>(afrag, acc, in, lane);
-}
-
 // Epilogue bookkeeping of the chunk pipeline: number of accumulator registers of chunk P that hold
 // real features, and the chunks whose epilogue runs "exposed" right behind their own GEMM instead of
 // inside the next chunk's: the member's last chunk, and the next-to-last chunk of lin1 and of lin2 -
@@ -708,6 +587,21 @@ __device__ __forceinline__ void blend_masks(const float* anch, float qx, float q
 // masks and a sort key = (wmask, hash(hmask)) - equal masks end up adjacent after the radix sort, so
 // the 8 wavefronts of a workgroup stream (nearly) the same members: no idle passes for members that
 // only a neighbouring tile needs, and the workgroups running together on an XCD share their weights.
+// Workgroup b runs on XCD b % 8.  The sorted tile list is cut into runs of XCD_RUN workgroups (equal or
+// neighbouring member sets) dealt to the XCDs in turn: an XCD's consecutive workgroups stay inside a run,
+// so its L2 keeps serving the same few members' weights instead of following, with all 8 XCDs, every
+// change of member set along the list (brick order: 5.4 GB of L2 fills per 256^3 launch, binned without
+// runs: 18.7 GB).  Grids are padded to whole rounds of 8 runs.
+#ifndef NPHM_XCD_RUN
+#define NPHM_XCD_RUN 64
+#endif
+constexpr unsigned XCD_RUN = NPHM_XCD_RUN;
+__device__ __forceinline__ unsigned binned_group(unsigned b) {
+  if (XCD_RUN <= 1) return b;
+  const unsigned xcd = b & 7u, i = b >> 3;                  // i-th workgroup of its XCD
+  return ((i / XCD_RUN) * 8u + xcd) * XCD_RUN + i % XCD_RUN;
+}
+
 __device__ __forceinline__ void tile_lane(const EvalArgs& p, unsigned t, int j, int& lx, int& iy, int& iz) {
   const int tz = int(t % unsigned(p.ntz));
   const unsigned r = t / unsigned(p.ntz);
@@ -791,7 +685,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     valid = g.valid; hack = g.hack; out_idx = g.out_idx; qx = g.qx; qy = g.qy; qz = g.qz;
   } else {
     // binned tiles: slot -> tile through the sorted order of tile_prepass_kernel
-    const unsigned slot = blockIdx.x * NW + wave;
+    const unsigned slot = binned_group(blockIdx.x) * NW + wave;
     const bool in_tile = slot < unsigned(p.n_tiles);
     tile = in_tile ? p.tile_order[in_tile ? slot : 0u] : 0u;
     tile = __builtin_amdgcn_readfirstlane(tile);
@@ -811,7 +705,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   if (MODE == 2) {
     const float2 sd = p.tile_sd[size_t(tile) * 32 + j];
     S = sd.x; denom = sd.y;
-    const bool in_tile = blockIdx.x * NW + wave < unsigned(p.n_tiles);
+    const bool in_tile = binned_group(blockIdx.x) * NW + wave < unsigned(p.n_tiles);
     wmask = in_tile ? p.tile_masks[2 * size_t(tile)] : 0ull;
     hmask = in_tile ? p.tile_masks[2 * size_t(tile) + 1] : 0ull;
   } else {
@@ -1186,7 +1080,9 @@ static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + l.temp, tb, a.tile_keys, reinterpret_cast<uint64_t*>(ws + l.keys_out),
                                                       a.tile_ids, reinterpret_cast<unsigned*>(ws + l.order), int(l.n_tiles), 0, 64, st);
     if (e != hipSuccess) return nphm_fail(who, e);
-    const dim3 grid(unsigned((l.n_tiles + nphm::NW - 1) / nphm::NW)), block(64 * nphm::NW);
+    const int64_t round = nphm::XCD_RUN > 1 ? 8 * int64_t(nphm::XCD_RUN) : 1;
+    const int64_t groups = ((l.n_tiles + nphm::NW - 1) / nphm::NW + round - 1) / round * round;
+    const dim3 grid((unsigned)groups), block(64 * nphm::NW);
     if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<2, 0>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((nphm::eval_kernel<2, 1>), grid, block, 0, st, a);
     e = hipGetLastError();
