@@ -301,6 +301,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   for (int t = 0; t < MT; ++t) value_lane[t] = (lane & 32) | ((32 * t + j) % PTS);
 
   const char* st = p.state + size_t(row) * p.state_row_bytes;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, 0x7fffffff, 0x00020000);
   const f32x16 zero16 = {};
   f32x16 acc[NTW][MT];
   Split8 packed_out[NTW][MT][2];
@@ -380,7 +381,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     coord_step(L, ni);
     __syncthreads();                                  // the previous layer's tile is complete
     if (ni > 0) {
-      const bf16x8* W = reinterpret_cast<const bf16x8*>(p.packed + L.w_off) + lane;
+      // A fragments through MUBUF loads: resource = the packed weights, VGPR offset = the lane's constant
+      // 16 bytes, tile / K-step offset in an SGPR - no per-load 64-bit VGPR address arithmetic next to the
+      // MFMA stream (tools/micro/dma.hip: the issue cost of a VGPR-addressed load there is ~3x)
+      const unsigned w_lane = lane * 16;
       const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
       const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
       bf16x8 ah[2][NTW], al[2][NTW], bh[2][MT], bl[2][MT];
@@ -388,9 +392,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
           if (i < ni) {
-            const size_t o = (size_t(wave + WAVES * i) * ks + s) * 128;
-            ah[slot][i] = W[o];
-            al[slot][i] = W[o + 64];
+            const unsigned o = __builtin_amdgcn_readfirstlane(L.w_off + (unsigned(wave + WAVES * i) * unsigned(ks) + unsigned(s)) * 2048u);
+            ah[slot][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o, 0));
+            al[slot][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o + 1024u, 0));
           }
         }
       };
