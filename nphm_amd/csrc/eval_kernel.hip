@@ -507,6 +507,19 @@ __device__ __forceinline__ GridPoint grid_point(const EvalArgs& p, int lx, int i
   return g;
 }
 
+// Gaussian blend weight of an anchor at offset (dx, dy, dz): exp(-(|d| + 1e-5)^2 / 0.01)
+// (EnsembledDeepSDF.py:129-133).  Raw v_sqrt_f32 (1 ulp), a multiplication by 100 (what PyTorch's
+// division by the scalar 0.01 is on a GPU) and exp(t) = 2^hi (1 + lo ln2) with t log2(e) = hi + lo carried in
+// two floats, instead of the IEEE sqrt / divide / expf expansions of hipcc: 12 instead of 45 VALU
+// operations, to the same ulp - 39 of them per lattice point in the binning pre-pass.
+__device__ __forceinline__ float blend_weight(float dx, float dy, float dz) {
+  const float d = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
+  const float t = -(d * d) * 100.0f;
+  const float hi = t * 1.44269504f;                                          // log2(e) = 1.44269504 + 1.925963e-8
+  const float lo = fmaf(t, 1.44269504f, -hi) + t * 1.925963033e-8f;
+  return __builtin_amdgcn_exp2f(hi) * fmaf(lo, 0.693147181f, 1.0f);
+}
+
 // ---- blend normaliser and active-member masks (EnsembledDeepSDF.py:129-150) ------------------------
 // Per lane: S = sum of the 40 blend weights, denom = S + 1e-6.  Per GROUP of lanes (the whole
 // wavefront, or with SPLIT its two 32-lane halves = two tiles of the binning pre-pass):
@@ -526,8 +539,7 @@ __device__ __forceinline__ void blend_masks(const float* anch, float qx, float q
 #pragma unroll
   for (int k = 0; k < N_LOC; ++k) {
     const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
-    wv[k] = expf(-(d * d) / 0.01f);
+    wv[k] = blend_weight(dx, dy, dz);
     S += wv[k];
   }
   const float w_bg = expf(-0.2f / 0.01f);
@@ -554,21 +566,19 @@ __device__ __forceinline__ void blend_masks(const float* anch, float qx, float q
     else wmask[0] = b ? all : 0ull;
   } else {
     hmask[0] = hmask[1] = 0;
-    constexpr int NT = 6;
-    const float mult[NT] = {1.f, 2.f, 4.f, 8.f, 16.f, 40.f};
-    float below[NT];
+    // candidates 1, 2, 4, 8, 16, 40 x thr; below(c) = weight of the members not above c is monotone in c,
+    // so the largest fitting candidate is found by bisection: 3 passes over the 40 weights instead of 6
+    auto below = [&](float c) __attribute__((always_inline)) {
+      float sum = w_bg <= c ? w_bg : 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) below[t] = w_bg <= mult[t] * thr ? w_bg : 0.f;
-#pragma unroll
-    for (int k = 0; k < N_LOC; ++k) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) below[t] += wv[k] <= mult[t] * thr ? wv[k] : 0.f;
-    }
-    const float budget = float(N_MEMBERS) * thr;
-    float cut = thr;                     // the first candidate always fits: <= 40 members below prune_tol
-#pragma unroll
-    for (int t = 1; t < NT; ++t) cut = below[t] <= budget ? mult[t] * thr : cut;
-    thr = cut;
+      for (int k = 0; k < N_LOC; ++k) sum += wv[k] <= c ? wv[k] : 0.f;
+      return sum;
+    };
+    const float budget = float(N_MEMBERS) * thr;      // the first candidate always fits: <= 40 members below prune_tol
+    const bool f8 = below(8.f * thr) <= budget;
+    const bool fb = below(f8 ? 40.f * thr : 4.f * thr) <= budget;
+    const bool fc = below(f8 ? 16.f * thr : 2.f * thr) <= budget;
+    thr = f8 ? (fb ? 40.f * thr : fc ? 16.f * thr : 8.f * thr) : (fb ? 4.f * thr : fc ? 2.f * thr : thr);
     const bool live = valid && !hack;
 #pragma unroll
     for (int k = 0; k < N_LOC; ++k) any(live && wv[k] > thr, 1ull << k, wmask);
@@ -776,8 +786,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       const float ax = anch[3 * k], ay = anch[3 * k + 1], az = anch[3 * k + 2];
       cx = qx - ax; cy = qy - ay; cz = qz - az;
       const float dx = ax - qx, dy = ay - qy, dz = az - qz;
-      const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
-      wk = expf(-(d * d) / 0.01f);
+      wk = blend_weight(dx, dy, dz);
     }
     if (k < 2 * N_SYMM && (k & 1)) cx = -cx;
     const float b4 = p.packed_f32[size_t(member_set(k)) * SET_STRIDE + OFF_L4B];
