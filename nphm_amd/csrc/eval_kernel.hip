@@ -391,6 +391,9 @@ struct Streamer {
   }
 };
 
+#ifndef NPHM_L0_FUSED
+#define NPHM_L0_FUSED 1
+#endif
 #ifndef NPHM_PF_HEAVY
 #define NPHM_PF_HEAVY 1
 #endif
@@ -420,9 +423,9 @@ __host__ __device__ constexpr bool epilogue_exposed(int P) {
 // in the shadow of that MFMA (32 cycles of matrix pipe, 4 of issue) - measured in
 // tools/micro/overlap.hip: MFMA + softplus interleaved in one wavefront cost max(...) + ~15 %, not the sum.
 // sched_barrier(0) after every slot keeps hipcc from regrouping the stream.
-template <int NKS16, int FULL, int NIN, bool LIGHT, int PF, int NU, class Epi, class Pre>
+template <int NKS16, int FULL, int NIN, bool LIGHT, int PF, int NU, class Epi, class Pre, class Slot>
 __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc, const ActB (&in)[NIN],
-                                                  int lane, Epi&& epi, Pre&& pre) {
+                                                  int lane, Epi&& epi, Pre&& pre, Slot&& slot_hook) {
   const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
   bf16x8 wh[NKS16], wl[NKS16];
 #pragma unroll
@@ -449,6 +452,7 @@ __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc,
       else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], in[b].hi[sb], acc, 0, 0, 0);
       constexpr int slot = ks * NM + m;
       static_range<unit_begin(slot, NS, NU), unit_begin(slot + 1, NS, NU)>(epi);
+      slot_hook(kk, mm);                   // work with its own placement (the L0 epilogues inside lin1's first chunk)
       __builtin_amdgcn_sched_barrier(0);
     });
   });
@@ -796,6 +800,14 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     using Act = typename std::conditional<PREC == 0, f32x16, ActB>::type;
     Act H[7], G[4];
     f32x16 accs[2];    // accumulators of two consecutive chunks: GEMM(c) fills one while the epilogue of c-1 drains the other
+    f32x16 acc_x;      // bf16 path: third accumulator while the L0 blocks are drained inside lin1's first chunk
+    // accumulator of L0 block B: fp32 path accs[B & 1]; bf16 path accs[0] / acc_x (accs[1] belongs to chunk 1)
+    auto l0_acc = [&](auto BB) __attribute__((always_inline)) -> f32x16& {
+      constexpr int B = decltype(BB)::value;
+      if constexpr (PREC == 0) return accs[B & 1];
+      else if constexpr (B & 1) return acc_x;
+      else return accs[0];
+    };
     const float coords[3] = {cx, cy, cz};
 
     // ---- 19 chunks: 0 = L0 (3 coords -> 200), 1..4 = L1, 5..11 = L2, 12..18 = L3.  The NW wavefronts of
@@ -860,7 +872,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       constexpr int B = decltype(BB)::value, r = decltype(uu)::value;
       constexpr bool LIGHT = decltype(LL)::value;
       constexpr int NR = B == 6 ? LAST_BLOCK_REGS : 16;
-      f32x16& a = accs[B & 1];
+      f32x16& a = l0_acc(BB);
       const float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
       if constexpr (PREC == 0) {
         H[B][r] = x;
@@ -883,52 +895,64 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     };
 
     // one chunk between two barriers (LIGHT: this member runs single-pass for this wavefront)
+    // L0: lin0 restricted to the coordinates, folded bias as an extra K column (prep_kernels.hip): one
+    // MFMA (two on the fp32 path) per 32-feature block, from the member's chunk 0 (ring slot 0)
+    auto l0_mfma = [&](auto BB) __attribute__((always_inline)) {
+      constexpr int ob = decltype(BB)::value;
+      const char* buf = ws.slot(0);
+      f32x16 z = {};
+      if constexpr (PREC == 0) {
+        const float* A = reinterpret_cast<const float*>(buf) + lane;
+        const float bk0 = h ? cy : cx, bk1 = h ? 1.f : cz;
+        z = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob) * 64], bk0, z, 0, 0, 0);
+        l0_acc(BB) = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob + 1) * 64], bk1, z, 0, 0, 0);
+      } else {
+        const bf16x8* A = reinterpret_cast<const bf16x8*>(buf) + lane;
+        __bf16 xh[3], xl[3], xll[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          xh[i] = (__bf16)coords[i];
+          const float r1 = coords[i] - (float)xh[i];
+          xl[i] = (__bf16)r1;
+          xll[i] = (__bf16)(r1 - (float)xl[i]);
+        }
+        const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+        bf16x8 bv;
+        bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
+        bv[3] = h ? one : xl[0];
+        bv[4] = h ? xll[0] : xl[1];
+        bv[5] = h ? xll[1] : xl[2];
+        bv[6] = h ? xll[2] : one;
+        bv[7] = h ? zero : one;
+        l0_acc(BB) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ob * 64], bv, z, 0, 0, 0);
+      }
+    };
+    // bf16 path: the epilogues of the L0 blocks 1..6 ride inside lin1's FIRST chunk (its K-steps 2b, 2b+1
+    // read block b, so block b+1 is drained there and the MFMA of block b+2 is issued ahead); only block 0
+    // runs exposed.  fp32 path: all 7 blocks exposed in step 0 (an fp32 MFMA chain has shadow to spare).
+    constexpr bool L0_FUSED = PREC == 1 && NPHM_L0_FUSED;
     auto step = [&](auto cc, auto LL) __attribute__((always_inline)) {
       constexpr int c = decltype(cc)::value;
       constexpr bool LIGHT = decltype(LL)::value;
       const char* buf = ws.slot(c);
       if constexpr (c == 0) {
-        // L0: lin0 restricted to the coordinates, folded bias as an extra K column (prep_kernels.hip);
-        // one MFMA (two on the fp32 path) per 32-feature block, the next block's issued ahead of
-        // this block's epilogue
-        auto l0_mfma = [&](auto BB) __attribute__((always_inline)) {
-          constexpr int ob = decltype(BB)::value;
-          f32x16 z = {};
-          if constexpr (PREC == 0) {
-            const float* A = reinterpret_cast<const float*>(buf) + lane;
-            const float bk0 = h ? cy : cx, bk1 = h ? 1.f : cz;
-            z = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob) * 64], bk0, z, 0, 0, 0);
-            accs[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob + 1) * 64], bk1, z, 0, 0, 0);
-          } else {
-            const bf16x8* A = reinterpret_cast<const bf16x8*>(buf) + lane;
-            __bf16 xh[3], xl[3], xll[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              xh[i] = (__bf16)coords[i];
-              const float r1 = coords[i] - (float)xh[i];
-              xl[i] = (__bf16)r1;
-              xll[i] = (__bf16)(r1 - (float)xl[i]);
-            }
-            const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-            bf16x8 bv;
-            bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
-            bv[3] = h ? one : xl[0];
-            bv[4] = h ? xll[0] : xl[1];
-            bv[5] = h ? xll[1] : xl[2];
-            bv[6] = h ? xll[2] : one;
-            bv[7] = h ? zero : one;
-            accs[ob & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ob * 64], bv, z, 0, 0, 0);
-          }
-        };
         l0_mfma(std::integral_constant<int, 0>{});
-        static_for<7>([&](auto BB) __attribute__((always_inline)) {
-          constexpr int ob = decltype(BB)::value;
-          if constexpr (ob + 1 < 7) l0_mfma(std::integral_constant<int, ob + 1>{});
-          if constexpr (NPHM_DMA_INSTREAM && ob < WS::PIECES) ws.template prefetch_piece<0>(ob);
+        if constexpr (L0_FUSED) {
+          l0_mfma(std::integral_constant<int, 1>{});
+          if constexpr (NPHM_DMA_INSTREAM) ws.template prefetch<0>();
           __builtin_amdgcn_sched_barrier(0);
-          static_range<0, (ob == 6 ? LAST_BLOCK_REGS : 16)>([&](auto uu) __attribute__((always_inline)) { epi_l0(BB, LL, uu); });
+          static_range<0, 16>([&](auto uu) __attribute__((always_inline)) { epi_l0(std::integral_constant<int, 0>{}, LL, uu); });
           __builtin_amdgcn_sched_barrier(0);
-        });
+        } else {
+          static_for<7>([&](auto BB) __attribute__((always_inline)) {
+            constexpr int ob = decltype(BB)::value;
+            if constexpr (ob + 1 < 7) l0_mfma(std::integral_constant<int, ob + 1>{});
+            if constexpr (NPHM_DMA_INSTREAM && ob < WS::PIECES) ws.template prefetch_piece<0>(ob);
+            __builtin_amdgcn_sched_barrier(0);
+            static_range<0, (ob == 6 ? LAST_BLOCK_REGS : 16)>([&](auto uu) __attribute__((always_inline)) { epi_l0(BB, LL, uu); });
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
       } else {
         constexpr int g = c - 1;
         constexpr int P = c - 1;                       // chunk whose epilogue rides along
@@ -938,8 +962,21 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         };
         // the pieces of the chunk AHEAD of this one go out between the first K-steps, in MFMA shadow
         auto pre = [&](auto kk) __attribute__((always_inline)) {
-          if constexpr (NPHM_DMA_INSTREAM && decltype(kk)::value < WS::PIECES)
-            ws.template prefetch_piece<c>(decltype(kk)::value);
+          constexpr int ks = decltype(kk)::value;
+          if constexpr (NPHM_DMA_INSTREAM && ks < WS::PIECES) ws.template prefetch_piece<c>(ks);
+          if constexpr (L0_FUSED && c == 1 && ks % 2 == 0 && ks / 2 + 2 <= 6) l0_mfma(std::integral_constant<int, ks / 2 + 2>{});
+        };
+        auto slot_hook = [&](auto kk, auto mm) __attribute__((always_inline)) {
+          if constexpr (L0_FUSED && c == 1) {
+            constexpr int ks = decltype(kk)::value, m = decltype(mm)::value, NM = LIGHT ? 1 : 3;
+            constexpr int eb = ks / 2 + 1;             // L0 block drained during K-steps 2 (eb - 1), 2 (eb - 1) + 1
+            if constexpr (eb <= 6) {
+              constexpr int NRb = eb == 6 ? LAST_BLOCK_REGS : 16, sb = (ks & 1) * NM + m, nsb = 2 * NM;
+              static_range<unit_begin(sb, nsb, NRb), unit_begin(sb + 1, nsb, NRb)>([&](auto uu) __attribute__((always_inline)) {
+                epi_l0(std::integral_constant<int, eb>{}, LL, uu);
+              });
+            }
+          }
         };
         f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
         if constexpr (PREC == 0) {
@@ -948,9 +985,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           else d = gemm_fused_f32<L3_KS, 6, 7, NU>(buf, d, H, lane, epi, pre);
         } else {
           constexpr int PF = LIGHT ? NPHM_PF_LIGHT : NPHM_PF_HEAVY;
-          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, LIGHT, PF, NU>(buf, d, H, lane, epi, pre);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, LIGHT, PF, NU>(buf, d, G, lane, epi, pre);
-          else d = gemm_fused_bf16<L3_KS16, 6, 7, LIGHT, PF, NU>(buf, d, H, lane, epi, pre);
+          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, LIGHT, PF, NU>(buf, d, H, lane, epi, pre, slot_hook);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, LIGHT, PF, NU>(buf, d, G, lane, epi, pre, slot_hook);
+          else d = gemm_fused_bf16<L3_KS16, 6, 7, LIGHT, PF, NU>(buf, d, H, lane, epi, pre, slot_hook);
         }
         accs[c & 1] = d;
         if constexpr (epilogue_exposed(c)) {
