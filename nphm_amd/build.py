@@ -5,6 +5,7 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -20,17 +21,35 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-fno-honor-nans"]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every source for gfx950 (the translation units in parallel: eval_kernel.hip alone holds six
+    instantiations of the fused kernel) and link them into one shared library."""
     if not force and not _stale():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-fno-honor-nans",
-           "-I", os.path.join(HERE, "..", "include")]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    os.replace(OUT + ".tmp", OUT)
+    inc = ["-I", os.path.join(HERE, "..", "include")]
+    objdir = tempfile.mkdtemp(prefix="nphm_amd_build_")
+    try:
+        jobs = []
+        for src in SOURCES:
+            obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            cmd = [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, obj, subprocess.Popen(cmd)))
+        for cmd, _, proc in jobs:
+            if proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + [obj for _, obj, _ in jobs] + ["-o", OUT + ".tmp"]
+        if verbose:
+            print(" ".join(link))
+        subprocess.run(link, check=True)
+        os.replace(OUT + ".tmp", OUT)
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     return OUT
 
 

@@ -12,10 +12,10 @@ cd /tmp
 CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
 echo "cmd: $CMD" > "$OUT/README.txt"
 rocprofv3 -L > "$OUT/counters_list.txt" 2>&1 || true
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- $CMD > "$OUT/trace.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- $CMD > "$OUT/trace.log" 2>&1
 pass() { # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" -d "$OUT/$name" -o $name --output-format csv -- $CMD > "$OUT/$name.log" 2>&1
+  timeout 300 rocprofv3 --pmc "$@" -d "$OUT/$name" -o $name --output-format csv -- $CMD > "$OUT/$name.log" 2>&1
 }
 pass pmc_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS
 pass pmc_sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU
