@@ -37,3 +37,24 @@ def test_argument_validation_is_loud():
     lib = _lib.load()
     rc = lib.nphm_identity_eval_points(None, None, None, 1, 10, 0, 0.0, 0, None, None, None)
     assert rc != 0 and b"null pointer" in lib.nphm_last_error()
+
+
+def test_grid_workspace_size_query():
+    """Host-side size query of the binned grid traversal: covers the per-tile and per-point arrays,
+    grows with the slab, rejects empty slabs (no GPU needed)."""
+    lib = _lib.load()
+    def tiles(nx, ny, nz):
+        return ((nx + 3) // 4) * ((ny + 3) // 4) * ((nz + 1) // 2)
+    for dims in [(3, 5, 1), (37, 26, 19), (64, 64, 64), (256, 256, 256)]:
+        need = lib.nphm_identity_grid_workspace_bytes(*dims)
+        assert need >= tiles(*dims) * (4 + 4 + 8 + 8 + 16 + 32 * 8)
+    assert lib.nphm_identity_grid_workspace_bytes(0, 4, 4) == 0
+    assert lib.nphm_identity_grid_workspace_bytes(32, 256, 256) < lib.nphm_identity_grid_workspace_bytes(256, 256, 256)
+
+
+def test_to_host_passes_cpu_tensors_through():
+    import torch
+    from nphm_amd import reconstruction as R
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    a = R.to_host(t)
+    assert a.shape == (2, 3) and a.dtype.name == "float32" and float(a[1, 2]) == 5.0
