@@ -71,6 +71,9 @@ struct EvalArgs {
 #ifndef NPHM_ABLATE
 #define NPHM_ABLATE 0
 #endif
+#ifndef NPHM_PERIOD
+#define NPHM_PERIOD 2   // chunks per workgroup barrier
+#endif
 #ifndef NPHM_PROF
 #define NPHM_PROF 0  // 1: per-phase s_memtime accounting into stats[2..8] (timing builds only)
 #endif
@@ -328,34 +331,46 @@ struct Streamer {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) issue_piece(next, ci, i);
   }
-  // The ring runs two chunks ahead of the GEMMs: during step CI (between the barriers of chunks CI and
-  // CI + 1) the pieces of chunk CI + 2 go out - its slot held chunk CI - 3 (chunk CI - 2 across the
-  // member boundary, where the phantom position 19 keeps the slots static): every wavefront left that one
-  // before the barrier of chunk CI, and the slot of chunk CI - 1 stays intact, its tail is still read by a
-  // fused lin3 epilogue.  Steps 17, 18 fetch the next member's chunks 0, 1.  (Three chunks ahead: no gain.)
-  static constexpr int AHEAD = 2;
-  template <int CI> __device__ __forceinline__ void prefetch_piece(const int i) const {
-    constexpr int T = CI + AHEAD;
+  // Ring positions: chunk ci of the member being consumed sits at position ci, position 19 is a phantom
+  // (20 positions per member keep the slot of every chunk a compile-time constant), chunk ci of the NEXT
+  // member sits at 20 + ci.  The workgroup meets at ONE barrier per PERIOD = 2 chunks: at the barrier in
+  // front of chunks c, c + 1 (c even) every wavefront has left chunks <= c - 1, so the pieces of positions
+  // c + 2, c + 3 can go out - their slots held c - 3 and c - 2; the slot of chunk c - 1 stays intact, its
+  // tail is still read by the lin3 epilogue fused into chunk c.  Nothing younger than chunks c, c + 1 is in
+  // flight at that barrier, so a wavefront simply drains its DMAs (vmcnt 0) in front of it.
+  // (PERIOD = 1: a barrier per chunk, the pieces of chunk c + 2 go out in step c; 3 % slower.)
+  static constexpr int PERIOD = NPHM_PERIOD;
+  static_assert(PERIOD == 1 || PERIOD == 2, "one barrier per chunk or per pair of chunks");
+  static constexpr int POS_NEXT = CHUNKS_PER_MEMBER + 1;
+  template <int T> __device__ __forceinline__ void issue_position(const int i) const {
     if constexpr (T < CHUNKS_PER_MEMBER) issue_piece(false, T, i);
-    else issue_piece(true, T - CHUNKS_PER_MEMBER, i);
+    else if constexpr (PERIOD == 1) issue_piece(true, T - CHUNKS_PER_MEMBER, i);       // steps 17, 18: next member's chunks 0, 1
+    else if constexpr (T >= POS_NEXT) issue_piece(true, T - POS_NEXT, i);
+  }
+  template <int CI> static constexpr int prefetch_pieces() { return PERIOD == 1 ? PIECES : (CI % 2 == 0 ? 2 * PIECES : 0); }
+  template <int CI> __device__ __forceinline__ void prefetch_piece(const int i) const {
+    if (i < PIECES) issue_position<CI + 2>(i); else issue_position<CI + 3>(i - PIECES);
   }
   template <int CI> __device__ __forceinline__ void prefetch() const {
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) prefetch_piece<CI>(i);
+    for (int i = 0; i < prefetch_pieces<CI>(); ++i) prefetch_piece<CI>(i);
   }
   template <int N> __device__ static __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
   }
   // Every wavefront of the workgroup calls sync<CI>() exactly once per chunk, in the same order.
   template <int CI> __device__ __forceinline__ void sync() {
-    // chunk CI must have landed.  The only younger DMAs of this wavefront are those of chunk CI + 1: at
-    // least groups / NW of them.  VMEM completes in order, so waiting until at most that many operations
-    // are outstanding retires every load of chunk CI.
+    if constexpr (PERIOD == 2 && CI % 2 == 1) return;
+    // PERIOD 1: chunk CI must have landed; the only younger DMAs of this wavefront are those of chunk
+    // CI + 1, at least groups / NW of them, and VMEM completes in order: waiting until at most that many
+    // operations are outstanding retires every load of chunk CI.
     constexpr int T = CI + 1;
 #if NPHM_PROF
     const long long ta = clock64();
 #endif
     if constexpr ((NPHM_ABLATE & 16) != 0) {
+    } else if constexpr (PERIOD == 2) {
+      wait_vm<0>();
     } else if constexpr (T < CHUNKS_PER_MEMBER) {
       wait_vm<Stream<PREC>::groups(T) / NW>();
     } else {
@@ -947,7 +962,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           static_for<7>([&](auto BB) __attribute__((always_inline)) {
             constexpr int ob = decltype(BB)::value;
             if constexpr (ob + 1 < 7) l0_mfma(std::integral_constant<int, ob + 1>{});
-            if constexpr (NPHM_DMA_INSTREAM && ob < WS::PIECES) ws.template prefetch_piece<0>(ob);
+            if constexpr (NPHM_DMA_INSTREAM && ob < WS::template prefetch_pieces<0>()) ws.template prefetch_piece<0>(ob);
             __builtin_amdgcn_sched_barrier(0);
             static_range<0, (ob == 6 ? LAST_BLOCK_REGS : 16)>([&](auto uu) __attribute__((always_inline)) { epi_l0(BB, LL, uu); });
             __builtin_amdgcn_sched_barrier(0);
@@ -963,7 +978,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         // the pieces of the chunk AHEAD of this one go out between the first K-steps, in MFMA shadow
         auto pre = [&](auto kk) __attribute__((always_inline)) {
           constexpr int ks = decltype(kk)::value;
-          if constexpr (NPHM_DMA_INSTREAM && ks < WS::PIECES) ws.template prefetch_piece<c>(ks);
+          if constexpr (NPHM_DMA_INSTREAM && ks < WS::template prefetch_pieces<c>()) ws.template prefetch_piece<c>(ks);
           if constexpr (L0_FUSED && c == 1 && ks % 2 == 0 && ks / 2 + 2 <= 6) l0_mfma(std::integral_constant<int, ks / 2 + 2>{});
         };
         auto slot_hook = [&](auto kk, auto mm) __attribute__((always_inline)) {
