@@ -374,6 +374,15 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         sdf = _IdentityFieldFn.apply(self, xyz, lat_rows.detach(), anchors, b0f, b2f)
         return sdf, anchors
 
+    def predict_anchors(self, lat_rep: torch.Tensor) -> torch.Tensor:
+        """Anchors of the identity codes ``lat_rep`` [B, L, lat_dim] (row 0 of every batch entry): the
+        second return value of ``forward`` (EnsembledDeepSDF.py:228-229) without evaluating any SDF -
+        differentiable w.r.t. the global code.  The fitting loops call it instead of the reference's
+        one-point ``decoder(zeros, lat, None)`` whose SDF value they discard (fitting.py:58, :208)."""
+        B = lat_rep.shape[0]
+        anchors = self.mlp_pos(lat_rep[:, 0, :self.lat_dim_glob]).view(B, self.num_kps, 3)
+        return anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
+
     def _forward_composite(self, xyz, lat_rep):
         B, N, _ = xyz.shape
         A = self.num_kps + 1

@@ -37,6 +37,14 @@ def _frozen(*modules):
             p.requires_grad_(flag)
 
 
+def _anchors_of(decoder, lat_rep_shape, device):
+    """``_, anchors = decoder(zeros[1,1,3], lat, None)`` (fitting.py:58, :208): the mirrored identity net
+    answers from its anchor head alone; any other decoder gets the reference's one-point forward."""
+    if hasattr(decoder, "predict_anchors"):
+        return decoder.predict_anchors(lat_rep_shape)
+    return decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)[1]
+
+
 def _apply_schedule(j, step_scale, schedule_cfg, lambdas, optimizers, with_expr):
     """Hand-tuned learning-rate / loss-weight schedule (fitting.py:40-52, :197-206)."""
     key = int(j / step_scale)
@@ -132,8 +140,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             opt.zero_grad()
             opt_expr.zero_grad()
 
-            # anchors of the current identity code (N = 1 forward; only mlp_pos matters)
-            _, anchors = decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)
+            # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
+            anchors = _anchors_of(decoder, lat_rep_shape, device)
 
             obs_idx, obs = _sample_observations(all_obs, n_batch, n_points)
             obs_idx = obs_idx.long().to(device)
@@ -198,7 +206,7 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
         for j in range(int(n_steps * step_scale)):
             _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt,), False)
             opt.zero_grad()
-            _, anchors = decoder(torch.zeros([1, 1, 3], device=device), lat_rep_shape, None)
+            anchors = _anchors_of(decoder, lat_rep_shape, device)
             _, obs = _sample_observations(all_obs, n_batch, n_points)
             cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
             sdf, _ = decoder(obs, cond, None)
