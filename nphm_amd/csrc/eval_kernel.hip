@@ -67,12 +67,15 @@ struct EvalArgs {
 #define NPHM_DMA_INSTREAM 1
 #endif
 // timing ablations (results are garbage): 1 = no weight streaming, 2 = no workgroup barrier, 4 = no epilogue arithmetic,
-// 16 = no wait for the weight DMA
+// 16 = no wait for the weight DMA, 32 = every member streams weight set 0 / member 0's state (L2-resident stream)
 #ifndef NPHM_ABLATE
 #define NPHM_ABLATE 0
 #endif
 #ifndef NPHM_PERIOD
 #define NPHM_PERIOD 2   // chunks per workgroup barrier
+#endif
+#ifndef NPHM_SOFTPLUS4
+#define NPHM_SOFTPLUS4 1   // 1: softplus as log2(1 + 2^d) + v_med3 (4 VALU), 0: max + log2(1 + 2^-|d|) (5 VALU)
 #endif
 #ifndef NPHM_PROF
 #define NPHM_PROF 0  // 1: per-phase s_memtime accounting into stats[2..8] (timing builds only)
@@ -90,11 +93,21 @@ struct EvalArgs {
 // here the log term is already 0 in fp32 for 100 d > 16.7, so the two agree to < 1e-9 in d units.
 __device__ __forceinline__ float softplus2(float d) {
   if (NPHM_ABLATE & 4) return d;
+#if NPHM_SOFTPLUS4
+  // log2(1 + 2^d') directly: v_exp_f32, v_add_f32, v_log_f32 (raw instructions) and ONE v_med3_f32 that
+  // returns d' itself once 2^d' has overflowed (d' > 127: the log is +inf; for d' <= 126 the log lies in
+  // [d', 127], at the crossover it equals d') - 4 issue slots instead of 5.  Same accuracy class as the
+  // max / log(1 + 2^-|d'|) form: 1 + 2^d' carries a relative rounding error of 2^-24, i.e. 9e-8 absolute
+  // in the logarithm, next to the result's own ulp.
+  const float r = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(d));
+  return __builtin_amdgcn_fmed3f(d, r, 127.f);
+#else
   const float t = __builtin_amdgcn_exp2f(-fabsf(d));                 // raw v_exp_f32
   // relu: built with -fno-honor-nans so that it is ONE v_max_f32 (otherwise a canonicalising
   // v_max(x, x) is put in front; inline asm is not an option - it would read MFMA results without
   // the hazard wait states the compiler inserts for its own instructions)
   return fmaxf(d, 0.f) + __builtin_amdgcn_logf(1.f + t);             // raw v_log_f32, arg in [1,2]
+#endif
 }
 
 // Softplus for "light" members (adaptive precision: their GEMMs run single-pass, hi x hi only): the correction term
@@ -102,11 +115,21 @@ __device__ __forceinline__ float softplus2(float d) {
 // domain (2.9e-5 in activation units, the size of the single-pass bf16 rounding these members already
 // carry; it enters the blend scaled by a weight < light_tol).  Plain multiply-adds in place of the
 // two quarter-rate transcendentals: a light chunk becomes MFMA-bound instead of VALU-bound.
+#ifndef NPHM_LIGHT_POW
+#define NPHM_LIGHT_POW 2   // power of the polynomial correction of softplus2_light: 8, 4 or 2 (max abs error 4.2e-3 / 1.6e-2 / 4.6e-2)
+#endif
 __device__ __forceinline__ float softplus2_light(float d) {
   if (NPHM_ABLATE & 4) return d;
+#if NPHM_LIGHT_POW == 8
   float q = fmaxf(fmaf(fabsf(d), -0.06564446f, 1.00028698f), 0.f);
   q *= q;
   q *= q;
+#elif NPHM_LIGHT_POW == 4
+  float q = fmaxf(fmaf(fabsf(d), -0.11704907f, 0.99590697f), 0.f);
+  q *= q;
+#else
+  const float q = fmaxf(fmaf(fabsf(d), -0.18805397f, 0.9767937f), 0.f);
+#endif
   return fmaf(q, q, fmaxf(d, 0.f));
 }
 
@@ -120,9 +143,18 @@ constexpr int LAST_BLOCK_REGS = 4;
 
 // one 32-feature block of activations as split-bf16 B operands of v_mfma_f32_32x32x16_bf16:
 // K-step s consumes registers 8s..8s+7 of the block (k-slot 8h+i <-> register 8s+i)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 struct ActB {
-  bf16x8 hi[2], lo[2];
+  u32x4 hi[2], lo[2];     // dword q of hi[s] / lo[s] = k-slots 2q, 2q + 1 (bf16 pairs)
 };
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+// two floats -> one dword of bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 __device__ __forceinline__ f32x16 load_frag16(const float* p) {
   // 16 consecutive floats (64-byte aligned) -> f32x16
@@ -162,17 +194,19 @@ __host__ __device__ constexpr int unit_begin(int s, int ns, int nu) { return (s 
 // for hi and lo); LIGHT members carry no lo part
 template <int R, bool LIGHT>
 __device__ __forceinline__ void pack_pair(const f32x16& a, ActB& o) {
-  constexpr int s = R >> 3, i = R & 7;
-  const __bf16 h0 = (__bf16)a[R], h1 = (__bf16)a[R + 1];
-  o.hi[s][i] = h0;
-  o.hi[s][i + 1] = h1;
+  constexpr int s = R >> 3, q = (R & 7) >> 1;
+  // hi pair: one packed convert; its two halves widened back with a shift / a mask; lo pair: the residuals
+  // through a second packed convert - 6 VALU per pair (written out: the generic __bf16 casts made hipcc
+  // convert every value twice and shuffle the packed registers)
+  const unsigned ph = cvt_pk_bf16(a[R], a[R + 1]);
+  o.hi[s][q] = ph;
   if constexpr (!LIGHT) {
-    o.lo[s][i] = (__bf16)(a[R] - (float)h0);
-    o.lo[s][i + 1] = (__bf16)(a[R + 1] - (float)h1);
+    const float h0 = __builtin_bit_cast(float, ph << 16), h1 = __builtin_bit_cast(float, ph & 0xffff0000u);
+    o.lo[s][q] = cvt_pk_bf16(a[R] - h0, a[R + 1] - h1);
   }
   // pin the finished operand registers here: LLVM otherwise sinks the pure epilogue
   // arithmetic to its use in the next layer's GEMM and keeps the accumulator alive until then
-  if constexpr (i == 6) {
+  if constexpr (q == 3) {
     asm volatile("" : "+v"(o.hi[s]));
     if constexpr (!LIGHT) asm volatile("" : "+v"(o.lo[s]));
   }
@@ -300,8 +334,9 @@ struct Streamer {
   // tail (one wavefront).  Every wavefront issues at least Q loads per chunk (sync() counts on it).
   static constexpr int PIECES = 3;
   __device__ __forceinline__ void issue_piece(const bool next, const int ci, const int i) const {
-    const int k = next ? k_nxt : k_cur;
+    int k = next ? k_nxt : k_cur;
     if (k < 0 || (NPHM_ABLATE & 1)) return;
+    if (NPHM_ABLATE & 32) k = 0;
     int l = lane;
     asm volatile("" : "+v"(l));           // the lane offset is recomputed per site, not kept live
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(ring + (ci % RING) * SLOT_BYTES));
@@ -462,9 +497,9 @@ __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc,
     constexpr int sb = ks < 2 * FULL ? (ks & 1) : 0;
     static_for<NM>([&](auto mm) __attribute__((always_inline)) {
       constexpr int m = decltype(mm)::value;
-      if constexpr (m == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].hi[sb], acc, 0, 0, 0);
-      else if constexpr (m == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], in[b].lo[sb], acc, 0, 0, 0);
-      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], in[b].hi[sb], acc, 0, 0, 0);
+      if constexpr (m == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], as_bf16x8(in[b].hi[sb]), acc, 0, 0, 0);
+      else if constexpr (m == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], as_bf16x8(in[b].lo[sb]), acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], as_bf16x8(in[b].hi[sb]), acc, 0, 0, 0);
       constexpr int slot = ks * NM + m;
       static_range<unit_begin(slot, NS, NU), unit_begin(slot + 1, NS, NU)>(epi);
       slot_hook(kk, mm);                   // work with its own placement (the L0 epilogues inside lin1's first chunk)
@@ -873,9 +908,8 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           if constexpr (r == NR - 1 && NR < 16) {
             // padding features of a layer's last block: zero operands (their weights are zero too,
             // but 0 x garbage could be NaN)
-            const __bf16 z = (__bf16)0.f;
 #pragma unroll
-            for (int q = NR; q < 8; ++q) { dst.hi[0][q] = z; dst.lo[0][q] = z; }
+            for (int q = NR / 2; q < 4; ++q) { dst.hi[0][q] = 0u; dst.lo[0][q] = 0u; }
             asm volatile("" : "+v"(dst.hi[0]));
             asm volatile("" : "+v"(dst.lo[0]));
           }
@@ -900,9 +934,8 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         a[r] = x;
         if constexpr (r & 1) pack_pair<r - 1, LIGHT>(a, H[B]);
         if constexpr (r == NR - 1 && NR < 16) {
-          const __bf16 z = (__bf16)0.f;
 #pragma unroll
-          for (int q = NR; q < 8; ++q) { H[B].hi[0][q] = z; H[B].lo[0][q] = z; }
+          for (int q = NR / 2; q < 4; ++q) { H[B].hi[0][q] = 0u; H[B].lo[0][q] = 0u; }
           asm volatile("" : "+v"(H[B].hi[0]));
           asm volatile("" : "+v"(H[B].lo[0]));
         }

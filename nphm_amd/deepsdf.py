@@ -97,6 +97,21 @@ class DeepSDF(nn.Module):
         return x
 
     # ---- HIP tier ----------------------------------------------------------------------------
+    def invalidate_pack(self):
+        """Drop the cached split-bf16 copy of the weights (see FastEnsembleDeepSDFMirrored.invalidate_pack:
+        needed after writes that bypass the parameters' version counters)."""
+        self._pack_cache = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_pack()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_pack()
+        return out
+
     def _arch(self):
         return (self.lat_dim, self.hidden_dim, self.nlayers, self.n_out)
 

@@ -215,7 +215,11 @@ class _IdentityFieldFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
+        # first order only: differentiating these gradients again (eikonal / normal losses built with
+        # create_graph=True) raises instead of silently dropping the second-order term; such losses run
+        # on the composite tier (module.backend = "composite", or parameters that require grad)
         lib = _lib.load()
         module = ctx.module
         xyz, out, packed, state, tiles, plist = ctx.saved_tensors
@@ -277,6 +281,24 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         self._pack_bwd_cache = None     # (key, transposed pack for the backward kernel)
 
     # ------------------------------------------------------------------------------------------
+    def invalidate_pack(self):
+        """Drop the cached MFMA-fragment copies of the weights.  The caches are keyed on the parameters'
+        (address, version counter, device), which covers optimizer steps, ``load_state_dict`` and
+        ``.to()``; writes that bypass the version counter (``param.data.copy_(...)``, raw pointer writes)
+        need this call.  ``load_state_dict`` and ``_apply`` (``.to()/.float()/.cuda()``) call it themselves."""
+        self._pack_cache = None
+        self._pack_bwd_cache = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_pack()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_pack()
+        return out
+
     def hip_supported(self) -> bool:
         lib = _lib.load()
         return bool(lib.nphm_identity_supported(self.lat_dim_glob, self.lat_dim_loc, self.num_kps,
@@ -333,6 +355,9 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         ws, bs = self._lin_params()
         pw = [self.mlp_pos[i].weight for i in (0, 2, 4)]
         pb = [self.mlp_pos[i].bias for i in (0, 2, 4)]
+        for t in pw + pb:
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.NphmAmdError("mlp_pos parameters must be contiguous fp32 on the query device")
         stream = torch.cuda.current_stream(device).cuda_stream
         _lib.check(lib.nphm_identity_prepare_latent(
             packed.data_ptr(), _lib.ptr_array5(ws), _lib.ptr_array5(bs), _lib.ptr_array3(pw),
@@ -402,9 +427,11 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         if not self.training:
             # reference quirk (EnsembledDeepSDF.py:260-261): in eval mode every member's value of
             # the LAST point of each batch row is overwritten with 1
-            keep = torch.ones(N, dtype=f.dtype, device=f.device)
-            keep[-1] = 0.0
-            f = f * keep[None, None, :, None] + (1.0 - keep)[None, None, :, None]
+            # (channel 0 only, like `sdf_pred[:, :, -1, 0] = 1`; written as a blend so that autograd sees no
+            # in-place update)
+            keep = torch.ones(N, f.shape[-1], dtype=f.dtype, device=f.device)
+            keep[-1, 0] = 0.0
+            f = f * keep[None, None] + (1.0 - keep)[None, None]
         pred = sample_point_feature(xyz[..., :3], anchors, f.permute(1, 2, 0, 3), background=True, var=0.1 ** 2)
         return pred, anchors
 

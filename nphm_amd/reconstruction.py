@@ -195,22 +195,15 @@ def _hip_ready(decoder, device) -> bool:
             and device.type == "cuda" and decoder.hip_supported())
 
 
-_GRID_WORKSPACE = {}
-
-
 def grid_workspace(device, n_x_local: int, ry: int, rz: int) -> torch.Tensor:
-    """Scratch buffer of the binned grid traversal (nphm_identity_grid_workspace_bytes), one per device
-    and stream, grown on demand and reused by every call: the kernels of consecutive launches on one
-    stream are ordered, so they can share it."""
+    """Scratch buffer of the binned grid traversal (nphm_identity_grid_workspace_bytes: ~9.5 B per voxel),
+    allocated per call from torch's caching allocator: stream-ordered like every other temporary, returned
+    to the cache when the caller drops it (``torch.cuda.empty_cache()`` can reclaim it), nothing is kept
+    alive by this module."""
     need = int(_lib.load().nphm_identity_grid_workspace_bytes(int(n_x_local), int(ry), int(rz)))
     if need == 0:
         raise _lib.NphmAmdError("grid too large for one launch")
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _GRID_WORKSPACE.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(need, dtype=torch.uint8, device=device)
-        _GRID_WORKSPACE[key] = buf
-    return buf
+    return torch.empty(need, dtype=torch.uint8, device=device)
 
 
 def evaluate_grid(decoder: FastEnsembleDeepSDFMirrored, encoding: torch.Tensor, axes: Sequence,
