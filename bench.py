@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""bench.py — SDF-query throughput of the NPHM identity field (BASELINE.json metric).
+"""bench.py — SDF-query throughput of the NPHM identity field (BASELINE.json metric), plus every other
+BASELINE config and precision mode as sub-records of the same JSON line.
 
 A "step" = one dense extraction of the NPHM 39-anchor identity SDF on the res^3 lattice of the
 reference (bounds fitting_pointclouds.py:166-167): latent prologue (anchors + folded biases) +
@@ -10,7 +11,14 @@ fused grid kernel (+ all-gather of the x-slabs when N > 1), output resident in H
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement): the contract fields describe configs[1]
+in the default precision; at N = 1 the line also carries
+  "precisions"  the same workload with --precision bf16x3 and f32 (value + roofline each),
+  "configs"     configs[0] (NPM 64^3), configs[2] (two-stage 256^3), configs[4] (latent fitting, 250 steps,
+                final loss next to the all-composite PyTorch-ROCm loop),
+  "mfma_sustained"  the matrix-pipe rate an MFMA-only loop sustains on THIS box (power-limited clock),
+  "cpu_baseline"    the reference's PyTorch operation sequence on the host cores (oracle/torch_reference.py),
+  "cpu_baseline_port" the numpy oracle, "pytorch_rocm_baseline" the eager chunk loop on the same GPU.
 """
 import argparse
 import json
@@ -28,7 +36,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_DENSE = 9_616_000            # reference formulation, 40 x 2 x 120 200
 FLOP_MEMBER_FOLDED = 2 * 81_800   # one member, one point, latent folded
+FLOP_DEFORMATION_FOLDED = 2 * 1_074_688   # deformation backbone, latent folded
+FLOP_NPM_FOLDED = 2 * 6_292_480
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16x3a": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
+DTYPE = {"f32": "f32", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)",
+         "bf16x3a": "bf16x3 adaptive(split-bf16 MFMA for blend weights >= 1e-3, single-pass bf16 below)"}
 
 
 def parse():
@@ -40,51 +52,29 @@ def parse():
     ap.add_argument("--prune-tol", type=float, default=None)
     ap.add_argument("--precision", default="bf16x3a", choices=["f32", "bf16x3", "bf16x3a"])
     ap.add_argument("--chunk", type=int, default=25000, help="get_logits chunk whose last voxel is overwritten (eval mode)")
-    ap.add_argument("--workload", default="identity", choices=["identity", "two_stage", "npm", "fitting"],
-                    help="identity = BASELINE.json configs[1] (the contract line); the others are the remaining "
-                         "configs (two_stage = configs[2], npm = configs[0], fitting = configs[4]), single GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="all", choices=["all", "identity", "two_stage", "npm", "fitting"],
+                    help="all (default) = the contract line for configs[1] with every other config / precision as "
+                         "sub-records; identity = the contract line alone; the others = one of the remaining configs "
+                         "as a line of its own (two_stage = configs[2], npm = configs[0], fitting = configs[4])")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU / eager PyTorch-ROCm baselines")
+    ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (kernel timing experiments)")
     ap.add_argument("--no-binning", action="store_true", help="brick-order traversal instead of tiles binned by member set")
     ap.add_argument("--no-mesh", action="store_true", help="skip the mesh-extract leg (kernel timing experiments)")
-    ap.add_argument("--cpu-sample", type=int, default=40000)
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="lattice points of the PyTorch-CPU baseline (prefix)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0 = min(cores, 64))")
+    ap.add_argument("--fit-steps", type=int, default=1000, help="n_steps of the fitting config (run at step_scale 1/4)")
     return ap.parse_args()
 
 
 def measured_traffic(kernel, n_points):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
-    (profiles/traffic.json; the counters cannot be read live from inside the process), scaled to this
-    launch's point count.  None if no profile covers the kernel."""
+    """HBM bytes per launch of a kernel, from the committed rocprofv3 PMC passes (profiles/traffic.json;
+    the counters cannot be read live from inside the process), scaled to this launch's point count.
+    None if no profile covers the kernel."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
         return t["traffic_bytes"] * n_points / t["points_per_launch"]
     except Exception:
         return None
-
-
-def cpu_baseline(net, lat, axes, n_sample):
-    """The oracle (numpy port of the reference arithmetic) on the host cores, on the first
-    n_sample lattice points of the same workload."""
-    from oracle import nphm_oracle as O
-    import _util as U
-    params, amean = U.np_state(net), U.anchors_mean()
-    g = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
-    # a z-column prefix would be all far-field; take a strided sample of whole-volume points
-    idx = np.linspace(0, g.shape[0] - 1, n_sample).astype(np.int64)
-    pts = g[idx][None].astype(np.float32)
-    latn = lat.cpu().numpy()[None, None]
-    threads = 1
-    try:                                         # numpy's BLAS pool is what the oracle's GEMMs run on
-        from threadpoolctl import threadpool_info
-        threads = max([1] + [int(i.get("num_threads", 1)) for i in threadpool_info()])
-    except Exception:
-        pass
-    t0 = time.perf_counter()
-    O.nphm_identity_forward(params, amean, pts, latn, training=False)
-    dt = time.perf_counter() - t0
-    return {"value": n_sample / dt / 1e6, "unit": "Mpoints/s", "cores": threads, "host_cores": os.cpu_count(),
-            "kind": "port",
-            "sample": f"{n_sample} lattice points (uniform stride over the {len(axes[0])}^3 volume), "
-                      f"oracle/nphm_oracle.py numpy fp32, dense 40-member evaluation, {dt:.1f} s"}
 
 
 def _timed(fn, steps, warmup):
@@ -102,91 +92,347 @@ def _timed(fn, steps, warmup):
     return time.perf_counter() - t0, [a.elapsed_time(b) for a, b in ev]
 
 
-def other_workloads(args):
-    """BASELINE.json configs other than the contract line, one GPU, same JSON shape."""
+# ------------------------------------------------------------------------------------------------------
+# configs[1]: NPHM identity field on the lattice (the contract line; also the per-precision sub-records)
+# ------------------------------------------------------------------------------------------------------
+class IdentityBench:
+    def __init__(self, args, dev, world, rank, distributed=False):
+        import _util as U
+        from nphm_amd import _lib
+        from nphm_amd import reconstruction as R
+        self.args, self.dev, self.world, self.rank = args, dev, world, rank
+        self.distributed = distributed or world > 1     # torch.distributed.run with N = 1 takes the collective path too
+        self.R, self.lib, self._lib = R, _lib.load(), _lib
+        self.net = U.build_identity(device=dev).eval()
+        if args.prune_tol is not None:
+            self.net.prune_tol = args.prune_tol
+        self.lat = U.sample_latent(0).to(dev)
+        self.axes = R.grid_axes(U.MINI, U.MAXI, args.res)
+        self.axes_dev = [torch.from_numpy(a).to(dev) for a in self.axes]
+        self.rx = self.ry = self.rz = args.res
+        self.plane = self.ry * self.rz
+        # N > 1: every rank takes the x-planes of every N-th 8-plane brick slab (work-balanced)
+        self.planes = R.cyclic_planes(self.rx, world, rank)
+        self.planes_dev = torch.from_numpy(self.planes).to(dev)
+        self.n_planes = len(self.planes)
+        self.depth = R.shard_depth(self.rx, world)
+        # the kernel writes straight into this rank's (padded) shard of the all-gather
+        self.shard = torch.zeros(max(self.depth, 1) * self.plane, dtype=torch.float32, device=dev)
+        self.gathered = (torch.empty(world * self.depth * self.plane, dtype=torch.float32, device=dev)
+                         if self.distributed else None)
+        self.full = None
+
+    def step(self, precision, binned, stats=None, ev=None):
+        net, R = self.net, self.R
+        net.precision = precision
+        packed, state, _ = net.prepare_latent(self.lat[None])
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        ws = R.grid_workspace(self.dev, self.n_planes, self.ry, self.rz) if binned and self.n_planes else None
+        if ev is not None:
+            ev[0].record()                     # HIP events on the launch stream bracket the dominant kernel
+        if self.n_planes:
+            self._lib.check(self.lib.nphm_identity_eval_grid_planes(
+                packed.data_ptr(), state.data_ptr(), self.axes_dev[0].data_ptr(), self.axes_dev[1].data_ptr(),
+                self.axes_dev[2].data_ptr(), self.rx, self.ry, self.rz, self.planes_dev.data_ptr(), self.n_planes,
+                self.args.chunk, float(net.prune_tol), net._precision_code(), self.shard.data_ptr(),
+                None if stats is None else stats.data_ptr(), None if ws is None else ws.data_ptr(),
+                0 if ws is None else ws.numel(), stream), "eval_grid_planes")
+        if ev is not None:
+            ev[1].record()
+        if self.distributed:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.gathered, self.shard)
+            self.full = R.reorder_gathered(self.gathered, self.rx, self.plane, self.world)
+
+    def barrier(self):
+        if self.distributed:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(self, precision, steps, warmup, binned=True):
+        """(seconds of `steps` steps [max over ranks], mean kernel ms, kernel counters)"""
+        stats = torch.zeros(16, dtype=torch.int64, device=self.dev)
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for _ in range(warmup):
+            self.step(precision, binned)
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(precision, binned, stats, events[i])
+        self.barrier()
+        dt = time.perf_counter() - t0
+        k_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        if self.distributed:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, k_ms, stats.cpu().numpy()
+
+    def record(self, precision, steps, warmup, binned=True):
+        """value + roofline of one precision mode (the contract line's fields for this rank layout)"""
+        dt, k_ms, active = self.measure(precision, steps, warmup, binned)
+        n_total = self.rx * self.ry * self.rz
+        n_local = max(1, self.n_planes * self.plane)
+        mean_active = float(active[0]) / max(1, steps) / n_local            # evaluated member-points / point
+        passes = 1 if precision == "f32" else 3     # the split-bf16 path issues 3 bf16 MFMA products per fp32 product
+        mean_light = float(active[15]) / max(1, steps) / n_local            # single-pass pairs (adaptive mode)
+        exec_flops = (passes * (mean_active - mean_light) + mean_light) * FLOP_MEMBER_FOLDED * n_local
+        peak = PEAK_TFLOPS[precision]
+        achieved = exec_flops / (k_ms * 1e-3) / 1e12
+        # the events bracket the whole grid call: with binning that is the tile pre-pass + radix sort
+        # (together ~1 % of it) + the dominant kernel
+        kname = "nphm::eval_kernel<%d,%d>" % (2 if binned else 1, 0 if precision == "f32" else 1)
+        tkey = kname if precision == "bf16x3a" else kname + ":" + precision
+        return {
+            "value": n_total * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "dtype": DTYPE[precision],
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": measured_traffic(tkey, n_local), "algorithmic_bytes": 4 * n_local,
+                         "kernel": kname, "rank0_planes": self.n_planes, "binned_tiles": binned,
+                         "kernel_ms": k_ms, "points_per_launch": n_local,
+                         "executed_flops_per_point": exec_flops / n_local, "mean_single_pass_members": mean_light,
+                         "mfma_passes": passes, "mean_active_members": mean_active,
+                         "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12},
+        }
+
+    def mesh_extract(self, precision, binned):
+        """second half of the BASELINE metric: latent -> SDF volume (all ranks) -> marching cubes -> vertices/faces,
+        measured once outside the timed region"""
+        R, rx, ry, rz = self.R, self.rx, self.ry, self.rz
+        self.barrier()
+        t_m0 = time.perf_counter()
+        self.step(precision, binned)
+        self.barrier()
+        t_m1 = time.perf_counter()
+        if self.rank != 0:
+            return None
+        vol_dev = self.full if self.distributed else self.shard[: rx * self.plane]
+        vol_host = R.to_host(vol_dev)
+        t_m2 = time.perf_counter()
+        vh, fh = R.marching_cubes(vol_host.reshape(rx, ry, rz), 0.0, negate=True)     # host extractor
+        t_m3 = time.perf_counter()
+        m = SimpleNamespace(vertices=vh, faces=fh)
+        # the same mesh without the volume leaving the device: GPU marching cubes, only the mesh travels
+        torch.cuda.synchronize()
+        t_d0 = time.perf_counter()
+        vd, fd = R.marching_cubes_device(vol_dev.view(rx, ry, rz), 0.0, negate=True)
+        vd_h, fd_h = R.to_host(vd), R.to_host(fd)
+        t_d1 = time.perf_counter()
+        cold_ms = (t_d1 - t_d0) * 1e3
+        # once more, warm (kernels loaded, scratch and pinned staging buffers cached), like the timed kernel steps
+        del vd, fd, vd_h, fd_h
+        torch.cuda.synchronize()
+        t_d0 = time.perf_counter()
+        vd, fd = R.marching_cubes_device(vol_dev.view(rx, ry, rz), 0.0, negate=True)
+        vd_h, fd_h = R.to_host(vd), R.to_host(fd)
+        t_d1 = time.perf_counter()
+        return {"wall_ms": (t_m1 - t_m0) * 1e3 + (t_d1 - t_d0) * 1e3, "volume_ms": (t_m1 - t_m0) * 1e3,
+                "device_marching_cubes_ms": (t_d1 - t_d0) * 1e3, "device_marching_cubes_first_call_ms": cold_ms,
+                "n_vertices": int(len(vd_h)), "n_faces": int(len(fd_h)),
+                "reference_order": {"wall_ms": (t_m3 - t_m0) * 1e3, "d2h_ms": (t_m2 - t_m1) * 1e3,
+                                    "host_marching_cubes_ms": (t_m3 - t_m2) * 1e3,
+                                    "note": "get_logits -> numpy volume on the host -> mesh_from_logits (host marching cubes, <= 16 threads)"},
+                "same_mesh": bool(len(vd_h) == len(m.vertices) and np.array_equal(fd_h, np.asarray(m.faces))),
+                "note": "wall = latent -> SDF volume (all ranks, all-gathered) -> marching cubes on the GPU -> vertices/faces on the host; "
+                        "PyMCubes of the reference is absent, both extractors are this repo's (bit-identical meshes)"}
+
+
+# ------------------------------------------------------------------------------------------------------
+# configs[2], configs[0], configs[4]
+# ------------------------------------------------------------------------------------------------------
+def two_stage_record(args, dev, steps, warmup):
+    """configs[2]: deformation -> identity on the 256^3 lattice (get_logits_backward semantics with anchors)"""
     import _util as U
     from nphm_amd import reconstruction as R
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    base = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "data": "synthetic (seeded random-init weights, latents ~ shipped statistics)"}
-    if args.workload == "two_stage":
-        g = U.golden("deformation")
-        inet = U.build_identity(device=dev).eval()
-        dnet = U.build_deformation(device=dev).eval()
-        lat_id = torch.from_numpy(g["lat"].reshape(-1)[:1344]).to(dev)
-        lat_ex = torch.from_numpy(g["lat"].reshape(-1)).to(dev)
-        axes = [torch.from_numpy(a).to(dev) for a in R.grid_axes(U.MINI, U.MAXI, args.res)]
-        n = args.res ** 3
-        anchors = inet.prepare_latent(lat_id[None])[2]
-        mlp, cond = R._expr_condition(dnet, lat_ex, anchors, dev)
-        dt, _ = _timed(lambda: R.evaluate_grid_two_stage(inet, dnet, lat_id, lat_ex, axes, hack_chunk=args.chunk),
-                       args.steps, args.warmup)
-        _, k_ms = _timed(lambda: R.evaluate_grid_mlp(mlp, cond, axes, add_input=True), args.steps, 1)
-        flops = 3 * 2 * 1_074_688
-        ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
-        out = dict(base, metric="SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice",
-                   value=n * args.steps / dt / 1e6, unit="Mpoints/s", ms_per_step=dt / args.steps * 1e3,
-                   dtype="bf16x3(split-bf16 MFMA) deformation + " + inet.precision + " identity",
-                   config={"workload": f"NPHM identity + forward-deformation field, {args.res}^3 (BASELINE.json configs[2])",
-                           "res": args.res},
-                   roofline={"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                             "traffic": None, "kernel": "nphm::mlp::mlp_eval_kernel<2,2,1,0> (deformation stage, "
-                                                        "the longer of the two kernels)", "kernel_ms": float(np.mean(k_ms)),
-                             "executed_flops_per_point": flops}, cpu_baseline=None)
-    elif args.workload == "npm":
-        from oracle import nphm_oracle as O
-        gn = U.golden("npm")
-        npm = U.build_npm(device=dev).eval()
-        res = 64
-        axes = R.grid_axes(U.MINI, U.MAXI, res)
-        axes_dev = [torch.from_numpy(a).to(dev) for a in axes]
-        lat = torch.from_numpy(gn["lat"][None]).to(dev)
-        n = res ** 3
-        dt, k_ms = _timed(lambda: R.evaluate_grid_mlp(npm, lat, axes_dev), args.steps, args.warmup)
-        flops = 3 * 2 * 6_292_480
-        ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
-        cpu = None
-        if not args.no_cpu_baseline:
-            pts = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)[:, :20000]
-            latn = np.repeat(gn["lat"][None, None], pts.shape[1], axis=1)
-            t0 = time.perf_counter()
-            O.deepsdf_forward(U.np_state(npm), "", pts, latn, nlayers=8)
-            tc = time.perf_counter() - t0
-            cpu = {"value": pts.shape[1] / tc / 1e6, "unit": "Mpoints/s", "cores": os.cpu_count(), "kind": "port",
-                   "sample": f"first {pts.shape[1]} lattice points, oracle numpy fp32, {tc:.1f} s"}
-        out = dict(base, metric="SDF query throughput, NPM global DeepSDF, dense lattice", value=n * args.steps / dt / 1e6,
-                   unit="Mpoints/s", ms_per_step=dt / args.steps * 1e3, dtype="bf16x3(split-bf16 MFMA, fp32 accumulate)",
-                   config={"workload": "NPM global DeepSDF (lat 512, hidden 1024, 8 layers), 64^3 lattice "
-                                       "(BASELINE.json configs[0])", "res": res},
-                   roofline={"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                             "traffic": None, "kernel": "nphm::mlp::mlp_eval_kernel<1,4,1,0>", "kernel_ms": float(np.mean(k_ms)),
-                             "executed_flops_per_point": flops}, cpu_baseline=cpu)
-    else:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_fitting as BF
-        from nphm_amd import fitting as F
+    g = U.golden("deformation")
+    inet = U.build_identity(device=dev).eval()
+    dnet = U.build_deformation(device=dev).eval()
+    lat_id = torch.from_numpy(g["lat"].reshape(-1)[:1344]).to(dev)
+    lat_ex = torch.from_numpy(g["lat"].reshape(-1)).to(dev)
+    axes = [torch.from_numpy(a).to(dev) for a in R.grid_axes(U.MINI, U.MAXI, args.res)]
+    n = args.res ** 3
+    anchors = inet.prepare_latent(lat_id[None])[2]
+    mlp, cond = R._expr_condition(dnet, lat_ex, anchors, dev)
+    dt, _ = _timed(lambda: R.evaluate_grid_two_stage(inet, dnet, lat_id, lat_ex, axes, hack_chunk=args.chunk), steps, warmup)
+    _, k_ms = _timed(lambda: R.evaluate_grid_mlp(mlp, cond, axes, add_input=True), steps, 1)
+    flops = 3 * FLOP_DEFORMATION_FOLDED
+    ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
+    kname = "nphm::mlp::mlp_eval_kernel<2,2,1,0>"
+    return {"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice",
+            "value": n * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "dtype": "bf16x3(split-bf16 MFMA) deformation + " + inet.precision + " identity",
+            "config": {"workload": f"NPHM identity + forward-deformation field, {args.res}^3 (BASELINE.json configs[2])",
+                       "res": args.res},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                         "traffic": measured_traffic(kname, n), "algorithmic_bytes": 12 * n,
+                         "kernel": kname + " (deformation stage, the longer of the two kernels)",
+                         "kernel_ms": float(np.mean(k_ms)), "executed_flops_per_point": flops}}
+
+
+def npm_record(args, dev, steps, warmup, cpu):
+    """configs[0]: NPM global DeepSDF on the 64^3 lattice; its CPU side = the reference's PyTorch-CPU path"""
+    import _util as U
+    from nphm_amd import reconstruction as R
+    gn = U.golden("npm")
+    npm = U.build_npm(device=dev).eval()
+    res = 64
+    axes = R.grid_axes(U.MINI, U.MAXI, res)
+    axes_dev = [torch.from_numpy(a).to(dev) for a in axes]
+    lat = torch.from_numpy(gn["lat"][None]).to(dev)
+    n = res ** 3
+    dt, k_ms = _timed(lambda: R.evaluate_grid_mlp(npm, lat, axes_dev), steps, warmup)
+    flops = 3 * FLOP_NPM_FOLDED
+    ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
+    kname = "nphm::mlp::mlp_eval_kernel<1,4,1,0>"
+    out = {"metric": "SDF query throughput, NPM global DeepSDF, dense lattice", "value": n * steps / dt / 1e6,
+           "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "dtype": "bf16x3(split-bf16 MFMA, fp32 accumulate)",
+           "config": {"workload": "NPM global DeepSDF (lat 512, hidden 1024, 8 layers), 64^3 lattice "
+                                  "(BASELINE.json configs[0])", "res": res},
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                        "traffic": measured_traffic(kname, n), "algorithmic_bytes": 4 * n, "kernel": kname,
+                        "kernel_ms": float(np.mean(k_ms)), "executed_flops_per_point": flops}}
+    if cpu:
+        # the whole config on the host cores, the way the reference runs it: chunked get_logits, fp32 PyTorch-CPU
+        from oracle import torch_reference as T
+        threads = _cpu_threads(args)
+        torch.set_num_threads(threads)
+        sd = {k: v.detach().cpu() for k, v in npm.state_dict().items()}
+        grid = torch.from_numpy(R.create_grid_points_from_bounds(U.MINI, U.MAXI, res)).float()[None]
+        enc = torch.from_numpy(gn["lat"])[None, None]
+        fwd = lambda p, l: T.deepsdf_forward(sd, "", p, l, nlayers=8)
+        T.get_logits(fwd, enc, grid[:, :args.chunk], args.chunk)              # warm-up: one chunk
+        t0 = time.perf_counter()
+        T.get_logits(fwd, enc, grid, args.chunk)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / tc / 1e6, "unit": "Mpoints/s", "cores": threads, "host_cores": os.cpu_count(),
+                               "kind": "port", "sample": f"all {n} lattice points, chunked get_logits over the reference's "
+                               f"PyTorch op sequence (oracle/torch_reference.py), PyTorch-CPU fp32, one run after a one-chunk warm-up, {tc:.1f} s"}
+    return out
+
+
+FIT_LAMBDAS = {"surface": 2.0, "reg_expr": 0.01, "reg_global": 0.25, "reg_unobserved": 10, "reg_loc": 0.05,
+               "symm_dist": 5.0}                                                   # fitting_pointclouds.py:253-259
+FIT_SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 500: 9999},
+                "reg_glob": {200: 3, 600: 10}, "reg_loc": {500: 3, 600: 10}, "reg_expr": {600: 10}}   # :261-266
+
+
+def fitting_record(args, dev, with_reference_loop=True):
+    """configs[4]: latent fitting (fitting_pointclouds.py:253-276: n_steps 1000, the published schedule) at the
+    reference's own step_scale 1/4 = 250 Adam steps through every transition of the schedule; synthetic
+    observations on the level set of a seeded ground-truth identity.  Final loss next to the SAME loop on the
+    all-composite PyTorch-ROCm tier (the reference's arithmetic on this GPU)."""
+    import _util as U
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_fitting as BF
+    from nphm_amd import fitting as F
+    step_scale = 0.25
+    n_iter = int(args.fit_steps * step_scale)
+
+    def run(backend):
         shape_net = U.build_identity(device=dev)
         expr_net = U.build_deformation(device=dev).eval()
         obs = BF.synthetic_observations(shape_net, dev)
         shape_net.train()
-        cfg = {k: dict(v) for k, v in BF.SCHEDULE.items()}
+        if backend:
+            shape_net.backend = backend
+            expr_net.backend = backend
+        cfg = lambda: {k: dict(v) for k, v in FIT_SCHEDULE.items()}
         torch.manual_seed(0)
-        F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(BF.LAMBDAS), args.warmup, cfg, verbose=False)
+        F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(FIT_LAMBDAS), 8, cfg(), verbose=False)   # warm-up
         torch.cuda.synchronize()
-        steps = max(args.steps, 20)
+        hist = []
+        torch.manual_seed(0)
         t0 = time.perf_counter()
-        F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(BF.LAMBDAS), steps, cfg, verbose=False)
+        F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(FIT_LAMBDAS), args.fit_steps, cfg(),
+                                                 step_scale=step_scale, verbose=False, history=hist)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out = dict(base, steps=steps, metric="latent-code fitting steps/s (inference_iterative_root_finding_joint)",
-                   value=steps / dt, unit="steps/s", ms_per_step=dt / steps * 1e3,
-                   dtype="bf16x3 kernels + fp32 PyTorch ops",
-                   config={"workload": "latent fitting, 3 synthetic observations x 2500 points, 5 x 1000 points per step, "
-                                       "Adam on identity + expression codes (BASELINE.json configs[4])"},
-                   roofline=None, cpu_baseline=None,
-                   note="host-latency bound: ~8 ms of Python/launch overhead per step against ~2 ms of kernels")
-    print(json.dumps(out))
+        tail = hist[-20:]
+        return {"steps_per_s": len(hist) / dt, "ms_per_step": dt / len(hist) * 1e3, "steps": len(hist),
+                "first_surface_loss": hist[0]["surface"], "final_surface_loss": float(np.mean([h["surface"] for h in tail])),
+                "final_total_loss": float(np.mean([h["loss"] for h in tail])),
+                "final_valid_correspondences": float(np.mean([h["n_valid"] for h in tail]))}
+
+    ours = run(None)
+    out = {"metric": "latent-code fitting steps/s (inference_iterative_root_finding_joint)", "value": ours["steps_per_s"],
+           "unit": "steps/s", "ms_per_step": ours["ms_per_step"], "steps": ours["steps"],
+           "dtype": "bf16x3 kernels + fp32 PyTorch ops",
+           "config": {"workload": "latent fitting, 3 synthetic observations x 2500 points, 5 x 1000 points per step, Adam on "
+                                  f"identity + expression codes, n_steps {args.fit_steps} at step_scale 1/4 = {n_iter} steps through "
+                                  "the whole published schedule (BASELINE.json configs[4])"},
+           "first_surface_loss": ours["first_surface_loss"], "final_surface_loss": ours["final_surface_loss"],
+           "final_total_loss": ours["final_total_loss"], "final_valid_correspondences": ours["final_valid_correspondences"],
+           "roofline": None, "note": "surface losses = mean over the last 20 steps; the step is host-latency bound (DESIGN.md section 9)"}
+    if with_reference_loop:
+        ref = run("composite")
+        out["reference_loop_same_gpu"] = dict(ref, note="the same loop with every field on the composite tier = the reference's "
+                                                        "PyTorch arithmetic on this GPU (eager PyTorch-ROCm, fp32)")
+        out["final_surface_loss_ratio"] = ours["final_surface_loss"] / max(ref["final_surface_loss"], 1e-30)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# baselines
+# ------------------------------------------------------------------------------------------------------
+def _cpu_threads(args):
+    return args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64)
+
+
+def cpu_baseline(net, lat, axes, args):
+    """The reference's PyTorch operation sequence (oracle/torch_reference.py: per-point latent repeat, materialised
+    conditioning, bmm over the expanded weights) on the host cores, chunked like get_logits, on the first
+    n_sample lattice points of the same workload (dense 40-member evaluation: the cost does not depend on where
+    the points lie).  One warm-up chunk, then 3 runs, median."""
+    from oracle import torch_reference as T
+    import _util as U
+    threads = _cpu_threads(args)
+    torch.set_num_threads(threads)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    amean = torch.from_numpy(U.anchors_mean()).float()
+    n = args.cpu_sample
+    idx = np.arange(n)
+    ry, rz = len(axes[1]), len(axes[2])
+    pts = torch.from_numpy(np.stack([axes[0][idx // (ry * rz)], axes[1][(idx // rz) % ry], axes[2][idx % rz]], -1))[None]
+    enc = lat.detach().cpu().reshape(1, 1, -1)
+    fwd = lambda p, l: T.nphm_identity_forward(sd, amean, p, l, training=False)[0]
+    T.get_logits(fwd, enc, pts[:, :args.chunk], args.chunk)
+    runs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        T.get_logits(fwd, enc, pts, args.chunk)
+        runs.append(time.perf_counter() - t0)
+    dt = float(np.median(runs))
+    return {"value": n / dt / 1e6, "unit": "Mpoints/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"first {n} lattice points of the {len(axes[0])}^3 volume in chunks of {args.chunk}, the reference's PyTorch "
+                      f"op sequence (oracle/torch_reference.py; /root/reference cannot travel to the GPU box), PyTorch-CPU fp32, "
+                      f"dense 40-member evaluation, 1 warm-up chunk + 3 runs, median {dt:.1f} s (runs: "
+                      + ", ".join(f"{r:.1f}" for r in runs) + ")"}
+
+
+def cpu_baseline_port(net, lat, axes, n_sample=20000):
+    """The numpy oracle on the host cores (second field; slower than the PyTorch sequence above)."""
+    from oracle import nphm_oracle as O
+    import _util as U
+    params, amean = U.np_state(net), U.anchors_mean()
+    g = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
+    idx = np.linspace(0, g.shape[0] - 1, n_sample).astype(np.int64)
+    pts = g[idx][None].astype(np.float32)
+    latn = lat.cpu().numpy()[None, None]
+    threads = 1
+    try:                                         # numpy's BLAS pool is what the oracle's GEMMs run on
+        from threadpoolctl import threadpool_info
+        threads = max([1] + [int(i.get("num_threads", 1)) for i in threadpool_info()])
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    O.nphm_identity_forward(params, amean, pts, latn, training=False)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt / 1e6, "unit": "Mpoints/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_sample} lattice points (uniform stride over the volume), oracle/nphm_oracle.py numpy fp32, "
+                      f"dense 40-member evaluation, {dt:.1f} s"}
 
 
 def pytorch_rocm_line(net, lat, axes_dev, chunk, n_chunks=20):
@@ -220,177 +466,102 @@ def pytorch_rocm_line(net, lat, axes_dev, chunk, n_chunks=20):
                       f"per-chunk latent repeat and device->host copy as in get_logits, {dt * 1e3:.0f} ms"}
 
 
+def mfma_sustained(dev):
+    """Matrix-pipe rate of an MFMA-only loop on this box (nphm_probe_mfma_rate: every SIMD issues dependent-free
+    v_mfma_f32_32x32x16_bf16 with non-trivial operands for ~5 ms): what the chip's power management lets the matrix
+    cores sustain - the practical ceiling under the 2.5 PFLOP/s datasheet peak that `roofline.peak` uses."""
+    import ctypes
+    from nphm_amd import _lib
+    lib = _lib.load()
+    if not hasattr(lib, "nphm_probe_mfma_rate"):
+        return None
+    tf, ghz = ctypes.c_double(), ctypes.c_double()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(2):
+        _lib.check(lib.nphm_probe_mfma_rate(ctypes.byref(tf), ctypes.byref(ghz), stream), "nphm_probe_mfma_rate")
+    return {"tflops": tf.value, "clock_ghz": ghz.value, "frac_of_peak": tf.value / 2500.0,
+            "note": "bf16 32x32x16 MFMA only, 2 wavefronts per SIMD, A fragments re-read from LDS, pseudo-random operands"}
+
+
+# ------------------------------------------------------------------------------------------------------
+def single_workload(args):
+    """--workload two_stage | npm | fitting: one of the other configs as a line of its own (one GPU)."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    base = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "data": "synthetic (seeded random-init weights, latents ~ shipped statistics)"}
+    if args.workload == "two_stage":
+        rec = two_stage_record(args, dev, args.steps, args.warmup)
+    elif args.workload == "npm":
+        rec = npm_record(args, dev, args.steps, args.warmup, not args.no_cpu_baseline)
+    else:
+        rec = fitting_record(args, dev, with_reference_loop=not args.no_cpu_baseline)
+    rec.setdefault("cpu_baseline", None)
+    print(json.dumps(dict(base, **rec)))
+
+
 def main():
     args = parse()
-    if args.workload != "identity":
-        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
-            raise SystemExit("--workload other than identity runs on one GPU")
-        return other_workloads(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload not in ("all", "identity"):
+        if world != 1:
+            raise SystemExit("--workload other than all / identity runs on one GPU")
+        return single_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run (any N)
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", device_id=dev)
 
-    import _util as U
-    from nphm_amd import _lib
-    from nphm_amd import reconstruction as R
-
-    net = U.build_identity(device=dev).eval()
-    if args.prune_tol is not None:
-        net.prune_tol = args.prune_tol
-    if args.precision is not None:
-        net.precision = args.precision
-    lat = U.sample_latent(0).to(dev)
-    axes = R.grid_axes(U.MINI, U.MAXI, args.res)
-    axes_dev = [torch.from_numpy(a).to(dev) for a in axes]
-    rx = ry = rz = args.res
-    n_total = rx * ry * rz
-    plane = ry * rz
-    # N > 1: every rank takes the x-planes of every N-th 8-plane brick slab (work-balanced)
-    planes = R.cyclic_planes(rx, world, rank)
-    planes_dev = torch.from_numpy(planes).to(dev)
-    n_planes = len(planes)
-
-    lib = _lib.load()
-    stats = torch.zeros(16, dtype=torch.int64, device=dev)
-    shard = torch.zeros(max(n_planes, 1) * plane, dtype=torch.float32, device=dev)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    box = {"full": None}
-    ws = None if args.no_binning or not n_planes else R.grid_workspace(dev, n_planes, ry, rz)
-    ws_ptr, ws_bytes = (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
-
-    def step(timed, ev=None):
-        packed, state, _ = net.prepare_latent(lat[None])
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        if timed:
-            ev[0].record()                     # HIP events on the launch stream bracket the dominant kernel
-        if n_planes:
-            _lib.check(lib.nphm_identity_eval_grid_planes(
-                packed.data_ptr(), state.data_ptr(), axes_dev[0].data_ptr(), axes_dev[1].data_ptr(),
-                axes_dev[2].data_ptr(), rx, ry, rz, planes_dev.data_ptr(), n_planes, args.chunk,
-                float(net.prune_tol), net._precision_code(), shard.data_ptr(),
-                stats.data_ptr() if timed else None, ws_ptr, ws_bytes, stream), "eval_grid_planes")
-        if timed:
-            ev[1].record()
-        if world > 1:
-            box["full"] = R.gather_planes(shard[: n_planes * plane], rx, plane)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(True, events[i])
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    # ---- mesh-extract wall-clock (second half of the BASELINE metric): latent -> SDF volume (all
-    # ranks) -> host -> marching cubes -> vertices/faces, measured once outside the timed region
-    mesh = None
-    barrier()
-    t_m0 = time.perf_counter()
-    if not args.no_mesh:
-        step(False)
-    barrier()
-    t_m1 = time.perf_counter()
-    if rank == 0 and not args.no_mesh:
-        vol_dev = shard if world == 1 else box["full"]
-        vol_host = R.to_host(vol_dev)
-        t_m2 = time.perf_counter()
-        vh, fh = R.marching_cubes(vol_host.reshape(rx, ry, rz), 0.0, negate=True)     # host extractor
-        t_m3 = time.perf_counter()
-        m = SimpleNamespace(vertices=vh, faces=fh)
-        # the same mesh without the volume leaving the device: GPU marching cubes, only the mesh travels
-        torch.cuda.synchronize()
-        t_d0 = time.perf_counter()
-        vd, fd = R.marching_cubes_device(vol_dev.view(rx, ry, rz), 0.0, negate=True)
-        vd_h, fd_h = R.to_host(vd), R.to_host(fd)
-        t_d1 = time.perf_counter()
-        cold_ms = (t_d1 - t_d0) * 1e3
-        # once more, warm (kernels loaded, scratch and pinned staging buffers cached), like the timed kernel steps
-        del vd, fd, vd_h, fd_h
-        torch.cuda.synchronize()
-        t_d0 = time.perf_counter()
-        vd, fd = R.marching_cubes_device(vol_dev.view(rx, ry, rz), 0.0, negate=True)
-        vd_h, fd_h = R.to_host(vd), R.to_host(fd)
-        t_d1 = time.perf_counter()
-        mesh = {"wall_ms": (t_m1 - t_m0) * 1e3 + (t_d1 - t_d0) * 1e3, "volume_ms": (t_m1 - t_m0) * 1e3,
-                "device_marching_cubes_ms": (t_d1 - t_d0) * 1e3, "device_marching_cubes_first_call_ms": cold_ms,
-                "n_vertices": int(len(vd_h)), "n_faces": int(len(fd_h)),
-                "reference_order": {"wall_ms": (t_m3 - t_m0) * 1e3, "d2h_ms": (t_m2 - t_m1) * 1e3,
-                                    "host_marching_cubes_ms": (t_m3 - t_m2) * 1e3,
-                                    "note": "get_logits -> numpy volume on the host -> mesh_from_logits (host marching cubes, <= 16 threads)"},
-                "same_mesh": bool(len(vd_h) == len(m.vertices) and np.array_equal(fd_h, np.asarray(m.faces))),
-                "note": "wall = latent -> SDF volume (all ranks, all-gathered) -> marching cubes on the GPU -> vertices/faces on the host; "
-                        "PyMCubes of the reference is absent, both extractors are this repo's (bit-identical meshes)"}
+    ib = IdentityBench(args, dev, world, rank, distributed)
+    binned = not args.no_binning
+    rec = ib.record(args.precision, args.steps, args.warmup, binned)
+    mesh = None if args.no_mesh else ib.mesh_extract(args.precision, binned)
 
     if rank == 0:
-        n_local = n_planes * plane
-        k_ms = float(np.mean(kernel_ms))
-        active = stats.cpu().numpy()
-        mean_active = float(active[0]) / max(1, args.steps) / n_local     # evaluated member-points / point
-        # executed matrix-pipe FLOPs: the split-bf16 path issues 3 bf16 MFMA products per fp32 product
-        passes = 1 if net.precision == "f32" else 3
-        mean_light = float(active[15]) / max(1, args.steps) / n_local       # single-pass pairs (adaptive mode)
-        exec_flops = (passes * (mean_active - mean_light) + mean_light) * FLOP_MEMBER_FOLDED * n_local
-        peak = PEAK_TFLOPS[net.precision]
-        achieved = exec_flops / (k_ms * 1e-3) / 1e12
-        # the events bracket the whole grid call: with binning that is the tile pre-pass + radix sort
-        # (together ~1 % of it) + the dominant kernel
-        kname = "nphm::eval_kernel<%d,%d>" % (1 if ws is None else 2, min(net._precision_code(), 1))
         out = {
             "metric": "SDF query throughput, NPHM 39-anchor identity field, dense lattice extraction",
-            "value": n_total * args.steps / dt / 1e6, "unit": "Mpoints/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)",
-                      "bf16x3a": "bf16x3 adaptive(split-bf16 MFMA for blend weights >= 1e-3, single-pass bf16 below)"}[net.precision],
-            "data": "synthetic (seeded random-init weights, latent ~ shipped mean/std x0.85)",
+            "value": rec["value"], "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": rec["dtype"], "data": "synthetic (seeded random-init weights, latent ~ shipped mean/std x0.85)",
             "config": {"workload": f"NPHM 39-anchor identity net, {args.res}^3 lattice extraction "
                                    f"(BASELINE.json configs[1]), eval-mode get_logits chunk {args.chunk}",
-                       "res": args.res, "prune_tol": net.prune_tol, "precision": net.precision,
-                       "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather" if world > 1 else "single GPU")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak,
-                         "traffic": measured_traffic(kname, n_local),
-                         "algorithmic_bytes": 4 * n_local,
-                         "kernel": kname, "rank0_planes": n_planes, "binned_tiles": ws is not None,
-                         "kernel_ms": k_ms, "points_per_launch": n_local,
-                         "executed_flops_per_point": exec_flops / n_local, "mean_single_pass_members": mean_light,
-                         "mfma_passes": passes,
-                         "mean_active_members": mean_active,
-                         "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12,
-                         "note": "achieved counts EXECUTED matrix FLOPs: the adaptive default issues one pass instead "
-                                 "of three for ~46% of the evaluated members, so it is faster at a lower FLOP rate "
-                                 "(--precision bf16x3: 3 passes everywhere, ~281 Mpoints/s at frac ~0.34); the kernel is "
-                                 "held back by the per-chunk weight streaming / barrier and the VALU epilogue threaded through the MFMA chain (ablations in DESIGN.md section 4.1)"},
+                       "res": args.res, "prune_tol": ib.net.prune_tol, "precision": args.precision,
+                       "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather" if distributed else "single GPU")},
+            "roofline": dict(rec["roofline"], note=(
+                "achieved counts EXECUTED matrix FLOPs (tile padding excluded): the adaptive default issues one pass instead "
+                "of three for ~46% of the evaluated members, so it is faster at a lower FLOP rate; `peak` is the datasheet figure - "
+                "an MFMA-only loop sustains `mfma_sustained.tflops` on this box (power-limited clock, tools/micro/chain.hip), "
+                "which with the kernel's 17.6% tile padding bounds `frac` at about 0.5 (DESIGN.md section 4.1)")),
+            "mesh_extract": mesh,
         }
-        out["mesh_extract"] = mesh
+        if world == 1 and args.workload == "all" and not args.no_sub:
+            sub_steps = max(2, min(args.steps, 5))
+            out["mfma_sustained"] = mfma_sustained(dev)
+            out["precisions"] = {p: ib.record(p, sub_steps if p != "f32" else 2, 1, binned)
+                                 for p in ("bf16x3", "f32") if p != args.precision}
+            out["configs"] = {
+                "npm_64": npm_record(args, dev, max(sub_steps, 5), 2, not args.no_cpu_baseline),
+                "two_stage_256": two_stage_record(args, dev, sub_steps, 1),
+                "fitting": fitting_record(args, dev, with_reference_loop=not args.no_cpu_baseline),
+            }
+            ib.net.precision = args.precision
         if not args.no_cpu_baseline and world == 1:
-            out["pytorch_rocm_baseline"] = pytorch_rocm_line(net, lat, axes_dev, args.chunk)
-            out["cpu_baseline"] = cpu_baseline(net, lat, axes, args.cpu_sample)
+            out["pytorch_rocm_baseline"] = pytorch_rocm_line(ib.net, ib.lat, ib.axes_dev, args.chunk)
+            out["cpu_baseline"] = cpu_baseline(ib.net, ib.lat, ib.axes, args)
+            out["cpu_baseline_port"] = cpu_baseline_port(ib.net, ib.lat, ib.axes)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

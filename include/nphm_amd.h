@@ -31,6 +31,13 @@ extern "C" {
 int nphm_abi_version(void);
 const char* nphm_last_error(void);
 
+/* Measurement aid (bench.py's `mfma_sustained`; not on any product path, no reference counterpart):
+ * runs an MFMA-only loop shaped like the kernels' GEMM body (bf16 32x32x16, 2 wavefronts per SIMD,
+ * A fragments re-read from LDS, pseudo-random operands) for a few ms on `stream`, SYNCHRONISES, and
+ * returns the executed TFLOP/s and the shader clock it ran at - the matrix-pipe rate the chip's power
+ * management sustains, to read next to the 2.5 PFLOP/s datasheet peak. */
+int nphm_probe_mfma_rate(double* tflops, double* clock_ghz, void* stream);
+
 /* ---- NPHM identity field: FastEnsembleDeepSDFMirrored -------------------------------- */
 /* Architecture the fused kernel is specialised for (scripts/configs/nphm.yaml:1-7):
  * lat_dim_glob 64, lat_dim_loc 32, n_loc 39, n_symm_pairs 16, hidden 200, n_layers 4,

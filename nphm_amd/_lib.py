@@ -23,6 +23,7 @@ _PtrArr3 = c_void_p * 3
 SYMBOLS = {
     "nphm_abi_version": (c_int, []),
     "nphm_last_error": (c_char_p, []),
+    "nphm_probe_mfma_rate": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_void_p]),
     "nphm_identity_supported": (c_int, [c_int] * 8),
     "nphm_identity_packed_bytes": (c_size_t, []),
     "nphm_identity_latent_state_bytes": (c_size_t, [c_int]),

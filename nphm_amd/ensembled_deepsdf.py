@@ -292,6 +292,9 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self.invalidate_pack()
+        # NPHM_AMD_VALIDATE=1: check the fast mode against the dense fp32 kernel once per loaded checkpoint
+        # (numerics.validate_numerics, at the first HIP evaluation, with that call's latent)
+        self._needs_validation = os.environ.get("NPHM_AMD_VALIDATE", "0") not in ("", "0")
         return out
 
     def _apply(self, fn, *args, **kwargs):
@@ -346,6 +349,10 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         """lat_rows [B, lat_dim] -> (latent_state, anchors [B,n_loc,3]) via the HIP prologue kernel."""
         lib = _lib.load()
         device = lat_rows.device
+        if getattr(self, "_needs_validation", False):
+            from .numerics import validate_numerics
+            self._needs_validation = False
+            validate_numerics(self, lat_rows[:1].detach(), n=1 << 14)
         packed = self._packed(device)
         B = lat_rows.shape[0]
         lat_rows = lat_rows.contiguous().float()

@@ -367,12 +367,18 @@ def gather_planes(local: torch.Tensor, rx: int, plane: int, group=None, unit: in
     """Reassemble the volume from the ranks' cyclic plane sets: ONE all_gather_into_tensor (RCCL
     over xGMI on ROCm) of shards padded to the largest plane count, then one index_select that
     restores the flattened 'ij' order.  ``local``: this rank's planes [n_planes*plane] in
-    ``cyclic_planes`` order.  Returns the full volume [rx*plane] on every rank."""
+    ``cyclic_planes`` order, or already the padded shard [shard_depth*plane] (what
+    ``evaluate_grid_sharded`` hands over: the kernel wrote straight into it, no staging copy).
+    Returns the full volume [rx*plane] on every rank."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     depth = shard_depth(rx, world, unit)
-    shard = torch.zeros(depth * plane, dtype=local.dtype, device=local.device)
-    shard[: local.numel()] = local.reshape(-1)
+    if local.numel() == depth * plane and local.is_contiguous():
+        shard = local.reshape(-1)
+    else:
+        shard = torch.empty(depth * plane, dtype=local.dtype, device=local.device)
+        shard[: local.numel()] = local.reshape(-1)
+        shard[local.numel():].zero_()
     gathered = torch.empty(world * depth * plane, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, shard, group=group)
     return reorder_gathered(gathered, rx, plane, world, unit)
@@ -397,24 +403,50 @@ def reorder_gathered(gathered: torch.Tensor, rx: int, plane: int, world_size: in
 def evaluate_grid_sharded(decoder, encoding, axes, *, hack_chunk: Optional[int] = None, group=None,
                           evaluate=None, unit: int = 8):
     """Multi-GPU lattice evaluation: every rank evaluates its cyclic set of x-planes
-    (``cyclic_planes``; one kernel launch) and one all-gather + reorder reassembles the full volume
-    on every rank (``gather_planes``).  The chunk overwrite uses global indices, so the result is
-    bit-identical to the single-GPU volume.  ``evaluate(planes: int32 ndarray) -> tensor`` can be
-    injected (two-stage evaluation via contiguous ranges, CPU/gloo tests)."""
+    (``cyclic_planes``; one kernel launch that writes straight into the rank's padded shard) and one
+    all-gather + reorder reassembles the full volume on every rank (``gather_planes``).  The chunk
+    overwrite uses global indices, so the result is bit-identical to the single-GPU volume.
+    ``evaluate(planes: int32 ndarray, out: tensor)`` can be injected (CPU/gloo tests, other fields): it fills
+    ``out`` [len(planes)*ry*rz] with the values of those planes."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     rx, ry, rz = (len(a) for a in axes)
+    plane = ry * rz
     planes = cyclic_planes(rx, world, rank, unit)
     if evaluate is None:
         if hack_chunk is None:
             hack_chunk = 0 if decoder.training else rx * ry * rz
-        evaluate = lambda pl: evaluate_grid(decoder, encoding, axes, hack_chunk=hack_chunk, x_planes=pl)
-    if len(planes):
-        local = evaluate(planes)
-    else:
-        local = torch.empty(0, dtype=torch.float32, device=encoding.device)
-    return gather_planes(local, rx, ry * rz, group, unit)
+        evaluate = lambda pl, out: evaluate_grid(decoder, encoding, axes, hack_chunk=hack_chunk, x_planes=pl, out=out)
+    shard = torch.empty(shard_depth(rx, world, unit) * plane, dtype=torch.float32, device=encoding.device)
+    n = len(planes) * plane
+    if n:
+        evaluate(planes, shard[:n])
+    shard[n:].zero_()                           # padding of the ranks with fewer planes
+    return gather_planes(shard, rx, plane, group, unit)
+
+
+def evaluate_grid_two_stage_sharded(decoder_shape, decoder_expr, encoding_shape, encoding_expr, axes, *,
+                                    anchors=None, hack_chunk: Optional[int] = None, group=None, unit: int = 8):
+    """Multi-GPU form of ``evaluate_grid_two_stage`` (configs[2] sharded like configs[3]): the same cyclic
+    partition; a rank runs the deformation + identity kernels once per contiguous ``unit``-plane slab of its
+    set (256^3 on 8 ranks: 4 slabs), writing into its padded shard; one all-gather + reorder."""
+    rx, ry, rz = (len(a) for a in axes)
+    plane = ry * rz
+    if hack_chunk is None:
+        hack_chunk = 0 if decoder_shape.training else rx * ry * rz
+
+    def evaluate(planes, out):
+        planes = np.asarray(planes)
+        starts = np.flatnonzero(np.diff(planes, prepend=planes[0] - 2) != 1)      # first plane of every contiguous run
+        for i, s in enumerate(starts):
+            e = starts[i + 1] if i + 1 < len(starts) else len(planes)
+            evaluate_grid_two_stage(decoder_shape, decoder_expr, encoding_shape, encoding_expr, axes, anchors=anchors,
+                                    hack_chunk=hack_chunk, x_range=(int(planes[s]), int(planes[e - 1]) + 1),
+                                    out=out[s * plane:e * plane])
+
+    return evaluate_grid_sharded(decoder_shape, encoding_shape, axes, hack_chunk=hack_chunk, group=group,
+                                 evaluate=evaluate, unit=unit)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -30,15 +30,33 @@ def _worker(rank, world, port, shape, q):
         axes = [np.arange(n, dtype=np.float32) for n in shape]
         plane = ry * rz
 
-        def evaluate(planes):
+        def evaluate(planes, out):
             # value = global flat index, as the kernel's plane-list output would hold for f(i) = i
             p = torch.from_numpy(planes.astype(np.int64))
-            return (p[:, None] * plane + torch.arange(plane)[None, :]).reshape(-1).float()
+            out.copy_((p[:, None] * plane + torch.arange(plane)[None, :]).reshape(-1).float())
 
         ok = True
         for unit in (8, 2):
             full = R.evaluate_grid_sharded(None, torch.zeros(1), axes, evaluate=evaluate, unit=unit)
             ok = ok and torch.equal(full, torch.arange(rx * plane, dtype=torch.float32))
+        # the two-stage sharding cuts a rank's plane set into contiguous runs and evaluates run by run
+        calls = []
+        orig = R.evaluate_grid_two_stage
+
+        def fake_two_stage(ds, de, es, ee, ax, *, anchors=None, hack_chunk=None, x_range=None, out=None, **kw):
+            calls.append(x_range)
+            i = torch.arange(x_range[0] * plane, x_range[1] * plane, dtype=torch.float32)
+            out.copy_(i)
+            return out
+
+        R.evaluate_grid_two_stage = fake_two_stage
+        try:
+            dec = type("D", (), {"training": True})()
+            full = R.evaluate_grid_two_stage_sharded(dec, None, torch.zeros(1), None, axes, unit=2)
+        finally:
+            R.evaluate_grid_two_stage = orig
+        ok = ok and torch.equal(full, torch.arange(rx * plane, dtype=torch.float32))
+        ok = ok and all(b - a <= 2 for a, b in calls) and sum(b - a for a, b in calls) == len(R.cyclic_planes(rx, world, rank, 2))
         q.put((rank, bool(ok), R.cyclic_planes(rx, world, rank, 2).tolist()))
     finally:
         dist.destroy_process_group()
