@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 2
+#define NPHM_AMD_ABI_VERSION 3
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -145,13 +145,24 @@ int nphm_identity_eval_grid_planes(const void* packed, const void* latent_state,
  *     untouched); the host blends them.  Serves the forward of the autograd tier, whose query points are
  *     scattered surface samples (a brick-coherent wavefront of eval_points would touch most members). */
 size_t nphm_identity_bwd_packed_bytes(void);
+/* The (row, member) point lists of the two kernels above, built ON THE DEVICE with fixed capacity (no size
+ * travels to the host: no synchronisation, static shapes, hipGraph-capturable).  With T =
+ * nphm_identity_list_tiles(n_points) = ceil(n_points / 64): blend_weights [n_rows, n_points, 40] = normalised
+ * blend weight of every (point, member), 0 where the pruning rule of the fused kernel drops the member
+ * (prune_tol < 0: nothing dropped; EnsembledDeepSDF.py:129-150 for the weights); tiles = room for
+ * 2 * n_rows * 40 * T entries of 4 ints (the used tiles end up compacted at the front, the second half is
+ * scratch); *n_tiles_used (device int) = their number; point_list [n_rows * 40 * 64 T].  The kernels take the
+ * capacity n_rows * 40 * T as n_tiles and the device count as n_tiles_dev. */
+int nphm_identity_list_tiles(int64_t n_points);
+int nphm_identity_build_lists(const void* latent_state, const float* xyz, int n_rows, int64_t n_points, float prune_tol,
+                              float* blend_weights, int* tiles, int* n_tiles_used, int* point_list, void* stream);
 int nphm_identity_member_forward(const void* packed, const void* packed_bwd, const void* latent_state,
                                  const float* xyz, int64_t n_points, const int* tiles, int n_tiles,
-                                 const int* point_list, float* member_sdf, void* stream);
+                                 const int* n_tiles_dev, const int* point_list, float* member_sdf, void* stream);
 int nphm_identity_pack_bwd(const float* const lin_weight[5], void* packed_bwd, void* stream);
 int nphm_identity_backward(const void* packed, const void* packed_bwd, const void* latent_state,
                            const float* xyz, const float* sdf, const float* grad_sdf, int64_t n_points,
-                           const int* tiles, int n_tiles, const int* point_list,
+                           const int* tiles, int n_tiles, const int* n_tiles_dev, const int* point_list,
                            float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2, void* stream);
 
 /* Second stage of the two-stage evaluation get_logits_backward (src/NPHM/models/reconstruction.py:28-56):

@@ -41,10 +41,13 @@ SYMBOLS = {
                                                c_void_p, c_size_t, c_void_p]),
     "nphm_identity_bwd_packed_bytes": (c_size_t, []),
     "nphm_identity_pack_bwd": (c_int, [_PtrArr5, c_void_p, c_void_p]),
+    "nphm_identity_list_tiles": (c_int, [c_int64]),
+    "nphm_identity_build_lists": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p]),
     "nphm_identity_member_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
-                                             c_void_p, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_eval_grid_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                                c_void_p]),
@@ -93,7 +96,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 2:
+    if lib.nphm_abi_version() != 3:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -101,6 +101,8 @@ struct BwdArgs {
   const float* gout;              // [n_rows, n_points] d L / d sdf
   const int* tiles;               // [n_tiles][4] = row, member, offset into list, count (<= 64)
   const int* list;                // point indices (within their row)
+  int n_tiles;                    // tiles in the table ...
+  const int* n_tiles_dev;         // ... or, if not NULL, their number in device memory (tables built on the device)
   int64_t n_points;
   float* gxyz;                    // [n_rows, n_points, 3]   (+=)
   float* ganch;                   // [n_rows, 39, 3]         (+=)
@@ -175,7 +177,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // query points are scattered surface samples for which the brick-coherent kernel of eval_kernel.hip
 // prunes poorly (a wavefront of 32 unrelated points touches most members).
 template <bool BWD>
-__global__ __launch_bounds__(64 * WAVES, 2) void ident_member_kernel(BwdArgs p) {
+__device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_index) {
   __shared__ __attribute__((aligned(16))) char act_hi[PLANE_BYTES];
   __shared__ __attribute__((aligned(16))) char act_lo[PLANE_BYTES];
   __shared__ float part[WAVES][M];          // per-wave partial of lin4 / of the coordinate gradient
@@ -188,8 +190,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ident_member_kernel(BwdArgs p) 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, j = lane & 31;
-  const int* tile = p.tiles + 4 * blockIdx.x;
+  const int* tile = p.tiles + 4 * tile_index;
   const int row = tile[0], k = tile[1], off = tile[2], cnt = tile[3];
+  if (cnt <= 0) return;                   // empty slot of a fixed-capacity tile table
   const int set = member_set(k);
   const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
   const float* anch = st + LS_OFF_ANCH;
@@ -498,6 +501,134 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ident_member_kernel(BwdArgs p) 
   }
 }
 
+// Workgroups walk the tile table with a grid stride.  A table built on the device has a fixed capacity and its
+// number of used tiles lives in device memory (no host round trip): the launch is sized for the capacity but
+// capped at a few workgroups per CU - an EMPTY workgroup of this kernel (512 threads, 57 KiB of LDS) still
+// costs ~0.17 us of dispatch, 0.4 ms for the 2400 unused slots of a 5 x 1000-point fitting batch.
+template <bool BWD>
+__global__ __launch_bounds__(64 * WAVES, 2) void ident_member_kernel(BwdArgs p) {
+  const int n = p.n_tiles_dev ? *p.n_tiles_dev : p.n_tiles;
+  for (int t = blockIdx.x; t < n; t += gridDim.x) {
+    member_tile<BWD>(p, t);
+    __syncthreads();                       // the LDS staging arrays are reused by the next tile
+  }
+}
+
+// ---- (row, member) point lists on the device ------------------------------------------------------------
+// The member-centric kernels above work on lists of the points that keep a member under the pruning rule of
+// the fused kernel (eval_kernel.hip, blend_masks: per point the smallest normalised blend weights are dropped
+// while they sum to <= 40 * prune_tol; prune_tol < 0: every member).  Built here with FIXED capacity - every
+// (row, member) pair owns a list segment of ceil(N / 64) * 64 entries and ceil(N / 64) tile slots (count 0 =
+// unused) - so the host needs no size from the device: no synchronisation, static shapes (hipGraph capture).
+//   weights_kernel : one thread per point - the 40 normalised weights (0 where pruned) into what[B,N,40]
+//   lists_kernel   : one workgroup per (row, member) - order-preserving compaction of its points + tile slots
+struct ListArgs {
+  const float* state;       // [n_rows, LS_ROW_STRIDE]
+  const float* xyz;         // [n_rows, n_points, 3]
+  int n_rows;
+  int64_t n_points;
+  float prune_tol;
+  float* what;              // [n_rows, n_points, 40]
+  int* tiles;               // [n_rows * 40 * T][4]
+  int* list;                // [n_rows * 40 * 64 T]
+  int T;
+};
+
+__global__ __launch_bounds__(256) void weights_kernel(ListArgs p) {
+  const int row = blockIdx.y;
+  const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= p.n_points) return;
+  const float* anch = p.state + size_t(row) * LS_ROW_STRIDE + LS_OFF_ANCH;
+  const float* q = p.xyz + (int64_t(row) * p.n_points + n) * 3;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  float w[N_MEMBERS];
+  float S = 0.f;
+#pragma unroll
+  for (int a = 0; a < N_LOC; ++a) {
+    const float dx = anch[3 * a] - qx, dy = anch[3 * a + 1] - qy, dz = anch[3 * a + 2] - qz;
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
+    w[a] = expf(-(d * d) / 0.01f);
+    S += w[a];
+  }
+  w[N_LOC] = expf(-0.2f / 0.01f);
+  const float denom = S + w[N_LOC] + 1e-6f;
+#pragma unroll
+  for (int a = 0; a < N_MEMBERS; ++a) w[a] /= denom;
+  float cut = -1.f;                                   // prune_tol < 0: keep everything
+  if (p.prune_tol >= 0.f) {
+    cut = p.prune_tol;
+    const float budget = float(N_MEMBERS) * p.prune_tol;
+    const float mults[5] = {2.f, 4.f, 8.f, 16.f, 40.f};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float lim = mults[c] * p.prune_tol;
+      float below = 0.f;
+#pragma unroll
+      for (int a = 0; a < N_MEMBERS; ++a) below += w[a] <= lim ? w[a] : 0.f;
+      if (below <= budget) cut = lim;
+    }
+  }
+  float* o = p.what + (int64_t(row) * p.n_points + n) * N_MEMBERS;
+#pragma unroll
+  for (int a = 0; a < N_MEMBERS; ++a) o[a] = w[a] > cut ? w[a] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void lists_kernel(ListArgs p) {
+  __shared__ int wave_count[4];
+  __shared__ int base;
+  const int pair = blockIdx.x;                       // row * 40 + member
+  const int row = pair / N_MEMBERS, k = pair % N_MEMBERS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cap = 64 * p.T;
+  int* list = p.list + int64_t(pair) * cap;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int64_t n0 = 0; n0 < p.n_points; n0 += 256) {
+    const int64_t n = n0 + threadIdx.x;
+    const bool keep = n < p.n_points && p.what[(int64_t(row) * p.n_points + n) * N_MEMBERS + k] > 0.f;
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) wave_count[wave] = __popcll(b);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_count[w];
+    if (keep) list[off + __popcll(b & ((1ull << lane) - 1ull))] = int(n);
+    __syncthreads();
+    if (threadIdx.x == 0) base += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    __syncthreads();
+  }
+  const int count = base;
+  for (int t = threadIdx.x; t < p.T; t += blockDim.x) {
+    int* tile = p.tiles + (int64_t(pair) * p.T + t) * 4;
+    const int c = count - 64 * t;
+    tile[0] = row; tile[1] = k; tile[2] = pair * cap + 64 * t; tile[3] = c < 0 ? 0 : (c > 64 ? 64 : c);
+  }
+}
+
+// used tile slots -> front of the table, in slot order (deterministic); their number -> *n_used
+__global__ __launch_bounds__(1024) void compact_tiles_kernel(const int* slots, int n_slots, int* tiles, int* n_used) {
+  __shared__ int wave_count[16];
+  __shared__ int base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n_slots; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i < n_slots) v = reinterpret_cast<const int4*>(slots)[i];
+    const bool used = v.w > 0;
+    const unsigned long long b = __ballot(used);
+    if (lane == 0) wave_count[wave] = __popcll(b);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_count[w];
+    if (used) reinterpret_cast<int4*>(tiles)[off + __popcll(b & ((1ull << lane) - 1ull))] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wave_count[w]; base += s; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_used = base;
+}
+
 }  // namespace bwd
 }  // namespace nphm
 
@@ -505,6 +636,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ident_member_kernel(BwdArgs p) 
 // C ABI (include/nphm_amd.h)
 // ============================================================================================
 extern "C" {
+
+// grid of the member-centric kernels: one workgroup per tile; with a device-side tile count (capacity-sized
+// table) at most 4 workgroups per CU, which then stride over the used tiles
+static unsigned member_grid(int n_tiles, const int* n_tiles_dev) {
+  if (!n_tiles_dev) return unsigned(n_tiles);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int cap = 4 * (cus > 0 ? cus : 256);
+  return unsigned(n_tiles < cap ? n_tiles : cap);
+}
 
 size_t nphm_identity_bwd_packed_bytes(void) { return size_t(nphm::N_SETS) * nphm::bwd::BWD_SET_STRIDE * 2; }
 
@@ -523,9 +664,32 @@ int nphm_identity_pack_bwd(const float* const lin_weight[5], void* packed_bwd, v
   return 0;
 }
 
+int nphm_identity_list_tiles(int64_t n_points) { return n_points <= 0 ? 0 : int((n_points + 63) / 64); }
+
+int nphm_identity_build_lists(const void* latent_state, const float* xyz, int n_rows, int64_t n_points, float prune_tol,
+                              float* blend_weights, int* tiles, int* n_tiles_used, int* point_list, void* stream) {
+  if (!latent_state || !xyz || !blend_weights || !tiles || !n_tiles_used || !point_list)
+    return nphm_fail_msg("nphm_identity_build_lists: null pointer");
+  if (n_rows <= 0 || n_points <= 0 || n_points > 0x7fffff00LL / (nphm::N_MEMBERS * int64_t(n_rows)) - 64)
+    return nphm_fail_msg("nphm_identity_build_lists: bad sizes");
+  nphm::bwd::ListArgs a;
+  a.state = static_cast<const float*>(latent_state);
+  a.xyz = xyz; a.n_rows = n_rows; a.n_points = n_points; a.prune_tol = prune_tol;
+  a.T = nphm_identity_list_tiles(n_points);
+  const int n_slots = n_rows * nphm::N_MEMBERS * a.T;
+  a.what = blend_weights; a.tiles = tiles + 4 * size_t(n_slots); a.list = point_list;     // slot table: second half
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(nphm::bwd::weights_kernel, dim3(unsigned((n_points + 255) / 256), n_rows), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(nphm::bwd::lists_kernel, dim3(n_rows * nphm::N_MEMBERS), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(nphm::bwd::compact_tiles_kernel, dim3(1), dim3(1024), 0, st, a.tiles, n_slots, tiles, n_tiles_used);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_build_lists launch", e);
+  return 0;
+}
+
 int nphm_identity_backward(const void* packed, const void* packed_bwd, const void* latent_state,
                            const float* xyz, const float* sdf, const float* grad_sdf, int64_t n_points,
-                           const int* tiles, int n_tiles, const int* point_list,
+                           const int* tiles, int n_tiles, const int* n_tiles_dev, const int* point_list,
                            float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2, void* stream) {
   if (!packed || !packed_bwd || !latent_state || !xyz || !sdf || !grad_sdf || !tiles || !point_list || !grad_xyz ||
       !grad_anchors || !grad_b0 || !grad_b2)
@@ -539,9 +703,10 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
   a.state = static_cast<const float*>(latent_state);
   a.xyz = xyz; a.sdf = sdf; a.gout = grad_sdf;
   a.tiles = tiles; a.list = point_list; a.n_points = n_points;
+  a.n_tiles = n_tiles; a.n_tiles_dev = n_tiles_dev;
   a.gxyz = grad_xyz; a.ganch = grad_anchors; a.gb0 = grad_b0; a.gb2 = grad_b2;
   a.fmem = nullptr;
-  hipLaunchKernelGGL(nphm::bwd::ident_member_kernel<true>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+  hipLaunchKernelGGL(nphm::bwd::ident_member_kernel<true>, dim3(member_grid(n_tiles, n_tiles_dev)), dim3(64 * nphm::bwd::WAVES), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_backward launch", e);
@@ -550,7 +715,7 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
 
 int nphm_identity_member_forward(const void* packed, const void* packed_bwd, const void* latent_state,
                                  const float* xyz, int64_t n_points, const int* tiles, int n_tiles,
-                                 const int* point_list, float* member_sdf, void* stream) {
+                                 const int* n_tiles_dev, const int* point_list, float* member_sdf, void* stream) {
   if (!packed || !latent_state || !xyz || !tiles || !point_list || !member_sdf)
     return nphm_fail_msg("nphm_identity_member_forward: null pointer");
   if (n_points <= 0 || n_tiles < 0) return nphm_fail_msg("nphm_identity_member_forward: bad sizes");
@@ -564,8 +729,9 @@ int nphm_identity_member_forward(const void* packed, const void* packed_bwd, con
   a.xyz = xyz;
   a.sdf = xyz; a.gout = xyz;                                      // read but ignored (valid memory)
   a.tiles = tiles; a.list = point_list; a.n_points = n_points;
+  a.n_tiles = n_tiles; a.n_tiles_dev = n_tiles_dev;
   a.fmem = member_sdf;
-  hipLaunchKernelGGL(nphm::bwd::ident_member_kernel<false>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+  hipLaunchKernelGGL(nphm::bwd::ident_member_kernel<false>, dim3(member_grid(n_tiles, n_tiles_dev)), dim3(64 * nphm::bwd::WAVES), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_member_forward launch", e);

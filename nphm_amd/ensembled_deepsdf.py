@@ -186,6 +186,25 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
     return what * mask, torch.from_numpy(tiles).to(xyz.device), idx[:, 2].to(torch.int32).contiguous()
 
 
+def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
+    """The same lists built on the device with fixed capacity (nphm_identity_build_lists): no host sync, static
+    shapes - what the autograd tier uses (the fitting step can be captured in a hipGraph).  Returns
+    (blend weights [B,N,A] zero where pruned, tile table int32 [B*A*T,4] with the used tiles at the front, their
+    number as a device int32 [1], point list)."""
+    lib = _lib.load()
+    B, N, _ = xyz.shape
+    T = int(lib.nphm_identity_list_tiles(N))
+    dev = xyz.device
+    what = torch.empty(B, N, n_members, dtype=torch.float32, device=dev)
+    tiles = torch.empty(2 * B * n_members * T, 4, dtype=torch.int32, device=dev)     # used tiles first | slot scratch
+    n_used = torch.empty(1, dtype=torch.int32, device=dev)
+    plist = torch.empty(B * n_members * T * 64, dtype=torch.int32, device=dev)
+    _lib.check(lib.nphm_identity_build_lists(state.data_ptr(), xyz.data_ptr(), B, N, float(prune_tol), what.data_ptr(),
+                                             tiles.data_ptr(), n_used.data_ptr(), plist.data_ptr(), stream),
+               "nphm_identity_build_lists")
+    return what, tiles[: B * n_members * T], n_used, plist
+
+
 class _IdentityFieldFn(torch.autograd.Function):
     """sdf = field(xyz; anchors, folded biases) with hand-written forward and first-order backward
     kernels (member-centric: one workgroup = one member x 64 of the points that member matters for).
@@ -199,19 +218,18 @@ class _IdentityFieldFn(torch.autograd.Function):
         B, N, _ = xyz.shape
         dev = xyz.device
         A = module.num_kps + 1
-        packed, state, anchors_hip = module.prepare_latent(lat_rows)
+        packed, state, _ = module.prepare_latent(lat_rows)
         xyz_c = xyz.detach().contiguous().float()
-        what, tiles, plist = _member_point_lists(anchors_hip, xyz_c, module.prune_tol, A)
-        fmem = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        if tiles.shape[0]:
-            _lib.check(lib.nphm_identity_member_forward(
-                packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N,
-                tiles.data_ptr(), tiles.shape[0], plist.data_ptr(), fmem.data_ptr(), stream),
-                "nphm_identity_member_forward")
+        what, tiles, n_used, plist = _member_point_lists_device(state, xyz_c, module.prune_tol, A, stream)
+        fmem = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
+        _lib.check(lib.nphm_identity_member_forward(
+            packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N,
+            tiles.data_ptr(), tiles.shape[0], n_used.data_ptr(), plist.data_ptr(), fmem.data_ptr(), stream),
+            "nphm_identity_member_forward")
         out = (what * fmem).sum(dim=2, keepdim=True)
         ctx.module = module
-        ctx.save_for_backward(xyz_c, out, packed, state, tiles, plist)
+        ctx.save_for_backward(xyz_c, out, packed, state, tiles, n_used, plist)
         return out
 
     @staticmethod
@@ -222,7 +240,7 @@ class _IdentityFieldFn(torch.autograd.Function):
         # on the composite tier (module.backend = "composite", or parameters that require grad)
         lib = _lib.load()
         module = ctx.module
-        xyz, out, packed, state, tiles, plist = ctx.saved_tensors
+        xyz, out, packed, state, tiles, n_used, plist = ctx.saved_tensors
         B, N, _ = xyz.shape
         dev = xyz.device
         A = module.num_kps + 1
@@ -235,7 +253,7 @@ class _IdentityFieldFn(torch.autograd.Function):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.nphm_identity_backward(
                 packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz.data_ptr(),
-                out.data_ptr(), g.data_ptr(), N, tiles.data_ptr(), tiles.shape[0], plist.data_ptr(), gx.data_ptr(),
+                out.data_ptr(), g.data_ptr(), N, tiles.data_ptr(), tiles.shape[0], n_used.data_ptr(), plist.data_ptr(), gx.data_ptr(),
                 ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_backward")
         return None, gx, None, ga, gb0, gb2
 

@@ -62,28 +62,61 @@ def _apply_schedule(j, step_scale, schedule_cfg, lambdas, optimizers, with_expr)
         lambdas["reg_expr"] /= schedule_cfg["reg_expr"][key]
 
 
-def _sample_observations(all_obs, n_batch, n_points):
-    """n_batch observations with replacement, <= n_points points each with replacement
-    (fitting.py:61-70); two torch.randint streams in the reference's order."""
-    obs_idx = torch.randint(0, len(all_obs), [n_batch])
-    picked = []
-    for i in range(n_batch):
-        cloud = all_obs[obs_idx[i]]
-        n = min(n_points, cloud.shape[0])
-        sub = torch.randint(0, cloud.shape[0], [n])
-        picked.append(cloud.clone()[sub, :])
-    return obs_idx, torch.stack(picked, dim=0)
+class _ObservationSampler:
+    """n_batch observations with replacement, <= n_points points each with replacement (fitting.py:61-70):
+    the same torch.randint calls in the same order as the reference (host RNG), but the picked indices travel
+    to the device in ONE pinned upload and the points are gathered from one padded [n_obs, P, 3] tensor in one
+    indexing kernel (the reference indexes every cloud with a host index tensor: one blocking copy each)."""
+
+    def __init__(self, all_obs, n_batch, n_points):
+        self.sizes = [int(c.shape[0]) for c in all_obs]
+        self.n_batch, self.n_points = n_batch, n_points
+        self.device = all_obs[0].device
+        pmax = max(self.sizes)
+        self.clouds = torch.zeros(len(all_obs), pmax, all_obs[0].shape[1], dtype=all_obs[0].dtype, device=self.device)
+        for i, c in enumerate(all_obs):
+            self.clouds[i, : c.shape[0]] = c
+        self.on_gpu = self.device.type == "cuda"
+
+    def draw(self):
+        """host side: (obs_idx [n_batch], point indices [n_batch, n]) as one int64 tensor [n_batch, 1 + n]"""
+        obs_idx = torch.randint(0, len(self.sizes), [self.n_batch])
+        rows = []
+        for i in range(self.n_batch):
+            size = self.sizes[int(obs_idx[i])]
+            rows.append(torch.randint(0, size, [min(self.n_points, size)]))
+        if len({r.shape[0] for r in rows}) != 1:
+            raise RuntimeError("stack expects each tensor to be equal size (observations of different sizes below "
+                               "n_points, as in the reference)")
+        return torch.cat([obs_idx[:, None], torch.stack(rows, 0)], dim=1)
+
+    def upload(self, drawn, out=None):
+        if self.on_gpu:
+            drawn = drawn.pin_memory()
+        if out is None:
+            return drawn.to(self.device, non_blocking=True)
+        out.copy_(drawn, non_blocking=True)
+        return out
+
+    def gather(self, drawn_dev):
+        """device side: (obs_idx [n_batch] long, points [n_batch, n, 3])"""
+        obs_idx = drawn_dev[:, 0]
+        return obs_idx, self.clouds[obs_idx[:, None], drawn_dev[:, 1:]]
 
 
-def _clamped_surface_loss(sdf, j, step_scale):
-    """mean |sdf| over the points below a shrinking threshold (fitting.py:119-132)."""
+def _clamped_surface_loss(sdf, j, step_scale, valid=None):
+    """mean |sdf| over the (valid) points below a shrinking threshold (fitting.py:115-132).  The reference
+    compacts the tensor with boolean masks (a device->host sync per mask); here the same mean is a masked
+    sum / count: static shapes, no sync."""
     l = sdf.abs()
-    l = l[l < 0.1]
+    keep = l < 0.1
+    if valid is not None:
+        keep = keep & valid.reshape(valid.shape + (1,) * (l.dim() - valid.dim()))
     if j > int(250 * step_scale):
-        l = l[l < 0.05]
+        keep = keep & (l < 0.05)
     if j > int(500 * step_scale):
-        l = l[l < 0.0075]
-    return l.mean()
+        keep = keep & (l < 0.0075)
+    return (l * keep).sum() / keep.sum()
 
 
 def _shape_regularisers(decoder, lat_rep_shape, loss_dict):
@@ -112,6 +145,41 @@ def _report(j, lambdas, loss_dict, extra=None):
     print(line) if extra is None else print(line, extra)
 
 
+def _inverse3x3(J):
+    """Batched inverse without the singularity check of ``Tensor.inverse()`` (= linalg.inv: the same LU
+    factorisation followed by a blocking read of the error flag)."""
+    return torch.linalg.inv_ex(J)[0]
+
+
+class _History:
+    """Per-step loss terms kept on the device and fetched ONCE after the loop (a ``float()`` per term and step
+    is a device->host synchronisation each)."""
+
+    def __init__(self, history, keys, n_iter, device, extra=()):
+        self.history, self.keys, self.extra = history, list(keys), list(extra)
+        self.buf = None if history is None else torch.zeros(max(n_iter, 1), len(self.keys) + 1 + len(self.extra),
+                                                            dtype=torch.float32, device=device)
+
+    def record(self, j, loss_dict, loss, **extra):
+        if self.buf is None:
+            return
+        vals = [torch.as_tensor(loss_dict[k], dtype=torch.float32, device=self.buf.device).detach().reshape(())
+                for k in self.keys]
+        vals.append(loss.detach().reshape(()).float())
+        vals += [torch.as_tensor(extra[k], device=self.buf.device).detach().reshape(()).float() for k in self.extra]
+        self.buf[j] = torch.stack(vals)
+
+    def flush(self, n_done):
+        if self.buf is None:
+            return
+        rows = self.buf[:n_done].cpu().numpy()
+        for r in rows:
+            d = {k: float(v) for k, v in zip(self.keys + ["loss"], r)}
+            for k, v in zip(self.extra, r[len(self.keys) + 1:]):
+                d[k] = int(round(float(v)))
+            self.history.append(d)
+
+
 def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[torch.Tensor], lambdas, n_steps,
                                            schedule_cfg: Dict, step_scale=1, lr_scale=1, *, verbose: bool = True,
                                            history: Optional[list] = None, compute_unused_sdf_grad: bool = False):
@@ -120,7 +188,13 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
 
     The reference also evaluates ``nabla(decoder, p_corresp, ...)`` every step (:112) and never uses
     the result; it has no side effect on the fit (no RNG, no parameter, no in-place update), so it is
-    skipped unless ``compute_unused_sdf_grad`` — the fitted latents are identical either way."""
+    skipped unless ``compute_unused_sdf_grad`` — the fitted latents are identical either way.
+
+    Same arithmetic as the reference, arranged without host synchronisation inside a step: conditioning is passed
+    as one row per batch entry ([B,1,L] / anchors [B,39,3]: the fields broadcast it; the reference ``repeat``s it per
+    point), the sampled points are gathered on the device, the surface loss over the converged correspondences is
+    a masked mean, the loss trace stays on the device until the loop ends (``verbose`` printing reads it every
+    step, like the reference)."""
     device = all_obs[0].device
     n_obs = len(all_obs)
     n_batch, n_points = 5, 1000
@@ -133,9 +207,13 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     opt_expr = optim.Adam(params=[lat_rep], lr=0.01 * lr_scale)
     local = hasattr(decoder, "lat_dim_loc")
     anchors = None
+    sampler = _ObservationSampler(all_obs, n_batch, n_points)
+    n_iter = int(n_steps * step_scale)
+    hist = _History(history, lambdas.keys(), n_iter, device, extra=("n_valid",))
+    done = 0
 
     with _frozen(decoder, decoder_expr):
-        for j in range(int(n_steps * step_scale)):
+        for j in range(n_iter):
             _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt, opt_expr), True)
             opt.zero_grad()
             opt_expr.zero_grad()
@@ -143,35 +221,30 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
             anchors = _anchors_of(decoder, lat_rep_shape, device)
 
-            obs_idx, obs = _sample_observations(all_obs, n_batch, n_points)
-            obs_idx = obs_idx.long().to(device)
-            glob_cond = torch.cat([lat_rep_shape.repeat(n_batch, 1, 1), lat_rep[obs_idx, :, :]], dim=-1)
+            obs_idx, obs = sampler.gather(sampler.upload(sampler.draw()))
+            glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), lat_rep[obs_idx, :, :]], dim=-1)   # [B,1,L]
+            anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
 
             # canonical correspondences by Broyden root finding (no gradient flows through it)
-            anchors_rep = anchors.clone().unsqueeze(1).repeat(n_batch, obs.shape[1], 1, 1) if local else None
-            p_corresp, search_result = search(obs, glob_cond.repeat(1, obs.shape[1], 1), decoder_expr, anchors_rep,
-                                              multi_corresp=False)
+            p_corresp, search_result = search(obs, glob_cond, decoder_expr,
+                                              None if anchors_b is None else anchors_b.detach(), multi_corresp=False)
             p_corresp = p_corresp.detach()
-            _anchors = None
-            if anchors is not None:
-                _anchors = anchors.clone().unsqueeze(1).repeat(n_batch, p_corresp.shape[1], 1, 1)
+            valid = search_result["valid_ids"]
 
             # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
-            cond_rep = glob_cond.repeat(1, p_corresp.shape[1], 1)
-            preds_posed, _ = decoder_expr(p_corresp, cond_rep, _anchors)
+            preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
             preds_posed = preds_posed + p_corresp
-            grad_inv = jac(decoder_expr, p_corresp, cond_rep, _anchors).inverse()
+            grad_inv = _inverse3x3(jac(decoder_expr, p_corresp, glob_cond, anchors_b))
             correction = preds_posed - preds_posed.detach()
             correction = torch.einsum("bnij,bnj->bni", -grad_inv.detach(), correction)
             xc = p_corresp + correction
 
-            shape_cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
+            shape_cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
             sdf, _ = decoder(xc, shape_cond, None)
             if compute_unused_sdf_grad:
                 _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
 
-            sdf = sdf[search_result["valid_ids"], :]
-            loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale),
+            loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale, valid),
                          "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
             _shape_regularisers(decoder, lat_rep_shape, loss_dict)
 
@@ -181,11 +254,11 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             loss.backward()
             opt.step()
             opt_expr.step()
-            if history is not None:
-                history.append({k: float(torch.as_tensor(loss_dict[k]).detach()) for k in lambdas.keys()} |
-                               {"loss": float(loss.detach()), "n_valid": int(search_result["valid_ids"].sum())})
+            hist.record(j, loss_dict, loss, n_valid=valid.sum())
+            done = j + 1
             if verbose:
-                _report(j, lambdas, loss_dict, search_result["valid_ids"].sum().item())
+                _report(j, lambdas, loss_dict, valid.sum().item())
+    hist.flush(done)
 
     return lat_rep, lat_rep_shape, anchors
 
@@ -201,14 +274,18 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
     opt = optim.Adam(params=[lat_rep_shape], lr=0.01 * lr_scale)
     local = hasattr(decoder, "lat_dim_loc")
     anchors = None
+    sampler = _ObservationSampler(all_obs, n_batch, n_points)
+    n_iter = int(n_steps * step_scale)
+    hist = _History(history, lambdas.keys(), n_iter, device)
+    done = 0
 
     with _frozen(decoder):
-        for j in range(int(n_steps * step_scale)):
+        for j in range(n_iter):
             _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt,), False)
             opt.zero_grad()
             anchors = _anchors_of(decoder, lat_rep_shape, device)
-            _, obs = _sample_observations(all_obs, n_batch, n_points)
-            cond = lat_rep_shape.repeat(n_batch, 1, 1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
+            _, obs = sampler.gather(sampler.upload(sampler.draw()))
+            cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
             sdf, _ = decoder(obs, cond, None)
             loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale)}
             _shape_regularisers(decoder, lat_rep_shape, loss_dict)
@@ -217,10 +294,10 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
                 loss = loss + loss_dict[k] * lambdas[k]
             loss.backward()
             opt.step()
-            if history is not None:
-                history.append({k: float(torch.as_tensor(loss_dict[k]).detach()) for k in lambdas.keys()} |
-                               {"loss": float(loss.detach())})
+            hist.record(j, loss_dict, loss)
+            done = j + 1
             if verbose:
                 _report(j, lambdas, loss_dict)
+    hist.flush(done)
 
     return lat_rep_shape, anchors

@@ -77,25 +77,32 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
         obs = obs.repeat_interleave(n_init, dim=1)
         cond = cond[:, 0, :].unsqueeze(1).repeat(1, xc_init.shape[1], 1)
         if anchors is not None:
-            anchors = anchors[:, 0, :, :].unsqueeze(1).repeat(1, xc_init.shape[1], 1, 1)
+            a0 = anchors[:, 0, :, :] if anchors.dim() == 4 else anchors
+            anchors = a0.unsqueeze(1).repeat(1, xc_init.shape[1], 1, 1)
     else:
         xc_init = obs.detach().clone()
 
-    J_inv_init = jac(decoder_expr, xc_init, cond, anchors).inverse().flatten(0, 1)
+    # the reference's `.inverse()` = linalg.inv = inv_ex + a blocking read of the error flag: same factorisation
+    J_inv_init = torch.linalg.inv_ex(jac(decoder_expr, xc_init, cond, anchors))[0].flatten(0, 1)
     x0 = xc_init.reshape(-1, 3, 1)
+    # conditioning may come as one row per batch entry (cond [B,1,L], anchors [B,K,3]: what the mirrored fitting
+    # loop passes); the python solver below wants the reference's per-point tensors
+    n_pts = xc_init.shape[1]
+    cond_full = cond if cond.shape[1] == n_pts else cond.expand(-1, n_pts, -1)
+    anchors_full = anchors if anchors is None or anchors.dim() == 4 else anchors.unsqueeze(1).expand(-1, n_pts, -1, -1)
 
     def residual(xc_flat, mask=None):
         # the field is evaluated for ALL points, the mask is applied afterwards (reference :131-149)
         if multi_corresp:
             xc = xc_flat.reshape(B, -1, 3)
-            xd = decoder_expr(xc, cond, anchors)[0] + xc
+            xd = decoder_expr(xc, cond_full, anchors_full)[0] + xc
         else:
             xc = xc_flat.reshape(1, xc_flat.shape[0], 3)
             if cond.shape[0] != 1:
-                xd = decoder_expr(xc, cond.reshape(1, -1, cond.shape[2]),
-                                  None if anchors is None else anchors.reshape(1, -1, anchors.shape[2], 3))[0]
+                xd = decoder_expr(xc, cond_full.reshape(1, -1, cond.shape[2]),
+                                  None if anchors is None else anchors_full.reshape(1, -1, anchors_full.shape[2], 3))[0]
             else:
-                xd = decoder_expr(xc, cond, anchors)[0]
+                xd = decoder_expr(xc, cond_full, anchors_full)[0]
             xd = xd + xc
         err = xd - (obs.reshape(1, -1, 3) if obs.shape[0] != 1 else obs)
         return err.flatten(0, 1)[mask].unsqueeze(-1)
@@ -103,13 +110,14 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
     result = None
     if hasattr(decoder_expr, "broyden"):
         # fused solver: same per-point state machine, one launch, no host syncs (None: not applicable)
-        if multi_corresp or cond.shape[0] == 1:
+        if multi_corresp or cond.shape[0] == 1 or cond.shape[1] == 1:
+            # batch rows stay batch rows (one conditioning row each): no flattening, nothing to re-discover
             result = decoder_expr.broyden(obs, xc_init, J_inv_init, cond, anchors, max_steps=15, cvg_thresh=1e-6,
                                           dvg_thresh=0.2)
         else:      # the reference flattens the batch into one row of points (:137-139)
             result = decoder_expr.broyden(obs.reshape(1, -1, 3), xc_init.reshape(1, -1, 3), J_inv_init,
-                                          cond.reshape(1, -1, cond.shape[2]),
-                                          None if anchors is None else anchors.reshape(1, -1, anchors.shape[2], 3),
+                                          cond_full.reshape(1, -1, cond.shape[2]),
+                                          None if anchors is None else anchors_full.reshape(1, -1, anchors_full.shape[2], 3),
                                           max_steps=15, cvg_thresh=1e-6, dvg_thresh=0.2)
     if result is None:
         with torch.no_grad():

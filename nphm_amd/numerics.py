@@ -86,7 +86,7 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
                 fmem = torch.zeros(1, N, A, dtype=torch.float32, device=dev)
                 _lib.check(lib.nphm_identity_member_forward(packed.data_ptr(), decoder._packed_bwd(dev).data_ptr(),
                                                             state.data_ptr(), pts.data_ptr(), N, tiles.data_ptr(),
-                                                            tiles.shape[0], plist.data_ptr(), fmem.data_ptr(), stream),
+                                                            tiles.shape[0], None, plist.data_ptr(), fmem.data_ptr(), stream),
                            "nphm_identity_member_forward")
                 contrib = what_all * fmem.abs()                                   # w_k |f_k|, [1,N,A]
                 if decoder.prune_tol >= 0:
