@@ -233,6 +233,12 @@ int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                      int max_steps, float cvg_thresh, float dvg_thresh, float eps,
                      float* x_out, float* diff_out, unsigned char* valid_out, void* stream);
 
+/* Batched inverse of n row-major 3x3 matrices (adjugate formula, one thread each): the `.inverse()` calls on
+ * the deformation Jacobians in the correspondence search and the implicit differentiation of the fitting loop
+ * (src/NPHM/models/iterative_root_finding.py:118, src/NPHM/models/fitting.py:102) without the blocking
+ * error-flag read of torch.linalg.inv. */
+int nphm_inverse3x3(const float* matrices, float* inverses, int64_t n, void* stream);
+
 /* The same on the x-slab [ix0, ix1) of an [rx,ry,rz] 'ij' lattice (utils/reconstruction.py:5-20):
  * out [(ix1-ix0)*ry*rz, out_dim] in flattened lattice order. */
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,

@@ -62,6 +62,7 @@ SYMBOLS = {
                                                         c_void_p, c_void_p]),
     "nphm_mlp_broyden": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                                 c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_inverse3x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nphm_mlp_eval_grid": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nphm_mc_extract": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_int, c_int,

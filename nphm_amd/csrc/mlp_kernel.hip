@@ -565,6 +565,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   }
 }
 
+// batched 3x3 inverse by the adjugate formula (the inverse Jacobians of the correspondence search and of the
+// implicit differentiation, iterative_root_finding.py:118 / fitting.py:102 `.inverse()`): one thread per matrix
+__global__ __launch_bounds__(256) void inverse3x3_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) a[c] = in[i * 9 + c];
+  const float c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+  const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+  const float r = 1.f / det;
+  float* o = out + i * 9;
+  o[0] = c00 * r; o[1] = (a[2] * a[7] - a[1] * a[8]) * r; o[2] = (a[1] * a[5] - a[2] * a[4]) * r;
+  o[3] = c01 * r; o[4] = (a[0] * a[8] - a[2] * a[6]) * r; o[5] = (a[2] * a[3] - a[0] * a[5]) * r;
+  o[6] = c02 * r; o[7] = (a[1] * a[6] - a[0] * a[7]) * r; o[8] = (a[0] * a[4] - a[1] * a[3]) * r;
+}
+
 template <int MT, int NTW>
 constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) * 16 * 2 + (WAVES + 1) * 32 * MT * 4 * 4; }
 
@@ -744,6 +761,16 @@ int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   a.max_steps = max_steps;
   a.cvg = cvg_thresh; a.dvg = dvg_thresh; a.eps = eps;
   return launch_eval<0, 2>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+}
+
+int nphm_inverse3x3(const float* matrices, float* inverses, int64_t n, void* stream) {
+  if (!matrices || !inverses) return nphm_fail_msg("nphm_inverse3x3: null pointer");
+  if (n <= 0) return n == 0 ? 0 : nphm_fail_msg("nphm_inverse3x3: negative count");
+  hipLaunchKernelGGL(nphm::mlp::inverse3x3_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), matrices, inverses, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_inverse3x3 launch", e);
+  return 0;
 }
 
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,

@@ -35,3 +35,18 @@ def gradient(outputs, inputs):
     g = torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=ones, create_graph=True,
                             retain_graph=True, only_inputs=True, allow_unused=True)[0]
     return g[:, :, -3:]
+
+
+def inverse3x3(J):
+    """Batched 3x3 inverse.  The reference's ``Tensor.inverse()`` (= linalg.inv) is an LU factorisation followed
+    by a blocking read of its error flag; on a ROCm device the adjugate formula runs in one small kernel
+    (``nphm_inverse3x3``: no host sync, no library workspace - capturable in a hipGraph), elsewhere inv_ex."""
+    if J.is_cuda and J.dtype == torch.float32:
+        from . import _lib
+        lib = _lib.load()
+        Jc = J.detach().contiguous()
+        out = torch.empty_like(Jc)
+        _lib.check(lib.nphm_inverse3x3(Jc.data_ptr(), out.data_ptr(), Jc.numel() // 9,
+                                       torch.cuda.current_stream(J.device).cuda_stream), "nphm_inverse3x3")
+        return out
+    return torch.linalg.inv_ex(J)[0]

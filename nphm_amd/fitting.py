@@ -16,6 +16,7 @@ from typing import Dict, List, Optional
 import torch
 from torch import optim
 
+from .diff_operators import inverse3x3 as _inverse3x3
 from .iterative_root_finding import jac, nabla, search
 
 _UNOBSERVED = (30, 31, 39)          # local codes that the single-view scans never see (fitting.py:148)
@@ -90,6 +91,10 @@ class _ObservationSampler:
                                "n_points, as in the reference)")
         return torch.cat([obs_idx[:, None], torch.stack(rows, 0)], dim=1)
 
+    def draw_like(self):
+        """an index tensor of the shape ``draw`` returns, WITHOUT touching the RNG (allocation of the static input)"""
+        return torch.zeros(self.n_batch, 1 + min(self.n_points, min(self.sizes)), dtype=torch.int64)
+
     def upload(self, drawn, out=None):
         if self.on_gpu:
             drawn = drawn.pin_memory()
@@ -145,12 +150,6 @@ def _report(j, lambdas, loss_dict, extra=None):
     print(line) if extra is None else print(line, extra)
 
 
-def _inverse3x3(J):
-    """Batched inverse without the singularity check of ``Tensor.inverse()`` (= linalg.inv: the same LU
-    factorisation followed by a blocking read of the error flag)."""
-    return torch.linalg.inv_ex(J)[0]
-
-
 class _History:
     """Per-step loss terms kept on the device and fetched ONCE after the loop (a ``float()`` per term and step
     is a device->host synchronisation each)."""
@@ -160,14 +159,17 @@ class _History:
         self.buf = None if history is None else torch.zeros(max(n_iter, 1), len(self.keys) + 1 + len(self.extra),
                                                             dtype=torch.float32, device=device)
 
-    def record(self, j, loss_dict, loss, **extra):
-        if self.buf is None:
-            return
-        vals = [torch.as_tensor(loss_dict[k], dtype=torch.float32, device=self.buf.device).detach().reshape(())
-                for k in self.keys]
+    def row(self, loss_dict, loss, **extra):
+        """the step's record as ONE tensor (built inside the step so that it can live in a captured graph)"""
+        dev = loss.device
+        vals = [torch.as_tensor(loss_dict[k], dtype=torch.float32, device=dev).detach().reshape(()) for k in self.keys]
         vals.append(loss.detach().reshape(()).float())
-        vals += [torch.as_tensor(extra[k], device=self.buf.device).detach().reshape(()).float() for k in self.extra]
-        self.buf[j] = torch.stack(vals)
+        vals += [torch.as_tensor(extra[k], device=dev).detach().reshape(()).float() for k in self.extra]
+        return torch.stack(vals)
+
+    def record(self, j, row):
+        if self.buf is not None:
+            self.buf[j].copy_(row)
 
     def flush(self, n_done):
         if self.buf is None:
@@ -180,9 +182,96 @@ class _History:
             self.history.append(d)
 
 
+class _StepControls:
+    """Everything the schedule changes between steps, as device scalars the step READS (so that one captured
+    graph serves all steps): the loss weights in ``lambdas`` order and the clamp of the surface loss
+    (fitting.py:119-132: |sdf| < 0.1, then < 0.05 after step 250, < 0.0075 after step 500 - nested masks = the
+    smallest threshold).  ``refresh`` uploads only when a value changed."""
+
+    def __init__(self, lambdas, device):
+        self.keys = list(lambdas.keys())
+        self.lam = torch.zeros(len(self.keys), dtype=torch.float32, device=device)
+        self.thr = torch.zeros((), dtype=torch.float32, device=device)
+        self._lam_host, self._thr_host = None, None
+
+    def refresh(self, lambdas, j, step_scale):
+        lam = [float(lambdas[k]) for k in self.keys]
+        thr = 0.0075 if j > int(500 * step_scale) else (0.05 if j > int(250 * step_scale) else 0.1)
+        if lam != self._lam_host:
+            self.lam.copy_(torch.tensor(lam, dtype=torch.float32))
+            self._lam_host = lam
+        if thr != self._thr_host:
+            self.thr.fill_(thr)
+            self._thr_host = thr
+
+    def total(self, loss_dict):
+        loss = 0
+        for i, k in enumerate(self.keys):
+            loss = loss + loss_dict[k] * self.lam[i]
+        return loss
+
+
+def _masked_surface_loss(sdf, thr, valid=None):
+    """``_clamped_surface_loss`` with the clamp as a device scalar"""
+    l = sdf.abs()
+    keep = l < thr
+    if valid is not None:
+        keep = keep & valid.reshape(valid.shape + (1,) * (l.dim() - valid.dim()))
+    return (l * keep).sum() / keep.sum()
+
+
+class _GraphedStep:
+    """Runs ``body()`` eagerly for the first ``warm`` calls (real steps: they consume the RNG and move the
+    latents like any other), then records it ONCE into a hipGraph (torch.cuda.CUDAGraph: forward, backward and
+    every fused kernel launched on the capture stream) and replays the graph for each later step.  ``body`` reads
+    its inputs from static tensors and returns static tensors; the optimizer steps stay outside.  Any failure to
+    capture falls back to eager execution for the rest of the loop."""
+
+    def __init__(self, body, enabled, params, warm=3):
+        self.body, self.enabled, self.params, self.warm = body, bool(enabled), list(params), warm
+        self.calls, self.graph, self.out = 0, None, None
+
+    def zero_grad(self):
+        if self.graph is None:                       # once captured, backward REWRITES the static .grad buffers
+            for p in self.params:
+                p.grad = None
+
+    def __call__(self):
+        if not self.enabled or (self.graph is None and self.calls < self.warm):
+            self.calls += 1
+            return self.body()
+        if self.graph is None:
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.out = self.body()
+                self.graph = graph
+            except Exception as e:                   # noqa: BLE001 - any capture problem: stay eager
+                import warnings
+                warnings.warn(f"nphm_amd.fitting: hipGraph capture of the fitting step failed ({e!r}); running eagerly")
+                torch.cuda.synchronize()
+                self.enabled = False
+                for p in self.params:
+                    p.grad = None
+                return self.body()
+        self.graph.replay()
+        return self.out
+
+
+def _graph_default(device, verbose, *decoders):
+    """hipGraph replay of the step: on by default for HIP-backed decoders on a ROCm device when nothing has to be
+    printed per step (NPHM_AMD_FIT_GRAPH=0 turns it off)."""
+    import os
+    if os.environ.get("NPHM_AMD_FIT_GRAPH", "1") in ("0", "") or verbose or device.type != "cuda":
+        return False
+    return all(getattr(d, "backend", "hip") == "hip" for d in decoders if d is not None)
+
+
 def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[torch.Tensor], lambdas, n_steps,
                                            schedule_cfg: Dict, step_scale=1, lr_scale=1, *, verbose: bool = True,
-                                           history: Optional[list] = None, compute_unused_sdf_grad: bool = False):
+                                           history: Optional[list] = None, compute_unused_sdf_grad: bool = False,
+                                           use_graph: Optional[bool] = None):
     """Joint fit of one identity code and one expression code per observation (fitting.py:14-177).
     Returns (lat_rep [n_obs,1,lat_dim_expr], lat_rep_shape [1,1,lat_dim], anchors).
 
@@ -193,8 +282,9 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     Same arithmetic as the reference, arranged without host synchronisation inside a step: conditioning is passed
     as one row per batch entry ([B,1,L] / anchors [B,39,3]: the fields broadcast it; the reference ``repeat``s it per
     point), the sampled points are gathered on the device, the surface loss over the converged correspondences is
-    a masked mean, the loss trace stays on the device until the loop ends (``verbose`` printing reads it every
-    step, like the reference)."""
+    a masked mean, loss weights / the loss clamp are device scalars, the loss trace stays on the device until the
+    loop ends (``verbose`` printing reads it every step, like the reference).  On a ROCm device the whole step
+    (forward, backward, every fused kernel) is then recorded once into a hipGraph and replayed (``use_graph``)."""
     device = all_obs[0].device
     n_obs = len(all_obs)
     n_batch, n_points = 5, 1000
@@ -206,65 +296,74 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     opt = optim.Adam(params=[lat_rep_shape], lr=0.01 * lr_scale)
     opt_expr = optim.Adam(params=[lat_rep], lr=0.01 * lr_scale)
     local = hasattr(decoder, "lat_dim_loc")
-    anchors = None
     sampler = _ObservationSampler(all_obs, n_batch, n_points)
     n_iter = int(n_steps * step_scale)
     hist = _History(history, lambdas.keys(), n_iter, device, extra=("n_valid",))
-    done = 0
+    ctl = _StepControls(lambdas, device)
+    drawn_dev = sampler.upload(sampler.draw_like())          # static input of the step: the sampled indices
+    if use_graph is None:
+        use_graph = _graph_default(device, verbose, decoder, decoder_expr) and not compute_unused_sdf_grad
 
+    def body():
+        # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
+        anchors = _anchors_of(decoder, lat_rep_shape, device)
+        obs_idx, obs = sampler.gather(drawn_dev)
+        glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), lat_rep[obs_idx, :, :]], dim=-1)   # [B,1,L]
+        anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
+
+        # canonical correspondences by Broyden root finding (no gradient flows through it)
+        p_corresp, search_result = search(obs, glob_cond, decoder_expr,
+                                          None if anchors_b is None else anchors_b.detach(), multi_corresp=False)
+        p_corresp = p_corresp.detach()
+        valid = search_result["valid_ids"]
+
+        # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
+        preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
+        preds_posed = preds_posed + p_corresp
+        grad_inv = _inverse3x3(jac(decoder_expr, p_corresp, glob_cond, anchors_b))
+        correction = preds_posed - preds_posed.detach()
+        correction = torch.einsum("bnij,bnj->bni", -grad_inv.detach(), correction)
+        xc = p_corresp + correction
+
+        shape_cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
+        sdf, _ = decoder(xc, shape_cond, None)
+        if compute_unused_sdf_grad:
+            _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
+
+        loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr, valid),
+                     "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
+        _shape_regularisers(decoder, lat_rep_shape, loss_dict)
+        loss = ctl.total(loss_dict)
+        loss.backward()
+        return hist.row(loss_dict, loss, n_valid=valid.sum()), anchors.detach()
+
+    step = _GraphedStep(body, use_graph, [lat_rep_shape, lat_rep])
+    anchors = None
+    done = 0
     with _frozen(decoder, decoder_expr):
         for j in range(n_iter):
             _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt, opt_expr), True)
-            opt.zero_grad()
-            opt_expr.zero_grad()
-
-            # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
-            anchors = _anchors_of(decoder, lat_rep_shape, device)
-
-            obs_idx, obs = sampler.gather(sampler.upload(sampler.draw()))
-            glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), lat_rep[obs_idx, :, :]], dim=-1)   # [B,1,L]
-            anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
-
-            # canonical correspondences by Broyden root finding (no gradient flows through it)
-            p_corresp, search_result = search(obs, glob_cond, decoder_expr,
-                                              None if anchors_b is None else anchors_b.detach(), multi_corresp=False)
-            p_corresp = p_corresp.detach()
-            valid = search_result["valid_ids"]
-
-            # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
-            preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
-            preds_posed = preds_posed + p_corresp
-            grad_inv = _inverse3x3(jac(decoder_expr, p_corresp, glob_cond, anchors_b))
-            correction = preds_posed - preds_posed.detach()
-            correction = torch.einsum("bnij,bnj->bni", -grad_inv.detach(), correction)
-            xc = p_corresp + correction
-
-            shape_cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
-            sdf, _ = decoder(xc, shape_cond, None)
-            if compute_unused_sdf_grad:
-                _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
-
-            loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale, valid),
-                         "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
-            _shape_regularisers(decoder, lat_rep_shape, loss_dict)
-
-            loss = 0
-            for k in lambdas.keys():
-                loss = loss + loss_dict[k] * lambdas[k]
-            loss.backward()
+            ctl.refresh(lambdas, j, step_scale)
+            step.zero_grad()
+            sampler.upload(sampler.draw(), out=drawn_dev)
+            row, anchors = step()
             opt.step()
             opt_expr.step()
-            hist.record(j, loss_dict, loss, n_valid=valid.sum())
+            hist.record(j, row)
             done = j + 1
             if verbose:
-                _report(j, lambdas, loss_dict, valid.sum().item())
+                r = row.cpu().numpy()
+                _report(j, lambdas, dict(zip(ctl.keys, r)), int(round(float(r[-1]))))
     hist.flush(done)
+    if anchors is not None:
+        anchors = anchors.clone()                              # out of the graph's memory pool
 
     return lat_rep, lat_rep_shape, anchors
 
 
 def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_steps, schedule_cfg: Dict,
-                             step_scale=1, lr_scale=1, *, verbose: bool = False, history: Optional[list] = None):
+                             step_scale=1, lr_scale=1, *, verbose: bool = False, history: Optional[list] = None,
+                             use_graph: Optional[bool] = None):
     """Identity-only fit on neutral observations (fitting.py:180-288): no deformation field, the
     observed points are canonical points.  Returns (lat_rep_shape, anchors)."""
     device = all_obs[0].device
@@ -273,31 +372,42 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
     lat_rep_shape.requires_grad = True
     opt = optim.Adam(params=[lat_rep_shape], lr=0.01 * lr_scale)
     local = hasattr(decoder, "lat_dim_loc")
-    anchors = None
     sampler = _ObservationSampler(all_obs, n_batch, n_points)
     n_iter = int(n_steps * step_scale)
     hist = _History(history, lambdas.keys(), n_iter, device)
-    done = 0
+    ctl = _StepControls(lambdas, device)
+    drawn_dev = sampler.upload(sampler.draw_like())
+    if use_graph is None:
+        use_graph = _graph_default(device, verbose, decoder)
 
+    def body():
+        anchors = _anchors_of(decoder, lat_rep_shape, device)
+        _, obs = sampler.gather(drawn_dev)
+        cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
+        sdf, _ = decoder(obs, cond, None)
+        loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr)}
+        _shape_regularisers(decoder, lat_rep_shape, loss_dict)
+        loss = ctl.total(loss_dict)
+        loss.backward()
+        return hist.row(loss_dict, loss), anchors.detach()
+
+    step = _GraphedStep(body, use_graph, [lat_rep_shape])
+    anchors = None
+    done = 0
     with _frozen(decoder):
         for j in range(n_iter):
             _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt,), False)
-            opt.zero_grad()
-            anchors = _anchors_of(decoder, lat_rep_shape, device)
-            _, obs = sampler.gather(sampler.upload(sampler.draw()))
-            cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
-            sdf, _ = decoder(obs, cond, None)
-            loss_dict = {"surface": _clamped_surface_loss(sdf, j, step_scale)}
-            _shape_regularisers(decoder, lat_rep_shape, loss_dict)
-            loss = 0
-            for k in lambdas.keys():
-                loss = loss + loss_dict[k] * lambdas[k]
-            loss.backward()
+            ctl.refresh(lambdas, j, step_scale)
+            step.zero_grad()
+            sampler.upload(sampler.draw(), out=drawn_dev)
+            row, anchors = step()
             opt.step()
-            hist.record(j, loss_dict, loss)
+            hist.record(j, row)
             done = j + 1
             if verbose:
-                _report(j, lambdas, loss_dict)
+                _report(j, lambdas, dict(zip(ctl.keys, row.cpu().numpy())))
     hist.flush(done)
+    if anchors is not None:
+        anchors = anchors.clone()
 
     return lat_rep_shape, anchors

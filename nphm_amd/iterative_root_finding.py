@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import torch
 
-from .diff_operators import gradient, jac
+from .diff_operators import gradient, inverse3x3, jac
 
 
 def broyden(g, x_init, J_inv_init, max_steps=50, cvg_thresh=1e-5, dvg_thresh=1, eps=1e-6):
@@ -82,8 +82,7 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
     else:
         xc_init = obs.detach().clone()
 
-    # the reference's `.inverse()` = linalg.inv = inv_ex + a blocking read of the error flag: same factorisation
-    J_inv_init = torch.linalg.inv_ex(jac(decoder_expr, xc_init, cond, anchors))[0].flatten(0, 1)
+    J_inv_init = inverse3x3(jac(decoder_expr, xc_init, cond, anchors)).flatten(0, 1)    # the reference: `.inverse()`
     x0 = xc_init.reshape(-1, 3, 1)
     # conditioning may come as one row per batch entry (cond [B,1,L], anchors [B,K,3]: what the mirrored fitting
     # loop passes); the python solver below wants the reference's per-point tensors
