@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub --no-mesh $*"
 echo "cmd: $CMD" > "$OUT/README.txt"
 rocprofv3 -L > "$OUT/counters_list.txt" 2>&1 || true
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- $CMD > "$OUT/trace.log" 2>&1
