@@ -233,6 +233,28 @@ int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                      int max_steps, float cvg_thresh, float dvg_thresh, float eps,
                      float* x_out, float* diff_out, unsigned char* valid_out, void* stream);
 
+/* First-order backward of the skip-MLP with respect to its conditioning rows, for the fitting loop's
+ * loss.backward() through decoder_expr(p_corresp, cond) (src/NPHM/models/fitting.py:99-106 with the decoders
+ * frozen and the query points detached).  Covers the hidden <= 512, out_dim <= 3 variant (the deformation
+ * backbone); *_bytes return 0 otherwise.
+ *   nphm_mlp_eval_points_saving : nphm_mlp_eval_points that also leaves sigma'(d_l) of every hidden layer in
+ *     `saved` (nphm_mlp_saved_bytes(..., n_rows, n_points) bytes);
+ *   nphm_mlp_pack_bwd           : transposed split-bf16 pack of lin1..lin_last (nphm_mlp_bwd_packed_bytes);
+ *   nphm_mlp_backward_cond      : grad_out [n_rows, n_points, out_dim] -> bias gradients of lin0 and of the skip
+ *     layer, grad_bias0 / grad_bias_skip [n_rows, hidden_dim] (ACCUMULATED into: zero them first).  The caller maps
+ *     them onto the conditioning: d L / d cond = grad_bias0 W0[:, 3:] + grad_bias_skip W_skip[:, K+3:] / sqrt(2). */
+size_t nphm_mlp_saved_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows, int64_t n_points);
+int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                                const void* packed, const void* latent_state,
+                                const float* xyz, int n_rows, int64_t n_points, int add_input,
+                                float* out, void* saved, void* stream);
+size_t nphm_mlp_bwd_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim);
+int nphm_mlp_pack_bwd(int lat_dim, int hidden_dim, int nlayers, int out_dim, const float* const* lin_weight,
+                      void* packed_bwd, void* stream);
+int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim, const void* packed_bwd,
+                           const void* saved, const float* grad_out, int n_rows, int64_t n_points,
+                           float* grad_bias0, float* grad_bias_skip, void* stream);
+
 /* Batched inverse of n row-major 3x3 matrices (adjugate formula, one thread each): the `.inverse()` calls on
  * the deformation Jacobians in the correspondence search and the implicit differentiation of the fitting loop
  * (src/NPHM/models/iterative_root_finding.py:118, src/NPHM/models/fitting.py:102) without the blocking

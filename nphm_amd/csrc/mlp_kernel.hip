@@ -157,6 +157,10 @@ struct EvalArgs {
   // MODE 1: x-slab [ix0, ix1) of an 'ij' lattice, points in flattened lattice order
   const float* ax; const float* ay; const float* az;
   int rx, ry, rz, ix0, ix1;
+  // KIND 3: the forward that also leaves sigma'(d_l) of every hidden layer for mlp_bwd_kernel.hip
+  float* sig_out;         // [n_rows][n_workgroups][sig_tiles][MT][64 lanes][16]: register dumps of the owning wavefront
+  int sig_tiles;          // tiles per workgroup = sum of n_tiles over the hidden layers
+  int sig_base[MAX_LINEAR];   // first tile of layer l
 };
 
 // k softplus(d / k) in base 2 (see mlp_layout.h); agrees with nn.Softplus(beta=100, threshold=20)
@@ -232,7 +236,7 @@ __device__ __forceinline__ bf16x8 unit_operand(int c) {
 // wavefronts through LDS; a workgroup leaves as soon as none of its points is active.
 template <int MT, int NTW, int MODE, int KIND>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
-  constexpr bool JVP = KIND == 1, BROY = KIND == 2;
+  constexpr bool JVP = KIND == 1, BROY = KIND == 2, SAVE = KIND == 3;
   constexpr int M = 32 * MT;               // columns per workgroup
   constexpr int PTS = JVP ? M / 4 : M;     // points per workgroup
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
@@ -307,12 +311,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   Split8 packed_out[NTW][MT][2];
 
   // epilogue of the wavefront's tiles: softplus, re-split (registers only)
-  auto activate = [&](int ni) __attribute__((always_inline)) {
+  auto activate = [&](int ni, int layer) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
+          if constexpr (SAVE) {
+            float* so = p.sig_out + ((((size_t(row) * gridDim.x + blockIdx.x) * p.sig_tiles + p.sig_base[layer] + wave + WAVES * i) * MT + t) * 64 + lane) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+              float4 sg = make_float4(sigmoid2(acc[i][t][r]), sigmoid2(acc[i][t][r + 1]), sigmoid2(acc[i][t][r + 2]), sigmoid2(acc[i][t][r + 3]));
+              *reinterpret_cast<float4*>(so + r) = sg;
+            }
+          }
           float v[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     const LayerDev& L = p.layer[0];
     const int ni = tiles_of(L.n_tiles);
     coord_step(L, ni);
-    activate(ni);
+    activate(ni, 0);
     store_tiles(ni);
   }
 
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
         if (s + 3 < ks) load_a(1, s + 3);
       }
     }
-    activate(ni);
+    activate(ni, l);
     __syncthreads();                                  // every wavefront has read the old tile
     store_tiles(ni);
   }
@@ -605,6 +617,8 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   }
   a.n_linear = plan.n_linear;
   a.state_row_bytes = plan.state_row_bytes;
+  a.sig_tiles = 0;
+  for (int l = 0; l < plan.n_linear - 1; ++l) { a.sig_base[l] = a.sig_tiles; a.sig_tiles += plan.layer[l].n_tiles; }
   const int M = (plan.variant == 0 ? 64 : 32) / (KIND == 1 ? 4 : 1);      // points per workgroup
   const int64_t tiles = (n_pts + M - 1) / M;
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
@@ -616,6 +630,8 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
+  } else if constexpr (KIND == 3) {
+    return nphm_fail_msg("nphm_mlp_eval_points_saving: only the hidden <= 512 variant has a backward kernel");
   } else {
     auto k = mlp_eval_kernel<1, 4, MODE, KIND>;
     constexpr size_t lds = lds_bytes<1, 4>();
@@ -713,6 +729,36 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   a.xyz = xyz;
   a.n_points = n_points;
   return launch_eval<0>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+}
+
+size_t nphm_mlp_saved_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows, int64_t n_points) {
+  Plan plan;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) || plan.variant != 0 || n_rows <= 0 || n_points <= 0) return 0;
+  size_t tiles = 0;
+  for (int l = 0; l < plan.n_linear - 1; ++l) tiles += plan.layer[l].n_tiles;
+  const size_t wgs = size_t((n_points + 63) / 64);
+  return size_t(n_rows) * wgs * tiles * 2 * 64 * 16 * sizeof(float);
+}
+
+int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                                const void* packed, const void* latent_state,
+                                const float* xyz, int n_rows, int64_t n_points, int add_input,
+                                float* out, void* saved, void* stream) {
+  Plan plan;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points_saving: unsupported architecture");
+  if (!packed || !latent_state || !xyz || !out || !saved) return nphm_fail_msg("nphm_mlp_eval_points_saving: null pointer");
+  if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_mlp_eval_points_saving: empty input");
+  nphm::mlp::EvalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const char*>(packed);
+  a.state = static_cast<const char*>(latent_state);
+  a.out = out;
+  a.out_dim = out_dim;
+  a.add_input = add_input;
+  a.xyz = xyz;
+  a.n_points = n_points;
+  a.sig_out = static_cast<float*>(saved);
+  return launch_eval<0, 3>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
 }
 
 int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,

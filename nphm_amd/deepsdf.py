@@ -29,6 +29,55 @@ from .ensembled_deepsdf import sample_point_feature  # noqa: F401  (re-exported 
 _SQRT2 = float(np.sqrt(2))
 
 
+class _MlpCondFn(torch.autograd.Function):
+    """out = mlp(xyz; cond_rows) with the fused forward kernel and a hand-written first-order backward with respect
+    to the CONDITIONING rows (mlp_bwd_kernel.hip): what the fitting loop differentiates through the deformation
+    field (fitting.py:99-106; the query points are detached roots, the decoder is frozen).  The forward leaves
+    sigma' of every hidden layer in a scratch buffer; the backward kernel returns the bias gradients of lin0 and of
+    the skip layer, which the two latent blocks of those layers map onto the conditioning vector."""
+
+    @staticmethod
+    def forward(ctx, module, xyz, cond_rows, add_input):
+        lib = _lib.load()
+        R, n, _ = xyz.shape
+        dev = xyz.device
+        packed, state = module.prepare_latent(cond_rows.detach())
+        xyz_c = xyz.detach().contiguous().float()
+        out = torch.empty(R, n, module.n_out, dtype=torch.float32, device=dev)
+        saved = torch.empty(lib.nphm_mlp_saved_bytes(*module._arch(), R, n), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.nphm_mlp_eval_points_saving(*module._arch(), packed.data_ptr(), state.data_ptr(), xyz_c.data_ptr(),
+                                                   R, n, int(bool(add_input)), out.data_ptr(), saved.data_ptr(), stream),
+                   "nphm_mlp_eval_points_saving")
+        ctx.module, ctx.shape = module, (R, n)
+        ctx.save_for_backward(saved)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        module = ctx.module
+        (saved,) = ctx.saved_tensors
+        R, n = ctx.shape
+        dev = grad_out.device
+        H = module.hidden_dim
+        gb0 = torch.zeros(R, H, dtype=torch.float32, device=dev)
+        gbs = torch.zeros(R, H, dtype=torch.float32, device=dev)
+        g = grad_out.detach().contiguous().float()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.nphm_mlp_backward_cond(*module._arch(), module._packed_bwd(dev).data_ptr(), saved.data_ptr(),
+                                              g.data_ptr(), R, n, gb0.data_ptr(), gbs.data_ptr(), stream),
+                   "nphm_mlp_backward_cond")
+        d = module.input_dim
+        skip = module.skip_in[0]
+        W0 = module.lin0.weight                                   # [H, d + lat]
+        Ws = getattr(module, f"lin{skip}").weight                 # [H, k_act + d + lat]
+        k_act = Ws.shape[1] - W0.shape[1]
+        grad_cond = gb0 @ W0[:, d:] + (gbs @ Ws[:, k_act + d:]) / _SQRT2
+        return None, None, grad_cond, None
+
+
 class DeepSDF(nn.Module):
     """Skip-MLP SDF / vector field (deepSDF.py:6-89).  dims = [d_in] + [hidden]*nlayers + [out];
     the input is re-injected (concatenated, divided by sqrt 2) before layer ``nlayers//2``;
@@ -48,6 +97,7 @@ class DeepSDF(nn.Module):
         self.beta = beta
         self.backend = "hip"            # "hip" | "composite"
         self._pack_cache = None         # (key, packed tensor)
+        self._pack_bwd_cache = None     # (key, transposed pack of the backward kernel)
         print(d_in)
         print(hidden_dim)
         dims = [d_in] + [hidden_dim] * nlayers + [out_dim]
@@ -101,6 +151,7 @@ class DeepSDF(nn.Module):
         """Drop the cached split-bf16 copy of the weights (see FastEnsembleDeepSDFMirrored.invalidate_pack:
         needed after writes that bypass the parameters' version counters)."""
         self._pack_cache = None
+        self._pack_bwd_cache = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -141,6 +192,26 @@ class DeepSDF(nn.Module):
                                      stream), "nphm_mlp_pack")
         self._pack_cache = (key, packed)
         return packed
+
+    def _packed_bwd(self, device):
+        """Transposed split-bf16 pack for nphm_mlp_backward_cond (cached like _packed)."""
+        ws, _ = self._lin_params()
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in ws) + (str(device),)
+        if self._pack_bwd_cache is not None and self._pack_bwd_cache[0] == key:
+            return self._pack_bwd_cache[1]
+        lib = _lib.load()
+        packed = torch.empty(lib.nphm_mlp_bwd_packed_bytes(*self._arch()), dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.nphm_mlp_pack_bwd(*self._arch(), _lib.ptr_array(ws), packed.data_ptr(), stream), "nphm_mlp_pack_bwd")
+        self._pack_bwd_cache = (key, packed)
+        return packed
+
+    def hip_backward_supported(self) -> bool:
+        return bool(_lib.load().nphm_mlp_bwd_packed_bytes(*self._arch())) and self.hip_supported()
+
+    def forward_hip_cond_grad(self, xyz, cond_rows, add_input=False):
+        """``forward_hip`` that is differentiable (first order) with respect to ``cond_rows``."""
+        return _MlpCondFn.apply(self, xyz, cond_rows, add_input)
 
     def prepare_latent(self, cond_rows: torch.Tensor):
         """cond_rows [B, lat_dim] -> (packed weights, per-row state) via the HIP prologue kernel."""
@@ -205,9 +276,11 @@ class DeepSDF(nn.Module):
                                         diff.data_ptr(), valid.data_ptr(), stream), "nphm_mlp_broyden")
         return x, diff, valid.bool()
 
-    def _hip_rows(self, xyz, cond):
+    def _hip_rows(self, xyz, cond, cond_grad_ok=False):
         """How the HIP tier can serve this call: returns (xyz_view [R,n,3], cond_rows [R,lat_dim]) or
-        None (-> composite tier).  Raises on a CPU tensor without the explicit opt-in.
+        None (-> composite tier).  Raises on a CPU tensor without the explicit opt-in.  ``cond_grad_ok``: the
+        caller can differentiate with respect to the conditioning (``forward_hip_cond_grad``), so a graph that
+        only needs THAT gradient (frozen parameters, detached points: the fitting loop) stays on the HIP tier.
 
         Besides a row-constant conditioning ([B,1,L] or a ``repeat`` along the points) it recognises
         the flattened batch the reference's root finder passes (iterative_root_finding.py:137-139):
@@ -221,7 +294,12 @@ class DeepSDF(nn.Module):
                 "(set module.backend = 'composite' explicitly for the PyTorch formulation)")
         needs_graph = torch.is_grad_enabled() and (
             xyz.requires_grad or cond.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_graph or xyz.dtype != torch.float32 or not self.hip_supported():
+        if needs_graph:
+            cond_only = (cond_grad_ok and not xyz.requires_grad and not any(p.requires_grad for p in self.parameters())
+                         and cond.shape[1] == 1 and self.hip_backward_supported())
+            if not cond_only:
+                return None
+        if xyz.dtype != torch.float32 or not self.hip_supported():
             return None
         B, N = xyz.shape[0], xyz.shape[1]
         if cond.shape[1] == 1:
@@ -248,9 +326,10 @@ class DeepSDF(nn.Module):
     def forward(self, xyz, lat_rep, anchors=None):
         squeeze = xyz.dim() < 3
         x3 = xyz.unsqueeze(0) if squeeze else xyz
-        plan = self._hip_rows(x3, lat_rep)
+        plan = self._hip_rows(x3, lat_rep, cond_grad_ok=True)
         if plan is not None:
-            out = self.forward_hip(*plan).reshape(x3.shape[0], x3.shape[1], self.n_out)
+            fwd = self.forward_hip_cond_grad if (torch.is_grad_enabled() and lat_rep.requires_grad) else self.forward_hip
+            out = fwd(*plan).reshape(x3.shape[0], x3.shape[1], self.n_out)
             return (out.squeeze(0) if squeeze else out), None
         return self.evaluate(self._embed(xyz), lat_rep), None
 
@@ -339,9 +418,14 @@ class DeformationNetwork(nn.Module):
         if xyz.dim() < 3:
             xyz = xyz.unsqueeze(0)
         cond = self._condition(xyz, lat_rep, anchors)
-        plan = self.defDeepSDF._hip_rows(xyz, cond)
+        # the compressor / latent slices stay ordinary autograd; the backbone is differentiated by the HIP backward
+        # kernel when only the conditioning needs a gradient (compressor parameters frozen like the backbone's)
+        own_frozen = not any(p.requires_grad for p in self.parameters())
+        plan = self.defDeepSDF._hip_rows(xyz, cond, cond_grad_ok=own_frozen)
         if plan is not None:
-            pred = self.defDeepSDF.forward_hip(*plan).reshape(xyz.shape[0], xyz.shape[1], -1)
+            fwd = (self.defDeepSDF.forward_hip_cond_grad if (torch.is_grad_enabled() and cond.requires_grad)
+                   else self.defDeepSDF.forward_hip)
+            pred = fwd(*plan).reshape(xyz.shape[0], xyz.shape[1], -1)
         else:
             pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
         return pred[..., :3], pred[..., -1:]

@@ -390,3 +390,65 @@ def test_two_stage_full_size_256_cubed_properties(dnet, dev):
     ref, _ = O.nphm_identity_forward(U.np_state(inet), U.anchors_mean(), (pts[None, sub] + off_o).astype(np.float32),
                                      g["lat"][:, :, :1344], training=True)
     assert U.maxdiff(vol[k][sub].cpu().numpy(), ref.reshape(-1)) < TOL_BAR
+
+
+# ---------------------------------------------------------------------------------------------
+# hand-written backward of the deformation backbone w.r.t. its conditioning (fitting loop)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 64, 777])
+def test_backward_wrt_conditioning_matches_autograd(dev, n):
+    """d/d(lat_rep, anchors) of sum(offsets * cotangent) through DeformationNetwork with frozen parameters and
+    detached points: HIP forward + mlp_bwd_kernel vs autograd through the composite formulation."""
+    net = U.build_deformation(device=dev).eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(11)
+    xyz = ((torch.rand(2, n, 3, generator=g) - 0.5) * 0.6).to(dev)
+    cot = torch.randn(2, n, 3, generator=g).to(dev)
+    lat0 = (torch.randn(2, 1, 1544, generator=g) * 0.05).to(dev)
+    anc0 = (torch.from_numpy(U.anchors_mean()).float()[None] + 0.01 * torch.randn(2, 39, 3, generator=g)).to(dev)
+
+    def run(backend):
+        net.backend = backend
+        lat = lat0.clone().requires_grad_(True)
+        anc = anc0.clone().requires_grad_(True)
+        off, rest = net(xyz, lat, anc)
+        ((off * cot).sum() + 0.3 * rest.sum()).backward()
+        return off.detach(), lat.grad, anc.grad
+
+    called, restore = _spy(net.defDeepSDF, "forward_hip_cond_grad")
+    try:
+        off_h, gl_h, ga_h = run("hip")
+    finally:
+        restore()
+    assert called.get("n", 0) == 1                     # the HIP autograd tier served the call
+    off_c, gl_c, ga_c = run("composite")
+    net.backend = "hip"
+    assert U.maxdiff(off_h.cpu(), off_c.cpu()) < TOL_TIGHT
+    for a, b in ((gl_h, gl_c), (ga_h, ga_c)):
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) < 2e-5 * scale + 1e-9
+
+
+def test_backward_tier_selection(dev):
+    """points or parameters that require grad, or per-point conditioning, keep the composite tier; double backward
+    through the HIP tier raises"""
+    net = U.build_deformation(device=dev).eval()
+    g = U.golden("deformation")
+    xyz, lat, anc = _t(g["xyz"], dev), _t(g["lat"], dev), _t(g["anchors"], dev)
+    called, restore = _spy(net.defDeepSDF, "forward_hip_cond_grad")
+    try:
+        net(xyz, lat.clone().requires_grad_(True), anc)                       # parameters still require grad
+        for p in net.parameters():
+            p.requires_grad_(False)
+        net(xyz.clone().requires_grad_(True), lat.clone().requires_grad_(True), anc)    # d/dxyz wanted
+        net(xyz, lat.repeat(1, xyz.shape[1], 1).requires_grad_(True), anc)              # per-point conditioning
+        assert called.get("n", 0) == 0
+        l2 = lat.clone().requires_grad_(True)
+        off, _ = net(xyz, l2, anc)
+        assert called.get("n", 0) == 1
+        (gl,) = torch.autograd.grad(off.sum(), l2, create_graph=True)
+        with pytest.raises(RuntimeError):
+            gl.sum().backward()
+    finally:
+        restore()
