@@ -98,6 +98,98 @@ def test_search_multi_corresp_shapes_cpu():
     assert ok.any() and float(((xc[:, :, 0] + off - obs)[ok]).norm(dim=-1).max()) < 1e-5
 
 
+# ---------------------------------------------------------------------------------------------
+# long horizon: the reference's own loop over 250 steps through every transition of the published schedule
+# (tests/golden/make_golden_fitting_long.py: fitting_pointclouds.py:253-276 at step_scale 1/4)
+# ---------------------------------------------------------------------------------------------
+LONG_SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 500: 9999},
+                 "reg_glob": {200: 3, 600: 10}, "reg_loc": {500: 3, 600: 10}, "reg_expr": {600: 10}}
+
+
+def _run_long(device, backend, n_steps=None, **kw):
+    g = U.golden("fitting_long")
+    shape_net = U.build_identity(device=device).train()
+    expr_net = U.build_deformation(device=device).eval()
+    assert U.state_hash(shape_net) == str(g["shape_sha256"]) and U.state_hash(expr_net) == str(g["expr_sha256"])
+    if backend is not None:
+        shape_net.backend = backend
+        expr_net.backend = backend
+    obs = [torch.from_numpy(g[f"obs{i}"]).to(device) for i in range(3)]
+    hist = []
+    torch.manual_seed(0)
+    lat_e, lat_s, anc = F.inference_iterative_root_finding_joint(
+        shape_net, expr_net, obs, dict(LAMBDAS), int(g["n_steps"]) if n_steps is None else n_steps,
+        {k: dict(v) for k, v in LONG_SCHEDULE.items()}, step_scale=float(g["step_scale"]), verbose=False, history=hist, **kw)
+    keys = [str(k) for k in g["keys"]]
+    table = np.array([[h[k] for k in keys] + [h["n_valid"]] for h in hist])
+    return g, keys, table, lat_e.detach().cpu().numpy(), lat_s.detach().cpu().numpy(), anc.detach().cpu().numpy()
+
+
+def test_long_fixture_prefix_cpu():
+    """the first 10 of the 250 reference steps on the composite tier (the whole horizon runs on the GPU)"""
+    g, keys, table, *_ = _run_long("cpu", "composite", n_steps=40)
+    ref = g["history"][:10]
+    assert table.shape == ref.shape and np.array_equal(table[:, -1], ref[:, -1])
+    diff = np.abs(table - ref).max(0)
+    for k, d in zip(keys, diff):
+        assert d < (5e-6 if k == "surface" else 2e-4), (k, d)
+
+
+def _check_long(g, keys, table, lat_e, lat_s, anc):
+    """Tolerances of the 250-step comparison (measured on MI355X: surface trace 2e-5..3e-5 abs / 1.4..1.9 % rel,
+    final surface loss 2e-5..1e-4 rel, latents 5e-4 / 2.5e-3 max).  Two fp32 implementations of a 250-step Adam
+    trajectory drift apart slowly (components whose gradient is round-off are normalised to +-lr steps early on,
+    the backward kernels sum with atomics), so the trace is compared step by step with a relative band and the
+    END of the fit - what the caller keeps - tightly."""
+    ref = g["history"]
+    assert table.shape == ref.shape
+    assert np.array_equal(table[:, -1], ref[:, -1])                     # converged correspondences, every step
+    surf, rsurf = table[:, keys.index("surface")], ref[:, keys.index("surface")]
+    d = np.abs(surf - rsurf)
+    assert d.max() < 1e-4 and (d / rsurf).max() < 0.05 and (d / rsurf)[:50].max() < 1e-3
+    assert abs(surf[-50:].mean() / rsurf[-50:].mean() - 1) < 1e-2        # final surface loss
+    for k in ("reg_expr", "reg_global", "reg_loc"):
+        a, b = table[-50:, keys.index(k)].mean(), ref[-50:, keys.index(k)].mean()
+        assert abs(a / b - 1) < 0.03, (k, a, b)
+    lam_end = {"surface": 2.0, "reg_expr": 0.001, "reg_global": 0.25 / 30, "reg_unobserved": 10, "reg_loc": 0.05 / 30,
+               "symm_dist": 5.0 / 10 / 9999}                              # the weights after the last transition
+    tot = lambda t: sum(lam_end[k] * t[-50:, keys.index(k)].mean() for k in keys)
+    assert abs(tot(table) / tot(ref) - 1) < 1e-2                        # final total loss
+    ds = np.abs(lat_s - g["lat_shape"]).reshape(-1)
+    assert np.median(ds) < 2e-4 and np.quantile(ds, 0.9) < 2e-3 and ds.max() < 1e-2
+    assert U.maxdiff(lat_e, g["lat_expr"]) < 2e-3 and U.maxdiff(anc, g["anchors"]) < 5e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_long_horizon_joint_fit_matches_reference_loop_gpu(use_graph):
+    """250 steps, the product's tier mix (fused kernels end to end; hipGraph replay or eager)"""
+    _check_long(*_run_long(torch.device("cuda:0"), None, use_graph=use_graph))
+
+
+@pytest.mark.gpu
+def test_long_horizon_identity_space_fit_gpu():
+    """inference_identity_space over the same horizon.  The reference prints nothing for this loop; the fixture holds
+    the total loss of every step (recorded at loss.backward()) and the fitted code.  The early trace is spiky (the
+    symmetry term is a norm at zero), so: the first steps tightly, the end of the fit within 1 %."""
+    g = U.golden("fitting_long")
+    dev = torch.device("cuda:0")
+    net = U.build_identity(device=dev).train()
+    lam = {k: v for k, v in LAMBDAS.items() if k != "reg_expr"}
+    hist = []
+    torch.manual_seed(1)
+    lat_s, anc = F.inference_identity_space(net, [torch.from_numpy(g[f"obs{i}"]).to(dev) for i in range(3)], lam,
+                                            int(g["n_steps"]), {k: dict(v) for k, v in LONG_SCHEDULE.items()},
+                                            step_scale=float(g["step_scale"]), history=hist)
+    tot, ref = np.array([h["loss"] for h in hist]), g["id_total_loss"]
+    assert tot.shape == ref.shape
+    assert np.abs(tot[:2] - ref[:2]).max() < 1e-5 and np.abs(tot[:6] / ref[:6] - 1).max() < 5e-3
+    assert abs(tot[-20:].mean() / ref[-20:].mean() - 1) < 1e-2
+    d = np.abs(lat_s.detach().cpu().numpy() - g["id_lat_shape"]).reshape(-1)
+    assert np.median(d) < 2e-4 and np.quantile(d, 0.9) < 2e-3 and d.max() < 1e-2
+    assert U.maxdiff(anc.detach().cpu().numpy(), g["id_anchors"]) < 2e-4
+
+
 @pytest.mark.gpu
 def test_joint_fit_matches_reference_loop_gpu():
     g, table, lat_e, lat_s, anc = _run_joint(torch.device("cuda:0"), None)
