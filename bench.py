@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--no-binning", action="store_true", help="brick-order traversal instead of tiles binned by member set")
     ap.add_argument("--no-mesh", action="store_true", help="skip the mesh-extract leg (kernel timing experiments)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="lattice points of the PyTorch-CPU baseline (prefix)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0 = min(cores, 64))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0 = min(cores, 32): the fastest of 8..256 on the 256-core GPU box)")
     ap.add_argument("--fit-steps", type=int, default=1000, help="n_steps of the fitting config (run at step_scale 1/4)")
     return ap.parse_args()
 
@@ -378,7 +378,7 @@ def fitting_record(args, dev, with_reference_loop=True):
 # baselines
 # ------------------------------------------------------------------------------------------------------
 def _cpu_threads(args):
-    return args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64)
+    return args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 32)
 
 
 def cpu_baseline(net, lat, axes, args):

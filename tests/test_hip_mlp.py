@@ -392,6 +392,29 @@ def test_two_stage_full_size_256_cubed_properties(dnet, dev):
     assert U.maxdiff(vol[k][sub].cpu().numpy(), ref.reshape(-1)) < TOL_BAR
 
 
+def test_npm_full_size_64_cubed_vs_reference_sequence(npm, dev):
+    """BASELINE.json configs[0] at its stated size: NPM global DeepSDF on the 64^3 lattice through get_logits
+    (chunk 25 000), against the reference's PyTorch operation sequence evaluated in full on the host
+    (oracle/torch_reference.py: chunked get_logits, fp32), plus determinism and slab invariance."""
+    from oracle import torch_reference as T
+    res = 64
+    g = U.golden("npm")
+    grid = torch.from_numpy(R.create_grid_points_from_bounds(U.MINI, U.MAXI, res)).float()[None]
+    lat = _t(g["lat"], dev)
+    vol = R.get_logits(npm, lat, grid.to(dev), nbatch_points=25000)
+    assert vol.shape == (res ** 3,) and vol.dtype == np.float32 and np.isfinite(vol).all()
+    assert np.array_equal(vol, R.get_logits(npm, lat, grid.to(dev), nbatch_points=25000))          # deterministic
+    axes = R.grid_axes(U.MINI, U.MAXI, res)
+    slab = R.evaluate_grid_mlp(npm, lat[None], axes, x_range=(24, 32))
+    assert np.array_equal(slab.reshape(-1).cpu().numpy(), vol.reshape(res, -1)[24:32].reshape(-1))
+    sd = {k: v.detach().cpu() for k, v in npm.state_dict().items()}
+    ref = T.get_logits(lambda p, l: T.deepsdf_forward(sd, "", p, l, nlayers=8), torch.from_numpy(g["lat"])[None, None],
+                       grid, 25000)
+    e = U.maxdiff(vol, ref)
+    print(f"NPM 64^3 max abs err vs the reference op sequence: {e:.3e} (max |sdf| {np.abs(ref).max():.3f})")
+    assert e < 2e-5
+
+
 # ---------------------------------------------------------------------------------------------
 # hand-written backward of the deformation backbone w.r.t. its conditioning (fitting loop)
 # ---------------------------------------------------------------------------------------------
