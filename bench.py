@@ -319,6 +319,28 @@ FIT_SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 5
                 "reg_glob": {200: 3, 600: 10}, "reg_loc": {500: 3, 600: 10}, "reg_expr": {600: 10}}   # :261-266
 
 
+def grid512_record(args, dev, steps=2):
+    """configs[3] on ONE GPU: the whole 512^3 lattice in one launch, and rank 0's share of the 8-rank cyclic
+    partition (the launch every rank of the 8-GPU job runs; the all-gather of 64 MiB per rank comes on top)."""
+    big = argparse.Namespace(**vars(args))
+    big.res = 512
+    ib = IdentityBench(big, dev, 1, 0)
+    full = ib.record(args.precision, steps, 1)
+    share = IdentityBench(big, dev, 8, 0)
+    share.distributed = False
+    dt, k_ms, _ = share.measure(args.precision, steps, 1)
+    n_share = share.n_planes * share.plane
+    return {"metric": "SDF query throughput, NPHM identity field, 512^3 lattice", "value": full["value"], "unit": "Mpoints/s",
+            "ms_per_step": full["ms_per_step"], "steps": steps, "dtype": full["dtype"],
+            "config": {"workload": "NPHM 39-anchor identity net, 512^3 lattice on one GPU (BASELINE.json configs[3] needs 8 GPUs: "
+                                   "its per-rank launch is timed below)", "res": 512},
+            "roofline": full["roofline"],
+            "rank0_of_8": {"planes": share.n_planes, "points": n_share, "kernel_ms": k_ms,
+                           "projected_8gpu_mpoints_per_s_without_allgather": 512 ** 3 / (k_ms * 1e-3) / 1e6,
+                           "note": "cyclic 8-plane slabs of rank 0 in one launch on this GPU; every rank's share costs the same "
+                                   "within 2 % (tools/slab_balance.py)"}}
+
+
 def fitting_record(args, dev, with_reference_loop=True):
     """configs[4]: latent fitting (fitting_pointclouds.py:253-276: n_steps 1000, the published schedule) at the
     reference's own step_scale 1/4 = 250 Adam steps through every transition of the schedule; synthetic
@@ -551,6 +573,7 @@ def main():
                 "npm_64": npm_record(args, dev, max(sub_steps, 5), 2, not args.no_cpu_baseline),
                 "two_stage_256": two_stage_record(args, dev, sub_steps, 1),
                 "fitting": fitting_record(args, dev, with_reference_loop=not args.no_cpu_baseline),
+                "grid512_one_gpu": grid512_record(args, dev),
             }
             ib.net.precision = args.precision
         if not args.no_cpu_baseline and world == 1:

@@ -297,6 +297,11 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         self.precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3a")
         self._pack_cache = None         # (key, packed tensor)
         self._pack_bwd_cache = None     # (key, transposed pack for the backward kernel)
+        # latent fitting with the REFERENCE's unchanged fitting.py: it leaves the decoder's parameters trainable and
+        # lets autograd fill their .grad, which nothing reads.  True (or NPHM_AMD_ASSUME_FROZEN=1) treats the
+        # parameters as frozen when choosing the tier, so that loop reaches the HIP autograd tier too (their .grad
+        # stays None).  nphm_amd.fitting freezes them itself and does not need it.
+        self.assume_frozen_parameters = os.environ.get("NPHM_AMD_ASSUME_FROZEN", "0") not in ("", "0")
 
     # ------------------------------------------------------------------------------------------
     def invalidate_pack(self):
@@ -411,16 +416,21 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         """Differentiable (first order) w.r.t. xyz and the latent rows; values from the fused kernel."""
         B = xyz.shape[0]
         g, A = self.lat_dim_glob, self.num_kps + 1
-        anchors = self.mlp_pos(lat_rows[:, :g]).view(B, self.num_kps, 3)
+        # parameters enter as constants here when they are (treated as) frozen: no .grad is produced for them
+        const = (lambda t: t.detach()) if self.assume_frozen_parameters else (lambda t: t)
+        h = lat_rows[:, :g]
+        for i, lin in enumerate(self.mlp_pos):
+            h = torch.nn.functional.linear(h, const(lin.weight), const(lin.bias)) if isinstance(lin, nn.Linear) else lin(h)
+        anchors = h.view(B, self.num_kps, 3)
         anchors = anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
         cond = torch.cat([lat_rows[:, None, :g].expand(B, A, g), lat_rows[:, g:].reshape(B, A, self.lat_dim_loc)], dim=-1)
         e = self.ensembled_deep_sdf
         d_in = self.input_dim
         n1 = e.lin1.out_features                          # width of the skip layer's hidden part
-        W0 = e.lin0.member_weight()[:, :, d_in:]          # [A, H, 96] latent columns of lin0
-        W2 = e.lin2.member_weight()[:, :, n1 + d_in:]     # [A, H, 96] latent columns of the skip layer
-        b0f = torch.einsum("bkc,kfc->bkf", cond, W0) + e.lin0.member_bias()[None]
-        b2f = torch.einsum("bkc,kfc->bkf", cond, W2) / _SQRT2 + e.lin2.member_bias()[None]
+        W0 = const(e.lin0.member_weight())[:, :, d_in:]          # [A, H, 96] latent columns of lin0
+        W2 = const(e.lin2.member_weight())[:, :, n1 + d_in:]     # [A, H, 96] latent columns of the skip layer
+        b0f = torch.einsum("bkc,kfc->bkf", cond, W0) + const(e.lin0.member_bias())[None]
+        b2f = torch.einsum("bkc,kfc->bkf", cond, W2) / _SQRT2 + const(e.lin2.member_bias())[None]
         sdf = _IdentityFieldFn.apply(self, xyz, lat_rows.detach(), anchors, b0f, b2f)
         return sdf, anchors
 
@@ -470,8 +480,8 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         B, N, _ = xyz.shape
         assert self.lat_dim == lat_rep.shape[-1], "lat dim {}, lat_rep {}".format(self.lat_dim, lat_rep.shape)
 
-        needs_graph = torch.is_grad_enabled() and (
-            xyz.requires_grad or lat_rep.requires_grad or any(p.requires_grad for p in self.parameters()))
+        params_train = (not self.assume_frozen_parameters) and any(p.requires_grad for p in self.parameters())
+        needs_graph = torch.is_grad_enabled() and (xyz.requires_grad or lat_rep.requires_grad or params_train)
         if self.backend == "composite":
             return self._forward_composite(xyz, lat_rep)
         if not xyz.is_cuda:
@@ -487,7 +497,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         if needs_graph:
             # first-order HIP autograd tier: latent fitting (no parameter requires grad, train mode, no
             # chunk overwrite to differentiate around); everything else builds the composite graph
-            if self.training and not any(p.requires_grad for p in self.parameters()):
+            if self.training and not params_train:
                 return self._forward_hip_autograd(xyz, lat_rep[:, 0, :])
             return self._forward_composite(xyz, lat_rep)
         return self._forward_hip(xyz, lat_rep[:, 0, :])
