@@ -82,26 +82,28 @@ struct PrepArgs {
   char* state;         // [n_rows, state_row_bytes]
 };
 
-__global__ __launch_bounds__(256) void mlp_prepare_kernel(PrepArgs a) {
+__global__ __launch_bounds__(1024) void mlp_prepare_kernel(PrepArgs a) {
   __shared__ float bias[1024];
   __shared__ float lat[1024];
   const int l = blockIdx.x, row = blockIdx.y, t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6, n_waves = blockDim.x >> 6;
   const Layer& L = a.plan.layer[l];
   const float* W = a.t.w[l];
   const float* cond = a.cond + size_t(row) * a.lat_dim;
   for (int j = t; j < a.lat_dim; j += blockDim.x) lat[j] = cond[j];
   __syncthreads();
-  for (int o = t; o < 32 * L.n_tiles; o += blockDim.x) {
+  // folded bias of output o: one WAVEFRONT per output, its lanes stride over the latent columns (coalesced reads of
+  // the weight row, butterfly reduction) - a thread per output walked the rows with a stride of in_dim floats
+  for (int o = wave; o < 32 * L.n_tiles; o += n_waves) {
     float v = 0.f;
-    if (o < L.out_dim) {
-      if (L.lat_col >= 0) {
-        const float* wl = W + size_t(o) * L.in_dim + L.lat_col;
-        for (int j = 0; j < a.lat_dim; ++j) v = fmaf(wl[j], lat[j], v);
-        v *= L.in_scale;
-      }
-      v = (v + a.t.b[l][o]) * L.add_scale;
+    if (o < L.out_dim && L.lat_col >= 0) {
+      const float* wl = W + size_t(o) * L.in_dim + L.lat_col;
+      for (int j = lane; j < a.lat_dim; j += 64) v = fmaf(wl[j], lat[j], v);
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+      v *= L.in_scale;
     }
-    bias[o] = v;
+    if (lane == 0) bias[o] = o < L.out_dim ? (v + a.t.b[l][o]) * L.add_scale : 0.f;
   }
   __syncthreads();
   uint16_t* out = reinterpret_cast<uint16_t*>(a.state + size_t(row) * a.plan.state_row_bytes + L.c_off);
@@ -619,12 +621,28 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   a.state_row_bytes = plan.state_row_bytes;
   a.sig_tiles = 0;
   for (int l = 0; l < plan.n_linear - 1; ++l) { a.sig_base[l] = a.sig_tiles; a.sig_tiles += plan.layer[l].n_tiles; }
-  const int M = (plan.variant == 0 ? 64 : 32) / (KIND == 1 ? 4 : 1);      // points per workgroup
+  // Small Broyden batches of the hidden <= 512 nets (the fitting loop: 5 x 1000 points) run 32 points per workgroup:
+  // twice the workgroups (the 64-point form occupies 79 of the 256 CUs) at 64 KiB of LDS: 272 -> 205 us.
+  constexpr bool SMALL_OK = KIND == 2 && MODE == 0;      // (the value+Jacobian launch measured 244 us with 32 columns, 213 with 64)
+  const bool small = SMALL_OK && plan.variant == 0 && n_pts * int64_t(n_rows) * (KIND == 1 ? 4 : 1) <= 64 * 1024
+#ifdef NPHM_MLP_NO_SMALL
+                     && false
+#endif
+      ;
+  const int M = (small ? 32 : plan.variant == 0 ? 64 : 32) / (KIND == 1 ? 4 : 1);      // points per workgroup
   const int64_t tiles = (n_pts + M - 1) / M;
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * WAVES);
   hipError_t e;
-  if (plan.variant == 0) {
+  if (small) {
+    if constexpr (SMALL_OK) {
+      auto k = mlp_eval_kernel<1, 2, MODE, KIND>;
+      constexpr size_t lds = lds_bytes<1, 2>();
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
+      hipLaunchKernelGGL(k, grid, block, lds, st, a);
+    }
+  } else if (plan.variant == 0) {
     auto k = mlp_eval_kernel<2, 2, MODE, KIND>;
     constexpr size_t lds = lds_bytes<2, 2>();
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -704,7 +722,7 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
   a.cond = cond_rows;
   a.lat_dim = lat_dim;
   a.state = static_cast<char*>(latent_state);
-  hipLaunchKernelGGL(nphm::mlp::mlp_prepare_kernel, dim3(a.plan.n_linear, n_rows), dim3(256), 0,
+  hipLaunchKernelGGL(nphm::mlp::mlp_prepare_kernel, dim3(a.plan.n_linear, n_rows), dim3(1024), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_mlp_prepare_latent launch", e);

@@ -17,6 +17,7 @@ Execution tiers (same policy as the identity field, ensembled_deepsdf.py):
 from __future__ import annotations
 
 import math
+from contextlib import contextmanager
 from typing import Optional
 
 import numpy as np
@@ -98,6 +99,7 @@ class DeepSDF(nn.Module):
         self.backend = "hip"            # "hip" | "composite"
         self._pack_cache = None         # (key, packed tensor)
         self._pack_bwd_cache = None     # (key, transposed pack of the backward kernel)
+        self._state_scope = None        # inside DeformationNetwork.condition_scope(): {cond tensor key: (tensor, state)}
         print(d_in)
         print(hidden_dim)
         dims = [d_in] + [hidden_dim] * nlayers + [out_dim]
@@ -218,6 +220,14 @@ class DeepSDF(nn.Module):
         lib = _lib.load()
         device = cond_rows.device
         packed = self._packed(device)
+        key = None
+        if self._state_scope is not None:
+            # same conditioning tensor again inside one condition_scope (the scope keeps it alive: no address reuse)
+            key = (cond_rows.data_ptr(), cond_rows._version, tuple(cond_rows.shape), tuple(cond_rows.stride()))
+            hit = self._state_scope.get(key)
+            if hit is not None:
+                return packed, hit[1]
+        cond_in = cond_rows
         cond_rows = cond_rows.contiguous().float()
         B = cond_rows.shape[0]
         state = torch.empty(lib.nphm_mlp_latent_state_bytes(*self._arch(), B), dtype=torch.uint8, device=device)
@@ -226,6 +236,8 @@ class DeepSDF(nn.Module):
         _lib.check(lib.nphm_mlp_prepare_latent(*self._arch(), _lib.ptr_array(ws), _lib.ptr_array(bs),
                                                cond_rows.data_ptr(), B, state.data_ptr(), stream),
                    "nphm_mlp_prepare_latent")
+        if key is not None:
+            self._state_scope[key] = (cond_in, state)
         return packed, state
 
     def forward_hip(self, xyz, cond_rows, add_input=False):
@@ -379,8 +391,35 @@ class DeformationNetwork(nn.Module):
                                   geometric_init=False, out_dim=out_dim, input_dim=input_dim).float()
         self.anchors = anchors
 
+    @contextmanager
+    def condition_scope(self):
+        """Inside the scope, calls that pass the SAME ``lat_rep`` / ``anchors`` tensors (same storage and version;
+        no gradient involved) share one conditioning row and one kernel prologue - the fitting step evaluates the
+        field four times per step on one set of codes (search Jacobian, Broyden, posed points, Jacobian of the
+        implicit differentiation).  The scope holds the tensors, so an address cannot be recycled under it."""
+        self._cond_scope, self.defDeepSDF._state_scope = {}, {}
+        try:
+            yield self
+        finally:
+            self._cond_scope, self.defDeepSDF._state_scope = None, None
+
     def _condition(self, xyz, lat_rep, anchors):
         """Conditioning vector [B,Lr,lat_dim] (Lr = 1 when it is constant along the points)."""
+        scope = getattr(self, "_cond_scope", None)
+        key = None
+        if (scope is not None and self.mode == "compress" and not self.training and anchors is not None
+                and not (torch.is_grad_enabled() and (lat_rep.requires_grad or anchors.requires_grad))):
+            key = (lat_rep.data_ptr(), lat_rep._version, tuple(lat_rep.shape), tuple(lat_rep.stride()),
+                   anchors.data_ptr(), anchors._version, tuple(anchors.shape), tuple(anchors.stride()))
+            hit = scope.get(key)
+            if hit is not None:
+                return hit[0]
+        cond = self._condition_impl(xyz, lat_rep, anchors)
+        if key is not None:
+            scope[key] = (cond, lat_rep, anchors)
+        return cond
+
+    def _condition_impl(self, xyz, lat_rep, anchors):
         B, N, _ = xyz.shape
         e = self.lat_dim_expr
         g = self.lat_dim_glob_shape

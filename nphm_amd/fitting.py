@@ -10,7 +10,7 @@ Same signatures, RNG consumption order, schedules and loss terms as the referenc
 keyword-only (``verbose``, ``history``)."""
 from __future__ import annotations
 
-from contextlib import contextmanager
+from contextlib import contextmanager, nullcontext
 from typing import Dict, List, Optional
 
 import torch
@@ -305,6 +305,10 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         use_graph = _graph_default(device, verbose, decoder, decoder_expr) and not compute_unused_sdf_grad
 
     def body():
+        with (decoder_expr.condition_scope() if hasattr(decoder_expr, "condition_scope") else nullcontext()):
+            return body_in_scope()
+
+    def body_in_scope():
         # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
         anchors = _anchors_of(decoder, lat_rep_shape, device)
         obs_idx, obs = sampler.gather(drawn_dev)
