@@ -220,6 +220,18 @@ __device__ __forceinline__ void pack_pair(const f32x16& a, ActB& o) {
 constexpr int NW = NPHM_NW;
 // voxel brick of a workgroup in grid mode: every wavefront owns a 4x4x2 sub-brick
 constexpr int BRX = NW == 8 ? 8 : 4, BRY = NW == 8 ? 8 : 4, BRZ = NW == 8 ? 4 : 8;
+// voxel tile of ONE wavefront (32 points): TLX x TLY x TLZ, z fastest: 4 x 4 x 2.  2 x 4 x 4 (-DNPHM_TILE_Z=4: 16-byte instead of
+// 8-byte z-runs per store, the same compactness - 8.6 x 19.6 x 21.2 against 17.2 x 19.6 x 10.6 lattice spacings of the fitting box
+// at 256^3) measured WRITE_SIZE 155 -> 131 MB per 256^3 launch (67 MB of payload) at -0.8 % throughput: not taken, the
+// writes are 0.4 % of the launch's HBM time either way.
+#ifndef NPHM_TILE_Z
+#define NPHM_TILE_Z 2
+#endif
+constexpr int TLZ = NPHM_TILE_Z, TLY = 4, TLX = 32 / (TLY * TLZ);
+static_assert(TLX * TLY * TLZ == 32 && (TLZ == 2 || TLZ == 4), "a wavefront's tile holds 32 voxels");
+__host__ __device__ constexpr int tile_dx(int j) { return j / (TLY * TLZ); }
+__host__ __device__ constexpr int tile_dy(int j) { return (j / TLZ) % TLY; }
+__host__ __device__ constexpr int tile_dz(int j) { return j % TLZ; }
 // bricks are enumerated super-brick by super-brick (2x4x4 bricks) so that the workgroups resident
 // on one XCD at any time cover a compact region and stream the same few members (L2 reuse)
 constexpr int SBX = 2, SBY = 4, SBZ = 4;
@@ -670,9 +682,9 @@ __device__ __forceinline__ void tile_lane(const EvalArgs& p, unsigned t, int j, 
   const int tz = int(t % unsigned(p.ntz));
   const unsigned r = t / unsigned(p.ntz);
   const int ty = int(r % unsigned(p.nty)), tlx = int(r / unsigned(p.nty));
-  lx = tlx * 4 + (j >> 3);
-  iy = ty * 4 + ((j >> 1) & 3);
-  iz = tz * 2 + (j & 1);
+  lx = tlx * TLX + tile_dx(j);
+  iy = ty * TLY + tile_dy(j);
+  iz = tz * TLZ + tile_dz(j);
 }
 
 __global__ __launch_bounds__(256) void tile_prepass_kernel(EvalArgs p) {
@@ -742,10 +754,12 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     const int bx = bid * SBX + inner / (SBY * SBZ);
     const int by = sy * SBY + (inner / SBZ) % SBY;
     const int bz = sz * SBZ + inner % SBZ;
-    const int wx = NW == 8 ? (wave & 1) : 0, wy = NW == 8 ? ((wave >> 1) & 1) : 0;
-    const int wz = NW == 8 ? (wave >> 2) : wave;
-    const GridPoint g = grid_point(p, bx * BRX + wx * 4 + (j >> 3), by * BRY + wy * 4 + ((j >> 1) & 3),
-                                   bz * BRZ + wz * 2 + (j & 1), true);
+    // the wavefronts' tiles fill the brick x-fastest
+    constexpr int WTX = BRX / TLX, WTY = BRY / TLY;
+    static_assert(BRX % TLX == 0 && BRY % TLY == 0 && BRZ % TLZ == 0 && WTX * WTY * (BRZ / TLZ) == NW, "brick = NW tiles");
+    const int wx = wave % WTX, wy = (wave / WTX) % WTY, wz = wave / (WTX * WTY);
+    const GridPoint g = grid_point(p, bx * BRX + wx * TLX + tile_dx(j), by * BRY + wy * TLY + tile_dy(j),
+                                   bz * BRZ + wz * TLZ + tile_dz(j), true);
     valid = g.valid; hack = g.hack; out_idx = g.out_idx; qx = g.qx; qy = g.qy; qz = g.qz;
   } else {
     // binned tiles: slot -> tile through the sorted order of tile_prepass_kernel
@@ -1125,7 +1139,7 @@ struct BinLayout {
   size_t order, ids, keys_in, keys_out, masks, sd, temp, temp_bytes, bytes;
 };
 bool bin_layout(int nlx, int ry, int rz, BinLayout& l) {
-  l.ntx = (nlx + 3) / 4; l.nty = (ry + 3) / 4; l.ntz = (rz + 1) / 2;
+  l.ntx = (nlx + nphm::TLX - 1) / nphm::TLX; l.nty = (ry + nphm::TLY - 1) / nphm::TLY; l.ntz = (rz + nphm::TLZ - 1) / nphm::TLZ;
   l.n_tiles = int64_t(l.ntx) * l.nty * l.ntz;
   if (l.n_tiles <= 0 || l.n_tiles > 0x3fffffffLL) return false;
   size_t o = 0;
