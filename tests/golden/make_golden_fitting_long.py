@@ -112,7 +112,8 @@ def main():
                anchors=anc.detach().numpy(), id_keys=np.array(keys_id), id_total_loss=hist_id,
                id_lat_shape=lat_s2.detach().numpy(), id_anchors=anc2.detach().numpy(),
                shape_sha256=G.state_hash(shape_net), expr_sha256=G.state_hash(expr_net))
-    np.savez_compressed(os.path.join(HERE, "fitting_long.npz"), **out)
+    out["torch_threads"] = np.int64(torch.get_num_threads())
+    np.savez_compressed(os.environ.get("NPHM_GOLDEN_OUT", os.path.join(HERE, "fitting_long.npz")), **out)
     print("fitting_long.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
     print(hist[::25])
 
