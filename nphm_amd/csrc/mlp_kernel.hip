@@ -167,21 +167,43 @@ struct EvalArgs {
 
 // k softplus(d / k) in base 2 (see mlp_layout.h); agrees with nn.Softplus(beta=100, threshold=20)
 // to < 1e-9 in unscaled units
+#ifndef NPHM_MLP_SOFTPLUS4
+#define NPHM_MLP_SOFTPLUS4 1
+#endif
 __device__ __forceinline__ float softplus2(float d) {
+#if NPHM_MLP_SOFTPLUS4
+  // log2(1 + 2^d') + one v_med3 that returns d' once 2^d' has overflowed (eval_kernel.hip: 4 issue slots instead of 5)
+  const float r = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(d));
+  return __builtin_amdgcn_fmed3f(d, r, 127.f);
+#else
   const float t = __builtin_amdgcn_exp2f(-fabsf(d));
   return fmaxf(d, 0.f) + __builtin_amdgcn_logf(1.f + t);   // one v_max_f32 under -fno-honor-nans
+#endif
 }
 
 struct Split8 { bf16x8 hi, lo; };
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// 8 values -> bf16 hi | lo operands: per pair one packed convert, a shift / a mask back to fp32, the residuals through a
+// second packed convert (the generic __bf16 casts made hipcc convert every value twice)
 __device__ __forceinline__ Split8 split8(const float* x) {
-  Split8 o;
+  u32x4 h, l;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 hb = (__bf16)x[i];
-    o.hi[i] = hb;
-    o.lo[i] = (__bf16)(x[i] - (float)hb);
+  for (int q = 0; q < 4; ++q) {
+    const unsigned ph = cvt_pk_bf16(x[2 * q], x[2 * q + 1]);
+    const float h0 = __builtin_bit_cast(float, ph << 16), h1 = __builtin_bit_cast(float, ph & 0xffff0000u);
+    h[q] = ph;
+    l[q] = cvt_pk_bf16(x[2 * q] - h0, x[2 * q + 1] - h1);
   }
+  Split8 o;
+  o.hi = __builtin_bit_cast(bf16x8, h);
+  o.lo = __builtin_bit_cast(bf16x8, l);
   return o;
 }
 
