@@ -386,17 +386,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   };
   auto tiles_of = [&](int n_tiles) { return n_tiles > wave ? (n_tiles - wave + WAVES - 1) / WAVES : 0; };
   // accumulator init: coordinate K-step (bias, folded latent, xyz columns)
-  auto coord_step = [&](const LayerDev& L, int ni) __attribute__((always_inline)) {
+  bf16x8 cfrag[NTW];
+  auto coord_load = [&](const LayerDev& L, int ni) __attribute__((always_inline)) {
     const bf16x8* C = reinterpret_cast<const bf16x8*>(st + L.c_off) + lane;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+      if (i < ni) cfrag[i] = C[(wave + WAVES * i) * 64];
+  };
+  auto coord_mma = [&](int ni) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
-        const bf16x8 a = C[(wave + WAVES * i) * 64];
 #pragma unroll
         for (int t = 0; t < MT; ++t)
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv[t], zero16, 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag[i], bv[t], zero16, 0, 0, 0);
       }
     }
+  };
+  auto coord_step = [&](const LayerDev& L, int ni) __attribute__((always_inline)) {
+    coord_load(L, ni);
+    coord_mma(ni);
   };
 
   // ---- layer 0: coordinates only ---------------------------------------------------------------
@@ -409,31 +418,44 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   }
 
   // ---- hidden layers ---------------------------------------------------------------------------
+  // A fragments through MUBUF loads: resource = the packed weights, VGPR offset = the lane's constant
+  // 16 bytes, tile / K-step offset in an SGPR - no per-load 64-bit VGPR address arithmetic next to the
+  // MFMA stream (tools/micro/dma.hip: the issue cost of a VGPR-addressed load there is ~3x).
+  // The two-slot register ring lives across the layers: the first two K-steps of layer l+1 are requested right
+  // behind the last MFMAs of layer l (NPHM_MLP_XPREFETCH), so their L2 latency runs under the epilogue and the two
+  // workgroup barriers instead of in front of the next layer's first MFMA.
+#ifndef NPHM_MLP_XPREFETCH
+#define NPHM_MLP_XPREFETCH 1
+#endif
+  const unsigned w_lane = lane * 16;
+  bf16x8 ah[2][NTW], al[2][NTW];
+  auto load_a = [&](const LayerDev& L, int ni, int slot, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (i < ni) {
+        const unsigned o = __builtin_amdgcn_readfirstlane(L.w_off + (unsigned(wave + WAVES * i) * unsigned(L.k_steps) + unsigned(s)) * 2048u);
+        ah[slot][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o, 0));
+        al[slot][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o + 1024u, 0));
+      }
+    }
+  };
+  if (NPHM_MLP_XPREFETCH && p.n_linear > 2) {
+    const LayerDev& L1 = p.layer[1];
+    const int n1 = tiles_of(L1.n_tiles);
+    load_a(L1, n1, 0, 0);
+    load_a(L1, n1, 1, 1);
+  }
 #pragma unroll 1
   for (int l = 1; l < p.n_linear - 1; ++l) {
     const LayerDev& L = p.layer[l];
     const int ni = tiles_of(L.n_tiles);
     const int ks = L.k_steps;
-    coord_step(L, ni);
+    coord_step(L, ni);       // (requesting these fragments a layer ahead as well: +-0, and the Broyden variants spill)
     __syncthreads();                                  // the previous layer's tile is complete
     if (ni > 0) {
-      // A fragments through MUBUF loads: resource = the packed weights, VGPR offset = the lane's constant
-      // 16 bytes, tile / K-step offset in an SGPR - no per-load 64-bit VGPR address arithmetic next to the
-      // MFMA stream (tools/micro/dma.hip: the issue cost of a VGPR-addressed load there is ~3x)
-      const unsigned w_lane = lane * 16;
       const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
       const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
-      bf16x8 ah[2][NTW], al[2][NTW], bh[2][MT], bl[2][MT];
-      auto load_a = [&](int slot, int s) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-          if (i < ni) {
-            const unsigned o = __builtin_amdgcn_readfirstlane(L.w_off + (unsigned(wave + WAVES * i) * unsigned(ks) + unsigned(s)) * 2048u);
-            ah[slot][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o, 0));
-            al[slot][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o + 1024u, 0));
-          }
-        }
-      };
+      bf16x8 bh[2][MT], bl[2][MT];
       auto load_b = [&](int slot, int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -454,8 +476,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           }
         }
       };
-      load_a(0, 0);
-      load_a(1, 1);
+      if (!NPHM_MLP_XPREFETCH) {
+        load_a(L, ni, 0, 0);
+        load_a(L, ni, 1, 1);
+      }
       load_b(0, 0);
 #pragma unroll 1
       for (int s = 0; s < ks; s += 2) {
@@ -463,12 +487,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         mma(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < ks) { load_a(0, s + 2); load_b(0, s + 2); }
+        if (s + 2 < ks) { load_a(L, ni, 0, s + 2); load_b(0, s + 2); }
         __builtin_amdgcn_sched_barrier(0);
         mma(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 3 < ks) load_a(1, s + 3);
+        if (s + 3 < ks) load_a(L, ni, 1, s + 3);
       }
+    }
+    if (NPHM_MLP_XPREFETCH && l + 1 < p.n_linear - 1) {
+      const LayerDev& Ln = p.layer[l + 1];
+      const int nn = tiles_of(Ln.n_tiles);
+      load_a(Ln, nn, 0, 0);
+      load_a(Ln, nn, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     activate(ni, l);
     __syncthreads();                                  // every wavefront has read the old tile
