@@ -389,14 +389,29 @@ def shard_depth(rx: int, world_size: int, unit: int = 8) -> int:
     return max(len(cyclic_planes(rx, world_size, r, unit)) for r in range(world_size))
 
 
+_REORDER_INDEX = {}
+
+
+def reorder_index(rx: int, world_size: int, unit: int, device) -> torch.Tensor:
+    """Row of the gathered [world * depth, plane] buffer that holds global x-plane i, as a device index tensor
+    (cached per partition and device: built and uploaded once, not per step)."""
+    key = (rx, world_size, unit, str(device))
+    index = _REORDER_INDEX.get(key)
+    if index is None:
+        depth = shard_depth(rx, world_size, unit)
+        src = np.empty(rx, np.int64)
+        for r in range(world_size):
+            p = cyclic_planes(rx, world_size, r, unit)
+            src[p] = r * depth + np.arange(len(p))
+        index = torch.from_numpy(src).to(device)
+        _REORDER_INDEX[key] = index
+    return index
+
+
 def reorder_gathered(gathered: torch.Tensor, rx: int, plane: int, world_size: int, unit: int = 8) -> torch.Tensor:
     """[world * depth * plane] rank-major shards of the cyclic partition -> volume in 'ij' order."""
     depth = shard_depth(rx, world_size, unit)
-    src = np.empty(rx, np.int64)                # row of `gathered` that holds global plane x
-    for r in range(world_size):
-        p = cyclic_planes(rx, world_size, r, unit)
-        src[p] = r * depth + np.arange(len(p))
-    index = torch.from_numpy(src).to(gathered.device)
+    index = reorder_index(rx, world_size, unit, gathered.device)
     return gathered.view(world_size * depth, plane).index_select(0, index).reshape(-1)
 
 
