@@ -206,19 +206,21 @@ def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
 
 
 class _IdentityFieldFn(torch.autograd.Function):
-    """sdf = field(xyz; anchors, folded biases) with hand-written forward and first-order backward
-    kernels (member-centric: one workgroup = one member x 64 of the points that member matters for).
-    The kernels work on the HIP prologue's state (built from the detached latent rows); ``anchors`` /
-    ``b0f`` / ``b2f`` are the same quantities as differentiable torch tensors and only receive
-    gradients."""
+    """sdf = field(xyz; latent rows, anchors) with hand-written forward and first-order backward kernels
+    (member-centric: one workgroup = one member x 64 of the points that member matters for).  The kernels work on
+    the HIP prologue's state (built from the latent rows); the backward kernel returns d/dxyz, d/danchors and the
+    gradients of the folded biases of lin0 / the skip layer, which the latent blocks of those two layers map onto
+    the latent rows right here (one batched matrix product) - the latent enters the field through nothing else;
+    ``anchors`` is the differentiable ``mlp_pos`` output and only receives its gradient (chained by autograd).
+    The decoder's parameters are constants on this tier."""
 
     @staticmethod
-    def forward(ctx, module, xyz, lat_rows, anchors, b0f, b2f):
+    def forward(ctx, module, xyz, lat_rows, anchors):
         lib = _lib.load()
         B, N, _ = xyz.shape
         dev = xyz.device
         A = module.num_kps + 1
-        packed, state, _ = module.prepare_latent(lat_rows)
+        packed, state, _ = module.prepare_latent(lat_rows.detach())
         xyz_c = xyz.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         what, tiles, n_used, plist = _member_point_lists_device(state, xyz_c, module.prune_tol, A, stream)
@@ -255,7 +257,12 @@ class _IdentityFieldFn(torch.autograd.Function):
                 packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz.data_ptr(),
                 out.data_ptr(), g.data_ptr(), N, tiles.data_ptr(), tiles.shape[0], n_used.data_ptr(), plist.data_ptr(), gx.data_ptr(),
                 ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_backward")
-        return None, gx, None, ga, gb0, gb2
+        # folded bias of member k: W0[k][:, lat] cond_k + b (lin0), W2[k][:, lat] cond_k / sqrt2 + b (skip layer), with
+        # cond_k = [z_glob | z_k]: d/dcond_k = gb0_k W0_lat[k] + gb2_k W2_lat[k] / sqrt2, then back onto the latent layout
+        g_cond = torch.bmm(torch.cat([gb0, gb2], dim=2).transpose(0, 1), module._latent_blocks(dev)).transpose(0, 1)   # [B,A,96]
+        g = module.lat_dim_glob
+        g_lat = torch.cat([g_cond[..., :g].sum(dim=1), g_cond[..., g:].reshape(B, -1)], dim=-1)
+        return None, gx, g_lat, ga
 
 
 class FastEnsembleDeepSDFMirrored(nn.Module):
@@ -311,6 +318,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         need this call.  ``load_state_dict`` and ``_apply`` (``.to()/.float()/.cuda()``) call it themselves."""
         self._pack_cache = None
         self._pack_bwd_cache = None
+        self._lat_blocks_cache = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -354,6 +362,22 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
                    "nphm_identity_pack")
         self._pack_cache = (key, packed)
         return packed
+
+    def _latent_blocks(self, device):
+        """[A, 2H, 96]: per member the latent columns of lin0 stacked on those of the skip layer (/ sqrt 2) - what maps
+        the backward kernel's bias gradients onto the latent rows (cached like _packed)."""
+        e = self.ensembled_deep_sdf
+        ws = [e.lin0.weight, e.lin2.weight]
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in ws) + (str(device),)
+        cache = getattr(self, "_lat_blocks_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        with torch.no_grad():
+            d_in, n1 = self.input_dim, e.lin1.out_features
+            blocks = torch.cat([e.lin0.member_weight()[:, :, d_in:], e.lin2.member_weight()[:, :, n1 + d_in:] / _SQRT2],
+                               dim=1).to(device).contiguous()
+        self._lat_blocks_cache = (key, blocks)
+        return blocks
 
     def _packed_bwd(self, device):
         """Transposed split-bf16 pack of lin0..lin3 for nphm_identity_backward (cached like _packed)."""
@@ -423,15 +447,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             h = torch.nn.functional.linear(h, const(lin.weight), const(lin.bias)) if isinstance(lin, nn.Linear) else lin(h)
         anchors = h.view(B, self.num_kps, 3)
         anchors = anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
-        cond = torch.cat([lat_rows[:, None, :g].expand(B, A, g), lat_rows[:, g:].reshape(B, A, self.lat_dim_loc)], dim=-1)
-        e = self.ensembled_deep_sdf
-        d_in = self.input_dim
-        n1 = e.lin1.out_features                          # width of the skip layer's hidden part
-        W0 = const(e.lin0.member_weight())[:, :, d_in:]          # [A, H, 96] latent columns of lin0
-        W2 = const(e.lin2.member_weight())[:, :, n1 + d_in:]     # [A, H, 96] latent columns of the skip layer
-        b0f = torch.einsum("bkc,kfc->bkf", cond, W0) + const(e.lin0.member_bias())[None]
-        b2f = torch.einsum("bkc,kfc->bkf", cond, W2) / _SQRT2 + const(e.lin2.member_bias())[None]
-        sdf = _IdentityFieldFn.apply(self, xyz, lat_rows.detach(), anchors, b0f, b2f)
+        sdf = _IdentityFieldFn.apply(self, xyz, lat_rows, anchors)
         return sdf, anchors
 
     def predict_anchors(self, lat_rep: torch.Tensor) -> torch.Tensor:
