@@ -10,7 +10,11 @@ surface-loss clamp (steps 62 and 125).  Observations: three synthetic scans of 4
 level set of a seeded ground-truth identity (random points projected onto the level set of the
 reference network by Newton steps along its gradient; no dataset here).  Stored: observations,
 per-step loss terms as the reference prints them (8 decimals), the fitted codes and anchors; for the
-identity-only loop (which prints nothing) the total loss of every step and the fitted code."""
+identity-only loop (which prints nothing) the total loss of every step and the fitted code.
+
+Takes ~40 minutes on 8 cores (the reference's dense 40-member double-graph step on the CPU).  Regenerating it in
+the build container (8 torch threads, recorded in the fixture) reproduced every array of the committed file bit
+for bit."""
 import io
 import os
 import sys
