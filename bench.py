@@ -573,14 +573,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # dry runs of the N > 1 code path on a box with ONE GPU: NPHM_BENCH_DEVICE=0 puts every rank on that device and
+    # NPHM_BENCH_DIST_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device); timings are meaningless
+    dev_index = int(os.environ.get("NPHM_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("NPHM_BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run (any N)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     ib = IdentityBench(args, dev, world, rank, distributed)
     binned = not args.no_binning
