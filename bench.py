@@ -38,9 +38,10 @@ FLOP_DENSE = 9_616_000            # reference formulation, 40 x 2 x 120 200 (SUR
 FLOP_MEMBER_FOLDED = 2 * 81_800   # one member, one point, latent folded
 FLOP_DEFORMATION_FOLDED = 2 * 1_074_688   # deformation backbone, latent folded
 FLOP_NPM_FOLDED = 2 * 6_292_480
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16x3a": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16x3a": 2500.0, "bf16x3a2": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
 DTYPE = {"f32": "f32", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)",
-         "bf16x3a": "bf16x3 adaptive(split-bf16 MFMA for blend weights >= 1e-3, single-pass bf16 below)"}
+         "bf16x3a": "bf16x3 adaptive(split-bf16 MFMA for blend weights >= 1e-3, single-pass bf16 below)",
+         "bf16x3a2": "bf16x3 adaptive(split-bf16 MFMA: 3 passes for blend weights >= 1e-2, 2 passes >= 1e-3, single-pass bf16 below)"}
 
 
 def parse():
@@ -50,7 +51,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--prune-tol", type=float, default=None)
-    ap.add_argument("--precision", default="bf16x3a", choices=["f32", "bf16x3", "bf16x3a"])
+    ap.add_argument("--precision", default="bf16x3a2", choices=["f32", "bf16x3", "bf16x3a", "bf16x3a2"])
     ap.add_argument("--chunk", type=int, default=25000, help="get_logits chunk whose last voxel is overwritten (eval mode)")
     ap.add_argument("--workload", default="all", choices=["all", "identity", "two_stage", "npm", "fitting"],
                     help="all (default) = the contract line for configs[1] with every other config / precision as "
@@ -196,14 +197,15 @@ class IdentityBench:
         n_local = max(1, self.n_planes * self.plane)
         mean_active = float(active[0]) / max(1, steps) / n_local            # evaluated member-points / point
         passes = 1 if precision == "f32" else 3     # the split-bf16 path issues 3 bf16 MFMA products per fp32 product
-        mean_light = float(active[15]) / max(1, steps) / n_local            # single-pass pairs (adaptive mode)
-        exec_flops = (passes * (mean_active - mean_light) + mean_light) * FLOP_MEMBER_FOLDED * n_local
+        mean_light = float(active[15]) / max(1, steps) / n_local            # single-pass pairs (adaptive modes)
+        mean_mid = float(active[14]) / max(1, steps) / n_local              # two-pass pairs (bf16x3a2)
+        exec_flops = (passes * (mean_active - mean_light - mean_mid) + 2 * mean_mid + mean_light) * FLOP_MEMBER_FOLDED * n_local
         peak = PEAK_TFLOPS[precision]
         achieved = exec_flops / (k_ms * 1e-3) / 1e12
         # the events bracket the whole grid call: with binning that is the tile pre-pass + radix sort
         # (together ~1 % of it) + the dominant kernel
         kname = "nphm::eval_kernel<%d,%d>" % (2 if binned else 1, 0 if precision == "f32" else 1)
-        tkey = kname if precision == "bf16x3a" else kname + ":" + precision
+        tkey = kname if precision in ("bf16x3a", "bf16x3a2") else kname + ":" + precision
         return {
             "value": n_total * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "dtype": DTYPE[precision],
@@ -212,6 +214,7 @@ class IdentityBench:
                          "kernel": kname, "rank0_planes": self.n_planes, "binned_tiles": binned,
                          "kernel_ms": k_ms, "points_per_launch": n_local,
                          "executed_flops_per_point": exec_flops / n_local, "mean_single_pass_members": mean_light,
+                         "mean_two_pass_members": mean_mid,
                          "mfma_passes": passes, "mean_active_members": mean_active,
                          "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12},
         }
@@ -607,7 +610,7 @@ def main():
                                        "kernel of step k+1)" if distributed else "single GPU")},
             "roofline": dict(rec["roofline"], note=(
                 "achieved counts EXECUTED matrix FLOPs (tile padding excluded): the adaptive default issues one pass instead "
-                "of three for ~46% of the evaluated members, so it is faster at a lower FLOP rate; `peak` is the datasheet figure - "
+                "of three for ~46% of the evaluated members and two for ~17%, so it is faster at a lower FLOP rate; `peak` is the datasheet figure - "
                 "an MFMA-only loop sustains `mfma_sustained.tflops` on this box (power-limited clock, tools/micro/chain.hip), "
                 "which with the kernel's 17.6% tile padding bounds `frac` at about 0.5 (DESIGN.md section 4.1)")),
             "mesh_extract": mesh,
@@ -616,7 +619,7 @@ def main():
             sub_steps = max(2, min(args.steps, 5))
             out["mfma_sustained"] = mfma_sustained(dev)
             out["precisions"] = {p: ib.record(p, sub_steps if p != "f32" else 2, 1, binned)
-                                 for p in ("bf16x3", "f32") if p != args.precision}
+                                 for p in ("bf16x3a", "bf16x3", "f32") if p != args.precision}
             out["configs"] = {
                 "npm_64": npm_record(args, dev, max(sub_steps, 5), 2, not args.no_cpu_baseline),
                 "two_stage_256": two_stage_record(args, dev, sub_steps, 1),

@@ -53,6 +53,9 @@ int nphm_identity_supported(int lat_dim_glob, int lat_dim_loc, int n_loc, int n_
                                         (hi*hi) for the others: their error enters the blend scaled by
                                         a weight < NPHM_LIGHT_TOL */
 #define NPHM_LIGHT_TOL 1e-3f
+#define NPHM_PREC_BF16X3_ADAPTIVE2 3 /* ... and two passes (xh*wh + xl*wh: weights rounded to bf16) for members that stay between
+                                        NPHM_LIGHT_TOL and NPHM_MID_TOL in the wavefront; three passes from NPHM_MID_TOL on */
+#define NPHM_MID_TOL 1e-2f
 
 size_t nphm_identity_packed_bytes(void);
 size_t nphm_identity_latent_state_bytes(int n_rows);

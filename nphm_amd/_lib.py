@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("NPHM_AMD_LIB") or os.path.join(_HERE, "libnphm_amd.so
 NPHM_PREC_F32 = 0
 NPHM_PREC_BF16X3 = 1
 NPHM_PREC_BF16X3_ADAPTIVE = 2
+NPHM_PREC_BF16X3_ADAPTIVE2 = 3
 
 _PtrArr5 = c_void_p * 5
 _PtrArr3 = c_void_p * 3

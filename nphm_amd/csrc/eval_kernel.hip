@@ -41,6 +41,7 @@ struct EvalArgs {
   unsigned long long* stats;
   float prune_tol;
   float light_tol;          // bf16 path: members below this normalised weight in a wavefront run single-pass
+  float mid_tol;            // ... members below THIS one (and >= light_tol) two-pass: xh wh + xl wh, weights rounded to bf16
   // MODE 0 (points)
   const float* xyz;         // [n_rows, n_points, 3]
   int64_t n_points;
@@ -53,7 +54,7 @@ struct EvalArgs {
   int64_t hack_chunk;
   // MODE 2 (grid, tiles binned by member mask; written by tile_prepass_kernel + a radix sort)
   const unsigned* tile_order;   // slot -> tile id, tiles of equal member masks adjacent
-  uint64_t* tile_masks;         // [tile][2]: members evaluated by the tile's wavefront, ... with 3 passes
+  uint64_t* tile_masks;         // [tile][3]: members evaluated by the tile's wavefront, ... with more than one pass, ... with three passes
   float2* tile_sd;              // [tile][32]: (sum of blend weights, normaliser) of every point
   uint64_t* tile_keys;          // sort keys (pre-pass output)
   unsigned* tile_ids;           // identity permutation (pre-pass output)
@@ -73,6 +74,9 @@ struct EvalArgs {
 #endif
 #ifndef NPHM_PERIOD
 #define NPHM_PERIOD 2   // chunks per workgroup barrier
+#endif
+#ifndef NPHM_HEAVY_PASSES
+#define NPHM_HEAVY_PASSES 3   // experiment: 2 = drop the wl x xh product of three-pass members (weights rounded to bf16)
 #endif
 #ifndef NPHM_SOFTPLUS4
 #define NPHM_SOFTPLUS4 1   // 1: softplus as log2(1 + 2^d) + v_med3 (4 VALU), 0: max + log2(1 + 2^-|d|) (5 VALU)
@@ -485,7 +489,7 @@ __host__ __device__ constexpr bool epilogue_exposed(int P) {
 // in the shadow of that MFMA (32 cycles of matrix pipe, 4 of issue) - measured in
 // tools/micro/overlap.hip: MFMA + softplus interleaved in one wavefront cost max(...) + ~15 %, not the sum.
 // sched_barrier(0) after every slot keeps hipcc from regrouping the stream.
-template <int NKS16, int FULL, int NIN, bool LIGHT, int PF, int NU, class Epi, class Pre, class Slot>
+template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, class Epi, class Pre, class Slot>
 __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc, const ActB (&in)[NIN],
                                                   int lane, Epi&& epi, Pre&& pre, Slot&& slot_hook) {
   const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
@@ -493,15 +497,15 @@ __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc,
 #pragma unroll
   for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
     wh[ks] = A[(2 * ks) * 64];
-    if (!LIGHT) wl[ks] = A[(2 * ks + 1) * 64];
+    if (NPASS == 3) wl[ks] = A[(2 * ks + 1) * 64];
   }
-  constexpr int NM = LIGHT ? 1 : 3;        // MFMAs per K-step
+  constexpr int NM = NPASS;                // MFMAs per K-step: hh | hh, hl | hh, hl, lh
   constexpr int NS = NKS16 * NM;           // issue slots
   static_for<NKS16>([&](auto kk) __attribute__((always_inline)) {
     constexpr int ks = decltype(kk)::value;
     if constexpr (ks + PF < NKS16) {
       wh[ks + PF] = A[(2 * (ks + PF)) * 64];
-      if (!LIGHT) wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
+      if (NPASS == 3) wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
     }
     pre(kk);                               // one piece of the weight prefetch (LDS-DMA issue) per K-step
     __builtin_amdgcn_sched_barrier(0);     // the reads above are issued HERE, ahead of the MFMAs
@@ -596,8 +600,8 @@ __device__ __forceinline__ float blend_weight(float dx, float dy, float dz) {
 // The cut is the largest of 6 candidate thresholds whose cumulated weight stays within the budget.
 template <bool SPLIT>
 __device__ __forceinline__ void blend_masks(const float* anch, float qx, float qy, float qz, bool valid, bool hack,
-                                            float prune_tol, float light_tol, float& S_out, float& denom_out,
-                                            uint64_t (&wmask)[2], uint64_t (&hmask)[2]) {
+                                            float prune_tol, float light_tol, float mid_tol, float& S_out, float& denom_out,
+                                            uint64_t (&wmask)[2], uint64_t (&hmask)[2], uint64_t (&fmask)[2]) {
   // the 39 anchor weights of this lane's point are computed ONCE and kept in registers: the three
   // passes below index them statically (unrolled)
   float wv[N_LOC];
@@ -624,7 +628,8 @@ __device__ __forceinline__ void blend_masks(const float* anch, float qx, float q
   };
   float thr = prune_tol * denom;
   wmask[0] = wmask[1] = 0;                 // members this wavefront evaluates (wave-uniform)
-  hmask[0] = hmask[1] = ~0ull;             // ... of which with the full split-bf16 product ("heavy")
+  hmask[0] = hmask[1] = ~0ull;             // ... of which with more than the single-pass product
+  fmask[0] = fmask[1] = ~0ull;             // ... of which with the full three-pass product ("heavy")
   if (prune_tol < 0.f) {
     const uint64_t b = __ballot(valid);
     const uint64_t all = (1ull << N_MEMBERS) - 1;
@@ -632,6 +637,7 @@ __device__ __forceinline__ void blend_masks(const float* anch, float qx, float q
     else wmask[0] = b ? all : 0ull;
   } else {
     hmask[0] = hmask[1] = 0;
+    fmask[0] = fmask[1] = 0;
     // candidates 1, 2, 4, 8, 16, 40 x thr; below(c) = weight of the members not above c is monotone in c,
     // so the largest fitting candidate is found by bisection: 3 passes over the 40 weights instead of 6
     auto below = [&](float c) __attribute__((always_inline)) {
@@ -654,6 +660,11 @@ __device__ __forceinline__ void blend_masks(const float* anch, float qx, float q
 #pragma unroll
     for (int k = 0; k < N_LOC; ++k) any(live && wv[k] >= heavy_thr, 1ull << k, hmask);
     any(live && w_bg >= heavy_thr, 1ull << N_LOC, hmask);
+    // ... and the three-pass product only if they weigh >= mid_tol somewhere (mid_tol <= light_tol: no two-pass tier)
+    const float full_thr = mid_tol * denom;
+#pragma unroll
+    for (int k = 0; k < N_LOC; ++k) any(live && wv[k] >= full_thr, 1ull << k, fmask);
+    any(live && w_bg >= full_thr, 1ull << N_LOC, fmask);
   }
 }
 
@@ -696,14 +707,15 @@ __global__ __launch_bounds__(256) void tile_prepass_kernel(EvalArgs p) {
   tile_lane(p, in_tile ? t : 0u, j, lx, iy, iz);
   const GridPoint g = grid_point(p, lx, iy, iz, in_tile);
   float S, denom;
-  uint64_t wmask[2], hmask[2];
-  blend_masks<true>(p.state + LS_OFF_ANCH, g.qx, g.qy, g.qz, g.valid, g.hack, p.prune_tol, p.light_tol, S, denom, wmask, hmask);
+  uint64_t wmask[2], hmask[2], fmask[2];
+  blend_masks<true>(p.state + LS_OFF_ANCH, g.qx, g.qy, g.qz, g.valid, g.hack, p.prune_tol, p.light_tol, p.mid_tol, S, denom, wmask, hmask, fmask);
   if (!in_tile) return;
   p.tile_sd[size_t(t) * 32 + j] = make_float2(S, denom);
   if (j == 0) {
-    const uint64_t w = wmask[half], h = hmask[half] & w;
-    p.tile_masks[2 * size_t(t)] = w;
-    p.tile_masks[2 * size_t(t) + 1] = hmask[half];
+    const uint64_t w = wmask[half], h = (hmask[half] & w) ^ ((fmask[half] & w) * 0x9E3779B97F4A7C15ull);
+    p.tile_masks[3 * size_t(t)] = w;
+    p.tile_masks[3 * size_t(t) + 1] = hmask[half];
+    p.tile_masks[3 * size_t(t) + 2] = fmask[half];
     // 40 mask bits + 24 bits that tell different heavy sets of one mask apart
     const uint64_t hh = (h * 0x9E3779B97F4A7C15ull) >> 40;
     p.tile_keys[t] = (w << 24) | hh;
@@ -778,18 +790,19 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
 
   // ---- blend normaliser and active-member mask: computed here, or read from the binning pre-pass ----
   float S, denom;
-  uint64_t wmask, hmask;
+  uint64_t wmask, hmask, fmask;
   const float w_bg = expf(-0.2f / 0.01f);
   if (MODE == 2) {
     const float2 sd = p.tile_sd[size_t(tile) * 32 + j];
     S = sd.x; denom = sd.y;
     const bool in_tile = binned_group(blockIdx.x) * NW + wave < unsigned(p.n_tiles);
-    wmask = in_tile ? p.tile_masks[2 * size_t(tile)] : 0ull;
-    hmask = in_tile ? p.tile_masks[2 * size_t(tile) + 1] : 0ull;
+    wmask = in_tile ? p.tile_masks[3 * size_t(tile)] : 0ull;
+    hmask = in_tile ? p.tile_masks[3 * size_t(tile) + 1] : 0ull;
+    fmask = in_tile ? p.tile_masks[3 * size_t(tile) + 2] : 0ull;
   } else {
-    uint64_t wm[2], hm[2];
-    blend_masks<false>(anch, qx, qy, qz, valid, hack, p.prune_tol, p.light_tol, S, denom, wm, hm);
-    wmask = wm[0]; hmask = hm[0];
+    uint64_t wm[2], hm[2], fm[2];
+    blend_masks<false>(anch, qx, qy, qz, valid, hack, p.prune_tol, p.light_tol, p.mid_tol, S, denom, wm, hm, fm);
+    wmask = wm[0]; hmask = hm[0]; fmask = fm[0];
   }
 
   const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
@@ -797,6 +810,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     atomicAdd(p.stats, nv * __popcll(wmask));
     atomicAdd(p.stats + 1, nv);
     atomicAdd(p.stats + 15, nv * __popcll(wmask & ~hmask));      // single-pass ("light") pairs
+    atomicAdd(p.stats + 14, nv * __popcll(wmask & hmask & ~fmask));   // two-pass pairs
   }
 
   // ---- union over the workgroup: the members whose weights get streamed ----------------------
@@ -845,6 +859,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     // adaptive precision (bf16 path): single-pass products for a member that weighs < light_tol at
     // every point of this wavefront (its error enters the blend scaled by that weight)
     const bool light = PREC == 1 && !((hmask >> k) & 1ull);
+    const bool mid = PREC == 1 && !light && !((fmask >> k) & 1ull);     // two-pass tier
 
     // local coordinates (EnsembledDeepSDF.py:240-244): anchor-relative, odd member of a
     // symmetric pair mirrored in x, background member uses global coordinates
@@ -885,7 +900,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     f32x4 w4q = {};
     auto epi_unit = [&](auto PP, auto LL, auto uu) __attribute__((always_inline)) {
       constexpr int P = decltype(PP)::value, r = decltype(uu)::value;
-      constexpr bool LIGHT = decltype(LL)::value;
+      constexpr bool LIGHT = decltype(LL)::value == 1;
       f32x16& a = accs[P & 1];
       constexpr int g = P - 1;
       constexpr bool last_block = P == 0 || g == L1_OB - 1 || g == L1_OB + L2_OB - 1 || P == CHUNKS_PER_MEMBER - 1;
@@ -933,7 +948,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     // unit r of the epilogue of L0 block B (accumulator accs[B & 1]) -> H[B]
     auto epi_l0 = [&](auto BB, auto LL, auto uu) __attribute__((always_inline)) {
       constexpr int B = decltype(BB)::value, r = decltype(uu)::value;
-      constexpr bool LIGHT = decltype(LL)::value;
+      constexpr bool LIGHT = decltype(LL)::value == 1;
       constexpr int NR = B == 6 ? LAST_BLOCK_REGS : 16;
       f32x16& a = l0_acc(BB);
       const float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
@@ -995,7 +1010,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     constexpr bool L0_FUSED = PREC == 1 && NPHM_L0_FUSED;
     auto step = [&](auto cc, auto LL) __attribute__((always_inline)) {
       constexpr int c = decltype(cc)::value;
-      constexpr bool LIGHT = decltype(LL)::value;
+      constexpr int TIER = decltype(LL)::value;            // 0: three passes, 1: one ("light"), 2: two
+      constexpr bool LIGHT = TIER == 1;
+      constexpr int NPASS = TIER == 1 ? 1 : TIER == 2 ? 2 : NPHM_HEAVY_PASSES;
       const char* buf = ws.slot(c);
       if constexpr (c == 0) {
         l0_mfma(std::integral_constant<int, 0>{});
@@ -1030,7 +1047,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         };
         auto slot_hook = [&](auto kk, auto mm) __attribute__((always_inline)) {
           if constexpr (L0_FUSED && c == 1) {
-            constexpr int ks = decltype(kk)::value, m = decltype(mm)::value, NM = LIGHT ? 1 : 3;
+            constexpr int ks = decltype(kk)::value, m = decltype(mm)::value, NM = NPASS;
             constexpr int eb = ks / 2 + 1;             // L0 block drained during K-steps 2 (eb - 1), 2 (eb - 1) + 1
             if constexpr (eb <= 6) {
               constexpr int NRb = eb == 6 ? LAST_BLOCK_REGS : 16, sb = (ks & 1) * NM + m, nsb = 2 * NM;
@@ -1047,9 +1064,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           else d = gemm_fused_f32<L3_KS, 6, 7, NU>(buf, d, H, lane, epi, pre);
         } else {
           constexpr int PF = LIGHT ? NPHM_PF_LIGHT : NPHM_PF_HEAVY;
-          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, LIGHT, PF, NU>(buf, d, H, lane, epi, pre, slot_hook);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, LIGHT, PF, NU>(buf, d, G, lane, epi, pre, slot_hook);
-          else d = gemm_fused_bf16<L3_KS16, 6, 7, LIGHT, PF, NU>(buf, d, H, lane, epi, pre, slot_hook);
+          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NPASS, PF, NU>(buf, d, H, lane, epi, pre, slot_hook);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NPASS, PF, NU>(buf, d, G, lane, epi, pre, slot_hook);
+          else d = gemm_fused_bf16<L3_KS16, 6, 7, NPASS, PF, NU>(buf, d, H, lane, epi, pre, slot_hook);
         }
         accs[c & 1] = d;
         if constexpr (epilogue_exposed(c)) {
@@ -1078,9 +1095,11 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       });
     };
     if constexpr (PREC == 0) {
-      run_member(std::false_type{});
+      run_member(std::integral_constant<int, 0>{});
     } else {
-      if (light) run_member(std::true_type{}); else run_member(std::false_type{});
+      if (light) run_member(std::integral_constant<int, 1>{});
+      else if (mid) run_member(std::integral_constant<int, 2>{});
+      else run_member(std::integral_constant<int, 0>{});
     }
 
     const float f = part + __shfl_xor(part, 32) + b4;
@@ -1112,8 +1131,20 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
 // ============================================================================================
 extern "C" {
 
+// two-pass tier of the adaptive mode: members whose normalised blend weight stays below this value (and reaches
+// NPHM_LIGHT_TOL) in a wavefront; NPHM_AMD_MID_TOL overrides the default (<= NPHM_LIGHT_TOL switches the tier off)
+static float nphm_mid_tol() {
+  static const float v = [] {
+    const char* e = getenv("NPHM_AMD_MID_TOL");
+    return e ? float(atof(e)) : NPHM_MID_TOL;
+  }();
+  return v;
+}
+
+static bool is_adaptive(int precision) { return precision == NPHM_PREC_BF16X3_ADAPTIVE || precision == NPHM_PREC_BF16X3_ADAPTIVE2; }
+
 static int check_prec(int precision) {
-  if (precision != NPHM_PREC_F32 && precision != NPHM_PREC_BF16X3 && precision != NPHM_PREC_BF16X3_ADAPTIVE)
+  if (precision != NPHM_PREC_F32 && precision != NPHM_PREC_BF16X3 && !is_adaptive(precision))
     return nphm_fail_msg("nphm_identity_eval: unsupported precision mode");
   return 0;
 }
@@ -1128,6 +1159,7 @@ static void fill_common(nphm::EvalArgs& a, const void* packed, const void* laten
   a.stats = stats;
   a.prune_tol = prune_tol;
   a.light_tol = -1.f;                    // set per precision mode by the callers
+  a.mid_tol = -1.f;
   a.hack_chunk = hack_chunk;
 }
 
@@ -1146,7 +1178,7 @@ bool bin_layout(int nlx, int ry, int rz, BinLayout& l) {
   auto take = [&](size_t b) { size_t r = o; o += (b + 255) / 256 * 256; return r; };
   const size_t n = size_t(l.n_tiles);
   l.order = take(n * 4); l.ids = take(n * 4); l.keys_in = take(n * 8); l.keys_out = take(n * 8);
-  l.masks = take(n * 16); l.sd = take(n * 32 * 8);
+  l.masks = take(n * 24); l.sd = take(n * 32 * 8);
   size_t tb = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, static_cast<const uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr),
                                            static_cast<const unsigned*>(nullptr), static_cast<unsigned*>(nullptr), int(n));
@@ -1165,7 +1197,8 @@ size_t nphm_identity_grid_workspace_bytes(int n_x_local, int ry, int rz) {
 
 static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t workspace_bytes, hipStream_t st,
                        const char* who) {
-  a.light_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE ? NPHM_LIGHT_TOL : -1.f;
+  a.light_tol = is_adaptive(precision) ? NPHM_LIGHT_TOL : -1.f;
+  a.mid_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE2 ? nphm_mid_tol() : -1.f;
 #if NPHM_PROF
   if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
 #endif
@@ -1227,7 +1260,8 @@ int nphm_identity_eval_points(const void* packed, const void* latent_state,
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_identity_eval_points: too many points");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * nphm::NW);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  a.light_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE ? NPHM_LIGHT_TOL : -1.f;
+  a.light_tol = is_adaptive(precision) ? NPHM_LIGHT_TOL : -1.f;
+  a.mid_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE2 ? nphm_mid_tol() : -1.f;
 #if NPHM_PROF
   if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
 #endif

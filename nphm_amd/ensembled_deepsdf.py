@@ -299,9 +299,10 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         # ---- execution knobs (defaults keep reference numerics within 1e-4) -------------------
         self.backend = "hip"            # "hip" | "composite"
         self.prune_tol = float(os.environ.get("NPHM_AMD_PRUNE_TOL", "1e-7"))
-        # "bf16x3a" (default): split-bf16 products for members that weigh >= 1e-3 somewhere in the
-        # wavefront, single-pass bf16 for the rest | "bf16x3": split-bf16 everywhere | "f32": exact products
-        self.precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3a")
+        # "bf16x3a2" (default): per wavefront, single-pass bf16 for members below 1e-3 normalised blend weight, two
+        # passes (weights rounded to bf16) below 1e-2, the full three-pass split-bf16 product from there on |
+        # "bf16x3a": the same without the two-pass tier | "bf16x3": split-bf16 everywhere | "f32": exact products
+        self.precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3a2")
         self._pack_cache = None         # (key, packed tensor)
         self._pack_bwd_cache = None     # (key, transposed pack for the backward kernel)
         # latent fitting with the REFERENCE's unchanged fitting.py: it leaves the decoder's parameters trainable and
@@ -421,7 +422,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
 
     def _precision_code(self):
         return {"f32": _lib.NPHM_PREC_F32, "bf16x3": _lib.NPHM_PREC_BF16X3,
-                "bf16x3a": _lib.NPHM_PREC_BF16X3_ADAPTIVE}[self.precision]
+                "bf16x3a": _lib.NPHM_PREC_BF16X3_ADAPTIVE, "bf16x3a2": _lib.NPHM_PREC_BF16X3_ADAPTIVE2}[self.precision]
 
     def _forward_hip(self, xyz, lat_rows):
         lib = _lib.load()

@@ -94,7 +94,7 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
                     pruned = (contrib * (~kept)).sum(dim=2)
                 else:
                     pruned = torch.zeros_like(contrib[..., 0])
-                light = contrib * (what_all < LIGHT_TOL) * 2.0 ** -8 if decoder.precision == "bf16x3a" else contrib * 0
+                light = contrib * (what_all < LIGHT_TOL) * 2.0 ** -8 if decoder.precision.startswith("bf16x3a") else contrib * 0
                 worst["max_abs_diff"] = max(worst["max_abs_diff"], float((fast - dense).abs().max()))
                 worst["max_pruned"] = max(worst["max_pruned"], float(pruned.max()))
                 worst["max_light"] = max(worst["max_light"], float(light.max()))

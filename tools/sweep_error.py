@@ -27,7 +27,7 @@ for wscale in (1.0, 1.5, 2.5):
             lat = U.sample_latent(seed, scale=lscale).to(dev)
             n.precision, n.prune_tol = "f32", -1.0
             ref = R.evaluate_grid(n, lat, axes, hack_chunk=0)
-            n.precision, n.prune_tol = "bf16x3a", 1e-7
+            n.precision, n.prune_tol = os.environ.get("NPHM_SWEEP_PRECISION", "bf16x3a2"), 1e-7
             got = R.evaluate_grid(n, lat, axes, hack_chunk=0)
             errs.append(float((got - ref).abs().max()))
             mags.append(float(ref.abs().max()))
