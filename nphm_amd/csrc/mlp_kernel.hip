@@ -72,7 +72,7 @@ __global__ void mlp_pack_kernel(PackArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // prepare: per latent row, the coordinate K-step fragments of every layer (folded latent + bias)
-// grid (n_linear, n_rows), 256 threads
+// (grid and block sizes: PREP_SPLIT / PREP_THREADS below)
 // ---------------------------------------------------------------------------------------------
 struct PrepArgs {
   PtrTable t;
@@ -82,37 +82,48 @@ struct PrepArgs {
   char* state;         // [n_rows, state_row_bytes]
 };
 
-__global__ __launch_bounds__(1024) void mlp_prepare_kernel(PrepArgs a) {
-  __shared__ float bias[1024];
+// grid (n_linear, n_rows, PREP_SPLIT): block z of a layer owns the 32-row tiles z, z + PREP_SPLIT, ...
+constexpr int PREP_SPLIT = 16, PREP_THREADS = 512;
+__global__ __launch_bounds__(PREP_THREADS) void mlp_prepare_kernel(PrepArgs a) {
+  __shared__ float bias[32];
   __shared__ float lat[1024];
   const int l = blockIdx.x, row = blockIdx.y, t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6, n_waves = blockDim.x >> 6;
+  const int lane = t & 63, wave = t >> 6;
+  constexpr int N_WAVES = PREP_THREADS / 64, PER_WAVE = 32 / N_WAVES;      // 8 wavefronts x 4 outputs = one tile
   const Layer& L = a.plan.layer[l];
   const float* W = a.t.w[l];
   const float* cond = a.cond + size_t(row) * a.lat_dim;
   for (int j = t; j < a.lat_dim; j += blockDim.x) lat[j] = cond[j];
-  __syncthreads();
-  // folded bias of output o: one WAVEFRONT per output, its lanes stride over the latent columns (coalesced reads of
-  // the weight row, butterfly reduction) - a thread per output walked the rows with a stride of in_dim floats
-  for (int o = wave; o < 32 * L.n_tiles; o += n_waves) {
-    float v = 0.f;
-    if (o < L.out_dim && L.lat_col >= 0) {
-      const float* wl = W + size_t(o) * L.in_dim + L.lat_col;
-      for (int j = lane; j < a.lat_dim; j += 64) v = fmaf(wl[j], lat[j], v);
-#pragma unroll
-      for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
-      v *= L.in_scale;
-    }
-    if (lane == 0) bias[o] = o < L.out_dim ? (v + a.t.b[l][o]) * L.add_scale : 0.f;
-  }
-  __syncthreads();
   uint16_t* out = reinterpret_cast<uint16_t*>(a.state + size_t(row) * a.plan.state_row_bytes + L.c_off);
-  for (int e = t; e < L.n_tiles * 64 * 8; e += blockDim.x) {
-    const int i = e & 7, lane = (e >> 3) & 63, n = e >> 9;
-    const int o = 32 * n + (lane & 31), hh = lane >> 5;
-    uint16_t v = 0;
+  for (int n = blockIdx.z; n < L.n_tiles; n += gridDim.z) {
+    __syncthreads();                       // lat is loaded / the previous tile's bias values have been consumed
+    // folded biases of the tile's 32 outputs: a WAVEFRONT per output (lanes stride over the latent columns: coalesced
+    // reads of the weight row, butterfly reduction), four outputs per wavefront with their loads in flight together -
+    // a thread per output walked the rows with a stride of in_dim floats (42 us per launch, now a few)
+    float v[PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+      const int o = 32 * n + wave * PER_WAVE + q;
+      v[q] = 0.f;
+      if (o < L.out_dim && L.lat_col >= 0) {
+        const float* wl = W + size_t(o) * L.in_dim + L.lat_col;
+        for (int j = lane; j < a.lat_dim; j += 64) v[q] = fmaf(wl[j], lat[j], v[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+      const int o = 32 * n + wave * PER_WAVE + q;
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1) v[q] += __shfl_xor(v[q], sft);
+      if (lane == 0) bias[wave * PER_WAVE + q] = o < L.out_dim ? (v[q] * L.in_scale + a.t.b[l][o]) * L.add_scale : 0.f;
+    }
+    __syncthreads();
+    const int e = t;                        // 64 lanes x 8 entries of the tile's coordinate-step fragment
+    const int i = e & 7, flane = (e >> 3) & 63;
+    const int o = 32 * n + (flane & 31), hh = flane >> 5;
+    uint16_t r = 0;
     if (o < L.out_dim) {
-      const float b = bias[o];
+      const float b = bias[flane & 31];
       const uint16_t bh = f32_to_bf16_rn(b);
       const float r1 = b - bf16_to_f32(bh);
       const uint16_t bm = f32_to_bf16_rn(r1);
@@ -122,10 +133,10 @@ __global__ __launch_bounds__(1024) void mlp_prepare_kernel(PrepArgs a) {
       };
       auto whi = [&](int c) { return f32_to_bf16_rn(wc(c)); };
       auto wlo = [&](int c) { const float w = wc(c); return f32_to_bf16_rn(w - bf16_to_f32(f32_to_bf16_rn(w))); };
-      if (hh == 0) v = i < 3 ? whi(i) : i < 6 ? whi(i - 3) : i == 6 ? bh : bm;
-      else v = i < 3 ? wlo(i) : i == 3 ? bl : i < 7 ? whi(i - 4) : uint16_t(0);
+      if (hh == 0) r = i < 3 ? whi(i) : i < 6 ? whi(i - 3) : i == 6 ? bh : bm;
+      else r = i < 3 ? wlo(i) : i == 3 ? bl : i < 7 ? whi(i - 4) : uint16_t(0);
     }
-    out[e] = v;
+    out[size_t(n) * 512 + e] = r;
   }
 }
 
@@ -775,7 +786,7 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
   a.cond = cond_rows;
   a.lat_dim = lat_dim;
   a.state = static_cast<char*>(latent_state);
-  hipLaunchKernelGGL(nphm::mlp::mlp_prepare_kernel, dim3(a.plan.n_linear, n_rows), dim3(1024), 0,
+  hipLaunchKernelGGL(nphm::mlp::mlp_prepare_kernel, dim3(a.plan.n_linear, n_rows, nphm::mlp::PREP_SPLIT), dim3(nphm::mlp::PREP_THREADS), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_mlp_prepare_latent launch", e);
