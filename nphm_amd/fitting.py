@@ -109,21 +109,6 @@ class _ObservationSampler:
         return obs_idx, self.clouds[obs_idx[:, None], drawn_dev[:, 1:]]
 
 
-def _clamped_surface_loss(sdf, j, step_scale, valid=None):
-    """mean |sdf| over the (valid) points below a shrinking threshold (fitting.py:115-132).  The reference
-    compacts the tensor with boolean masks (a device->host sync per mask); here the same mean is a masked
-    sum / count: static shapes, no sync."""
-    l = sdf.abs()
-    keep = l < 0.1
-    if valid is not None:
-        keep = keep & valid.reshape(valid.shape + (1,) * (l.dim() - valid.dim()))
-    if j > int(250 * step_scale):
-        keep = keep & (l < 0.05)
-    if j > int(500 * step_scale):
-        keep = keep & (l < 0.0075)
-    return (l * keep).sum() / keep.sum()
-
-
 def _shape_regularisers(decoder, lat_rep_shape, loss_dict):
     """Identity-code regularisers (fitting.py:139-166)."""
     if hasattr(decoder, "lat_dim_glob"):
@@ -212,7 +197,9 @@ class _StepControls:
 
 
 def _masked_surface_loss(sdf, thr, valid=None):
-    """``_clamped_surface_loss`` with the clamp as a device scalar"""
+    """mean |sdf| over the (valid) points below the clamp ``thr`` (fitting.py:115-132; ``_StepControls`` holds the
+    clamp as a device scalar).  The reference compacts the tensor with boolean masks (a device->host sync per mask);
+    the same mean as a masked sum / count has static shapes and needs no sync."""
     l = sdf.abs()
     keep = l < thr
     if valid is not None:
