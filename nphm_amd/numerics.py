@@ -9,8 +9,9 @@ weights that are tiny but not zero), so ``validate_numerics`` measures, for the 
 * ``max_abs_diff``: max |default mode - dense exact-fp32 kernel| over a sample of lattice and near-anchor points
   (the in-tree ``precision = "f32"``, ``prune_tol < 0`` kernel evaluates all 40 members with fp32 MFMA),
 * ``max_pruned``: the largest sum of w_k |f_k| over the members the pruning rule dropped at a point
-  (its exact error contribution), and ``max_light``: the largest w_k |f_k| of a single-pass member times the
-  bf16 rounding level 2^-8 (the size of the error it can carry),
+  (its exact error contribution), ``max_light``: the largest w_k |f_k| of a single-pass member times the
+  bf16 rounding level 2^-8 and ``max_two_pass``: ... of a two-pass member times 2^-9 (the size of the error each
+  tier can carry),
 
 and warns (or raises with ``strict=True``) above ``tol`` (default 1e-5, a tenth of the 1e-4 bar).
 ``NPHM_AMD_VALIDATE=1`` runs it once after every ``load_state_dict`` (at the first HIP evaluation, with that
@@ -26,6 +27,7 @@ import torch
 from . import _lib
 
 LIGHT_TOL = 1e-3
+MID_TOL = 1e-2
 
 
 def _sample_points(anchors: torch.Tensor, n: int, seed: int) -> torch.Tensor:
@@ -62,7 +64,8 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
     A = decoder.num_kps + 1
     saved = (decoder.precision, decoder.prune_tol, getattr(decoder, "_needs_validation", False))
     decoder._needs_validation = False
-    worst = {"max_abs_diff": 0.0, "max_pruned": 0.0, "max_light": 0.0, "max_abs_sdf": 0.0, "max_abs_member": 0.0}
+    worst = {"max_abs_diff": 0.0, "max_pruned": 0.0, "max_light": 0.0, "max_two_pass": 0.0, "max_abs_sdf": 0.0,
+             "max_abs_member": 0.0}
     try:
         with torch.no_grad():
             for r in range(latents.shape[0]):
@@ -95,9 +98,13 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
                 else:
                     pruned = torch.zeros_like(contrib[..., 0])
                 light = contrib * (what_all < LIGHT_TOL) * 2.0 ** -8 if decoder.precision.startswith("bf16x3a") else contrib * 0
+                # two-pass members (bf16x3a2): weights rounded to bf16, a 2^-9 relative perturbation of the member
+                mid = (contrib * ((what_all >= LIGHT_TOL) & (what_all < MID_TOL)) * 2.0 ** -9
+                       if decoder.precision == "bf16x3a2" else contrib * 0)
                 worst["max_abs_diff"] = max(worst["max_abs_diff"], float((fast - dense).abs().max()))
                 worst["max_pruned"] = max(worst["max_pruned"], float(pruned.max()))
                 worst["max_light"] = max(worst["max_light"], float(light.max()))
+                worst["max_two_pass"] = max(worst["max_two_pass"], float(mid.max()))
                 worst["max_abs_sdf"] = max(worst["max_abs_sdf"], float(dense.abs().max()))
                 worst["max_abs_member"] = max(worst["max_abs_member"], float(fmem.abs().max()))
     finally:
