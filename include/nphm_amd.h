@@ -251,6 +251,13 @@ int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int ou
                                 const void* packed, const void* latent_state,
                                 const float* xyz, int n_rows, int64_t n_points, int add_input,
                                 float* out, void* saved, void* stream);
+/* nphm_mlp_eval_points_jvp that also leaves sigma' of the VALUE stream in `saved` (same layout and size as
+ * nphm_mlp_eval_points_saving): posed points, their Jacobian and the state of the backward in one launch - what the
+ * fitting step needs at the canonical correspondences (fitting.py:99-103). */
+int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                                    const void* packed, const void* latent_state,
+                                    const float* xyz, int n_rows, int64_t n_points, int add_input,
+                                    float* out, void* saved, void* stream);
 size_t nphm_mlp_bwd_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim);
 int nphm_mlp_pack_bwd(int lat_dim, int hidden_dim, int nlayers, int out_dim, const float* const* lin_weight,
                       void* packed_bwd, void* stream);

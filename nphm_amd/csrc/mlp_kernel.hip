@@ -271,7 +271,7 @@ __device__ __forceinline__ bf16x8 unit_operand(int c) {
 // wavefronts through LDS; a workgroup leaves as soon as none of its points is active.
 template <int MT, int NTW, int MODE, int KIND>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
-  constexpr bool JVP = KIND == 1, BROY = KIND == 2, SAVE = KIND == 3;
+  constexpr bool JVP = KIND == 1 || KIND == 4, BROY = KIND == 2, SAVE = KIND == 3 || KIND == 4;   // 4: value+Jacobian, sigma' saved
   constexpr int M = 32 * MT;               // columns per workgroup
   constexpr int PTS = JVP ? M / 4 : M;     // points per workgroup
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
@@ -352,12 +352,27 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       if (i < ni) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-          if constexpr (SAVE) {
+          if constexpr (SAVE && !JVP) {
             float* so = p.sig_out + ((((size_t(row) * gridDim.x + blockIdx.x) * p.sig_tiles + p.sig_base[layer] + wave + WAVES * i) * MT + t) * 64 + lane) * 16;
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
               float4 sg = make_float4(sigmoid2(acc[i][t][r]), sigmoid2(acc[i][t][r + 1]), sigmoid2(acc[i][t][r + 2]), sigmoid2(acc[i][t][r + 3]));
               *reinterpret_cast<float4*>(so + r) = sg;
+            }
+          }
+          if constexpr (SAVE && JVP) {
+            // the value stream (columns 0 .. PTS-1 of point tile 0) into the 64-point-workgroup layout mlp_bwd_kernel reads:
+            // this workgroup's PTS = 16 points are lanes 16 (b & 1) .. + 15 of point tile (b >> 1) & 1 of workgroup b >> 2
+            static_assert(!JVP || PTS == 16, "value + Jacobian workgroups hold 16 points");
+            if (t == 0 && j < PTS) {
+              const unsigned b = blockIdx.x;
+              const size_t wg64 = size_t(row) * ((gridDim.x + 3) >> 2) + (b >> 2);
+              float* so = p.sig_out + (((wg64 * p.sig_tiles + p.sig_base[layer] + wave + WAVES * i) * MT + ((b >> 1) & 1)) * 64 + 32 * h + 16 * (b & 1) + j) * 16;
+#pragma unroll
+              for (int r = 0; r < 16; r += 4) {
+                float4 sg = make_float4(sigmoid2(acc[i][0][r]), sigmoid2(acc[i][0][r + 1]), sigmoid2(acc[i][0][r + 2]), sigmoid2(acc[i][0][r + 3]));
+                *reinterpret_cast<float4*>(so + r) = sg;
+              }
             }
           }
           float v[16];
@@ -693,7 +708,7 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
                      && false
 #endif
       ;
-  const int M = (small ? 32 : plan.variant == 0 ? 64 : 32) / (KIND == 1 ? 4 : 1);      // points per workgroup
+  const int M = (small ? 32 : plan.variant == 0 ? 64 : 32) / ((KIND == 1 || KIND == 4) ? 4 : 1);      // points per workgroup
   const int64_t tiles = (n_pts + M - 1) / M;
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * WAVES);
@@ -712,7 +727,7 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
-  } else if constexpr (KIND == 3) {
+  } else if constexpr (KIND == 3 || KIND == 4) {
     return nphm_fail_msg("nphm_mlp_eval_points_saving: only the hidden <= 512 variant has a backward kernel");
   } else {
     auto k = mlp_eval_kernel<1, 4, MODE, KIND>;
@@ -841,6 +856,27 @@ int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int ou
   a.n_points = n_points;
   a.sig_out = static_cast<float*>(saved);
   return launch_eval<0, 3>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+}
+
+int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                                    const void* packed, const void* latent_state,
+                                    const float* xyz, int n_rows, int64_t n_points, int add_input,
+                                    float* out, void* saved, void* stream) {
+  Plan plan;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: unsupported architecture");
+  if (!packed || !latent_state || !xyz || !out || !saved) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: null pointer");
+  if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: empty input");
+  nphm::mlp::EvalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const char*>(packed);
+  a.state = static_cast<const char*>(latent_state);
+  a.out = out;
+  a.out_dim = out_dim;
+  a.add_input = add_input;
+  a.xyz = xyz;
+  a.n_points = n_points;
+  a.sig_out = static_cast<float*>(saved);
+  return launch_eval<0, 4>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
 }
 
 int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,

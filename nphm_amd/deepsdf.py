@@ -38,19 +38,27 @@ class _MlpCondFn(torch.autograd.Function):
     the skip layer, which the two latent blocks of those layers map onto the conditioning vector."""
 
     @staticmethod
-    def forward(ctx, module, xyz, cond_rows, add_input):
+    def forward(ctx, module, xyz, cond_rows, add_input, with_jacobian=False):
+        """-> [R,n,out] or, ``with_jacobian``, [R,n,4,out] (value | d/dx | d/dy | d/dz as forward_hip_jvp; only the
+        value stream is differentiable)"""
         lib = _lib.load()
         R, n, _ = xyz.shape
         dev = xyz.device
         packed, state = module.prepare_latent(cond_rows.detach())
         xyz_c = xyz.detach().contiguous().float()
-        out = torch.empty(R, n, module.n_out, dtype=torch.float32, device=dev)
         saved = torch.empty(lib.nphm_mlp_saved_bytes(*module._arch(), R, n), dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.nphm_mlp_eval_points_saving(*module._arch(), packed.data_ptr(), state.data_ptr(), xyz_c.data_ptr(),
-                                                   R, n, int(bool(add_input)), out.data_ptr(), saved.data_ptr(), stream),
-                   "nphm_mlp_eval_points_saving")
-        ctx.module, ctx.shape = module, (R, n)
+        if with_jacobian:
+            out = torch.empty(R, n, 4, module.n_out, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_mlp_eval_points_jvp_saving(*module._arch(), packed.data_ptr(), state.data_ptr(),
+                                                           xyz_c.data_ptr(), R, n, int(bool(add_input)), out.data_ptr(),
+                                                           saved.data_ptr(), stream), "nphm_mlp_eval_points_jvp_saving")
+        else:
+            out = torch.empty(R, n, module.n_out, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_mlp_eval_points_saving(*module._arch(), packed.data_ptr(), state.data_ptr(), xyz_c.data_ptr(),
+                                                       R, n, int(bool(add_input)), out.data_ptr(), saved.data_ptr(), stream),
+                       "nphm_mlp_eval_points_saving")
+        ctx.module, ctx.shape, ctx.with_jacobian = module, (R, n), bool(with_jacobian)
         ctx.save_for_backward(saved)
         return out
 
@@ -65,7 +73,7 @@ class _MlpCondFn(torch.autograd.Function):
         H = module.hidden_dim
         gb0 = torch.zeros(R, H, dtype=torch.float32, device=dev)
         gbs = torch.zeros(R, H, dtype=torch.float32, device=dev)
-        g = grad_out.detach().contiguous().float()
+        g = (grad_out[:, :, 0] if ctx.with_jacobian else grad_out).detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.nphm_mlp_backward_cond(*module._arch(), module._packed_bwd(dev).data_ptr(), saved.data_ptr(),
                                               g.data_ptr(), R, n, gb0.data_ptr(), gbs.data_ptr(), stream),
@@ -76,7 +84,7 @@ class _MlpCondFn(torch.autograd.Function):
         Ws = getattr(module, f"lin{skip}").weight                 # [H, k_act + d + lat]
         k_act = Ws.shape[1] - W0.shape[1]
         grad_cond = gb0 @ W0[:, d:] + (gbs @ Ws[:, k_act + d:]) / _SQRT2
-        return None, None, grad_cond, None
+        return None, None, grad_cond, None, None
 
 
 class DeepSDF(nn.Module):
@@ -495,6 +503,23 @@ class DeformationNetwork(nn.Module):
                 return None
             out = self.defDeepSDF.forward_hip_jvp(*plan, add_input=True).reshape(x.shape[0], x.shape[1], 4, -1)
         return out[:, :, 0, :3], out[:, :, 1:, :3].transpose(-1, -2)
+
+    def posed_and_jacobian(self, xyz, lat_rep, anchors):
+        """(x + F_ex(x) [B,N,3] differentiable w.r.t. the conditioning, d (x + F_ex) / d x [B,N,3,3] detached) in ONE
+        launch - ``forward`` + ``jacobian`` at the same points, as the fitting step needs them at the canonical
+        correspondences (fitting.py:99-103).  None when the HIP autograd tier cannot serve the call (see ``forward``)."""
+        if xyz.dim() < 3:
+            xyz = xyz.unsqueeze(0)
+        if self.backend == "composite" or not xyz.is_cuda or self.defDeepSDF.n_out < 3 or xyz.requires_grad:
+            return None
+        cond = self._condition(xyz, lat_rep, anchors)
+        if not (torch.is_grad_enabled() and cond.requires_grad) or any(p.requires_grad for p in self.parameters()):
+            return None
+        plan = self.defDeepSDF._hip_rows(xyz, cond, cond_grad_ok=True)
+        if plan is None:
+            return None
+        out = _MlpCondFn.apply(self.defDeepSDF, plan[0], plan[1], True, True).reshape(xyz.shape[0], xyz.shape[1], 4, -1)
+        return out[:, :, 0, :3], out[:, :, 1:, :3].transpose(-1, -2).detach()
 
     def broyden(self, obs, x_init, jinv_init, lat_rep, anchors, max_steps=15, cvg_thresh=1e-6, dvg_thresh=0.2,
                 eps=1e-6):

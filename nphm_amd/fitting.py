@@ -309,9 +309,14 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         valid = search_result["valid_ids"]
 
         # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
-        preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
-        preds_posed = preds_posed + p_corresp
-        grad_inv = _inverse3x3(jac(decoder_expr, p_corresp, glob_cond, anchors_b))
+        fused = decoder_expr.posed_and_jacobian(p_corresp, glob_cond, anchors_b) if hasattr(decoder_expr, "posed_and_jacobian") else None
+        if fused is not None:              # posed points, Jacobian and the state of the backward in one launch
+            preds_posed, jac_posed = fused
+        else:
+            preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
+            preds_posed = preds_posed + p_corresp
+            jac_posed = jac(decoder_expr, p_corresp, glob_cond, anchors_b)
+        grad_inv = _inverse3x3(jac_posed)
         correction = preds_posed - preds_posed.detach()
         correction = torch.einsum("bnij,bnj->bni", -grad_inv.detach(), correction)
         xc = p_corresp + correction

@@ -475,3 +475,34 @@ def test_backward_tier_selection(dev):
             gl.sum().backward()
     finally:
         restore()
+
+
+@pytest.mark.parametrize("n", [5, 64, 1000])
+def test_posed_and_jacobian_in_one_launch(dev, n):
+    """DeformationNetwork.posed_and_jacobian = forward (+ x) and jacobian at the same points from ONE launch that also
+    leaves the backward's state: same values as the two separate calls, same conditioning gradient as autograd through
+    the composite formulation."""
+    net = U.build_deformation(device=dev).eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(21)
+    xyz = ((torch.rand(3, n, 3, generator=g) - 0.5) * 0.6).to(dev)
+    cot = torch.randn(3, n, 3, generator=g).to(dev)
+    lat0 = (torch.randn(3, 1, 1544, generator=g) * 0.05).to(dev)
+    anc = (torch.from_numpy(U.anchors_mean()).float()[None] + 0.01 * torch.randn(3, 39, 3, generator=g)).to(dev)
+    lat = lat0.clone().requires_grad_(True)
+    posed, J = net.posed_and_jacobian(xyz, lat, anc)
+    assert posed.shape == (3, n, 3) and J.shape == (3, n, 3, 3) and not J.requires_grad
+    with torch.no_grad():
+        off, _ = net(xyz, lat0, anc)
+    posed_ref, J_ref = net.jacobian(xyz, lat0, anc)
+    assert torch.equal(posed.detach(), posed_ref) and torch.equal(J, J_ref)
+    assert U.maxdiff((xyz + off).cpu(), posed.detach().cpu()) < 1e-6
+    (posed * cot).sum().backward()
+    net.backend = "composite"
+    lat_c = lat0.clone().requires_grad_(True)
+    off_c, _ = net(xyz, lat_c, anc)
+    ((off_c + xyz) * cot).sum().backward()
+    net.backend = "hip"
+    scale = float(lat_c.grad.abs().max())
+    assert float((lat.grad - lat_c.grad).abs().max()) < 2e-5 * scale + 1e-9
