@@ -71,8 +71,7 @@ class _MlpCondFn(torch.autograd.Function):
         R, n = ctx.shape
         dev = grad_out.device
         H = module.hidden_dim
-        gb0 = torch.zeros(R, H, dtype=torch.float32, device=dev)
-        gbs = torch.zeros(R, H, dtype=torch.float32, device=dev)
+        gb0, gbs = torch.zeros(2, R, H, dtype=torch.float32, device=dev).unbind(0)     # accumulated into: one zero-fill
         g = (grad_out[:, :, 0] if ctx.with_jacobian else grad_out).detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.nphm_mlp_backward_cond(*module._arch(), module._packed_bwd(dev).data_ptr(), saved.data_ptr(),

@@ -246,10 +246,12 @@ class _IdentityFieldFn(torch.autograd.Function):
         B, N, _ = xyz.shape
         dev = xyz.device
         A = module.num_kps + 1
-        gx = torch.zeros(B, N, 3, dtype=torch.float32, device=dev)
-        ga = torch.zeros(B, module.num_kps, 3, dtype=torch.float32, device=dev)
-        gb0 = torch.zeros(B, A, module.hidden_dim, dtype=torch.float32, device=dev)
-        gb2 = torch.zeros_like(gb0)
+        # the kernel accumulates into all four: ONE zero-fill, four views
+        H, K = module.hidden_dim, module.num_kps
+        sizes = [B * N * 3, B * K * 3, B * A * H, B * A * H]
+        parts = torch.zeros(sum(sizes), dtype=torch.float32, device=dev).split(sizes)
+        gx, ga = parts[0].view(B, N, 3), parts[1].view(B, K, 3)
+        gb0, gb2 = parts[2].view(B, A, H), parts[3].view(B, A, H)
         if tiles.shape[0]:
             g = grad_out.detach().reshape(B, N).contiguous().float()
             stream = torch.cuda.current_stream(dev).cuda_stream
