@@ -202,6 +202,11 @@ class IdentityBench:
         exec_flops = (passes * (mean_active - mean_light - mean_mid) + 2 * mean_mid + mean_light) * FLOP_MEMBER_FOLDED * n_local
         peak = PEAK_TFLOPS[precision]
         achieved = exec_flops / (k_ms * 1e-3) / 1e12
+        # what the matrix pipe actually ISSUES: 32x32 tiles pad 101 -> 128 / 200 -> 224 rows and 200 -> 208 / 104 -> 112
+        # columns - 583 / 391 / 199 MFMAs of 32768 FLOP per (wavefront of 32 points, member) with 3 / 2 / 1 passes
+        mfma = {3: 583, 2: 391, 1: 199}
+        issued_flops = ((mean_active - mean_light - mean_mid) * mfma[3] + mean_mid * mfma[2] + mean_light * mfma[1]) * 32768 / 32 * n_local \
+            if precision != "f32" else None
         # the events bracket the whole grid call: with binning that is the tile pre-pass + radix sort
         # (together ~1 % of it) + the dominant kernel
         kname = "nphm::eval_kernel<%d,%d>" % (2 if binned else 1, 0 if precision == "f32" else 1)
@@ -216,6 +221,7 @@ class IdentityBench:
                          "executed_flops_per_point": exec_flops / n_local, "mean_single_pass_members": mean_light,
                          "mean_two_pass_members": mean_mid,
                          "mfma_passes": passes, "mean_active_members": mean_active,
+                         "issued_tflops_with_tile_padding": None if issued_flops is None else issued_flops / (k_ms * 1e-3) / 1e12,
                          "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12},
         }
 
