@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 3
+#define NPHM_AMD_ABI_VERSION 4
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -167,6 +167,34 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
                            const float* xyz, const float* sdf, const float* grad_sdf, int64_t n_points,
                            const int* tiles, int n_tiles, const int* n_tiles_dev, const int* point_list,
                            float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2, void* stream);
+
+/* Training tier of the identity ensemble: what compute_loss needs from the 40 member MLPs
+ * (src/NPHM/models/loss_functions.py:36-49: decoder(...) followed by gradient(pred, x) with create_graph=True,
+ * diff_operators.py:6-16; training.py:124: loss.backward() w.r.t. every weight).  The host keeps the Gaussian
+ * blend (EnsembledDeepSDF.py:129-150) in autograd; these two kernels replace the member MLPs
+ * (EnsembledDeepSDF.py:101-126) and their double backward.  tiles [n_tiles][4] = (row, member, offset into
+ * point_list, count <= 32), ORDERED BY MEMBER (hence by weight set); point_list = point indices inside the row.
+ *   nphm_identity_train_forward : member_sdf [n_rows,n_points,40] = f_k, member_grad [n_rows,n_points,40,3] =
+ *     d f_k / d xyz for the listed triples (others untouched).
+ *   nphm_identity_train_backward : seeds grad_member_sdf = dL/df_k and grad_member_grad = dL/d(d f_k/d xyz) (NULL:
+ *     zero) -> ACCUMULATES grad_xyz, grad_anchors, grad_b0, grad_b2 (as nphm_identity_backward, for
+ *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k) and stores the operands of the weight gradients:
+ *     saved[i] = fp32 [nphm_identity_train_saved_rows(i)][n_cols], n_cols >= 64 n_tiles, column 64 t + 32 s + p =
+ *     tile t, stream s (0 value, 1 tangent along the seed direction), point p, all in the scaled domain
+ *     (k = 100 / ln 2):  i = 0..4 inputs of lin0..lin4 (local coords | direction, h0', h1' + coords, h2', h3'),
+ *     i = 5..8 adjoints of the pre-activations of lin0..lin3, i = 9 the output seeds (dL/df_k | 1).  Then
+ *       dW3 = S8 S3^T, dW2[:, :104] = S7 S2^T (x 1/sqrt2, coordinate columns x k/sqrt2), dW1 = S6 S1^T,
+ *       dW0[:, :3] = k S5 S0^T, dW4 = S4 S9^T / k, db_l = k (row sums of the value columns of S(5+l)),
+ *     each over the column range of one weight set. */
+int nphm_identity_train_saved_rows(int which);
+int nphm_identity_train_forward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
+                                int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
+                                float* member_sdf, float* member_grad, void* stream);
+int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
+                                 int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
+                                 const float* grad_member_sdf, const float* grad_member_grad,
+                                 float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2,
+                                 float* const saved[10], int64_t n_cols, void* stream);
 
 /* Second stage of the two-stage evaluation get_logits_backward (src/NPHM/models/reconstruction.py:28-56):
  * the identity field at displaced lattice points.  xyz_slab [(ix1-ix0)*ry*rz, 3] holds the canonical

@@ -49,6 +49,12 @@ SYMBOLS = {
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_train_saved_rows": (c_int, [c_int]),
+    "nphm_identity_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                            c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p * 10, c_int64, c_void_p]),
     "nphm_identity_eval_grid_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                                c_void_p]),
@@ -107,7 +113,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 3:
+    if lib.nphm_abi_version() != 4:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -25,34 +25,10 @@
 #include "capi_common.h"
 #include "layout.h"
 
+#include "member_common.h"
+
 namespace nphm {
 namespace bwd {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int WAVES = 8;
-constexpr int M = 64;                    // points per workgroup (2 m-tiles)
-constexpr int MT = 2;
-constexpr int NCH = 28;                  // 7 blocks x 4 K chunks of 8 features
-constexpr int PLANE_BYTES = NCH * M * 16;
-
-// transposed pack, per weight set (uint16 units): stage A = lin3^T, B = lin2^T (104 rows: h1 | coords),
-// C = lin1^T, D = lin0[:, :3]^T; fragments [ob][ks][hi|lo][lane][8] like the forward pack
-constexpr int A_OB = 7, A_KS = 13, B_OB = 4, B_KS = 13, C_OB = 7, C_KS = 7, D_OB = 1, D_KS = 13;
-constexpr int OFF_A = 0;
-constexpr int OFF_B = OFF_A + A_OB * A_KS * 1024;
-constexpr int OFF_C = OFF_B + B_OB * B_KS * 1024;
-constexpr int OFF_D = OFF_C + C_OB * C_KS * 1024;
-constexpr int BWD_SET_STRIDE = OFF_D + D_OB * D_KS * 1024;
-
-__device__ inline uint16_t f32_to_bf16_rn(float x) {
-  uint32_t u = __float_as_uint(x);
-  uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
-  return uint16_t(r >> 16);
-}
-__device__ inline float bf16_to_f32(uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
 
 struct PackArgs {
   const float* w[5];
@@ -110,67 +86,6 @@ struct BwdArgs {
   float* gb2;                     // [n_rows, 40, 200]       (+=)
   float* fmem;                    // forward-only kernel: [n_rows, n_points, 40] member predictions
 };
-
-__device__ __forceinline__ float softplus2(float d) {
-  const float t = __builtin_amdgcn_exp2f(-fabsf(d));
-  return fmaxf(d, 0.f) + __builtin_amdgcn_logf(1.f + t);   // one v_max_f32 under -fno-honor-nans
-}
-__device__ __forceinline__ float sigmoid2(float d) {
-  const float t = __builtin_amdgcn_exp2f(-fabsf(d));
-  return (d >= 0.f ? 1.f : t) * __builtin_amdgcn_rcpf(1.f + t);
-}
-
-struct Split8 { bf16x8 hi, lo; };
-__device__ __forceinline__ Split8 split8(const float* x) {
-  Split8 o;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 hb = (__bf16)x[i];
-    o.hi[i] = hb;
-    o.lo[i] = (__bf16)(x[i] - (float)hb);
-  }
-  return o;
-}
-
-// B operand of the coordinate K-step (prep_kernels.hip, L0 block): h=0: xh | xl | 1 1; h=1: xh | 1 | xll | 0
-__device__ __forceinline__ bf16x8 coord_operand(float x, float y, float z, int h) {
-  const float cs[3] = {x, y, z};
-  __bf16 xh[3], xl[3], xll[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    xh[i] = (__bf16)cs[i];
-    const float r1 = cs[i] - (float)xh[i];
-    xl[i] = (__bf16)r1;
-    xll[i] = (__bf16)(r1 - (float)xl[i]);
-  }
-  const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-  bf16x8 bv;
-  bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
-  bv[3] = h ? one : xl[0];
-  bv[4] = h ? xll[0] : xl[1];
-  bv[5] = h ? xll[1] : xl[2];
-  bv[6] = h ? xll[2] : one;
-  bv[7] = h ? zero : one;
-  return bv;
-}
-
-__device__ __forceinline__ f32x16 load_frag16(const float* p) {
-  const f32x4* q = reinterpret_cast<const f32x4*>(p);
-  f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
-  f32x16 o;
-  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
-  o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-  o[8] = c[0]; o[9] = c[1]; o[10] = c[2]; o[11] = c[3];
-  o[12] = d[0]; o[13] = d[1]; o[14] = d[2]; o[15] = d[3];
-  return o;
-}
-
-// sum over the 32 lanes of a half-wave (all lanes of the half end up with the total)
-__device__ __forceinline__ float half_wave_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 
 // BWD = false: the forward half only — per-member predictions f_k of the listed points into
 // fmem[row, point, member] (the host blends them); used by the autograd tier's forward, where the

@@ -1,0 +1,503 @@
+// ident_train_kernel.hip — the NPHM identity ensemble for TRAINING: member values with their spatial
+// gradients, and the reverse sweep of both.
+//
+// compute_loss (src/NPHM/models/loss_functions.py:20-110) evaluates the decoder, takes
+// gradient(pred, x, create_graph=True) (diff_operators.py:6-16) for the normal / eikonal terms and calls
+// loss.backward() (training.py:124): a double backward through the 40 member MLPs of
+// EnsembledDeepSDF.forward (EnsembledDeepSDF.py:101-126) w.r.t. every weight.  The host splits the field
+// into   per-member values f_k(c) and gradients grad_c f_k   (these kernels)   and   the Gaussian blend
+// (EnsembledDeepSDF.py:129-150; elementwise, left to autograd), and needs from here
+//
+//   forward  (train_kernel<false>): f_k and grad_c f_k for the listed (row, member, point) triples
+//            = the member's forward + ONE transposed sweep seeded with 1 (f_k is a scalar);
+//   backward (train_kernel<true>) : for seeds sbar = dL/df_k and v = dL/d(grad_x f_k) the gradient of
+//            phi = sbar f_k + v . grad f_k  w.r.t. the local coordinates, the folded biases of lin0 / the skip
+//            layer and, through saved operands, every weight.  By symmetry of the Hessian  v . grad f_k  is the
+//            directional derivative of f_k along v, so phi is the output of a forward pass that carries the
+//            VALUE stream and ONE TANGENT stream (direction v); its reverse sweep needs sigma'' once per layer:
+//                T_l = U_l s_l                       (adjoint of the tangent pre-activation tau_l)
+//                D_l = H_l s_l + U_l tau_l s'_l       (adjoint of the value pre-activation d_l)
+//                [H_{l-1} | U_{l-1}] = W_l^T [D_l | T_l],      dW_l = D_l h_{l-1}^T + T_l u_{l-1}^T
+//            with s = sigma'(d), s' = sigma''(d), h = sigma(d), u = s tau  (tests/test_train_math.py pins
+//            these formulas against torch.autograd in float64).
+//
+// Decomposition as in ident_bwd_kernel.hip: one workgroup = 8 wavefronts = one member x 32 listed points;
+// the 64 MFMA columns of a tile are [32 value columns | 32 tangent columns of the same points], so that the
+// value and the tangent of one (feature, point) sit in the SAME lane of two accumulator tiles and every
+// epilogue is lane-local.  Activations in LDS as split-bf16 K chunks, weights L2 -> VGPR from the forward
+// pack / the transposed pack, three MFMA passes per product (fp32-equivalent), scaled domain of layout.h.
+// Weight gradients: the kernel stores the operands of  dW_l = sum over columns delta_l (x) input_l  feature-major
+// ([feature][column], 128-byte coalesced rows from the accumulator layout); the host contracts them per weight
+// set with library GEMMs (tiles are ordered by weight set, so each set is one contiguous column range).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "capi_common.h"
+#include "layout.h"
+#include "member_common.h"
+
+namespace nphm {
+namespace train {
+
+using namespace nphm::bwd;
+
+constexpr int PTS = 32;                         // points per tile
+constexpr float LN2 = 0.6931471805599453f;
+
+// saved operands of the weight gradients, each [rows][n_cols] fp32 (column = 64 * tile + 32 * stream + point)
+enum { SV_IN0 = 0,    // 3   local coordinates | tangent direction
+       SV_IN1,        // 200 h0' | u0'
+       SV_IN2,        // 104 h1' | u1'  (rows 101..103: coordinates | direction)
+       SV_IN3,        // 200 h2' | u2'
+       SV_IN4,        // 200 h3' | u3'
+       SV_D0,         // 200 D0 | T0
+       SV_D1,         // 101 D1 | T1
+       SV_D2,         // 200 D2 | T2
+       SV_D3,         // 200 D3 | T3
+       SV_SEED,       // 1   sbar | 1 (valid points)
+       SV_COUNT };
+
+struct TrainArgs {
+  const uint16_t* packed_bf16;
+  const float* packed_f32;
+  const uint16_t* packed_bwd;
+  const float* state;             // [n_rows, LS_ROW_STRIDE]
+  const float* xyz;               // [n_rows, n_points, 3]
+  const int* tiles;               // [n_tiles][4] = row, member, offset into list, count (<= 32)
+  const int* list;
+  int n_tiles;
+  int64_t n_points;
+  float* member_sdf;              // forward: [n_rows, n_points, 40]
+  float* member_grad;             // forward: [n_rows, n_points, 40, 3]  d f_k / d xyz
+  const float* g_sdf;             // backward: [n_rows, n_points, 40]
+  const float* g_grad;            // backward: [n_rows, n_points, 40, 3] or NULL (no second-order seed)
+  float* gxyz;                    // [n_rows, n_points, 3]  (+=)
+  float* ganch;                   // [n_rows, 39, 3]        (+=)
+  float* gb0;                     // [n_rows, 40, 200]      (+=)
+  float* gb2;                     // [n_rows, 40, 200]      (+=)
+  float* save[SV_COUNT];
+  int64_t n_cols;
+};
+
+// coord_operand without the constant slots: the B operand of the tangent stream at lin0 (no bias)
+__device__ __forceinline__ bf16x8 tangent_operand(float x, float y, float z, int h) {
+  const float cs[3] = {x, y, z};
+  __bf16 xh[3], xl[3], xll[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    xh[i] = (__bf16)cs[i];
+    const float r1 = cs[i] - (float)xh[i];
+    xl[i] = (__bf16)r1;
+    xll[i] = (__bf16)(r1 - (float)xl[i]);
+  }
+  const __bf16 zero = (__bf16)0.f;
+  bf16x8 bv;
+  bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
+  bv[3] = h ? zero : xl[0];
+  bv[4] = h ? xll[0] : xl[1];
+  bv[5] = h ? xll[1] : xl[2];
+  bv[6] = h ? xll[2] : zero;
+  bv[7] = zero;
+  return bv;
+}
+
+template <bool SECOND>
+__global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
+  constexpr int NT = SECOND ? 2 : 1;                 // accumulator tiles: value | tangent
+  __shared__ __attribute__((aligned(16))) char act_hi[PLANE_BYTES];
+  __shared__ __attribute__((aligned(16))) char act_lo[PLANE_BYTES];
+  __shared__ float part[WAVES][PTS];
+  __shared__ float pt_c[PTS][4];              // local coordinates, validity
+  __shared__ float pt_v[PTS][4];              // tangent direction (local frame), seed sbar
+  __shared__ float pt_dc[PTS][4];             // d phi / d local coordinates
+  __shared__ int pt_idx[PTS];
+
+  const int tile_index = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int* tile = p.tiles + 4 * tile_index;
+  const int row = tile[0], k = tile[1], off = tile[2], cnt = tile[3];
+  if (cnt <= 0) return;
+  const int set = member_set(k);
+  const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
+  const float sign_x = (k < 2 * N_SYMM && (k & 1)) ? -1.f : 1.f;
+  const int64_t col0 = int64_t(tile_index) * 64;
+
+  if (threadIdx.x < PTS) {
+    const int m = threadIdx.x;
+    const bool ok = m < cnt;
+    const int n = p.list[off + (ok ? m : cnt - 1)];
+    const int64_t pt = int64_t(row) * p.n_points + n;
+    const float* q = p.xyz + pt * 3;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (k < N_LOC) { const float* a = st + LS_OFF_ANCH + 3 * k; ax = a[0]; ay = a[1]; az = a[2]; }
+    pt_c[m][0] = sign_x * (q[0] - ax); pt_c[m][1] = q[1] - ay; pt_c[m][2] = q[2] - az; pt_c[m][3] = ok ? 1.f : 0.f;
+    float vx = 0.f, vy = 0.f, vz = 0.f, sb = ok ? 1.f : 0.f;
+    if (SECOND) {
+      const int64_t pair = pt * N_MEMBERS + k;
+      sb = ok ? p.g_sdf[pair] : 0.f;
+      if (ok && p.g_grad) { const float* v = p.g_grad + pair * 3; vx = sign_x * v[0]; vy = v[1]; vz = v[2]; }
+    }
+    pt_v[m][0] = vx; pt_v[m][1] = vy; pt_v[m][2] = vz; pt_v[m][3] = sb;
+    pt_dc[m][0] = 0.f; pt_dc[m][1] = 0.f; pt_dc[m][2] = 0.f; pt_dc[m][3] = 0.f;
+    pt_idx[m] = ok ? n : -1;
+  }
+  __syncthreads();
+
+  const float cx = pt_c[j][0], cy = pt_c[j][1], cz = pt_c[j][2], valid = pt_c[j][3];
+  const float vx = pt_v[j][0], vy = pt_v[j][1], vz = pt_v[j][2], seed = pt_v[j][3];
+  bf16x8 bv[NT];
+  bv[0] = coord_operand(cx, cy, cz, h);
+  if (SECOND) bv[NT - 1] = tangent_operand(vx, vy, vz, h);
+
+  const uint16_t* fw = p.packed_bf16 + size_t(set) * BF_SET_STRIDE;
+  const uint16_t* bw = p.packed_bwd + size_t(set) * BWD_SET_STRIDE;
+  const float* tails = st + LS_OFF_TAIL + size_t(k) * GEMM_CHUNKS * TAIL_FLOATS;
+  const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
+  const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
+  const f32x16 zero16 = {};
+
+  // out tile `n` of a stage: acc[t] += sum over ks K-steps of A(n, s) x act(s)   (split-bf16 x3)
+  auto gemm_tile = [&](f32x16 (&acc)[NT], const uint16_t* frag_base, int n, int ks) __attribute__((always_inline)) {
+    const bf16x8* W = reinterpret_cast<const bf16x8*>(frag_base) + size_t(n) * ks * 128 + lane;
+    bf16x8 ah[2], al[2], bh[2][NT], bl[2][NT];
+    auto load = [&](int slot, int s) __attribute__((always_inline)) {
+      ah[slot] = W[s * 128];
+      al[slot] = W[s * 128 + 64];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bh[slot][t] = Bh[2 * s * M + 32 * t];
+        bl[slot][t] = Bl[2 * s * M + 32 * t];
+      }
+    };
+    auto mma = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot], bh[slot][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot], bl[slot][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot], bh[slot][t], acc[t], 0, 0, 0);
+      }
+    };
+    load(0, 0);
+#pragma unroll 1
+    for (int s = 0; s < ks; s += 2) {
+      if (s + 1 < ks) load(1, s + 1);
+      mma(0);
+      if (s + 2 < ks) load(0, s + 2);
+      if (s + 1 < ks) mma(1);
+    }
+  };
+  // D tile n -> LDS K chunks 4n + 2*half + h of the columns
+  auto store_tile = [&](int n, const f32x16 (&v)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float tmp[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmp[r] = v[t][r];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const Split8 s8 = split8(tmp + 8 * half);
+        const int o = ((4 * n + 2 * half + h) * M + 32 * t + j) * 16;
+        *reinterpret_cast<bf16x8*>(act_hi + o) = s8.hi;
+        *reinterpret_cast<bf16x8*>(act_lo + o) = s8.lo;
+      }
+    }
+  };
+  // D tile n -> rows feat_of(n, r, h) < rows of a saved operand (32 lanes = 128 contiguous bytes per row)
+  auto save_tile = [&](int which, int rows, int n, const f32x16 (&v)[NT]) __attribute__((always_inline)) {
+    if (!SECOND) return;
+    float* base = p.save[which] + col0 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = feat_of(n, r, h);
+      if (f < rows) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) base[int64_t(f) * p.n_cols + 32 * t] = v[t][r];
+      }
+    }
+  };
+  // activation: h' = softplus2(d'), u' = s tau ; keeps s = sigma'(d') and s' tau for the reverse sweep
+  auto activate = [&](const f32x16 (&acc)[NT], f32x16& s, f32x16& q, f32x16 (&val)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sg = sigmoid2(acc[0][r]);
+      s[r] = sg;
+      val[0][r] = softplus2(acc[0][r]);
+      if (SECOND) {
+        const float tau = acc[NT - 1][r];
+        val[NT - 1][r] = sg * tau;
+        q[r] = LN2 * sg * (1.f - sg) * tau;
+      }
+    }
+  };
+  // reverse through the activation: D = H s + U s' tau ; T = U s
+  auto deactivate = [&](const f32x16 (&acc)[NT], const f32x16& s, const f32x16& q, f32x16 (&val)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (SECOND) {
+        val[0][r] = fmaf(acc[0][r], s[r], acc[NT - 1][r] * q[r]);
+        val[NT - 1][r] = acc[NT - 1][r] * s[r];
+      } else {
+        val[0][r] = acc[0][r] * s[r];
+      }
+    }
+  };
+
+  f32x16 acc[NT], val[NT], s0, s1, s2, s3, q0, q1, q2, q3;
+  s0 = zero16; s1 = zero16; s2 = zero16; s3 = zero16; q0 = zero16; q1 = zero16; q2 = zero16; q3 = zero16;
+
+  if (SECOND && wave == 7) {                       // lin0's own inputs and the output seeds, as saved operands
+    if (h == 0) {
+      float* b = p.save[SV_IN0] + col0 + j;
+      b[0] = cx; b[p.n_cols] = cy; b[2 * p.n_cols] = cz;
+      b[32] = vx; b[p.n_cols + 32] = vy; b[2 * p.n_cols + 32] = vz;
+      float* sd = p.save[SV_SEED] + col0 + j;
+      sd[0] = seed; sd[32] = valid;
+    }
+  }
+
+  // ================================ forward =======================================================
+  // L0: lin0 on the local coordinates (folded bias inside the block), tangent: lin0[:, :3] v
+  if (wave < 7) {
+    const bf16x8* A0 = reinterpret_cast<const bf16x8*>(st + LS_OFF_L0B + size_t(k) * L0_BLOCK_FLOATS) + lane;
+    const bf16x8 a = A0[wave * 64];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv[t], zero16, 0, 0, 0);
+    activate(acc, s0, q0, val);
+    store_tile(wave, val);
+    save_tile(SV_IN1, HID, wave, val);
+  }
+  __syncthreads();
+  // L1: 200 -> 101 (4 tiles); the skip coordinates (tangent: the direction) join tile 3 as features 101..103
+  if (wave < L1_OB) {
+    acc[0] = load_frag16(tails + wave * TAIL_FLOATS + h * 16);
+    if (SECOND) acc[NT - 1] = zero16;
+    gemm_tile(acc, fw + BF_OFF_L1A, wave, L1_KS16);
+    activate(acc, s1, q1, val);
+    if (wave == L1_OB - 1) {
+      val[0][1] = h ? cx : val[0][1]; val[0][2] = h ? cy : val[0][2]; val[0][3] = h ? cz : val[0][3];
+      if (SECOND) {
+        val[NT - 1][1] = h ? vx : val[NT - 1][1]; val[NT - 1][2] = h ? vy : val[NT - 1][2]; val[NT - 1][3] = h ? vz : val[NT - 1][3];
+      }
+    }
+  }
+  __syncthreads();                       // every wavefront has read a0
+  if (wave < L1_OB) { store_tile(wave, val); save_tile(SV_IN2, L2_IN, wave, val); }
+  __syncthreads();
+  // L2: 104 -> 200
+  if (wave < 7) {
+    acc[0] = load_frag16(tails + (L1_OB + wave) * TAIL_FLOATS + h * 16);
+    if (SECOND) acc[NT - 1] = zero16;
+    gemm_tile(acc, fw + BF_OFF_L2A, wave, L2_KS16);
+    activate(acc, s2, q2, val);
+  }
+  __syncthreads();
+  if (wave < 7) { store_tile(wave, val); save_tile(SV_IN3, HID, wave, val); }
+  __syncthreads();
+  // L3: 200 -> 200, lin4 fused: f = sum h3' * w4 / k + b4
+  f32x16 w4v = zero16;
+  if (wave < 7) {
+    const float* tl = tails + (L1_OB + L2_OB + wave) * TAIL_FLOATS;
+    acc[0] = load_frag16(tl + h * 16);
+    if (SECOND) acc[NT - 1] = zero16;
+    gemm_tile(acc, fw + BF_OFF_L3A, wave, L3_KS16);
+    w4v = load_frag16(tl + 32 + h * 16);
+    activate(acc, s3, q3, val);
+    save_tile(SV_IN4, HID, wave, val);
+    if (!SECOND) {
+      float partial = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) partial = fmaf(val[0][r], w4v[r], partial);
+      partial += __shfl_xor(partial, 32);
+      if (h == 0) part[wave][j] = partial;
+    }
+  }
+  __syncthreads();
+  if (!SECOND && threadIdx.x < PTS) {
+    const int m = threadIdx.x;
+    float f = p.packed_f32[size_t(set) * SET_STRIDE + OFF_L4B];
+#pragma unroll
+    for (int w = 0; w < 7; ++w) f += part[w][m];
+    if (pt_idx[m] >= 0) p.member_sdf[(int64_t(row) * p.n_points + pt_idx[m]) * N_MEMBERS + k] = f;
+  }
+
+  // ================================ reverse =======================================================
+  // output seeds: H3 = sbar w4/k, U3 = w4/k (valid columns) -> D3 = H3 s3 + U3 s3' tau3, T3 = U3 s3
+  if (wave < 7) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (SECOND) {
+        val[0][r] = w4v[r] * fmaf(seed, s3[r], valid * q3[r]);
+        val[NT - 1][r] = valid * w4v[r] * s3[r];
+      } else {
+        val[0][r] = seed * w4v[r] * s3[r];
+      }
+    }
+    store_tile(wave, val);               // a2 is no longer needed (every wavefront passed the barriers above)
+    save_tile(SV_D3, HID, wave, val);
+  }
+  __syncthreads();
+  // stage A: [H2 | U2] = lin3^T [D3 | T3] ; bias gradient of the skip layer = k sum D2
+  if (wave < 7) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero16;
+    gemm_tile(acc, bw + OFF_A, wave, A_KS);
+    deactivate(acc, s2, q2, val);
+    if (SECOND) {
+      float* gb = p.gb2 + (size_t(row) * N_MEMBERS + k) * HID;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sum = half_wave_sum(val[0][r]);
+        const int f = feat_of(wave, r, h);
+        if (j == 0 && f < HID) atomicAdd(gb + f, sum * SP_SCALE);
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < 7) { store_tile(wave, val); save_tile(SV_D2, HID, wave, val); }
+  __syncthreads();
+  // stage B: rows 0..100: [H1 | U1] = (lin2a / sqrt2)^T [D2 | T2]; rows 101..103: d phi / d coords (skip path)
+  if (wave < B_OB) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero16;
+    gemm_tile(acc, bw + OFF_B, wave, B_KS);
+    deactivate(acc, s1, q1, val);
+    if (wave == B_OB - 1 && h) {          // features 101..103 = registers 1..3 of the upper half-wave
+      pt_dc[j][0] = acc[0][1]; pt_dc[j][1] = acc[0][2]; pt_dc[j][2] = acc[0][3];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { val[t][1] = 0.f; val[t][2] = 0.f; val[t][3] = 0.f; }
+    }
+  }
+  __syncthreads();
+  if (wave < B_OB) { store_tile(wave, val); save_tile(SV_D1, L1_OUT, wave, val); }
+  __syncthreads();
+  // stage C: [H0 | U0] = lin1^T [D1 | T1] ; bias gradient of lin0 = k sum D0
+  if (wave < 7) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero16;
+    gemm_tile(acc, bw + OFF_C, wave, C_KS);
+    deactivate(acc, s0, q0, val);
+    if (SECOND) {
+      float* gb = p.gb0 + (size_t(row) * N_MEMBERS + k) * HID;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sum = half_wave_sum(val[0][r]);
+        const int f = feat_of(wave, r, h);
+        if (j == 0 && f < HID) atomicAdd(gb + f, sum * SP_SCALE);
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < 7) { store_tile(wave, val); save_tile(SV_D0, HID, wave, val); }
+  __syncthreads();
+  // stage D: d phi / d coords (lin0 path) = (k lin0[:, :3])^T D0 ; one tile, wavefront 0
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero16;
+    gemm_tile(acc, bw + OFF_D, 0, D_KS);
+    if (h == 0) {                          // rows 0..2 of the tile = registers 0..2 of the lower half-wave
+      pt_dc[j][0] += acc[0][0]; pt_dc[j][1] += acc[0][1]; pt_dc[j][2] += acc[0][2];
+    }
+  }
+  __syncthreads();
+
+  // ---- per point: back to the global frame ---------------------------------------------------------
+  if (threadIdx.x < PTS) {
+    const int m = threadIdx.x;
+    const int n = pt_idx[m];
+    float gq[3] = {0.f, 0.f, 0.f};
+    if (n >= 0) { gq[0] = sign_x * pt_dc[m][0]; gq[1] = pt_dc[m][1]; gq[2] = pt_dc[m][2]; }   // c = flip (q - a)
+    if (!SECOND) {
+      if (n >= 0) {
+        float* o = p.member_grad + ((int64_t(row) * p.n_points + n) * N_MEMBERS + k) * 3;
+        o[0] = gq[0]; o[1] = gq[1]; o[2] = gq[2];
+      }
+    } else {
+      if (n >= 0) {
+        float* o = p.gxyz + (int64_t(row) * p.n_points + n) * 3;
+        atomicAdd(o, gq[0]); atomicAdd(o + 1, gq[1]); atomicAdd(o + 2, gq[2]);
+      }
+      float sx = gq[0], sy = gq[1], sz = gq[2];      // anchor gradient: minus the sum over the tile's points
+#pragma unroll
+      for (int o2 = 16; o2 > 0; o2 >>= 1) { sx += __shfl_xor(sx, o2); sy += __shfl_xor(sy, o2); sz += __shfl_xor(sz, o2); }
+      if (m == 0 && k < N_LOC) {
+        float* o = p.ganch + (size_t(row) * N_LOC + k) * 3;
+        atomicAdd(o, -sx); atomicAdd(o + 1, -sy); atomicAdd(o + 2, -sz);
+      }
+    }
+  }
+}
+
+}  // namespace train
+}  // namespace nphm
+
+// ============================================================================================
+// C ABI (include/nphm_amd.h)
+// ============================================================================================
+extern "C" {
+
+int nphm_identity_train_saved_rows(int which) {
+  static const int rows[nphm::train::SV_COUNT] = {3, nphm::HID, nphm::L2_IN, nphm::HID, nphm::HID,
+                                                  nphm::HID, nphm::L1_OUT, nphm::HID, nphm::HID, 1};
+  return (which < 0 || which >= nphm::train::SV_COUNT) ? -1 : rows[which];
+}
+
+static int train_common(nphm::train::TrainArgs& a, const void* packed, const void* packed_bwd, const void* latent_state,
+                        const float* xyz, int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
+                        const char* who) {
+  if (!packed || !packed_bwd || !latent_state || !xyz || !tiles || !point_list) return nphm_fail_msg(who);
+  if (n_points <= 0 || n_tiles < 0) return nphm_fail_msg(who);
+  memset(&a, 0, sizeof(a));
+  a.packed_f32 = static_cast<const float*>(packed);
+  a.packed_bf16 = reinterpret_cast<const uint16_t*>(static_cast<const char*>(packed) + nphm::PACKED_F32_FLOATS * 4);
+  a.packed_bwd = static_cast<const uint16_t*>(packed_bwd);
+  a.state = static_cast<const float*>(latent_state);
+  a.xyz = xyz; a.n_points = n_points; a.tiles = tiles; a.n_tiles = n_tiles; a.list = point_list;
+  return 0;
+}
+
+int nphm_identity_train_forward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
+                                int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
+                                float* member_sdf, float* member_grad, void* stream) {
+  nphm::train::TrainArgs a;
+  if (train_common(a, packed, packed_bwd, latent_state, xyz, n_points, tiles, n_tiles, point_list,
+                   "nphm_identity_train_forward: null pointer or bad sizes")) return 1;
+  if (!member_sdf || !member_grad) return nphm_fail_msg("nphm_identity_train_forward: null output");
+  if (n_tiles == 0) return 0;
+  a.member_sdf = member_sdf; a.member_grad = member_grad;
+  hipLaunchKernelGGL(nphm::train::train_kernel<false>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_train_forward launch", e);
+  return 0;
+}
+
+int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
+                                 int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
+                                 const float* grad_member_sdf, const float* grad_member_grad,
+                                 float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2,
+                                 float* const saved[10], int64_t n_cols, void* stream) {
+  nphm::train::TrainArgs a;
+  if (train_common(a, packed, packed_bwd, latent_state, xyz, n_points, tiles, n_tiles, point_list,
+                   "nphm_identity_train_backward: null pointer or bad sizes")) return 1;
+  if (!grad_member_sdf || !grad_xyz || !grad_anchors || !grad_b0 || !grad_b2 || !saved)
+    return nphm_fail_msg("nphm_identity_train_backward: null pointer");
+  if (n_cols < int64_t(n_tiles) * 64) return nphm_fail_msg("nphm_identity_train_backward: n_cols < 64 * n_tiles");
+  for (int i = 0; i < nphm::train::SV_COUNT; ++i) {
+    if (!saved[i]) return nphm_fail_msg("nphm_identity_train_backward: null saved-operand buffer");
+    a.save[i] = saved[i];
+  }
+  if (n_tiles == 0) return 0;
+  a.g_sdf = grad_member_sdf; a.g_grad = grad_member_grad;
+  a.gxyz = grad_xyz; a.ganch = grad_anchors; a.gb0 = grad_b0; a.gb2 = grad_b2;
+  a.n_cols = n_cols;
+  hipLaunchKernelGGL(nphm::train::train_kernel<true>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_train_backward launch", e);
+  return 0;
+}
+
+}  // extern "C"

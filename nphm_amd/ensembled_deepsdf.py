@@ -14,6 +14,11 @@ Execution tiers of ``FastEnsembleDeepSDFMirrored.forward``:
   backward = ``nphm_identity_backward`` (member-centric MFMA kernel) for d/dxyz, d/danchors and
   d/d(folded biases), chained through ``mlp_pos`` and the latent columns by ordinary autograd.  Not
   double-differentiable (training needs the composite tier, which it gets: its parameters require grad).
+* **HIP training** (twice differentiable in xyz, every parameter trainable): when parameters require grad,
+  in training mode (``compute_loss``: decoder -> gradient(pred, x, create_graph=True) -> loss.backward()).  The
+  member MLPs and their first / second-order backward run on ``nphm_identity_train_forward/backward``
+  (ident_train_kernel.hip), weight gradients as one library GEMM per layer and weight set over operands the
+  kernel stores; ``module.train_backend = "composite"`` (or NPHM_AMD_TRAIN_TIER=composite) opts out.
 * **composite**: a differentiable PyTorch formulation (latent columns of lin0 / the skip layer are
   applied once per latent instead of once per point).  Used when gradients are required
   (fitting / training, incl. double backward), for per-point latents and for other architectures.
@@ -152,13 +157,9 @@ def sample_point_feature(q, p, fea, var=0.1 ** 2, background=False):
     return (w.unsqueeze(-1) * fea).sum(dim=2)
 
 
-def _member_point_lists(anchors, xyz, prune_tol, n_members):
-    """(row, member) -> points that keep the member under the pruning rule of the fused kernel (per
-    point the smallest normalised blend weights are dropped while they sum to <= 40 * prune_tol; all
-    points if negative): blend weights [B,N,A] (zero where pruned), tile table int32 [T,4] = (row, member,
-    offset into the point list, count <= 64) and the point list int32 [P] (sorted by row, member,
-    point).  One host sync (the per-pair counts size the launch)."""
-    B, N, _ = xyz.shape
+def _blend_mask(anchors, xyz, prune_tol, n_members):
+    """Normalised blend weights [B,N,A] (EnsembledDeepSDF.py:129-150) and the members the fused kernel's pruning rule
+    keeps (per point the smallest weights are dropped while they sum to <= A * prune_tol; all if negative)."""
     A = n_members
     d = (anchors[:, None, :, :] - xyz[:, :, None, :]).norm(dim=3) + 1e-5
     w = torch.exp(-(d * d) / 0.01)
@@ -166,7 +167,6 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
     denom = w.sum(dim=2, keepdim=True) + w_bg + 1e-6
     what = torch.cat([w, torch.full_like(w[:, :, :1], w_bg)], dim=2) / denom
     if prune_tol >= 0:
-        # same rule as the fused kernel: per point, drop the smallest weights while they sum to <= A * tol
         tol = float(prune_tol)
         cut = torch.full_like(what[..., :1], tol)
         for mult in (2.0, 4.0, 8.0, 16.0, 40.0):
@@ -175,6 +175,18 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
         mask = what > cut
     else:
         mask = torch.ones_like(what, dtype=torch.bool)
+    return what, mask
+
+
+def _member_point_lists(anchors, xyz, prune_tol, n_members):
+    """(row, member) -> points that keep the member under the pruning rule of the fused kernel (per
+    point the smallest normalised blend weights are dropped while they sum to <= 40 * prune_tol; all
+    points if negative): blend weights [B,N,A] (zero where pruned), tile table int32 [T,4] = (row, member,
+    offset into the point list, count <= 64) and the point list int32 [P] (sorted by row, member,
+    point).  One host sync (the per-pair counts size the launch)."""
+    B, N, _ = xyz.shape
+    A = n_members
+    what, mask = _blend_mask(anchors, xyz, prune_tol, A)
     idx = mask.permute(0, 2, 1).nonzero()                      # sorted by (row, member, point)
     counts = torch.bincount(idx[:, 0] * A + idx[:, 1], minlength=B * A).cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(counts)])
@@ -184,6 +196,33 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
     tiles = np.stack([bk // A, bk % A, offs[bk] + 64 * within, np.minimum(64, counts[bk] - 64 * within)],
                      axis=1).astype(np.int32)
     return what * mask, torch.from_numpy(tiles).to(xyz.device), idx[:, 2].to(torch.int32).contiguous()
+
+
+def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
+    """Point lists of the training kernels (ident_train_kernel.hip): 32-point tiles ordered by (member, row), so the
+    tiles of one weight set are contiguous (``sets`` [A] = member -> set, non-decreasing).  Returns the tile table
+    int32 [T,4] = (row, member, offset, count <= 32), the point list int32, the weight set of every tile (long [T])
+    and the tile range of every set (list of (t0, t1)).  One host sync."""
+    B, N, _ = xyz.shape
+    A = n_members
+    with torch.no_grad():
+        _, mask = _blend_mask(anchors, xyz, prune_tol, A)
+        idx = mask.permute(2, 0, 1).nonzero()                  # sorted by (member, row, point)
+        counts = torch.bincount(idx[:, 0] * B + idx[:, 1], minlength=A * B).cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    n_t = (counts + 31) // 32
+    pair = np.repeat(np.arange(A * B), n_t)
+    within = np.arange(int(n_t.sum())) - np.repeat(np.cumsum(n_t) - n_t, n_t)
+    tiles = np.stack([pair % B, pair // B, offs[pair] + 32 * within, np.minimum(32, counts[pair] - 32 * within)],
+                     axis=1).astype(np.int32)
+    sets_np = sets.cpu().numpy()
+    set_of_tile = sets_np[pair // B]
+    per_set = np.bincount(set_of_tile, minlength=int(sets_np.max()) + 1)
+    ends = np.cumsum(per_set)
+    ranges = [(int(e - c), int(e)) for c, e in zip(per_set, ends)]
+    dev = xyz.device
+    return (torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(),
+            torch.from_numpy(set_of_tile.astype(np.int64)).to(dev), ranges)
 
 
 def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
@@ -267,6 +306,130 @@ class _IdentityFieldFn(torch.autograd.Function):
         return None, gx, g_lat, ga
 
 
+_K_SCALE = 100.0 / math.log(2.0)        # activation scale of the kernels (layout.h)
+_SAVED_ROWS = (3, 200, 104, 200, 200, 200, 101, 200, 200, 1)
+
+
+class _MemberFieldFn(torch.autograd.Function):
+    """Training tier, kernel half: (f_k, d f_k / d xyz) of the 40 member MLPs for every (point, member) the pruning
+    rule keeps (zeros elsewhere), by ``nphm_identity_train_forward``; backward = ``nphm_identity_train_backward``
+    (value + one tangent stream, reverse sweep with sigma'') plus one library GEMM per layer and weight set over the
+    operands that kernel stores.  Differentiable inputs: xyz, anchors, the folded biases of lin0 / the skip layer
+    (``b0f``, ``b2f`` [B,40,200]: graph handles - the kernels read the same quantities from the HIP prologue's state;
+    autograd chains them to the latent and to the latent columns of lin0 / lin2), the remaining weights and biases.
+
+    Contract with ``_AttachGradientFn`` (always used together): the FIRST-order term  dL/df_k * d f_k/d xyz  of
+    d/dxyz and d/danchors is returned
+      * by ``_AttachGradientFn.backward`` as differentiable PyTorch ops when the backward pass records a graph
+        (``gradient(pred, x)`` with create_graph=True) - this function then returns nothing (no parameter gradients
+        are produced by a graph-recording backward pass);
+      * by this function's kernel (which computes the total) otherwise (``loss.backward()``)."""
+
+    @staticmethod
+    def forward(ctx, module, xyz, anchors, lat_rows, b0f, b2f, W0, W1, W2, W3, W4, b1, b3, b4):
+        lib = _lib.load()
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        A = module.num_kps + 1
+        packed, state, anchors_k = module.prepare_latent(lat_rows.detach())
+        packed_bwd = module._packed_bwd(dev)
+        xyz_c = xyz.detach().contiguous().float()
+        tiles, plist, set_of_tile, ranges = _train_member_lists(anchors_k, xyz_c, module.prune_tol, A,
+                                                                module.ensembled_deep_sdf.lin0._sets)
+        S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
+        G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.nphm_identity_train_forward(
+            packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N, tiles.data_ptr(),
+            tiles.shape[0], plist.data_ptr(), S.data_ptr(), G.data_ptr(), stream), "nphm_identity_train_forward")
+        ctx.module = module
+        ctx.ranges = ranges
+        ctx.shapes = [t.shape for t in (W0, W1, W2, W3, W4, b1, b3, b4)]
+        ctx.save_for_backward(xyz_c, packed, packed_bwd, state, tiles, plist, set_of_tile)
+        ctx.set_materialize_grads(False)
+        return S, G
+
+    @staticmethod
+    def backward(ctx, gS, gG):
+        n_in = 14
+        if torch.is_grad_enabled():
+            # graph-recording pass (gradient(pred, x), create_graph=True): _AttachGradientFn supplies d/dxyz
+            if gG is not None:
+                raise RuntimeError("nphm_amd training tier: third-order derivatives are not implemented "
+                                   "(set module.train_backend = 'composite')")
+            return (None,) * n_in
+        lib = _lib.load()
+        module = ctx.module
+        xyz, packed, packed_bwd, state, tiles, plist, set_of_tile = ctx.saved_tensors
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        A, H, K = module.num_kps + 1, module.hidden_dim, module.num_kps
+        T = tiles.shape[0]
+        n_cols = 64 * T
+        sizes = [B * N * 3, B * K * 3, B * A * H, B * A * H]
+        parts = torch.zeros(sum(sizes), dtype=torch.float32, device=dev).split(sizes)
+        gx, ga = parts[0].view(B, N, 3), parts[1].view(B, K, 3)
+        gb0, gb2 = parts[2].view(B, A, H), parts[3].view(B, A, H)
+        shapes = ctx.shapes
+        grads = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in shapes]
+        gW0, gW1, gW2, gW3, gW4, gb1, gb3, gb4 = grads
+        if T and (gS is not None or gG is not None):
+            gS_c = torch.zeros(B, N, A, dtype=torch.float32, device=dev) if gS is None else gS.detach().contiguous().float()
+            gG_c = None if gG is None else gG.detach().contiguous().float()
+            saved = torch.empty(sum(_SAVED_ROWS), n_cols, dtype=torch.float32, device=dev).split(_SAVED_ROWS, dim=0)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.nphm_identity_train_backward(
+                packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N, tiles.data_ptr(), T,
+                plist.data_ptr(), gS_c.data_ptr(), None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(),
+                ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), _lib.ptr_array(saved), n_cols, stream),
+                "nphm_identity_train_backward")
+            in0, in1, in2, in3, in4, d0, d1, d2, d3, seed = saved
+            k, r2 = _K_SCALE, 1.0 / _SQRT2
+            n1, d_in = shapes[1][1], module.input_dim            # 101, 3
+            for s, (t0, t1) in enumerate(ctx.ranges):
+                if t1 <= t0:
+                    continue
+                c = slice(64 * t0, 64 * t1)
+                gW3[s] = d3[:, c] @ in3[:, c].T
+                gW2[s, :, :n1 + d_in] = d2[:, c] @ in2[:, c].T
+                gW1[s] = d1[:, c] @ in1[:, c].T
+                gW0[s, :, :d_in] = d0[:, c] @ in0[:, c].T
+                gW4[s, 0] = in4[:, c] @ seed[0, c]
+            gW2[:, :, :n1] *= r2
+            gW2[:, :, n1:n1 + d_in] *= k * r2
+            gW0[:, :, :d_in] *= k
+            gW4 /= k
+
+            def per_set(rows):        # k * sum over the value columns, per weight set -> [sets, F]
+                v = rows.view(rows.shape[0], T, 2, 32)[:, :, 0].sum(dim=-1)                    # [F, T]
+                return torch.zeros(rows.shape[0], shapes[0][0], dtype=torch.float32, device=dev).index_add_(1, set_of_tile, v).T
+            gb3.copy_(per_set(d3) * k)
+            gb1.copy_(per_set(d1) * k)
+            gb4.copy_(per_set(seed))
+        return (None, gx, ga, None, gb0, gb2, gW0, gW1, gW2, gW3, gW4, gb1, gb3, gb4)
+
+
+class _AttachGradientFn(torch.autograd.Function):
+    """Identity on the member values S that knows their spatial gradients G = dS/dxyz (an output of the same
+    kernel): in a graph-recording backward pass it returns dL/dxyz and dL/danchors as PyTorch ops on G, which makes
+    ``gradient(pred, x, create_graph=True)`` differentiable again (the second-order seed reaches ``_MemberFieldFn``
+    through G); otherwise ``_MemberFieldFn``'s kernel returns these two."""
+
+    @staticmethod
+    def forward(ctx, xyz, anchors, S, G):
+        ctx.save_for_backward(G)
+        ctx.n_kps = anchors.shape[1]
+        return S.clone()
+
+    @staticmethod
+    def backward(ctx, gS):
+        if not torch.is_grad_enabled():
+            return None, None, gS, None
+        (G,) = ctx.saved_tensors
+        gc = gS.unsqueeze(-1) * G                                    # [B,N,A,3]
+        return gc.sum(dim=2), -gc[:, :, :ctx.n_kps].sum(dim=1), gS, None
+
+
 class FastEnsembleDeepSDFMirrored(nn.Module):
     """NPHM identity SDF: one small MLP per facial anchor (+ one background MLP), evaluated in
     anchor-local coordinates (odd member of each symmetric pair mirrored in x) and blended by a
@@ -312,6 +475,9 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         # parameters as frozen when choosing the tier, so that loop reaches the HIP autograd tier too (their .grad
         # stays None).  nphm_amd.fitting freezes them itself and does not need it.
         self.assume_frozen_parameters = os.environ.get("NPHM_AMD_ASSUME_FROZEN", "0") not in ("", "0")
+        # tier of a training forward (parameters require grad, train mode): "hip" = member MLPs and their double
+        # backward by the kernels of ident_train_kernel.hip | "composite" = PyTorch formulation
+        self.train_backend = os.environ.get("NPHM_AMD_TRAIN_TIER", "hip")
 
     # ------------------------------------------------------------------------------------------
     def invalidate_pack(self):
@@ -453,6 +619,27 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         sdf = _IdentityFieldFn.apply(self, xyz, lat_rows, anchors)
         return sdf, anchors
 
+    def _forward_hip_train(self, xyz, lat_rows):
+        """Training tier: twice differentiable w.r.t. xyz, differentiable w.r.t. the latent rows and every
+        parameter.  Member MLPs (EnsembledDeepSDF.py:101-126) and their first / second-order backward on the
+        HIP kernels; anchors, the latent columns of lin0 / the skip layer and the Gaussian blend
+        (EnsembledDeepSDF.py:129-150) stay ordinary autograd (a few [B,N,40] elementwise ops)."""
+        B = xyz.shape[0]
+        g, A = self.lat_dim_glob, self.num_kps + 1
+        e = self.ensembled_deep_sdf
+        anchors = self.mlp_pos(lat_rows[:, :g]).view(B, self.num_kps, 3)
+        anchors = anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
+        cond = torch.cat([lat_rows[:, None, :g].expand(B, A, g), lat_rows[:, g:].reshape(B, A, self.lat_dim_loc)], dim=-1)
+        d_in, n1 = self.input_dim, e.lin1.out_features
+        W0m, W2m = e.lin0.member_weight(), e.lin2.member_weight()
+        b0f = torch.einsum("baf,aof->bao", cond, W0m[:, :, d_in:]) + e.lin0.member_bias()[None]
+        b2f = torch.einsum("baf,aof->bao", cond, W2m[:, :, n1 + d_in:]) / _SQRT2 + e.lin2.member_bias()[None]
+        S, G = _MemberFieldFn.apply(self, xyz, anchors, lat_rows, b0f, b2f, e.lin0.weight, e.lin1.weight, e.lin2.weight,
+                                    e.lin3.weight, e.lin4.weight, e.lin1.bias, e.lin3.bias, e.lin4.bias)
+        f = _AttachGradientFn.apply(xyz, anchors, S, G)
+        pred = sample_point_feature(xyz[..., :3], anchors, f.unsqueeze(-1), background=True, var=0.1 ** 2)
+        return pred, anchors
+
     def predict_anchors(self, lat_rep: torch.Tensor) -> torch.Tensor:
         """Anchors of the identity codes ``lat_rep`` [B, L, lat_dim] (row 0 of every batch entry): the
         second return value of ``forward`` (EnsembledDeepSDF.py:228-229) without evaluating any SDF -
@@ -518,5 +705,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             # chunk overwrite to differentiate around); everything else builds the composite graph
             if self.training and not params_train:
                 return self._forward_hip_autograd(xyz, lat_rep[:, 0, :])
+            if self.training and self.train_backend == "hip":
+                return self._forward_hip_train(xyz, lat_rep[:, 0, :])
             return self._forward_composite(xyz, lat_rep)
         return self._forward_hip(xyz, lat_rep[:, 0, :])

@@ -1,0 +1,119 @@
+"""GPU parity of the training tier: the loss of compute_loss
+(src/NPHM/models/loss_functions.py:20-110: decoder -> gradient(pred, x, create_graph=True) -> SDF / normal /
+eikonal / anchor terms -> loss.backward()) evaluated with the member MLPs and their double backward on the HIP
+kernels (ident_train_kernel.hip) against the composite PyTorch tier (fp32 autograd, the reference's arithmetic)
+on the same seeded inputs.  Tolerances are relative to the largest entry of the reference tensor: 2e-4 with all 40
+members (observed ~1e-5: split-bf16 products in the sweeps, fp32 GEMMs for the weight gradients), pruned members
+(blend weight <= prune_tol) add at most their share."""
+import numpy as np
+import pytest
+import torch
+
+import _util as U
+from nphm_amd.diff_operators import gradient
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _batch(dev, B, N, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.stack([U.sample_latent(10 + b) for b in range(B)])[:, None, :].to(dev)
+    xyz = ((torch.rand(B, N, 3, generator=g) - 0.5) * torch.tensor([0.7, 0.9, 0.7])).to(dev)
+    nrm = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1).to(dev)
+    return lat, xyz, nrm
+
+
+def _loss_terms(net, lat, xyz, nrm):
+    """The geometry terms of actual_compute_loss (loss_functions.py:36-75) with nphm.yaml's lambdas."""
+    x = xyz.clone().detach().requires_grad_()
+    pred, anchors = net(x, lat.repeat(1, x.shape[1], 1), None)
+    grad = gradient(pred, x)
+    loss = (2.0 * pred.abs().mean() + 0.3 * (grad - nrm).norm(2, dim=-1).mean()
+            + 0.1 * (grad.norm(dim=-1) - 1).abs().mean() + 0.01 * torch.exp(-1e1 * pred.abs()).mean()
+            + 7.5 * anchors.square().mean() + 0.01 * (lat.norm(dim=-1) ** 2).mean())
+    return loss, pred, grad
+
+
+def _run(net, backend, lat0, xyz, nrm):
+    net.train_backend = backend
+    net.zero_grad(set_to_none=True)
+    lat = lat0.clone().requires_grad_()
+    loss, pred, grad = _loss_terms(net, lat, xyz, nrm)
+    loss.backward()
+    out = {"pred": pred.detach(), "grad": grad.detach(), "lat": lat.grad.detach().clone(), "loss": loss.detach()}
+    for name, p in net.named_parameters():
+        out[name] = p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
+    return out
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("prune_tol,tol", [(-1.0, 2e-4), (1e-7, 1e-3)])
+def test_training_tier_matches_composite_double_backward(dev, prune_tol, tol):
+    net = U.build_identity(device=dev).train()
+    net.prune_tol = prune_tol
+    lat, xyz, nrm = _batch(dev, B=4, N=1000)
+    used = {}
+    orig = net._forward_hip_train
+    net._forward_hip_train = lambda *a, **k: used.setdefault("hip", True) and orig(*a, **k)
+    ref = _run(net, "composite", lat, xyz, nrm)
+    assert not used
+    out = _run(net, "hip", lat, xyz, nrm)
+    assert used.get("hip"), "the training tier did not run"
+    worst = {k: _rel(out[k], ref[k]) for k in ref}
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, f"training tier vs composite: {bad} (all: {worst})"
+    # every ensemble parameter received a gradient
+    for name in ("ensembled_deep_sdf.lin0.weight", "ensembled_deep_sdf.lin2.weight", "ensembled_deep_sdf.lin4.bias",
+                 "mlp_pos.0.weight"):
+        assert float(out[name].abs().max()) > 0
+
+
+def test_training_tier_first_order_only(dev):
+    """A loss without gradient terms (no create_graph pass): the kernel supplies d/dxyz itself."""
+    net = U.build_identity(device=dev).train()
+    net.prune_tol = -1.0
+    lat0, xyz, _ = _batch(dev, B=2, N=333, seed=3)
+    res = {}
+    for backend in ("composite", "hip"):
+        net.train_backend = backend
+        net.zero_grad(set_to_none=True)
+        lat = lat0.clone().requires_grad_()
+        x = xyz.clone().requires_grad_()
+        pred, _ = net(x, lat, None)
+        (pred.square().sum()).backward()
+        res[backend] = (pred.detach(), x.grad.clone(), lat.grad.clone(), net.ensembled_deep_sdf.lin3.weight.grad.clone())
+    for a, b in zip(res["hip"], res["composite"]):
+        assert _rel(a, b) < 2e-4
+
+
+def test_training_step_moves_like_composite(dev):
+    """Three Adam steps of training.py:110-135 (zero_grad, loss, backward, clip, step) on both tiers from the same
+    initial state: the losses stay together."""
+    lat0, xyz, nrm = _batch(dev, B=2, N=500, seed=5)
+    traces = {}
+    for backend in ("composite", "hip"):
+        net = U.build_identity(device=dev).train()
+        net.prune_tol = -1.0
+        net.train_backend = backend
+        lat = lat0.clone().requires_grad_()
+        opt = torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0.01)
+        opt_lat = torch.optim.Adam([lat], lr=1e-3)
+        trace = []
+        for _ in range(3):
+            opt.zero_grad(); opt_lat.zero_grad()
+            loss, _, _ = _loss_terms(net, lat, xyz, nrm)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=0.1)
+            opt.step(); opt_lat.step()
+            trace.append(float(loss))
+        traces[backend] = np.array(trace)
+    assert np.abs(traces["hip"] - traces["composite"]).max() < 1e-4 * np.abs(traces["composite"]).max()

@@ -1,0 +1,72 @@
+"""CPU check of the algebra behind ident_train_kernel.hip: the gradient of
+    phi = sbar * f(c) + v . grad_c f(c)
+w.r.t. the coordinates and every weight of one member MLP equals the reverse sweep of a forward pass that carries the
+value stream and ONE tangent stream along v, in the kernels' scaled domain (layout.h: activations times
+k = 100 / ln 2, softplus in base 2).  Compared with torch.autograd's double backward in float64."""
+import math
+
+import torch
+
+
+def test_two_stream_reverse_sweep_equals_double_backward():
+    torch.manual_seed(0)
+    dt = torch.float64
+    H, L1, P = 20, 11, 7
+    k, ln2, r2 = 100 / math.log(2), math.log(2), 1 / math.sqrt(2)
+    W0c = torch.randn(H, 3, dtype=dt) * 0.5; b0f = torch.randn(H, dtype=dt) * 0.02
+    W1 = torch.randn(L1, H, dtype=dt) * 0.3; b1 = torch.randn(L1, dtype=dt) * 0.02
+    W2a = torch.randn(H, L1, dtype=dt) * 0.3; W2c = torch.randn(H, 3, dtype=dt) * 0.5; b2f = torch.randn(H, dtype=dt) * 0.02
+    W3 = torch.randn(H, H, dtype=dt) * 0.3; b3 = torch.randn(H, dtype=dt) * 0.02
+    w4 = torch.randn(H, dtype=dt); b4 = torch.randn((), dtype=dt)
+    params = [W0c, b0f, W1, b1, W2a, W2c, b2f, W3, b3, w4, b4]
+    for p in params:
+        p.requires_grad_()
+    c = (torch.randn(P, 3, dtype=dt) * 0.05).requires_grad_()
+    sbar = torch.randn(P, dtype=dt)
+    v = torch.randn(P, 3, dtype=dt)
+    sp = torch.nn.Softplus(beta=100)
+
+    def f(c):       # one member of EnsembledDeepSDF.forward with the latent folded into b0f / b2f
+        h0 = sp(c @ W0c.T + b0f)
+        h1 = sp(h0 @ W1.T + b1)
+        x2 = torch.cat([h1, c], -1) / math.sqrt(2)
+        h2 = sp(x2 @ torch.cat([W2a, W2c], 1).T + b2f)
+        h3 = sp(h2 @ W3.T + b3)
+        return h3 @ w4 + b4
+
+    val = f(c)
+    g = torch.autograd.grad(val.sum(), c, create_graph=True)[0]
+    phi = (sbar * val).sum() + (v * g).sum()
+    ref = torch.autograd.grad(phi, [c] + params)
+
+    with torch.no_grad():
+        sp2 = lambda d: torch.clamp(d, min=0) + torch.log2(1 + torch.exp2(-d.abs()))
+        sg2 = lambda d: 1 / (1 + torch.exp2(-d))
+
+        def act(d, t):
+            s = sg2(d)
+            return s, sp2(d), s * t, ln2 * s * (1 - s) * t          # sigma', h', u', sigma'' tau
+
+        s0, h0, u0, q0 = act(k * (c @ W0c.T + b0f), k * (v @ W0c.T))
+        s1, h1, u1, q1 = act(h0 @ W1.T + k * b1, u0 @ W1.T)
+        s2, h2, u2, q2 = act(r2 * (h1 @ W2a.T) + k * r2 * (c @ W2c.T) + k * b2f, r2 * (u1 @ W2a.T) + k * r2 * (v @ W2c.T))
+        s3, h3, u3, q3 = act(h2 @ W3.T + k * b3, u2 @ W3.T)
+        assert (h3 @ (w4 / k) + b4 - val).abs().max() < 1e-12
+        assert (u3 @ (w4 / k) - (v * g).sum(-1)).abs().max() < 1e-12
+        H3, U3 = sbar[:, None] * (w4 / k), (w4 / k).expand(P, H)
+        D3, T3 = H3 * s3 + U3 * q3, U3 * s3
+        H2, U2 = D3 @ W3, T3 @ W3
+        D2, T2 = H2 * s2 + U2 * q2, U2 * s2
+        H1, U1, cbar = r2 * (D2 @ W2a), r2 * (T2 @ W2a), k * r2 * (D2 @ W2c)
+        D1, T1 = H1 * s1 + U1 * q1, U1 * s1
+        H0, U0 = D1 @ W1, T1 @ W1
+        D0, T0 = H0 * s0 + U0 * q0, U0 * s0
+        cbar = cbar + k * (D0 @ W0c)
+        mine = [cbar,
+                k * (D0.T @ c + T0.T @ v), k * D0.sum(0),
+                D1.T @ h0 + T1.T @ u0, k * D1.sum(0),
+                r2 * (D2.T @ h1 + T2.T @ u1), k * r2 * (D2.T @ c + T2.T @ v), k * D2.sum(0),
+                D3.T @ h2 + T3.T @ u2, k * D3.sum(0),
+                (sbar @ h3 + u3.sum(0)) / k, sbar.sum()]
+    for a, b in zip(mine, ref):
+        assert (a - b).abs().max() <= 1e-12 * (1 + b.abs().max())
