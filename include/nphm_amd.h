@@ -178,15 +178,16 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *     d f_k / d xyz for the listed triples (others untouched).
  *   nphm_identity_train_backward : seeds grad_member_sdf = dL/df_k and grad_member_grad = dL/d(d f_k/d xyz) (NULL:
  *     zero) -> ACCUMULATES grad_xyz, grad_anchors, grad_b0, grad_b2 (as nphm_identity_backward, for
- *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k) and stores the operands of the weight gradients:
- *     saved[i] = fp32 [nphm_identity_train_saved_rows(i)][n_cols], n_cols >= 64 n_tiles, column 64 t + 32 s + p =
- *     tile t, stream s (0 value, 1 tangent along the seed direction), point p, all in the scaled domain
- *     (k = 100 / ln 2):  i = 0..4 inputs of lin0..lin4 (local coords | direction, h0', h1' + coords, h2', h3'),
- *     i = 5..8 adjoints of the pre-activations of lin0..lin3, i = 9 the output seeds (dL/df_k | 1).  Then
- *       dW3 = S8 S3^T, dW2[:, :104] = S7 S2^T (x 1/sqrt2, coordinate columns x k/sqrt2), dW1 = S6 S1^T,
- *       dW0[:, :3] = k S5 S0^T, dW4 = S4 S9^T / k, db_l = k (row sums of the value columns of S(5+l)),
- *     each over the column range of one weight set. */
-int nphm_identity_train_saved_rows(int which);
+ *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k) and stores the operands of the weight gradients into
+ *     saved (nphm_identity_train_saved_bytes(n_tiles) bytes; per tile [1409 rows][64 columns] fp32, column =
+ *     32 * stream + point with stream 0 = value, 1 = tangent along the seed direction; rows = inputs of lin0..lin4
+ *     followed by the adjoints of the pre-activations of lin0..lin3 and the output seeds, scaled domain).
+ *   nphm_identity_train_weight_grads : contracts those operands over the columns, ADDING into parameter-shaped
+ *     gradients grad_weight[l] (shape of lin<l>.weight; the latent columns of lin0 / lin2 are not touched - they
+ *     receive theirs through grad_b0 / grad_b2) and grad_bias1/3/4.  chunks [n_chunks][4] = (weight set, first
+ *     tile, number of tiles, 0): consecutive tiles of ONE weight set each (the host cuts the member-ordered tile
+ *     table; a few dozen tiles per chunk keeps the atomics negligible). */
+size_t nphm_identity_train_saved_bytes(int n_tiles);
 int nphm_identity_train_forward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                 int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                 float* member_sdf, float* member_grad, void* stream);
@@ -194,7 +195,9 @@ int nphm_identity_train_backward(const void* packed, const void* packed_bwd, con
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
                                  float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2,
-                                 float* const saved[10], int64_t n_cols, void* stream);
+                                 float* saved, void* stream);
+int nphm_identity_train_weight_grads(const float* saved, const int* chunks, int n_chunks, float* const grad_weight[5],
+                                     float* grad_bias1, float* grad_bias3, float* grad_bias4, void* stream);
 
 /* Second stage of the two-stage evaluation get_logits_backward (src/NPHM/models/reconstruction.py:28-56):
  * the identity field at displaced lattice points.  xyz_slab [(ix1-ix0)*ry*rz, 3] holds the canonical

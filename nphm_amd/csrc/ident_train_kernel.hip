@@ -26,9 +26,11 @@
 // value and the tangent of one (feature, point) sit in the SAME lane of two accumulator tiles and every
 // epilogue is lane-local.  Activations in LDS as split-bf16 K chunks, weights L2 -> VGPR from the forward
 // pack / the transposed pack, three MFMA passes per product (fp32-equivalent), scaled domain of layout.h.
-// Weight gradients: the kernel stores the operands of  dW_l = sum over columns delta_l (x) input_l  feature-major
-// ([feature][column], 128-byte coalesced rows from the accumulator layout); the host contracts them per weight
-// set with library GEMMs (tiles are ordered by weight set, so each set is one contiguous column range).
+// Weight gradients: the reverse kernel stores the operands of  dW_l = sum over columns delta_l (x) input_l  per tile
+// as [1409 operand rows][64 columns] fp32 (one contiguous 352 KiB block per tile; a row of 32 columns of one stream
+// = 128 coalesced bytes straight from the accumulator layout); wgrad_kernel contracts them over the column axis
+// on the MFMA path (K = columns; split-bf16 x3) for chunks of tiles of one weight set (tiles are ordered by set)
+// and adds the per-chunk partial sums into the parameter-shaped gradients.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -45,7 +47,7 @@ using namespace nphm::bwd;
 constexpr int PTS = 32;                         // points per tile
 constexpr float LN2 = 0.6931471805599453f;
 
-// saved operands of the weight gradients, each [rows][n_cols] fp32 (column = 64 * tile + 32 * stream + point)
+// saved operands of the weight gradients: per tile [SV_ROWS][64] fp32, column = 32 * stream + point
 enum { SV_IN0 = 0,    // 3   local coordinates | tangent direction
        SV_IN1,        // 200 h0' | u0'
        SV_IN2,        // 104 h1' | u1'  (rows 101..103: coordinates | direction)
@@ -57,6 +59,14 @@ enum { SV_IN0 = 0,    // 3   local coordinates | tangent direction
        SV_D3,         // 200 D3 | T3
        SV_SEED,       // 1   sbar | 1 (valid points)
        SV_COUNT };
+constexpr int SV_ROWS = 3 + HID + L2_IN + HID + HID + HID + L1_OUT + HID + HID + 1;      // 1409
+__host__ __device__ constexpr int sv_offset(int which) {
+  constexpr int off[SV_COUNT] = {0, 3, 3 + HID, 3 + HID + L2_IN, 3 + 2 * HID + L2_IN, 3 + 3 * HID + L2_IN,
+                                 3 + 4 * HID + L2_IN, 3 + 4 * HID + L2_IN + L1_OUT, 3 + 5 * HID + L2_IN + L1_OUT,
+                                 3 + 6 * HID + L2_IN + L1_OUT};
+  return off[which];
+}
+static_assert(sv_offset(SV_SEED) + 1 == SV_ROWS, "saved-operand rows");
 
 struct TrainArgs {
   const uint16_t* packed_bf16;
@@ -76,8 +86,7 @@ struct TrainArgs {
   float* ganch;                   // [n_rows, 39, 3]        (+=)
   float* gb0;                     // [n_rows, 40, 200]      (+=)
   float* gb2;                     // [n_rows, 40, 200]      (+=)
-  float* save[SV_COUNT];
-  int64_t n_cols;
+  float* save;                    // backward: [n_tiles][SV_ROWS][64]
 };
 
 // coord_operand without the constant slots: the B operand of the tangent stream at lin0 (no bias)
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   const int set = member_set(k);
   const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
   const float sign_x = (k < 2 * N_SYMM && (k & 1)) ? -1.f : 1.f;
-  const int64_t col0 = int64_t(tile_index) * 64;
+  float* const save = SECOND ? p.save + size_t(tile_index) * SV_ROWS * 64 : nullptr;
 
   if (threadIdx.x < PTS) {
     const int m = threadIdx.x;
@@ -208,13 +217,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   // D tile n -> rows feat_of(n, r, h) < rows of a saved operand (32 lanes = 128 contiguous bytes per row)
   auto save_tile = [&](int which, int rows, int n, const f32x16 (&v)[NT]) __attribute__((always_inline)) {
     if (!SECOND) return;
-    float* base = p.save[which] + col0 + j;
+    float* base = save + sv_offset(which) * 64 + j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = feat_of(n, r, h);
       if (f < rows) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) base[int64_t(f) * p.n_cols + 32 * t] = v[t][r];
+        for (int t = 0; t < NT; ++t) base[f * 64 + 32 * t] = v[t][r];
       }
     }
   };
@@ -250,10 +259,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
 
   if (SECOND && wave == 7) {                       // lin0's own inputs and the output seeds, as saved operands
     if (h == 0) {
-      float* b = p.save[SV_IN0] + col0 + j;
-      b[0] = cx; b[p.n_cols] = cy; b[2 * p.n_cols] = cz;
-      b[32] = vx; b[p.n_cols + 32] = vy; b[2 * p.n_cols + 32] = vz;
-      float* sd = p.save[SV_SEED] + col0 + j;
+      float* b = save + sv_offset(SV_IN0) * 64 + j;
+      b[0] = cx; b[64] = cy; b[128] = cz;
+      b[32] = vx; b[64 + 32] = vy; b[128 + 32] = vz;
+      float* sd = save + sv_offset(SV_SEED) * 64 + j;
       sd[0] = seed; sd[32] = valid;
     }
   }
@@ -430,6 +439,156 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   }
 }
 
+
+// ---- weight gradients ---------------------------------------------------------------------------------------
+// One workgroup = one chunk (<= a few dozen tiles of ONE weight set) x one layer.  Per tile: the layer's INPUT
+// operand [rows_in][64 columns] goes through LDS as split-bf16 (every wavefront needs all of it), the ADJOINT
+// operand rows of wavefront w (output block w) come straight from HBM as the MFMA A fragments (lane = row, 8
+// consecutive columns); acc[b] += A x B over the tile's 4 K-steps of 16 columns for the 7 input blocks b.
+struct WgradArgs {
+  const float* saved;         // [n_tiles][SV_ROWS][64]
+  const int* chunks;          // [n_chunks][4] = weight set, first tile, number of tiles, -
+  float* gW[5];               // parameter-shaped gradients of lin0..lin4.weight  (+=)
+  float* gb1; float* gb3; float* gb4;    // of lin1/lin3/lin4.bias  (+=)
+};
+
+constexpr int WG_ROW_BYTES = 64 * 2 + 16;            // bf16 row of 64 columns, padded against bank conflicts
+constexpr int WG_PLANE = 224 * WG_ROW_BYTES;
+
+__device__ __forceinline__ Split8 split8v(const f32x4& a, const f32x4& b) {
+  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return split8(x);
+}
+
+__global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) char in_hi[WG_PLANE];
+  __shared__ __attribute__((aligned(16))) char in_lo[WG_PLANE];
+  const int* ch = p.chunks + 4 * blockIdx.x;
+  const int set = ch[0], tile0 = ch[1], n_tiles = ch[2];
+  const int layer = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+
+  if (layer == 4) {           // lin4: dW4[f] = sum_cols h3'|u3' [f][col] * seed[col] / k ; db4 = sum of the value seeds
+    if (tid <= HID) {
+      float acc = 0.f;
+      for (int t = 0; t < n_tiles; ++t) {
+        const float* blk = p.saved + size_t(tile0 + t) * SV_ROWS * 64;
+        const float* sd = blk + sv_offset(SV_SEED) * 64;
+        if (tid < HID) {
+          const float* r = blk + (sv_offset(SV_IN4) + tid) * 64;
+          for (int c = 0; c < 64; ++c) acc = fmaf(r[c], sd[c], acc);
+        } else {
+          for (int c = 0; c < 32; ++c) acc += sd[c];
+        }
+      }
+      if (tid < HID) atomicAdd(p.gW[4] + size_t(set) * HID + tid, acc / SP_SCALE);
+      else atomicAdd(p.gb4 + set, acc);
+    }
+    return;
+  }
+
+  // layer geometry
+  const int d_which = layer == 0 ? SV_D0 : layer == 1 ? SV_D1 : layer == 2 ? SV_D2 : SV_D3;
+  const int i_which = layer == 0 ? SV_IN0 : layer == 1 ? SV_IN1 : layer == 2 ? SV_IN2 : SV_IN3;
+  const int rows_out = layer == 1 ? L1_OUT : HID;
+  const int rows_in = layer == 0 ? 3 : layer == 2 ? L2_IN : HID;
+  const int ld = layer == 0 ? D_IN : HID;                    // row length of the parameter
+  const int nb_in = (rows_in + 31) / 32;
+  const bool active = 32 * wave < rows_out;
+  const int orow = 32 * wave + j;                            // this lane's adjoint row (A operand)
+  const bool row_ok = active && orow < rows_out;
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int b = 0; b < 7; ++b) acc[b] = f32x16{};
+  float bsum = 0.f;
+
+  // staging registers: the tile's input operand (7 passes of 32 rows x 16 float4) and this lane's adjoint row
+  f32x4 in_reg[7], d_reg[8];
+  const int srow = tid >> 4, sc4 = tid & 15;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const float* blk = p.saved + size_t(tile0 + t) * SV_ROWS * 64;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int r = 32 * q + srow;
+      in_reg[q] = r < rows_in ? *reinterpret_cast<const f32x4*>(blk + (sv_offset(i_which) + r) * 64 + 4 * sc4) : f32x4{};
+    }
+    const float* dr = blk + (sv_offset(d_which) + (row_ok ? orow : 0)) * 64 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      d_reg[2 * s] = row_ok ? *reinterpret_cast<const f32x4*>(dr + 16 * s) : f32x4{};
+      d_reg[2 * s + 1] = row_ok ? *reinterpret_cast<const f32x4*>(dr + 16 * s + 4) : f32x4{};
+    }
+  };
+
+  if (n_tiles > 0) fetch(0);
+  for (int t = 0; t < n_tiles; ++t) {
+    __syncthreads();                                   // the previous tile's LDS operand has been consumed
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int r = 32 * q + srow;
+      __bf16 hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)in_reg[q][e]; lo[e] = (__bf16)(in_reg[q][e] - (float)hi[e]); }
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<bf16x4*>(in_hi + r * WG_ROW_BYTES + 8 * sc4) = bf16x4{hi[0], hi[1], hi[2], hi[3]};
+      *reinterpret_cast<bf16x4*>(in_lo + r * WG_ROW_BYTES + 8 * sc4) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+    }
+    Split8 a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a[s] = split8v(d_reg[2 * s], d_reg[2 * s + 1]);
+      if (s < 2) {                                     // bias gradient: the value columns are columns 0..31
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum += d_reg[2 * s][e] + d_reg[2 * s + 1][e];
+      }
+    }
+    __syncthreads();
+    if (t + 1 < n_tiles) fetch(t + 1);                 // next tile's operands fly during the MFMAs
+    if (active) {
+#pragma unroll
+      for (int b = 0; b < 7; ++b) {
+        if (b < nb_in) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int o = (32 * b + j) * WG_ROW_BYTES + (16 * s + 8 * h) * 2;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(in_hi + o);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(in_lo + o);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].hi, bh, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].hi, bl, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].lo, bh, acc[b], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (!active) return;
+
+  // scaled-domain products -> parameter gradients
+  float* gw = p.gW[layer] + size_t(set) * rows_out * ld;
+#pragma unroll
+  for (int b = 0; b < 7; ++b) {
+    if (b < nb_in) {
+      const int icol = 32 * b + j;
+      float scale = 1.f;
+      if (layer == 0) scale = SP_SCALE;
+      if (layer == 2) scale = (icol >= L1_OUT ? SP_SCALE : 1.f) / INV_SQRT2_DIV;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < rows_out && icol < rows_in) atomicAdd(gw + size_t(row) * ld + icol, acc[b][r] * scale);
+      }
+    }
+  }
+  float* gb = layer == 1 ? p.gb1 : layer == 3 ? p.gb3 : nullptr;
+  if (gb) {
+    bsum += __shfl_xor(bsum, 32);
+    if (h == 0 && row_ok) atomicAdd(gb + size_t(set) * rows_out + orow, bsum * SP_SCALE);
+  }
+}
+
 }  // namespace train
 }  // namespace nphm
 
@@ -438,10 +597,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
 // ============================================================================================
 extern "C" {
 
-int nphm_identity_train_saved_rows(int which) {
-  static const int rows[nphm::train::SV_COUNT] = {3, nphm::HID, nphm::L2_IN, nphm::HID, nphm::HID,
-                                                  nphm::HID, nphm::L1_OUT, nphm::HID, nphm::HID, 1};
-  return (which < 0 || which >= nphm::train::SV_COUNT) ? -1 : rows[which];
+size_t nphm_identity_train_saved_bytes(int n_tiles) {
+  return n_tiles <= 0 ? 0 : size_t(n_tiles) * nphm::train::SV_ROWS * 64 * sizeof(float);
 }
 
 static int train_common(nphm::train::TrainArgs& a, const void* packed, const void* packed_bwd, const void* latent_state,
@@ -478,25 +635,40 @@ int nphm_identity_train_backward(const void* packed, const void* packed_bwd, con
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
                                  float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2,
-                                 float* const saved[10], int64_t n_cols, void* stream) {
+                                 float* saved, void* stream) {
   nphm::train::TrainArgs a;
   if (train_common(a, packed, packed_bwd, latent_state, xyz, n_points, tiles, n_tiles, point_list,
                    "nphm_identity_train_backward: null pointer or bad sizes")) return 1;
   if (!grad_member_sdf || !grad_xyz || !grad_anchors || !grad_b0 || !grad_b2 || !saved)
     return nphm_fail_msg("nphm_identity_train_backward: null pointer");
-  if (n_cols < int64_t(n_tiles) * 64) return nphm_fail_msg("nphm_identity_train_backward: n_cols < 64 * n_tiles");
-  for (int i = 0; i < nphm::train::SV_COUNT; ++i) {
-    if (!saved[i]) return nphm_fail_msg("nphm_identity_train_backward: null saved-operand buffer");
-    a.save[i] = saved[i];
-  }
   if (n_tiles == 0) return 0;
+  a.save = saved;
   a.g_sdf = grad_member_sdf; a.g_grad = grad_member_grad;
   a.gxyz = grad_xyz; a.ganch = grad_anchors; a.gb0 = grad_b0; a.gb2 = grad_b2;
-  a.n_cols = n_cols;
   hipLaunchKernelGGL(nphm::train::train_kernel<true>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_train_backward launch", e);
+  return 0;
+}
+
+int nphm_identity_train_weight_grads(const float* saved, const int* chunks, int n_chunks, float* const grad_weight[5],
+                                     float* grad_bias1, float* grad_bias3, float* grad_bias4, void* stream) {
+  if (!saved || !chunks || !grad_weight || !grad_bias1 || !grad_bias3 || !grad_bias4)
+    return nphm_fail_msg("nphm_identity_train_weight_grads: null pointer");
+  if (n_chunks < 0) return nphm_fail_msg("nphm_identity_train_weight_grads: bad sizes");
+  if (n_chunks == 0) return 0;
+  nphm::train::WgradArgs a;
+  a.saved = saved; a.chunks = chunks;
+  for (int i = 0; i < 5; ++i) {
+    if (!grad_weight[i]) return nphm_fail_msg("nphm_identity_train_weight_grads: null gradient pointer");
+    a.gW[i] = grad_weight[i];
+  }
+  a.gb1 = grad_bias1; a.gb3 = grad_bias3; a.gb4 = grad_bias4;
+  hipLaunchKernelGGL(nphm::train::wgrad_kernel, dim3(n_chunks, 5), dim3(64 * nphm::bwd::WAVES), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_train_weight_grads launch", e);
   return 0;
 }
 

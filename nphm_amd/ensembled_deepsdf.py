@@ -201,8 +201,8 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
 def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
     """Point lists of the training kernels (ident_train_kernel.hip): 32-point tiles ordered by (member, row), so the
     tiles of one weight set are contiguous (``sets`` [A] = member -> set, non-decreasing).  Returns the tile table
-    int32 [T,4] = (row, member, offset, count <= 32), the point list int32, the weight set of every tile (long [T])
-    and the tile range of every set (list of (t0, t1)).  One host sync."""
+    int32 [T,4] = (row, member, offset, count <= 32), the point list int32 and the chunk table of the weight-gradient
+    kernel int32 [C,4] = (weight set, first tile, number of tiles <= _WGRAD_CHUNK, 0).  One host sync."""
     B, N, _ = xyz.shape
     A = n_members
     with torch.no_grad():
@@ -219,10 +219,11 @@ def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
     set_of_tile = sets_np[pair // B]
     per_set = np.bincount(set_of_tile, minlength=int(sets_np.max()) + 1)
     ends = np.cumsum(per_set)
-    ranges = [(int(e - c), int(e)) for c, e in zip(per_set, ends)]
+    chunks = [(s, t, min(_WGRAD_CHUNK, e - t), 0) for s, (c, e) in enumerate(zip(per_set, ends))
+              for t in range(e - c, e, _WGRAD_CHUNK)]
     dev = xyz.device
     return (torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(),
-            torch.from_numpy(set_of_tile.astype(np.int64)).to(dev), ranges)
+            torch.tensor(chunks, dtype=torch.int32).reshape(-1, 4).to(dev))
 
 
 def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
@@ -306,15 +307,14 @@ class _IdentityFieldFn(torch.autograd.Function):
         return None, gx, g_lat, ga
 
 
-_K_SCALE = 100.0 / math.log(2.0)        # activation scale of the kernels (layout.h)
-_SAVED_ROWS = (3, 200, 104, 200, 200, 200, 101, 200, 200, 1)
+_WGRAD_CHUNK = int(os.environ.get("NPHM_AMD_WGRAD_CHUNK", "32"))     # tiles per workgroup of the weight-gradient kernel
 
 
 class _MemberFieldFn(torch.autograd.Function):
     """Training tier, kernel half: (f_k, d f_k / d xyz) of the 40 member MLPs for every (point, member) the pruning
     rule keeps (zeros elsewhere), by ``nphm_identity_train_forward``; backward = ``nphm_identity_train_backward``
-    (value + one tangent stream, reverse sweep with sigma'') plus one library GEMM per layer and weight set over the
-    operands that kernel stores.  Differentiable inputs: xyz, anchors, the folded biases of lin0 / the skip layer
+    (value + one tangent stream, reverse sweep with sigma'') followed by ``nphm_identity_train_weight_grads`` (the
+    stored operands contracted over the point axis on the MFMA path).  Differentiable inputs: xyz, anchors, the folded biases of lin0 / the skip layer
     (``b0f``, ``b2f`` [B,40,200]: graph handles - the kernels read the same quantities from the HIP prologue's state;
     autograd chains them to the latent and to the latent columns of lin0 / lin2), the remaining weights and biases.
 
@@ -334,8 +334,8 @@ class _MemberFieldFn(torch.autograd.Function):
         packed, state, anchors_k = module.prepare_latent(lat_rows.detach())
         packed_bwd = module._packed_bwd(dev)
         xyz_c = xyz.detach().contiguous().float()
-        tiles, plist, set_of_tile, ranges = _train_member_lists(anchors_k, xyz_c, module.prune_tol, A,
-                                                                module.ensembled_deep_sdf.lin0._sets)
+        tiles, plist, chunks = _train_member_lists(anchors_k, xyz_c, module.prune_tol, A,
+                                                   module.ensembled_deep_sdf.lin0._sets)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -343,9 +343,8 @@ class _MemberFieldFn(torch.autograd.Function):
             packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N, tiles.data_ptr(),
             tiles.shape[0], plist.data_ptr(), S.data_ptr(), G.data_ptr(), stream), "nphm_identity_train_forward")
         ctx.module = module
-        ctx.ranges = ranges
         ctx.shapes = [t.shape for t in (W0, W1, W2, W3, W4, b1, b3, b4)]
-        ctx.save_for_backward(xyz_c, packed, packed_bwd, state, tiles, plist, set_of_tile)
+        ctx.save_for_backward(xyz_c, packed, packed_bwd, state, tiles, plist, chunks)
         ctx.set_materialize_grads(False)
         return S, G
 
@@ -360,52 +359,28 @@ class _MemberFieldFn(torch.autograd.Function):
             return (None,) * n_in
         lib = _lib.load()
         module = ctx.module
-        xyz, packed, packed_bwd, state, tiles, plist, set_of_tile = ctx.saved_tensors
+        xyz, packed, packed_bwd, state, tiles, plist, chunks = ctx.saved_tensors
         B, N, _ = xyz.shape
         dev = xyz.device
         A, H, K = module.num_kps + 1, module.hidden_dim, module.num_kps
         T = tiles.shape[0]
-        n_cols = 64 * T
-        sizes = [B * N * 3, B * K * 3, B * A * H, B * A * H]
-        parts = torch.zeros(sum(sizes), dtype=torch.float32, device=dev).split(sizes)
-        gx, ga = parts[0].view(B, N, 3), parts[1].view(B, K, 3)
-        gb0, gb2 = parts[2].view(B, A, H), parts[3].view(B, A, H)
-        shapes = ctx.shapes
-        grads = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in shapes]
-        gW0, gW1, gW2, gW3, gW4, gb1, gb3, gb4 = grads
+        # every gradient is accumulated into by the kernels: ONE zero-fill, views
+        shapes = [torch.Size(sh) for sh in ([B, N, 3], [B, K, 3], [B, A, H], [B, A, H])] + list(ctx.shapes)
+        sizes = [sh.numel() for sh in shapes]
+        parts = [t.view(sh) for t, sh in zip(torch.zeros(sum(sizes), dtype=torch.float32, device=dev).split(sizes), shapes)]
+        gx, ga, gb0, gb2, gW0, gW1, gW2, gW3, gW4, gb1, gb3, gb4 = parts
         if T and (gS is not None or gG is not None):
             gS_c = torch.zeros(B, N, A, dtype=torch.float32, device=dev) if gS is None else gS.detach().contiguous().float()
             gG_c = None if gG is None else gG.detach().contiguous().float()
-            saved = torch.empty(sum(_SAVED_ROWS), n_cols, dtype=torch.float32, device=dev).split(_SAVED_ROWS, dim=0)
+            saved = torch.empty(lib.nphm_identity_train_saved_bytes(T), dtype=torch.uint8, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.nphm_identity_train_backward(
                 packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N, tiles.data_ptr(), T,
                 plist.data_ptr(), gS_c.data_ptr(), None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(),
-                ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), _lib.ptr_array(saved), n_cols, stream),
-                "nphm_identity_train_backward")
-            in0, in1, in2, in3, in4, d0, d1, d2, d3, seed = saved
-            k, r2 = _K_SCALE, 1.0 / _SQRT2
-            n1, d_in = shapes[1][1], module.input_dim            # 101, 3
-            for s, (t0, t1) in enumerate(ctx.ranges):
-                if t1 <= t0:
-                    continue
-                c = slice(64 * t0, 64 * t1)
-                gW3[s] = d3[:, c] @ in3[:, c].T
-                gW2[s, :, :n1 + d_in] = d2[:, c] @ in2[:, c].T
-                gW1[s] = d1[:, c] @ in1[:, c].T
-                gW0[s, :, :d_in] = d0[:, c] @ in0[:, c].T
-                gW4[s, 0] = in4[:, c] @ seed[0, c]
-            gW2[:, :, :n1] *= r2
-            gW2[:, :, n1:n1 + d_in] *= k * r2
-            gW0[:, :, :d_in] *= k
-            gW4 /= k
-
-            def per_set(rows):        # k * sum over the value columns, per weight set -> [sets, F]
-                v = rows.view(rows.shape[0], T, 2, 32)[:, :, 0].sum(dim=-1)                    # [F, T]
-                return torch.zeros(rows.shape[0], shapes[0][0], dtype=torch.float32, device=dev).index_add_(1, set_of_tile, v).T
-            gb3.copy_(per_set(d3) * k)
-            gb1.copy_(per_set(d1) * k)
-            gb4.copy_(per_set(seed))
+                ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), saved.data_ptr(), stream), "nphm_identity_train_backward")
+            _lib.check(lib.nphm_identity_train_weight_grads(
+                saved.data_ptr(), chunks.data_ptr(), chunks.shape[0], _lib.ptr_array5([gW0, gW1, gW2, gW3, gW4]),
+                gb1.data_ptr(), gb3.data_ptr(), gb4.data_ptr(), stream), "nphm_identity_train_weight_grads")
         return (None, gx, ga, None, gb0, gb2, gW0, gW1, gW2, gW3, gW4, gb1, gb3, gb4)
 
 
