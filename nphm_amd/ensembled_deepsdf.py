@@ -201,8 +201,11 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
 def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
     """Point lists of the training kernels (ident_train_kernel.hip): 32-point tiles ordered by (member, row), so the
     tiles of one weight set are contiguous (``sets`` [A] = member -> set, non-decreasing).  Returns the tile table
-    int32 [T,4] = (row, member, offset, count <= 32), the point list int32 and the chunk table of the weight-gradient
-    kernel int32 [C,4] = (weight set, first tile, number of tiles <= _WGRAD_CHUNK, 0).  One host sync."""
+    int32 [T,4] = (row, member, offset, count <= 32), the point list int32 and the work list of the backward pass:
+    the tile table is cut into pieces of <= _TRAIN_RING_TILES tiles (the backward kernel's stored operands of one
+    piece live in a ring buffer that fits the Infinity Cache), every piece into chunks of <= _WGRAD_CHUNK tiles of
+    ONE weight set for the weight-gradient kernel: ``pieces`` = list of (first tile, tiles, first chunk, chunks),
+    chunk table int32 [C,4] = (weight set, first tile RELATIVE to its piece, tiles, 0).  One host sync."""
     B, N, _ = xyz.shape
     A = n_members
     with torch.no_grad():
@@ -215,15 +218,23 @@ def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
     within = np.arange(int(n_t.sum())) - np.repeat(np.cumsum(n_t) - n_t, n_t)
     tiles = np.stack([pair % B, pair // B, offs[pair] + 32 * within, np.minimum(32, counts[pair] - 32 * within)],
                      axis=1).astype(np.int32)
-    sets_np = sets.cpu().numpy()
-    set_of_tile = sets_np[pair // B]
-    per_set = np.bincount(set_of_tile, minlength=int(sets_np.max()) + 1)
-    ends = np.cumsum(per_set)
-    chunks = [(s, t, min(_WGRAD_CHUNK, e - t), 0) for s, (c, e) in enumerate(zip(per_set, ends))
-              for t in range(e - c, e, _WGRAD_CHUNK)]
+    T = tiles.shape[0]
+    set_of_tile = sets.cpu().numpy()[pair // B]
+    ring = _TRAIN_RING_TILES if _TRAIN_RING_TILES > 0 else max(T, 1)
+    # chunk boundaries: every _WGRAD_CHUNK tiles inside a run of one weight set inside one piece
+    piece_of_tile = np.arange(T) // ring
+    run_start = np.flatnonzero(np.r_[True, (np.diff(set_of_tile) != 0) | (np.diff(piece_of_tile) != 0)]) if T else np.zeros(0, int)
+    run_len = np.diff(np.r_[run_start, T])
+    chunks, pieces = [], []
+    for r0, rl in zip(run_start, run_len):
+        for t in range(r0, r0 + rl, _WGRAD_CHUNK):
+            chunks.append((set_of_tile[r0], t - (t // ring) * ring, min(_WGRAD_CHUNK, r0 + rl - t), t // ring))
+    chunks = np.asarray(chunks, dtype=np.int32).reshape(-1, 4)
+    for pi in range((T + ring - 1) // ring):
+        sel = np.flatnonzero(chunks[:, 3] == pi)
+        pieces.append((pi * ring, min(ring, T - pi * ring), int(sel[0]), len(sel)))
     dev = xyz.device
-    return (torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(),
-            torch.tensor(chunks, dtype=torch.int32).reshape(-1, 4).to(dev))
+    return (torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(), torch.from_numpy(chunks).to(dev), pieces)
 
 
 def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
@@ -308,6 +319,11 @@ class _IdentityFieldFn(torch.autograd.Function):
 
 
 _WGRAD_CHUNK = int(os.environ.get("NPHM_AMD_WGRAD_CHUNK", "32"))     # tiles per workgroup of the weight-gradient kernel
+# tiles per piece of the backward pass (352 KiB of stored operands each; 0 = one piece): the reverse kernel writes the
+# operands of a piece into a buffer the weight-gradient kernel consumes before the next piece reuses it - a cap on the
+# memory of large batches (pieces of 512 tiles that would stay in the Infinity Cache measured 15-25 % SLOWER than
+# one piece: launch gaps and tail effects outweigh the saved HBM traffic)
+_TRAIN_RING_TILES = int(os.environ.get("NPHM_AMD_TRAIN_RING_TILES", "16384"))       # 5.5 GiB
 
 
 class _MemberFieldFn(torch.autograd.Function):
@@ -334,8 +350,8 @@ class _MemberFieldFn(torch.autograd.Function):
         packed, state, anchors_k = module.prepare_latent(lat_rows.detach())
         packed_bwd = module._packed_bwd(dev)
         xyz_c = xyz.detach().contiguous().float()
-        tiles, plist, chunks = _train_member_lists(anchors_k, xyz_c, module.prune_tol, A,
-                                                   module.ensembled_deep_sdf.lin0._sets)
+        tiles, plist, chunks, pieces = _train_member_lists(anchors_k, xyz_c, module.prune_tol, A,
+                                                           module.ensembled_deep_sdf.lin0._sets)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -343,6 +359,7 @@ class _MemberFieldFn(torch.autograd.Function):
             packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N, tiles.data_ptr(),
             tiles.shape[0], plist.data_ptr(), S.data_ptr(), G.data_ptr(), stream), "nphm_identity_train_forward")
         ctx.module = module
+        ctx.pieces = pieces
         ctx.shapes = [t.shape for t in (W0, W1, W2, W3, W4, b1, b3, b4)]
         ctx.save_for_backward(xyz_c, packed, packed_bwd, state, tiles, plist, chunks)
         ctx.set_materialize_grads(False)
@@ -372,15 +389,19 @@ class _MemberFieldFn(torch.autograd.Function):
         if T and (gS is not None or gG is not None):
             gS_c = torch.zeros(B, N, A, dtype=torch.float32, device=dev) if gS is None else gS.detach().contiguous().float()
             gG_c = None if gG is None else gG.detach().contiguous().float()
-            saved = torch.empty(lib.nphm_identity_train_saved_bytes(T), dtype=torch.uint8, device=dev)
+            saved = torch.empty(lib.nphm_identity_train_saved_bytes(max(n for _, n, _, _ in ctx.pieces)),
+                                dtype=torch.uint8, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(lib.nphm_identity_train_backward(
-                packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N, tiles.data_ptr(), T,
-                plist.data_ptr(), gS_c.data_ptr(), None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(),
-                ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), saved.data_ptr(), stream), "nphm_identity_train_backward")
-            _lib.check(lib.nphm_identity_train_weight_grads(
-                saved.data_ptr(), chunks.data_ptr(), chunks.shape[0], _lib.ptr_array5([gW0, gW1, gW2, gW3, gW4]),
-                gb1.data_ptr(), gb3.data_ptr(), gb4.data_ptr(), stream), "nphm_identity_train_weight_grads")
+            gws = _lib.ptr_array5([gW0, gW1, gW2, gW3, gW4])
+            for t0, nt, c0, nc in ctx.pieces:
+                _lib.check(lib.nphm_identity_train_backward(
+                    packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N,
+                    tiles.data_ptr() + 16 * t0, nt, plist.data_ptr(), gS_c.data_ptr(),
+                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), ga.data_ptr(), gb0.data_ptr(),
+                    gb2.data_ptr(), saved.data_ptr(), stream), "nphm_identity_train_backward")
+                _lib.check(lib.nphm_identity_train_weight_grads(
+                    saved.data_ptr(), chunks.data_ptr() + 16 * c0, nc, gws, gb1.data_ptr(), gb3.data_ptr(),
+                    gb4.data_ptr(), stream), "nphm_identity_train_weight_grads")
         return (None, gx, ga, None, gb0, gb2, gW0, gW1, gW2, gW3, gW4, gb1, gb3, gb4)
 
 
