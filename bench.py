@@ -15,7 +15,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement): the contract fi
 in the default precision; at N = 1 the line also carries
   "precisions"  the same workload with --precision bf16x3 and f32 (value + roofline each),
   "configs"     configs[0] (NPM 64^3), configs[2] (two-stage 256^3), configs[4] (latent fitting, 250 steps,
-                final loss next to the all-composite PyTorch-ROCm loop),
+                final loss next to the all-composite PyTorch-ROCm loop), 512^3 on one GPU and one training step of the
+                identity decoder at nphm.yaml's sizes next to the composite tier,
   "mfma_sustained"  the matrix-pipe rate an MFMA-only loop sustains on THIS box (power-limited clock),
   "cpu_baseline"    the reference's PyTorch operation sequence on the host cores (oracle/torch_reference.py),
   "cpu_baseline_port" the numpy oracle, "pytorch_rocm_baseline" the eager chunk loop on the same GPU.
@@ -53,7 +54,7 @@ def parse():
     ap.add_argument("--prune-tol", type=float, default=None)
     ap.add_argument("--precision", default="bf16x3a2", choices=["f32", "bf16x3", "bf16x3a", "bf16x3a2"])
     ap.add_argument("--chunk", type=int, default=25000, help="get_logits chunk whose last voxel is overwritten (eval mode)")
-    ap.add_argument("--workload", default="all", choices=["all", "identity", "two_stage", "npm", "fitting"],
+    ap.add_argument("--workload", default="all", choices=["all", "identity", "two_stage", "npm", "fitting", "training"],
                     help="all (default) = the contract line for configs[1] with every other config / precision as "
                          "sub-records; identity = the contract line alone; the others = one of the remaining configs "
                          "as a line of its own (two_stage = configs[2], npm = configs[0], fitting = configs[4])")
@@ -423,6 +424,51 @@ def fitting_record(args, dev, with_reference_loop=True):
     return out
 
 
+def training_record(args, dev, with_composite=True, steps=8):
+    """one training step of the identity decoder (training.py:110-135: compute_loss, backward w.r.t.
+    every weight and the latent codes, gradient clipping, AdamW) at nphm.yaml's sizes - batch 32, 750 face + 50
+    non-face + 800 near-surface + 93 far points per subject - on the HIP training tier next to the SAME step on the
+    composite PyTorch tier (the reference's arithmetic on this GPU).  Synthetic points, seeded random-init weights."""
+    import _util as U
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_train as BT
+    B, n_face = 32, 750
+    batch = BT.synthetic_batch(B, n_face, dev)
+    lat0 = torch.stack([U.sample_latent(10 + b) for b in range(B)])[:, None, :].to(dev)
+    n_pts = sum(batch[k].shape[1] for k in ("points_face", "points_non_face", "sup_grad_near", "sup_grad_far"))
+
+    def run(backend):
+        net = U.build_identity(device=dev).train()
+        net.train_backend = backend
+        lat = lat0.clone().requires_grad_()
+        opt = torch.optim.AdamW(list(net.parameters()) + [lat], lr=5e-4, weight_decay=0.01)
+        torch.cuda.reset_peak_memory_stats()
+        losses = [float(BT.step(net, lat, batch, opt)) for _ in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses += [BT.step(net, lat, batch, opt) for _ in range(steps)]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {"ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "first_loss": losses[0], "last_loss": float(losses[-1]),
+                "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "prune_tol": net.prune_tol}
+
+    ours = run("hip")
+    out = {"metric": "identity-decoder training steps/s (compute_loss + backward + AdamW)", "value": ours["steps_per_s"],
+           "unit": "steps/s", "ms_per_step": ours["ms_per_step"], "steps": steps,
+           "dtype": "bf16x3 kernels (member MLPs, their double backward, weight gradients) + fp32 PyTorch ops (blend, losses, optimizer)",
+           "config": {"workload": f"training step, batch {B} x {n_pts} points (nphm.yaml: 750 face + 50 non-face + 800 near + 93 far), "
+                                  "loss terms of loss_functions.py:20-110 with create_graph gradients, all decoder weights + latent codes trainable "
+                                  "(SURVEY 8 f4)", "prune_tol": ours["prune_tol"]},
+           "first_loss": ours["first_loss"], "last_loss": ours["last_loss"], "peak_mem_gb": ours["peak_mem_gb"], "roofline": None}
+    if with_composite:
+        ref = run("composite")
+        out["composite_same_gpu"] = dict(ref, note="the same step with the decoder on the composite PyTorch tier (fp32 autograd double "
+                                                   "backward, the four point sets as one batch) on this GPU")
+        out["speedup_vs_composite"] = ref["ms_per_step"] / ours["ms_per_step"]
+        out["last_loss_diff"] = abs(ours["last_loss"] - ref["last_loss"])
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------
 # baselines
 # ------------------------------------------------------------------------------------------------------
@@ -556,7 +602,7 @@ def mfma_sustained(dev):
 
 # ------------------------------------------------------------------------------------------------------
 def single_workload(args):
-    """--workload two_stage | npm | fitting: one of the other configs as a line of its own (one GPU)."""
+    """--workload two_stage | npm | fitting | training: one of the other configs as a line of its own (one GPU)."""
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     base = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
@@ -565,6 +611,8 @@ def single_workload(args):
         rec = two_stage_record(args, dev, args.steps, args.warmup)
     elif args.workload == "npm":
         rec = npm_record(args, dev, args.steps, args.warmup, not args.no_cpu_baseline)
+    elif args.workload == "training":
+        rec = training_record(args, dev, with_composite=not args.no_cpu_baseline, steps=max(args.steps, 5))
     else:
         rec = fitting_record(args, dev, with_reference_loop=not args.no_cpu_baseline)
     rec.setdefault("cpu_baseline", None)
@@ -631,6 +679,7 @@ def main():
                 "two_stage_256": two_stage_record(args, dev, sub_steps, 1),
                 "fitting": fitting_record(args, dev, with_reference_loop=not args.no_cpu_baseline),
                 "grid512_one_gpu": grid512_record(args, dev),
+                "training": training_record(args, dev, with_composite=not args.no_cpu_baseline),
             }
             ib.net.precision = args.precision
         if not args.no_cpu_baseline and world == 1:
