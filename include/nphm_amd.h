@@ -173,7 +173,9 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  * diff_operators.py:6-16; training.py:124: loss.backward() w.r.t. every weight).  The host keeps the Gaussian
  * blend (EnsembledDeepSDF.py:129-150) in autograd; these two kernels replace the member MLPs
  * (EnsembledDeepSDF.py:101-126) and their double backward.  tiles [n_tiles][4] = (row, member, offset into
- * point_list, count <= 32), ORDERED BY MEMBER (hence by weight set); point_list = point indices inside the row.
+ * point_list, count), ORDERED BY MEMBER (hence by weight set), count <= 64 for the forward kernel and <= 32 for the
+ * backward kernel (which spends the other 32 MFMA columns on the tangent stream); point_list = point indices inside
+ * the row.
  *   nphm_identity_train_forward : member_sdf [n_rows,n_points,40] = f_k, member_grad [n_rows,n_points,40,3] =
  *     d f_k / d xyz for the listed triples (others untouched).
  *   nphm_identity_train_backward : seeds grad_member_sdf = dL/df_k and grad_member_grad = dL/d(d f_k/d xyz) (NULL:

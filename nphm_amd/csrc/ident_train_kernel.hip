@@ -44,7 +44,6 @@ namespace train {
 
 using namespace nphm::bwd;
 
-constexpr int PTS = 32;                         // points per tile
 constexpr float LN2 = 0.6931471805599453f;
 
 // saved operands of the weight gradients: per tile [SV_ROWS][64] fp32, column = 32 * stream + point
@@ -74,7 +73,7 @@ struct TrainArgs {
   const uint16_t* packed_bwd;
   const float* state;             // [n_rows, LS_ROW_STRIDE]
   const float* xyz;               // [n_rows, n_points, 3]
-  const int* tiles;               // [n_tiles][4] = row, member, offset into list, count (<= 32)
+  const int* tiles;               // [n_tiles][4] = row, member, offset into list, count (<= 64 forward, <= 32 backward)
   const int* list;
   int n_tiles;
   int64_t n_points;
@@ -111,16 +110,22 @@ __device__ __forceinline__ bf16x8 tangent_operand(float x, float y, float z, int
   return bv;
 }
 
+// Both kernels work on 64 MFMA columns = two accumulator tiles of 32:
+//   forward  (SECOND = false): tile 1 = the NEXT 32 listed points (64 points per workgroup, value stream only);
+//   backward (SECOND = true) : tile 1 = the tangent stream of the SAME 32 points.
+// Per-layer state kept in registers for the reverse sweep: s = sigma'(d') of tile 0 and, in q, sigma'(d') of tile 1
+// (forward) or sigma''(d') tau (backward).
 template <bool SECOND>
 __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
-  constexpr int NT = SECOND ? 2 : 1;                 // accumulator tiles: value | tangent
+  constexpr int NT = 2;
+  constexpr int PTS = SECOND ? 32 : 64;              // points per tile
   __shared__ __attribute__((aligned(16))) char act_hi[PLANE_BYTES];
   __shared__ __attribute__((aligned(16))) char act_lo[PLANE_BYTES];
-  __shared__ float part[WAVES][PTS];
-  __shared__ float pt_c[PTS][4];              // local coordinates, validity
-  __shared__ float pt_v[PTS][4];              // tangent direction (local frame), seed sbar
-  __shared__ float pt_dc[PTS][4];             // d phi / d local coordinates
-  __shared__ int pt_idx[PTS];
+  __shared__ float part[WAVES][64];
+  __shared__ float pt_c[64][4];               // local coordinates, validity
+  __shared__ float pt_v[64][4];               // tangent direction (local frame), seed sbar
+  __shared__ float pt_dc[64][4];              // d phi / d local coordinates
+  __shared__ int pt_idx[64];
 
   const int tile_index = blockIdx.x;
   const int lane = threadIdx.x & 63;
@@ -134,9 +139,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   const float sign_x = (k < 2 * N_SYMM && (k & 1)) ? -1.f : 1.f;
   float* const save = SECOND ? p.save + size_t(tile_index) * SV_ROWS * 64 : nullptr;
 
-  if (threadIdx.x < PTS) {
+  if (threadIdx.x < 64) {
     const int m = threadIdx.x;
-    const bool ok = m < cnt;
+    const bool ok = m < cnt && m < PTS;
     const int n = p.list[off + (ok ? m : cnt - 1)];
     const int64_t pt = int64_t(row) * p.n_points + n;
     const float* q = p.xyz + pt * 3;
@@ -155,11 +160,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   }
   __syncthreads();
 
-  const float cx = pt_c[j][0], cy = pt_c[j][1], cz = pt_c[j][2], valid = pt_c[j][3];
-  const float vx = pt_v[j][0], vy = pt_v[j][1], vz = pt_v[j][2], seed = pt_v[j][3];
+  // this lane's column of tile 0 and of tile 1: point j and (forward) point 32 + j / (backward) its tangent
+  constexpr int J1 = SECOND ? 0 : 32;
+  const float cx = pt_c[j][0], cy = pt_c[j][1], cz = pt_c[j][2], valid = pt_c[j][3], seed = pt_v[j][3];
+  const float c1x = pt_c[J1 + j][0], c1y = pt_c[J1 + j][1], c1z = pt_c[J1 + j][2], seed1 = pt_v[J1 + j][3];
+  const float vx = pt_v[j][0], vy = pt_v[j][1], vz = pt_v[j][2];
+  // what tile 1 carries into the coordinate slots (lin0 operand, skip features 101..103)
+  const float e1x = SECOND ? vx : c1x, e1y = SECOND ? vy : c1y, e1z = SECOND ? vz : c1z;
   bf16x8 bv[NT];
   bv[0] = coord_operand(cx, cy, cz, h);
-  if (SECOND) bv[NT - 1] = tangent_operand(vx, vy, vz, h);
+  bv[1] = SECOND ? tangent_operand(vx, vy, vz, h) : coord_operand(c1x, c1y, c1z, h);
 
   const uint16_t* fw = p.packed_bf16 + size_t(set) * BF_SET_STRIDE;
   const uint16_t* bw = p.packed_bwd + size_t(set) * BWD_SET_STRIDE;
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
       }
     }
   };
-  // activation: h' = softplus2(d'), u' = s tau ; keeps s = sigma'(d') and s' tau for the reverse sweep
+  // activation: h' = softplus2(d') (backward, tile 1: u' = s tau); keeps the state of the reverse sweep
   auto activate = [&](const f32x16 (&acc)[NT], f32x16& s, f32x16& q, f32x16 (&val)[NT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -235,21 +245,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
       s[r] = sg;
       val[0][r] = softplus2(acc[0][r]);
       if (SECOND) {
-        const float tau = acc[NT - 1][r];
-        val[NT - 1][r] = sg * tau;
+        const float tau = acc[1][r];
+        val[1][r] = sg * tau;
         q[r] = LN2 * sg * (1.f - sg) * tau;
+      } else {
+        q[r] = sigmoid2(acc[1][r]);
+        val[1][r] = softplus2(acc[1][r]);
       }
     }
   };
-  // reverse through the activation: D = H s + U s' tau ; T = U s
+  // reverse through the activation.  backward: D = H s + U s' tau, T = U s ; forward: G_t = (W^T G)_t s_t
   auto deactivate = [&](const f32x16 (&acc)[NT], const f32x16& s, const f32x16& q, f32x16 (&val)[NT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (SECOND) {
-        val[0][r] = fmaf(acc[0][r], s[r], acc[NT - 1][r] * q[r]);
-        val[NT - 1][r] = acc[NT - 1][r] * s[r];
+        val[0][r] = fmaf(acc[0][r], s[r], acc[1][r] * q[r]);
+        val[1][r] = acc[1][r] * s[r];
       } else {
         val[0][r] = acc[0][r] * s[r];
+        val[1][r] = acc[1][r] * q[r];
       }
     }
   };
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   }
 
   // ================================ forward =======================================================
-  // L0: lin0 on the local coordinates (folded bias inside the block), tangent: lin0[:, :3] v
+  // L0: lin0 on the local coordinates (folded bias inside the block); tangent stream: lin0[:, :3] v
   if (wave < 7) {
     const bf16x8* A0 = reinterpret_cast<const bf16x8*>(st + LS_OFF_L0B + size_t(k) * L0_BLOCK_FLOATS) + lane;
     const bf16x8 a = A0[wave * 64];
@@ -282,14 +296,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   // L1: 200 -> 101 (4 tiles); the skip coordinates (tangent: the direction) join tile 3 as features 101..103
   if (wave < L1_OB) {
     acc[0] = load_frag16(tails + wave * TAIL_FLOATS + h * 16);
-    if (SECOND) acc[NT - 1] = zero16;
+    acc[1] = SECOND ? zero16 : acc[0];
     gemm_tile(acc, fw + BF_OFF_L1A, wave, L1_KS16);
     activate(acc, s1, q1, val);
     if (wave == L1_OB - 1) {
       val[0][1] = h ? cx : val[0][1]; val[0][2] = h ? cy : val[0][2]; val[0][3] = h ? cz : val[0][3];
-      if (SECOND) {
-        val[NT - 1][1] = h ? vx : val[NT - 1][1]; val[NT - 1][2] = h ? vy : val[NT - 1][2]; val[NT - 1][3] = h ? vz : val[NT - 1][3];
-      }
+      val[1][1] = h ? e1x : val[1][1]; val[1][2] = h ? e1y : val[1][2]; val[1][3] = h ? e1z : val[1][3];
     }
   }
   __syncthreads();                       // every wavefront has read a0
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   // L2: 104 -> 200
   if (wave < 7) {
     acc[0] = load_frag16(tails + (L1_OB + wave) * TAIL_FLOATS + h * 16);
-    if (SECOND) acc[NT - 1] = zero16;
+    acc[1] = SECOND ? zero16 : acc[0];
     gemm_tile(acc, fw + BF_OFF_L2A, wave, L2_KS16);
     activate(acc, s2, q2, val);
   }
@@ -310,21 +322,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   if (wave < 7) {
     const float* tl = tails + (L1_OB + L2_OB + wave) * TAIL_FLOATS;
     acc[0] = load_frag16(tl + h * 16);
-    if (SECOND) acc[NT - 1] = zero16;
+    acc[1] = SECOND ? zero16 : acc[0];
     gemm_tile(acc, fw + BF_OFF_L3A, wave, L3_KS16);
     w4v = load_frag16(tl + 32 + h * 16);
     activate(acc, s3, q3, val);
     save_tile(SV_IN4, HID, wave, val);
     if (!SECOND) {
-      float partial = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) partial = fmaf(val[0][r], w4v[r], partial);
-      partial += __shfl_xor(partial, 32);
-      if (h == 0) part[wave][j] = partial;
+      for (int t = 0; t < NT; ++t) {
+        float partial = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) partial = fmaf(val[t][r], w4v[r], partial);
+        partial += __shfl_xor(partial, 32);
+        if (h == 0) part[wave][32 * t + j] = partial;
+      }
     }
   }
   __syncthreads();
-  if (!SECOND && threadIdx.x < PTS) {
+  if (!SECOND && threadIdx.x < 64) {
     const int m = threadIdx.x;
     float f = p.packed_f32[size_t(set) * SET_STRIDE + OFF_L4B];
 #pragma unroll
@@ -333,15 +348,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   }
 
   // ================================ reverse =======================================================
-  // output seeds: H3 = sbar w4/k, U3 = w4/k (valid columns) -> D3 = H3 s3 + U3 s3' tau3, T3 = U3 s3
+  // backward: output seeds H3 = sbar w4/k, U3 = w4/k (valid columns) -> D3 = H3 s3 + U3 s3' tau3, T3 = U3 s3
+  // forward : G3 = w4/k s3 for both point tiles (seed 1 on valid points)
   if (wave < 7) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (SECOND) {
         val[0][r] = w4v[r] * fmaf(seed, s3[r], valid * q3[r]);
-        val[NT - 1][r] = valid * w4v[r] * s3[r];
+        val[1][r] = valid * w4v[r] * s3[r];
       } else {
         val[0][r] = seed * w4v[r] * s3[r];
+        val[1][r] = seed1 * w4v[r] * q3[r];
       }
     }
     store_tile(wave, val);               // a2 is no longer needed (every wavefront passed the barriers above)
@@ -375,6 +392,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     deactivate(acc, s1, q1, val);
     if (wave == B_OB - 1 && h) {          // features 101..103 = registers 1..3 of the upper half-wave
       pt_dc[j][0] = acc[0][1]; pt_dc[j][1] = acc[0][2]; pt_dc[j][2] = acc[0][3];
+      if (!SECOND) { pt_dc[32 + j][0] = acc[1][1]; pt_dc[32 + j][1] = acc[1][2]; pt_dc[32 + j][2] = acc[1][3]; }
 #pragma unroll
       for (int t = 0; t < NT; ++t) { val[t][1] = 0.f; val[t][2] = 0.f; val[t][3] = 0.f; }
     }
@@ -408,12 +426,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     gemm_tile(acc, bw + OFF_D, 0, D_KS);
     if (h == 0) {                          // rows 0..2 of the tile = registers 0..2 of the lower half-wave
       pt_dc[j][0] += acc[0][0]; pt_dc[j][1] += acc[0][1]; pt_dc[j][2] += acc[0][2];
+      if (!SECOND) { pt_dc[32 + j][0] += acc[1][0]; pt_dc[32 + j][1] += acc[1][1]; pt_dc[32 + j][2] += acc[1][2]; }
     }
   }
   __syncthreads();
 
   // ---- per point: back to the global frame ---------------------------------------------------------
-  if (threadIdx.x < PTS) {
+  if (threadIdx.x < 64) {
     const int m = threadIdx.x;
     const int n = pt_idx[m];
     float gq[3] = {0.f, 0.f, 0.f};
@@ -439,6 +458,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   }
 }
 
+}  // namespace train
+}  // namespace nphm
+
+namespace nphm {
+namespace train {
 
 // ---- weight gradients ---------------------------------------------------------------------------------------
 // One workgroup = one chunk (<= a few dozen tiles of ONE weight set) x one layer.  Per tile: the layer's INPUT

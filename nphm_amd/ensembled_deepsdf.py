@@ -200,8 +200,9 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
 
 def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
     """Point lists of the training kernels (ident_train_kernel.hip): 32-point tiles ordered by (member, row), so the
-    tiles of one weight set are contiguous (``sets`` [A] = member -> set, non-decreasing).  Returns the tile table
-    int32 [T,4] = (row, member, offset, count <= 32), the point list int32 and the work list of the backward pass:
+    tiles of one weight set are contiguous (``sets`` [A] = member -> set, non-decreasing).  Returns the forward
+    kernel's tile table (64-point tiles), the backward kernel's int32 [T,4] = (row, member, offset, count <= 32)
+    over the same point list, the point list int32 and the work list of the backward pass:
     the tile table is cut into pieces of <= _TRAIN_RING_TILES tiles (the backward kernel's stored operands of one
     piece live in a ring buffer that fits the Infinity Cache), every piece into chunks of <= _WGRAD_CHUNK tiles of
     ONE weight set for the weight-gradient kernel: ``pieces`` = list of (first tile, tiles, first chunk, chunks),
@@ -213,11 +214,16 @@ def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
         idx = mask.permute(2, 0, 1).nonzero()                  # sorted by (member, row, point)
         counts = torch.bincount(idx[:, 0] * B + idx[:, 1], minlength=A * B).cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(counts)])
-    n_t = (counts + 31) // 32
-    pair = np.repeat(np.arange(A * B), n_t)
-    within = np.arange(int(n_t.sum())) - np.repeat(np.cumsum(n_t) - n_t, n_t)
-    tiles = np.stack([pair % B, pair // B, offs[pair] + 32 * within, np.minimum(32, counts[pair] - 32 * within)],
-                     axis=1).astype(np.int32)
+
+    def cut(width):            # tiles of <= width consecutive list entries of one (member, row) pair
+        n_t = (counts + width - 1) // width
+        pair = np.repeat(np.arange(A * B), n_t)
+        within = np.arange(int(n_t.sum())) - np.repeat(np.cumsum(n_t) - n_t, n_t)
+        return pair, np.stack([pair % B, pair // B, offs[pair] + width * within,
+                               np.minimum(width, counts[pair] - width * within)], axis=1).astype(np.int32)
+
+    _, tiles_fwd = cut(64)
+    pair, tiles = cut(32)
     T = tiles.shape[0]
     set_of_tile = sets.cpu().numpy()[pair // B]
     ring = _TRAIN_RING_TILES if _TRAIN_RING_TILES > 0 else max(T, 1)
@@ -234,7 +240,8 @@ def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
         sel = np.flatnonzero(chunks[:, 3] == pi)
         pieces.append((pi * ring, min(ring, T - pi * ring), int(sel[0]), len(sel)))
     dev = xyz.device
-    return (torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(), torch.from_numpy(chunks).to(dev), pieces)
+    return (torch.from_numpy(tiles_fwd).to(dev), torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(),
+            torch.from_numpy(chunks).to(dev), pieces)
 
 
 def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
@@ -350,14 +357,14 @@ class _MemberFieldFn(torch.autograd.Function):
         packed, state, anchors_k = module.prepare_latent(lat_rows.detach())
         packed_bwd = module._packed_bwd(dev)
         xyz_c = xyz.detach().contiguous().float()
-        tiles, plist, chunks, pieces = _train_member_lists(anchors_k, xyz_c, module.prune_tol, A,
-                                                           module.ensembled_deep_sdf.lin0._sets)
+        tiles_fwd, tiles, plist, chunks, pieces = _train_member_lists(anchors_k, xyz_c, module.prune_tol, A,
+                                                                      module.ensembled_deep_sdf.lin0._sets)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.nphm_identity_train_forward(
-            packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N, tiles.data_ptr(),
-            tiles.shape[0], plist.data_ptr(), S.data_ptr(), G.data_ptr(), stream), "nphm_identity_train_forward")
+            packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N, tiles_fwd.data_ptr(),
+            tiles_fwd.shape[0], plist.data_ptr(), S.data_ptr(), G.data_ptr(), stream), "nphm_identity_train_forward")
         ctx.module = module
         ctx.pieces = pieces
         ctx.shapes = [t.shape for t in (W0, W1, W2, W3, W4, b1, b3, b4)]
