@@ -198,19 +198,18 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
     return what * mask, torch.from_numpy(tiles).to(xyz.device), idx[:, 2].to(torch.int32).contiguous()
 
 
-def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
-    """Point lists of the training kernels (ident_train_kernel.hip): 32-point tiles ordered by (member, row), so the
-    tiles of one weight set are contiguous (``sets`` [A] = member -> set, non-decreasing).  Returns the forward
+def _train_member_lists(mask, sets):
+    """Point lists of the training kernels (ident_train_kernel.hip) from ``mask`` [B,N,A] (the members the pruning
+    rule keeps per point): tiles ordered by (member, row), so the tiles of one weight set are contiguous (``sets``
+    [A] = member -> set, non-decreasing).  Returns the forward
     kernel's tile table (64-point tiles), the backward kernel's int32 [T,4] = (row, member, offset, count <= 32)
     over the same point list, the point list int32 and the work list of the backward pass:
     the tile table is cut into pieces of <= _TRAIN_RING_TILES tiles (the backward kernel's stored operands of one
     piece live in a ring buffer that fits the Infinity Cache), every piece into chunks of <= _WGRAD_CHUNK tiles of
     ONE weight set for the weight-gradient kernel: ``pieces`` = list of (first tile, tiles, first chunk, chunks),
     chunk table int32 [C,4] = (weight set, first tile RELATIVE to its piece, tiles, 0).  One host sync."""
-    B, N, _ = xyz.shape
-    A = n_members
+    B, N, A = mask.shape
     with torch.no_grad():
-        _, mask = _blend_mask(anchors, xyz, prune_tol, A)
         idx = mask.permute(2, 0, 1).nonzero()                  # sorted by (member, row, point)
         counts = torch.bincount(idx[:, 0] * B + idx[:, 1], minlength=A * B).cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(counts)])
@@ -239,7 +238,7 @@ def _train_member_lists(anchors, xyz, prune_tol, n_members, sets):
     for pi in range((T + ring - 1) // ring):
         sel = np.flatnonzero(chunks[:, 3] == pi)
         pieces.append((pi * ring, min(ring, T - pi * ring), int(sel[0]), len(sel)))
-    dev = xyz.device
+    dev = mask.device
     return (torch.from_numpy(tiles_fwd).to(dev), torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(),
             torch.from_numpy(chunks).to(dev), pieces)
 
@@ -357,11 +356,12 @@ class _MemberFieldFn(torch.autograd.Function):
         packed, state, anchors_k = module.prepare_latent(lat_rows.detach())
         packed_bwd = module._packed_bwd(dev)
         xyz_c = xyz.detach().contiguous().float()
-        tiles_fwd, tiles, plist, chunks, pieces = _train_member_lists(anchors_k, xyz_c, module.prune_tol, A,
-                                                                      module.ensembled_deep_sdf.lin0._sets)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        # members the pruning rule keeps per point: the list kernel's normalised blend weights (0 where pruned)
+        what = _member_point_lists_device(state, xyz_c, module.prune_tol, A, stream)[0]
+        tiles_fwd, tiles, plist, chunks, pieces = _train_member_lists(what > 0, module.ensembled_deep_sdf.lin0._sets)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.nphm_identity_train_forward(
             packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N, tiles_fwd.data_ptr(),
             tiles_fwd.shape[0], plist.data_ptr(), S.data_ptr(), G.data_ptr(), stream), "nphm_identity_train_forward")

@@ -32,7 +32,9 @@ def actual_compute_loss(batch_cuda, decoder, glob_cond):
     has_anchors = hasattr(decoder, "anchors")
     sizes = [batch_cuda[k].shape[1] for k in _POINT_SETS]
     x = torch.cat([batch_cuda[k] for k in _POINT_SETS], dim=1).clone().detach().requires_grad_()
-    pred, anchors = decoder(x, glob_cond.repeat(1, x.shape[1], 1), batch_cuda["gt_anchors"] if has_anchors else None)
+    # one code per subject: the decoders broadcast a [B,1,L] code over the points themselves (EnsembledDeepSDF.py:223,
+    # deepSDF.py); the reference's glob_cond.repeat(1, N, 1) would only be compared back to one row by the HIP tiers
+    pred, anchors = decoder(x, glob_cond, batch_cuda["gt_anchors"] if has_anchors else None)
     grad = gradient(pred, x)
     sdf_face, sdf_non, _, sdf_far = pred.squeeze(-1).split(sizes, dim=1)
     g_face, g_non, g_near, g_far = grad.split(sizes, dim=1)

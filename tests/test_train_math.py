@@ -70,3 +70,38 @@ def test_two_stream_reverse_sweep_equals_double_backward():
                 (sbar @ h3 + u3.sum(0)) / k, sbar.sum()]
     for a, b in zip(mine, ref):
         assert (a - b).abs().max() <= 1e-12 * (1 + b.abs().max())
+
+
+def test_training_work_lists_cover_every_kept_pair_once(monkeypatch):
+    """Host-side work lists of the training tier: forward tiles (<= 64 points) and backward tiles (<= 32) over one
+    point list ordered by (member, row); pieces and weight-gradient chunks tile the backward table exactly, every
+    chunk inside one weight set and one piece."""
+    import numpy as np
+
+    import nphm_amd.ensembled_deepsdf as E
+    monkeypatch.setattr(E, "_TRAIN_RING_TILES", 7)
+    monkeypatch.setattr(E, "_WGRAD_CHUNK", 3)
+    torch.manual_seed(0)
+    B, N, A = 2, 200, 40
+    anch, xyz = torch.randn(B, 39, 3) * 0.1, torch.randn(B, N, 3) * 0.15
+    sets = E._member_sets(A, 16)
+    _, mask = E._blend_mask(anch, xyz, 1e-7, A)
+    tiles_fwd, tiles, plist, chunks, pieces = E._train_member_lists(mask, sets)
+    tiles_fwd, tiles, plist, chunks = (t.numpy() for t in (tiles_fwd, tiles, plist, chunks))
+    for tab, width in ((tiles_fwd, 64), (tiles, 32)):
+        seen = np.zeros((B, N, A), int)
+        assert (tab[:, 3] > 0).all() and (tab[:, 3] <= width).all()
+        assert (np.diff(tab[:, 1]) >= 0).all()                              # member-major
+        for row, k, off, cnt in tab:
+            seen[row, plist[off:off + cnt], k] += 1
+        assert (seen == mask.numpy().astype(int)).all()
+    T = tiles.shape[0]
+    cover = np.zeros(T, int)
+    assert sum(n for _, n, _, _ in pieces) == T
+    for t0, nt, c0, nc in pieces:
+        assert nt <= 7
+        for s_, rel, n, _ in chunks[c0:c0 + nc]:
+            assert 0 < n <= 3 and rel + n <= nt
+            assert (sets.numpy()[tiles[t0 + rel:t0 + rel + n, 1]] == s_).all()
+            cover[t0 + rel:t0 + rel + n] += 1
+    assert (cover == 1).all()
