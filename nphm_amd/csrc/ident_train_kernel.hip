@@ -115,6 +115,9 @@ __device__ __forceinline__ bf16x8 tangent_operand(float x, float y, float z, int
 //   backward (SECOND = true) : tile 1 = the tangent stream of the SAME 32 points.
 // Per-layer state kept in registers for the reverse sweep: s = sigma'(d') of tile 0 and, in q, sigma'(d') of tile 1
 // (forward) or sigma''(d') tau (backward).
+// One workgroup per tile, tiles in table order.  Measured alternatives (32 x 1693-point batch, 28.6 k backward tiles):
+// persistent workgroups striding over the table +35 %; XCD-aware order (XCD x walks the x-th eighth of the
+// member-ordered table) +6 %; a fully unrolled K loop with 4..12 weight fragments in flight +10..30 %.
 template <bool SECOND>
 __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   constexpr int NT = 2;

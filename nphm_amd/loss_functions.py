@@ -36,16 +36,20 @@ def actual_compute_loss(batch_cuda, decoder, glob_cond):
     # deepSDF.py); the reference's glob_cond.repeat(1, N, 1) would only be compared back to one row by the HIP tiers
     pred, anchors = decoder(x, glob_cond, batch_cuda["gt_anchors"] if has_anchors else None)
     grad = gradient(pred, x)
-    sdf_face, sdf_non, _, sdf_far = pred.squeeze(-1).split(sizes, dim=1)
-    g_face, g_non, g_near, g_far = grad.split(sizes, dim=1)
-
-    normal_face = (g_face - batch_cuda["normals_face"]).norm(2, dim=-1)
-    normal_non = torch.clamp((g_non - batch_cuda["normals_non_face"]).norm(2, dim=-1), None, 0.75) / 2
-    eikonal = torch.cat([(g.norm(dim=-1) - 1).abs() for g in (g_face, g_non, g_far, g_near)], dim=-1)
-    out = {"surf_sdf": torch.cat([sdf_face.abs(), sdf_non.abs()], dim=-1).mean(),
-           "normals": torch.cat([normal_face, normal_non], dim=-1).mean(),
-           "space_sdf": torch.exp(-1e1 * sdf_far.abs()).mean(),
-           "grad": eikonal.mean(),
+    # the point sets are consecutive slices of the batch: [face | non-face | near | far].  The reference's means over
+    # concatenated per-set terms are means over slices of ONE tensor (same values, a fraction of the autograd nodes):
+    n_face, n_non, n_near, n_far = sizes
+    n_surf = n_face + n_non
+    sdf = pred.squeeze(-1)
+    normals = torch.cat([batch_cuda["normals_face"], batch_cuda["normals_non_face"]], dim=1)
+    normal_err = (grad[:, :n_surf] - normals).norm(2, dim=-1)
+    # non-face points: error clamped at 0.75 and halved (loss_functions.py:56-57)
+    cap = torch.cat([normal_err.new_full((n_face,), float("inf")), normal_err.new_full((n_non,), 0.75)])
+    scale = torch.cat([normal_err.new_ones(n_face), normal_err.new_full((n_non,), 0.5)])
+    out = {"surf_sdf": sdf[:, :n_surf].abs().mean(),
+           "normals": (torch.minimum(normal_err, cap) * scale).mean(),
+           "space_sdf": torch.exp(-1e1 * sdf[:, n_surf + n_near:].abs()).mean(),
+           "grad": (grad.norm(dim=-1) - 1).abs().mean(),          # all four sets (loss_functions.py:60-66)
            "lat_reg": (torch.norm(glob_cond, dim=-1) ** 2).mean()}
     if anchors is None:
         return out
