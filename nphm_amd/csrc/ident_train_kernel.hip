@@ -35,6 +35,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "capi_common.h"
 #include "layout.h"
 #include "member_common.h"
@@ -181,34 +183,61 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
   const f32x16 zero16 = {};
 
-  // out tile `n` of a stage: acc[t] += sum over ks K-steps of A(n, s) x act(s)   (split-bf16 x3)
-  auto gemm_tile = [&](f32x16 (&acc)[NT], const uint16_t* frag_base, int n, int ks) __attribute__((always_inline)) {
-    const bf16x8* W = reinterpret_cast<const bf16x8*>(frag_base) + size_t(n) * ks * 128 + lane;
-    bf16x8 ah[2], al[2], bh[2][NT], bl[2][NT];
-    auto load = [&](int slot, int s) __attribute__((always_inline)) {
+  // out tile `n` of a stage: acc[t] += sum over KS K-steps of A(n, s) x act(s)   (split-bf16 x3).  The A fragments
+  // come from L2, several hundred cycles away, with one wavefront pair per SIMD to hide that: four K-steps of them
+  // are kept in flight (B fragments from LDS: one step ahead).  Every load is unconditional (indices clamped to the
+  // last K-step): a branch around a prefetch makes the compiler's s_waitcnt insertion give up on counting and wait
+  // for ALL outstanding loads before each MFMA group - i.e. no prefetch at all.
+  auto gemm_tile = [&](f32x16 (&acc)[NT], const uint16_t* frag_base, int n, auto ks_c) __attribute__((always_inline)) {
+    constexpr int KS = decltype(ks_c)::value;
+    const bf16x8* W = reinterpret_cast<const bf16x8*>(frag_base) + size_t(n) * KS * 128 + lane;
+    bf16x8 ah[4], al[4], bh[2][NT], bl[2][NT];
+    auto load_a = [&](int slot, int s) __attribute__((always_inline)) {
+      s = s < KS - 1 ? s : KS - 1;
       ah[slot] = W[s * 128];
       al[slot] = W[s * 128 + 64];
+    };
+    auto load_b = [&](int slot, int s) __attribute__((always_inline)) {
+      s = s < KS - 1 ? s : KS - 1;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         bh[slot][t] = Bh[2 * s * M + 32 * t];
         bl[slot][t] = Bl[2 * s * M + 32 * t];
       }
     };
-    auto mma = [&](int slot) __attribute__((always_inline)) {
+    auto mma = [&](int sa, int sb) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot], bh[slot][t], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot], bl[slot][t], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot], bh[slot][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sa], bh[sb][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sa], bl[sb][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[sa], bh[sb][t], acc[t], 0, 0, 0);
       }
     };
-    load(0, 0);
+    // sched_barrier(0) after every group: hipcc otherwise sinks each load to just before its first use (one
+    // register set, s_waitcnt vmcnt(0) in front of every MFMA group)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_a(u, u);
+    load_b(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    int s = 0;
 #pragma unroll 1
-    for (int s = 0; s < ks; s += 2) {
-      if (s + 1 < ks) load(1, s + 1);
-      mma(0);
-      if (s + 2 < ks) load(0, s + 2);
-      if (s + 1 < ks) mma(1);
+    for (; s + 4 <= KS; s += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        load_b((u + 1) & 1, s + u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(u, u & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(u, s + u + 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KS % 4; ++u) {             // s = KS - KS % 4 here: slots u hold K-steps s + u
+      if (u + 1 < KS % 4) load_b((u + 1) & 1, KS - KS % 4 + u + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(u, u & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // D tile n -> LDS K chunks 4n + 2*half + h of the columns
@@ -300,7 +329,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   if (wave < L1_OB) {
     acc[0] = load_frag16(tails + wave * TAIL_FLOATS + h * 16);
     acc[1] = SECOND ? zero16 : acc[0];
-    gemm_tile(acc, fw + BF_OFF_L1A, wave, L1_KS16);
+    gemm_tile(acc, fw + BF_OFF_L1A, wave, std::integral_constant<int, L1_KS16>{});
     activate(acc, s1, q1, val);
     if (wave == L1_OB - 1) {
       val[0][1] = h ? cx : val[0][1]; val[0][2] = h ? cy : val[0][2]; val[0][3] = h ? cz : val[0][3];
@@ -314,7 +343,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   if (wave < 7) {
     acc[0] = load_frag16(tails + (L1_OB + wave) * TAIL_FLOATS + h * 16);
     acc[1] = SECOND ? zero16 : acc[0];
-    gemm_tile(acc, fw + BF_OFF_L2A, wave, L2_KS16);
+    gemm_tile(acc, fw + BF_OFF_L2A, wave, std::integral_constant<int, L2_KS16>{});
     activate(acc, s2, q2, val);
   }
   __syncthreads();
@@ -326,7 +355,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     const float* tl = tails + (L1_OB + L2_OB + wave) * TAIL_FLOATS;
     acc[0] = load_frag16(tl + h * 16);
     acc[1] = SECOND ? zero16 : acc[0];
-    gemm_tile(acc, fw + BF_OFF_L3A, wave, L3_KS16);
+    gemm_tile(acc, fw + BF_OFF_L3A, wave, std::integral_constant<int, L3_KS16>{});
     w4v = load_frag16(tl + 32 + h * 16);
     activate(acc, s3, q3, val);
     save_tile(SV_IN4, HID, wave, val);
@@ -372,7 +401,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   if (wave < 7) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero16;
-    gemm_tile(acc, bw + OFF_A, wave, A_KS);
+    gemm_tile(acc, bw + OFF_A, wave, std::integral_constant<int, A_KS>{});
     deactivate(acc, s2, q2, val);
     if (SECOND) {
       float* gb = p.gb2 + (size_t(row) * N_MEMBERS + k) * HID;
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   if (wave < B_OB) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero16;
-    gemm_tile(acc, bw + OFF_B, wave, B_KS);
+    gemm_tile(acc, bw + OFF_B, wave, std::integral_constant<int, B_KS>{});
     deactivate(acc, s1, q1, val);
     if (wave == B_OB - 1 && h) {          // features 101..103 = registers 1..3 of the upper half-wave
       pt_dc[j][0] = acc[0][1]; pt_dc[j][1] = acc[0][2]; pt_dc[j][2] = acc[0][3];
@@ -407,7 +436,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   if (wave < 7) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero16;
-    gemm_tile(acc, bw + OFF_C, wave, C_KS);
+    gemm_tile(acc, bw + OFF_C, wave, std::integral_constant<int, C_KS>{});
     deactivate(acc, s0, q0, val);
     if (SECOND) {
       float* gb = p.gb0 + (size_t(row) * N_MEMBERS + k) * HID;
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   if (wave == 0) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero16;
-    gemm_tile(acc, bw + OFF_D, 0, D_KS);
+    gemm_tile(acc, bw + OFF_D, 0, std::integral_constant<int, D_KS>{});
     if (h == 0) {                          // rows 0..2 of the tile = registers 0..2 of the lower half-wave
       pt_dc[j][0] += acc[0][0]; pt_dc[j][1] += acc[0][1]; pt_dc[j][2] += acc[0][2];
       if (!SECOND) { pt_dc[32 + j][0] += acc[1][0]; pt_dc[32 + j][1] += acc[1][1]; pt_dc[32 + j][2] += acc[1][2]; }
