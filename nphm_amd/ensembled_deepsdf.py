@@ -13,15 +13,15 @@ Execution tiers of ``FastEnsembleDeepSDFMirrored.forward``:
   fitting: only xyz / the latent are optimised), in training mode: forward = the same fused kernel,
   backward = ``nphm_identity_backward`` (member-centric MFMA kernel) for d/dxyz, d/danchors and
   d/d(folded biases), chained through ``mlp_pos`` and the latent columns by ordinary autograd.  Not
-  double-differentiable (training needs the composite tier, which it gets: its parameters require grad).
+  double-differentiable (training gets the HIP training tier below: its parameters require grad).
 * **HIP training** (twice differentiable in xyz, every parameter trainable): when parameters require grad,
   in training mode (``compute_loss``: decoder -> gradient(pred, x, create_graph=True) -> loss.backward()).  The
   member MLPs and their first / second-order backward run on ``nphm_identity_train_forward/backward``
-  (ident_train_kernel.hip), weight gradients as one library GEMM per layer and weight set over operands the
+  (ident_train_kernel.hip), the weight gradients on ``nphm_identity_train_weight_grads`` over operands the backward
   kernel stores; ``module.train_backend = "composite"`` (or NPHM_AMD_TRAIN_TIER=composite) opts out.
 * **composite**: a differentiable PyTorch formulation (latent columns of lin0 / the skip layer are
-  applied once per latent instead of once per point).  Used when gradients are required
-  (fitting / training, incl. double backward), for per-point latents and for other architectures.
+  applied once per latent instead of once per point).  Used for per-point latents, other architectures,
+  eval mode under autograd and by explicit opt-in (first- and second-order autograd).
   It is never chosen silently on a CPU tensor: that needs ``module.backend = "composite"``.
 """
 from __future__ import annotations
