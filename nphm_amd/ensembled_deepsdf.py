@@ -228,16 +228,21 @@ def _train_member_lists(mask, sets):
     ring = _TRAIN_RING_TILES if _TRAIN_RING_TILES > 0 else max(T, 1)
     # chunk boundaries: every _WGRAD_CHUNK tiles inside a run of one weight set inside one piece
     piece_of_tile = np.arange(T) // ring
-    run_start = np.flatnonzero(np.r_[True, (np.diff(set_of_tile) != 0) | (np.diff(piece_of_tile) != 0)]) if T else np.zeros(0, int)
-    run_len = np.diff(np.r_[run_start, T])
-    chunks, pieces = [], []
-    for r0, rl in zip(run_start, run_len):
-        for t in range(r0, r0 + rl, _WGRAD_CHUNK):
-            chunks.append((set_of_tile[r0], t - (t // ring) * ring, min(_WGRAD_CHUNK, r0 + rl - t), t // ring))
-    chunks = np.asarray(chunks, dtype=np.int32).reshape(-1, 4)
-    for pi in range((T + ring - 1) // ring):
-        sel = np.flatnonzero(chunks[:, 3] == pi)
-        pieces.append((pi * ring, min(ring, T - pi * ring), int(sel[0]), len(sel)))
+    if T:
+        run_start = np.flatnonzero(np.r_[True, (np.diff(set_of_tile) != 0) | (np.diff(piece_of_tile) != 0)])
+        run_len = np.diff(np.r_[run_start, T])
+        n_ch = (run_len + _WGRAD_CHUNK - 1) // _WGRAD_CHUNK                       # chunks per run
+        run = np.repeat(np.arange(len(run_start)), n_ch)
+        k_in_run = np.arange(int(n_ch.sum())) - np.repeat(np.cumsum(n_ch) - n_ch, n_ch)
+        first = run_start[run] + _WGRAD_CHUNK * k_in_run                          # first tile of every chunk
+        piece = first // ring
+        chunks = np.stack([set_of_tile[first], first - piece * ring,
+                           np.minimum(_WGRAD_CHUNK, run_start[run] + run_len[run] - first), piece], axis=1).astype(np.int32)
+        c_first = np.searchsorted(piece, np.arange(piece[-1] + 1), side="left")
+        c_count = np.diff(np.r_[c_first, len(piece)])
+        pieces = [(int(pi * ring), int(min(ring, T - pi * ring)), int(c0), int(nc)) for pi, (c0, nc) in enumerate(zip(c_first, c_count))]
+    else:
+        chunks, pieces = np.zeros((0, 4), np.int32), []
     dev = mask.device
     return (torch.from_numpy(tiles_fwd).to(dev), torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(),
             torch.from_numpy(chunks).to(dev), pieces)
@@ -358,7 +363,8 @@ class _MemberFieldFn(torch.autograd.Function):
         xyz_c = xyz.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         # members the pruning rule keeps per point: the list kernel's normalised blend weights (0 where pruned)
-        what = _member_point_lists_device(state, xyz_c, module.prune_tol, A, stream)[0]
+        tol = module.prune_tol if module.train_prune_tol is None else module.train_prune_tol
+        what = _member_point_lists_device(state, xyz_c, tol, A, stream)[0]
         tiles_fwd, tiles, plist, chunks, pieces = _train_member_lists(what > 0, module.ensembled_deep_sdf.lin0._sets)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
@@ -481,6 +487,10 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         # tier of a training forward (parameters require grad, train mode): "hip" = member MLPs and their double
         # backward by the kernels of ident_train_kernel.hip | "composite" = PyTorch formulation
         self.train_backend = os.environ.get("NPHM_AMD_TRAIN_TIER", "hip")
+        # pruning tolerance of the training tier (None: prune_tol).  Work is proportional to the kept (point, member)
+        # pairs: 16.6 per point at 1e-7 on near-surface training samples
+        self.train_prune_tol = (float(os.environ["NPHM_AMD_TRAIN_PRUNE_TOL"])
+                                if "NPHM_AMD_TRAIN_PRUNE_TOL" in os.environ else None)
 
     # ------------------------------------------------------------------------------------------
     def invalidate_pack(self):
