@@ -1,2 +1,3 @@
-"""Import-path shim for the reference's src/NPHM/models/loss_functions.py (identity-decoder loss)."""
-from nphm_amd.loss_functions import actual_compute_loss, compute_loss  # noqa: F401
+"""Import-path shim for the reference's src/NPHM/models/loss_functions.py."""
+from nphm_amd.loss_functions import (actual_compute_loss, compute_loss, compute_loss_corresp_forward,  # noqa: F401
+                                     loss_joint)

@@ -1,6 +1,7 @@
 """Training loss of the identity decoder - host-side mirror of ``compute_loss`` / ``actual_compute_loss``
 (src/NPHM/models/loss_functions.py:7-110): same arguments, same keys and values of the returned dictionary
-(the trainer weights them with cfg['lambdas'], training.py:119-124).
+(the trainer weights them with cfg['lambdas'], training.py:119-124), and of the deformation-stage losses
+``compute_loss_corresp_forward`` (:282-326) and ``loss_joint`` (:113-279).
 
 The reference evaluates the decoder four times per step (on-surface face / non-face points, near-surface and
 far points) and differentiates each prediction w.r.t. its points.  Per point the field is independent of its
@@ -18,10 +19,7 @@ _POINT_SETS = ("points_face", "points_non_face", "sup_grad_near", "sup_grad_far"
 
 def compute_loss(batch, decoder, latent_codes, device):
     """loss_functions.py:7-18: move the batch to ``device``, look the latent codes up, evaluate the loss terms."""
-    batch = {k: v for k, v in batch.items() if k != "path"}
-    idx = batch["idx"].to(device)
-    tensors = {k: v.to(device).float() for k, v in batch.items()}
-    return actual_compute_loss(tensors, decoder, latent_codes(idx))
+    return actual_compute_loss(_to_device(batch, device), decoder, latent_codes(batch["idx"].to(device)))
 
 
 def actual_compute_loss(batch_cuda, decoder, glob_cond):
@@ -55,16 +53,132 @@ def actual_compute_loss(batch_cuda, decoder, glob_cond):
         return out
 
     out["anchors"] = (anchors - batch_cuda["gt_anchors"]).square().mean()
-    if hasattr(decoder, "lat_dim_glob"):
-        # local codes of mirror-symmetric anchors should agree; the mid-line codes pairwise (an odd one out is skipped)
-        z = glob_cond.squeeze(1)
-        g, loc, n_symm = decoder.lat_dim_glob, decoder.lat_dim_loc, decoder.num_symm_pairs
-        pairs = z[:, g:g + 2 * n_symm * loc].view(z.shape[0], 2 * n_symm, loc)
-        middle = z[:, g + 2 * n_symm * loc:-loc].view(z.shape[0], decoder.num_kps - 2 * n_symm, loc)
-        n_mid = middle.shape[1] - middle.shape[1] % 2
-        out["symm_dist"] = torch.norm(pairs[:, ::2] - pairs[:, 1::2], dim=-1).mean()
-        out["middle_dist"] = torch.norm(middle[:, :n_mid:2] - middle[:, 1:n_mid:2], dim=-1).mean()
-    else:
-        out["symm_dist"] = None
-        out["middle_dist"] = None
+    out["symm_dist"], out["middle_dist"] = _lat_regularisers(decoder, glob_cond)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# deformation network (second training stage)
+# ------------------------------------------------------------------------------------------------------------------
+def _to_device(batch, device):
+    return {k: v.to(device).float() for k, v in batch.items() if k != "path"}
+
+
+def _lat_regularisers(decoder_shape, cond_shape):
+    """symm_dist / middle_dist of the identity codes (loss_functions.py:73-88, :219-234): None, None for a decoder
+    without local codes."""
+    if not hasattr(decoder_shape, "lat_dim_glob"):
+        return None, None
+    z = cond_shape.squeeze(1)
+    g, loc, n_symm = decoder_shape.lat_dim_glob, decoder_shape.lat_dim_loc, decoder_shape.num_symm_pairs
+    pairs = z[:, g:g + 2 * n_symm * loc].view(z.shape[0], 2 * n_symm, loc)
+    middle = z[:, g + 2 * n_symm * loc:-loc].view(z.shape[0], decoder_shape.num_kps - 2 * n_symm, loc)
+    n_mid = middle.shape[1] - middle.shape[1] % 2
+    return (torch.norm(pairs[:, ::2] - pairs[:, 1::2], dim=-1).mean(),
+            torch.norm(middle[:, :n_mid:2] - middle[:, 1:n_mid:2], dim=-1).mean())
+
+
+def compute_loss_corresp_forward(batch, decoder, decoder_shape, latent_codes, latent_codes_shape, device, epoch=-1,
+                                 exp_path=None):
+    """Loss of the forward-deformation network (loss_functions.py:282-326; trainer: training_corresp.py:159):
+    neutral points displaced by the field should land on their posed correspondences; the field should vanish on
+    uniform samples of the [-1.25, 1.25]^3 box; expression codes are regularised.  First order only."""
+    batch_cuda = _to_device(batch, device)
+    cond_shape = latent_codes_shape(batch["subj_ind"].to(device))
+    cond_pose = latent_codes(batch["idx"].to(device))
+    if decoder_shape is not None and decoder_shape.mlp_pos is not None:
+        # anchors of the identity code (EnsembledDeepSDF.py:228-229), as the deformation network is conditioned on them
+        anchors = decoder_shape.mlp_pos(cond_shape[..., :decoder_shape.lat_dim_glob]).view(cond_pose.shape[0], -1, 3)
+        anchors = anchors + decoder.anchors.squeeze(0)
+    else:
+        anchors = batch_cuda["gt_anchors"]
+    cond = torch.cat([cond_shape, cond_pose], dim=-1)
+
+    neutral = batch_cuda["points_neutral"].clone().detach().requires_grad_()
+    cond_rep = cond.repeat(1, neutral.shape[1], 1)
+    delta, _ = decoder(neutral, cond_rep, anchors)
+    posed = neutral + delta.squeeze()
+    samples = (torch.rand(cond_rep.shape[0], 100, 3, device=cond_rep.device, dtype=cond_rep.dtype) - 0.5) * 2.5
+    delta_free, _ = decoder(samples, cond_rep[:, :100, :], anchors)
+    return {"corresp": ((posed - batch_cuda["points_posed"][:, :, :3]) ** 2).mean(),
+            "lat_reg": (torch.norm(cond_pose, dim=-1) ** 2).mean(),
+            "loss_reg_zero": (delta_free ** 2).mean()}
+
+
+def loss_joint(batch, decoder_shape, decoder_expr, latent_codes_shape, latent_codes_expr, device, epoch):
+    """Joint loss of identity and deformation network (loss_functions.py:113-279): SDF / normal / eikonal terms of
+    the identity field at posed points pulled back through the deformation, canonical far points, latent
+    regularisers, anchor, correspondence and deformation regularisers.  The identity decoder is evaluated on its
+    training tier (twice differentiable in the canonical points, so the gradients w.r.t. the POSED points chain
+    through the deformation network's autograd graph)."""
+    batch_cuda = _to_device(batch, device)
+    cond_shape = latent_codes_shape(batch["subj_ind"].to(device))
+    cond_expr = latent_codes_expr(batch["idx"].to(device))
+    cond_cat = torch.cat([cond_shape, cond_expr], dim=-1)
+    neutral = batch_cuda["is_neutral"].squeeze(dim=-1) == 1
+    any_neutral = bool(neutral.sum() > 0)
+
+    def pulled_back(points, rows=None):
+        """(sdf, d sdf / d posed points, offsets) of posed points; ``rows``: boolean selection of batch entries."""
+        x = (points if rows is None else points[rows]).clone().detach().requires_grad_()
+        c_cat = cond_cat.repeat(1, x.shape[1], 1) if rows is None else cond_cat.repeat(1, x.shape[1], 1)[rows]
+        c_shape = cond_shape.repeat(1, x.shape[1], 1) if rows is None else cond_shape.repeat(1, x.shape[1], 1)[rows]
+        offsets, _ = decoder_expr(x, c_cat, None)
+        sdf, anchors = decoder_shape(x + offsets, c_shape, None)
+        return sdf, gradient(sdf, x), offsets, anchors
+
+    def clamped_normal(g, n):
+        return torch.clamp((g - n).norm(2, dim=-1), None, 0.75 * 100) / 2
+
+    sdf_s, g_s, off_s, _ = pulled_back(batch_cuda["points_surface"])
+    sdf_terms = [sdf_s.abs().squeeze(dim=-1).reshape(-1)]
+    normal_terms = [(g_s - batch_cuda["normals_surface"]).norm(2, dim=-1).reshape(-1)]
+    eikonal_terms = [(g_s.norm(dim=-1) - 1).abs().reshape(-1)]
+    if any_neutral:
+        sdf_o, g_o, off_o, _ = pulled_back(batch_cuda["points_surface_outer"], neutral)
+        sdf_f, g_f, off_f, _ = pulled_back(batch_cuda["points_off_surface"], neutral)
+        sdf_terms += [sdf_o.abs().squeeze(dim=-1).reshape(-1),
+                      (sdf_f - batch_cuda["sdfs_off_surface"][neutral]).abs().squeeze(dim=-1).reshape(-1)]
+        normal_terms += [clamped_normal(g_o, batch_cuda["normals_surface_outer"][neutral]).reshape(-1),
+                         clamped_normal(g_f, batch_cuda["normals_off_surface"][neutral]).reshape(-1)]
+        eikonal_terms += [(g_o.norm(dim=-1) - 1).abs().reshape(-1), (g_f.norm(dim=-1) - 1).abs().reshape(-1)]
+
+    # canonical space only: far points
+    far = batch_cuda["sup_grad_far"].clone().detach().requires_grad_()
+    sdf_far, anchors_pred = decoder_shape(far, cond_shape.repeat(1, far.shape[1], 1), None)
+    g_far = gradient(sdf_far, far)
+    eikonal_terms = [(g_far.norm(dim=-1) - 1).abs().reshape(-1)] + eikonal_terms
+
+    symm_dist, middle_dist = _lat_regularisers(decoder_shape, cond_shape)
+
+    corresp_posed = batch_cuda["corresp_posed"].clone().detach().requires_grad_()
+    if epoch < 3000:
+        delta, _ = decoder_expr(corresp_posed, cond_cat.repeat(1, corresp_posed.shape[1], 1), None)
+        loss_corresp = (corresp_posed + delta - batch_cuda["corresp_neutral"]).square().mean()
+        if epoch > 750:
+            loss_corresp = loss_corresp * 0.25
+    else:
+        loss_corresp = torch.zeros((), device=cond_cat.device, dtype=cond_cat.dtype)
+
+    n_free = min(100, batch_cuda["corresp_posed"].shape[1])
+    samples = (torch.rand(cond_shape.shape[0], n_free, 3, device=cond_shape.device, dtype=cond_shape.dtype) - 0.5) * 2.5
+    delta_free, _ = decoder_expr(samples, cond_cat.repeat(1, n_free, 1), None)
+    loss_reg_zero = delta_free.square().mean()
+
+    if any_neutral:
+        loss_neutral = off_s[neutral].square().mean() + off_o.square().mean() + off_f.square().mean()
+    else:
+        loss_neutral = torch.zeros_like(loss_reg_zero)
+
+    return {"surf_sdf_loss": torch.cat(sdf_terms).mean(),
+            "normal_loss": torch.cat(normal_terms).mean(),
+            "space_sdf_loss": torch.exp(-1e1 * sdf_far.abs()).mean(),
+            "eik_loss": torch.cat(eikonal_terms).mean(),
+            "reg_shape": (torch.norm(cond_shape, dim=-1) ** 2).mean(),
+            "reg_expr": (torch.norm(cond_expr, dim=-1) ** 2).mean(),
+            "anchors": (anchors_pred - batch_cuda["gt_anchors"]).square().mean().mean(),
+            "symm_dist": symm_dist.mean(),
+            "middle_dist": middle_dist.mean(),
+            "corresp": loss_corresp,
+            "loss_reg_zero": loss_reg_zero,
+            "loss_neutral_zero": loss_neutral}

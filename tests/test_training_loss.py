@@ -29,8 +29,8 @@ def _step(net, g, dev):
 def _check(net, g, losses, total, lat, tol_loss, tol_grad):
     assert U.state_hash(net) == str(g["state_hash"])
     for k, v in losses.items():
-        assert abs(float(v) - float(g["loss_" + k])) <= tol_loss * max(1.0, abs(float(g["loss_" + k]))), k
-    assert abs(float(total) - float(g["total"])) <= tol_loss
+        assert abs(float(v.detach()) - float(g["loss_" + k])) <= tol_loss * max(1.0, abs(float(g["loss_" + k]))), k
+    assert abs(float(total.detach()) - float(g["total"])) <= tol_loss
     rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
     assert rel(lat.grad.cpu().numpy(), g["grad_lat"]) < tol_grad
     grads = dict(net.named_parameters())
@@ -72,3 +72,102 @@ def test_loss_and_gradients_match_reference_hip():
     net.prune_tol = 1e-7
     losses, total, lat = _step(net, g, dev)
     _check(net, g, losses, total, lat, 1e-5, 2e-3)
+
+
+# ---- deformation-stage losses (compute_loss_corresp_forward, loss_joint) ----------------------------------------------
+from NPHM.models.loss_functions import compute_loss_corresp_forward, loss_joint   # noqa: E402
+
+import nphm_amd   # noqa: E402
+
+
+def _tables(g, dev):
+    shape = torch.nn.Embedding(*g["shape_table"].shape)
+    expr = torch.nn.Embedding(*g["expr_table"].shape)
+    with torch.no_grad():
+        shape.weight.copy_(torch.from_numpy(g["shape_table"]))
+        expr.weight.copy_(torch.from_numpy(g["expr_table"]))
+    return shape.to(dev), expr.to(dev)
+
+
+def _glob_only(dev):
+    anchors = torch.from_numpy(U.anchors_mean()).float().unsqueeze(0).unsqueeze(0)
+    torch.manual_seed(1)
+    return nphm_amd.DeformationNetwork(mode="glob_only", lat_dim_expr=200, lat_dim_id=32, lat_dim_glob_shape=64,
+                                       lat_dim_loc_shape=32, n_loc=39, anchors=anchors.to(dev), hidden_dim=400, nlayers=4,
+                                       input_dim=3, out_dim=3).to(dev)
+
+
+def _grad_norms(mods):
+    return np.array([0.0 if p.grad is None else float(p.grad.norm()) for _, m in mods for _, p in m.named_parameters()])
+
+
+def _batch(g, prefix, dev):
+    b = {k[len(prefix):]: torch.from_numpy(g[k]).to(dev) for k in g if k.startswith(prefix)}
+    b["subj_ind"], b["idx"] = torch.from_numpy(g["subj_ind"]), torch.from_numpy(g["idx"])
+    return b
+
+
+def _run_def_losses(dev, tol_loss, tol_grad):
+    g = U.golden("training_def")
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    shape_net = U.build_identity(device=dev).train()
+    if dev.type == "cpu":
+        shape_net.backend = "composite"
+    else:
+        shape_net.prune_tol = -1.0
+    lat_shape, lat_expr = _tables(g, dev)
+
+    # compute_loss_corresp_forward: 'compress' network in train mode, anchors from mlp_pos
+    expr_net = U.build_deformation(device=dev).train()
+    if dev.type == "cpu":
+        expr_net.backend = "composite"
+    assert U.state_hash(expr_net) == str(g["c_state_hash_expr"])
+    torch.manual_seed(int(g["seed_call"]))
+    losses = compute_loss_corresp_forward(_batch(g, "c_batch_", dev), expr_net, shape_net, lat_expr, lat_shape, dev, epoch=3)
+    sum(losses.values()).backward()
+    if dev.type == "cpu":                       # the CPU generator stream is the reference's
+        for k, v in losses.items():
+            assert abs(float(v.detach()) - float(g["c_loss_" + k])) <= tol_loss * max(1.0, abs(float(g["c_loss_" + k]))), k
+        assert rel(lat_expr.weight.grad.cpu().numpy(), g["c_grad_expr_table"]) < tol_grad
+        norms = _grad_norms([("expr", expr_net), ("shape", shape_net)])
+        assert np.abs(norms - g["c_grad_norms"]).max() <= tol_grad * g["c_grad_norms"].max()
+    else:                                       # device RNG differs: the deterministic term only
+        assert abs(float(losses["lat_reg"].detach()) - float(g["c_loss_lat_reg"])) < 1e-6
+        assert abs(float(losses["corresp"].detach()) - float(g["c_loss_corresp"])) < 0.05 * float(g["c_loss_corresp"])
+
+    # loss_joint: 'glob_only' network, identity decoder on its training tier
+    for m in (expr_net, shape_net, lat_expr, lat_shape):
+        m.zero_grad(set_to_none=True)
+    joint_net = _glob_only(dev).train()
+    if dev.type == "cpu":
+        joint_net.backend = "composite"
+    assert U.state_hash(joint_net) == str(g["j_state_hash_expr"])
+    torch.manual_seed(int(g["seed_call"]))
+    losses = loss_joint(_batch(g, "j_batch_", dev), shape_net, joint_net, lat_shape, lat_expr, dev, epoch=10)
+    assert set(losses) == {k[7:] for k in g if k.startswith("j_loss_")}
+    sum(losses.values()).backward()
+    random_terms = () if dev.type == "cpu" else ("loss_reg_zero",)
+    for k, v in losses.items():
+        if k not in random_terms:
+            assert abs(float(v.detach()) - float(g["j_loss_" + k])) <= tol_loss * max(1.0, abs(float(g["j_loss_" + k]))), k
+    assert rel(lat_shape.weight.grad.cpu().numpy(), g["j_grad_shape_table"]) < tol_grad
+    if dev.type == "cpu":
+        assert rel(lat_expr.weight.grad.cpu().numpy(), g["j_grad_expr_table"]) < tol_grad
+        norms = _grad_norms([("expr", joint_net), ("shape", shape_net)])
+        assert np.abs(norms - g["j_grad_norms"]).max() <= tol_grad * g["j_grad_norms"].max()
+    else:
+        names = list(g["j_grad_names"])
+        norms = _grad_norms([("expr", joint_net), ("shape", shape_net)])
+        sel = np.array([n.startswith("shape.") for n in names])          # the identity decoder: no random term reaches it
+        assert np.abs(norms[sel] - g["j_grad_norms"][sel]).max() <= tol_grad * g["j_grad_norms"][sel].max()
+
+
+def test_deformation_stage_losses_match_reference_cpu():
+    _run_def_losses(torch.device("cpu"), 1e-6, 2e-5)
+
+
+@pytest.mark.gpu
+def test_deformation_stage_losses_match_reference_hip():
+    """loss_joint differentiates the identity field w.r.t. POSED points through the deformation network: the training
+    tier's second-order gradient w.r.t. its (non-leaf) query points chains into the deformation network's graph."""
+    _run_def_losses(torch.device("cuda:0"), 2e-5, 1e-3)
