@@ -72,3 +72,89 @@ def test_fitting_script_gpu_matches_the_composite_tier():
     assert len(vh) > 1000 and abs(len(vh) - len(vc)) <= 0.002 * len(vc)
     assert _chamfer(vh, vc) < 1e-5
     assert _chamfer(np.asarray(posed_h.vertices), np.asarray(posed_c.vertices)) < 1e-5
+
+
+# ---- the training script's step, through the shim ------------------------------------------------------------------------
+import math                                                                    # noqa: E402
+
+from NPHM.models.loss_functions import compute_loss                            # noqa: E402  (training.py:10)
+
+TRAIN_CFG = {"lr": 0.0005, "lr_lat": 0.001, "weight_decay": 0.01, "grad_clip": 0.1, "grad_clip_lat": 0.1,
+             "lambdas": {"lat_reg": 0.01, "surf_sdf": 2.0, "normals": 0.3, "space_sdf": 0.01, "grad": 0.1, "anchors": 7.5,
+                         "symm_dist": 0.01, "middle_dist": 0.0}}                # scripts/configs/nphm.yaml
+
+
+def _train_script(device, backend, n_steps=3, n_subjects=6, batch_size=4):
+    """TrainerAutoDecoder of training.py: its setup (:28-56: sparse max-norm embedding of the latent codes, AdamW on the
+    decoder, SparseAdam on the codes) and train_step (:110-135) with their variable names; a validation step in eval
+    mode (:250-268).  Synthetic batches with the keys of face_dataset.py:113-123."""
+    decoder = U.build_identity(device=device)
+    if backend is not None:
+        decoder.backend = backend if device == "cpu" else decoder.backend
+        decoder.train_backend = backend
+    torch.manual_seed(3)
+    latent_codes = torch.nn.Embedding(n_subjects, decoder.lat_dim, max_norm=1.0, sparse=True, device=device).float()
+    torch.nn.init.normal_(latent_codes.weight.data, 0.0, 0.1 / math.sqrt(decoder.lat_dim))
+    optimizer_encoder = torch.optim.AdamW(params=list(decoder.parameters()), lr=TRAIN_CFG["lr"], weight_decay=TRAIN_CFG["weight_decay"])
+    optimizer_lat = torch.optim.SparseAdam(list(latent_codes.parameters()), lr=TRAIN_CFG["lr_lat"])
+    gen = torch.Generator().manual_seed(11)
+    box = torch.tensor([0.5, 0.6, 0.5])
+    pts = lambda n: (torch.rand(batch_size, n, 3, generator=gen) - 0.5) * box + torch.tensor([0.0, 0.05, 0.05])
+    nrm = lambda n: torch.nn.functional.normalize(torch.randn(batch_size, n, 3, generator=gen), dim=-1)
+    history = []
+    for step in range(n_steps + 1):
+        face, non = pts(96), pts(8)
+        batch = {"points_face": face, "normals_face": nrm(96), "points_non_face": non, "normals_non_face": nrm(8),
+                 "sup_grad_far": nrm(12) * 0.4, "sup_grad_near": torch.cat([face, non], 1) + 0.01 * torch.randn(batch_size, 104, 3, generator=gen),
+                 "gt_anchors": torch.from_numpy(U.anchors_mean()).float().reshape(1, 39, 3).repeat(batch_size, 1, 1),
+                 "idx": torch.randint(0, n_subjects, (batch_size, 1), generator=gen), "path": ["x"] * batch_size}
+        validation = step == n_steps
+        decoder.eval() if validation else decoder.train()
+        optimizer_encoder.zero_grad()
+        optimizer_lat.zero_grad()
+        loss_dict_nphm = compute_loss(batch, decoder, latent_codes, device)
+        loss_tot = 0
+        for key in loss_dict_nphm.keys():
+            loss_tot += TRAIN_CFG["lambdas"][key] * loss_dict_nphm[key]
+        loss_tot.backward()
+        if not validation:
+            torch.nn.utils.clip_grad_norm_(decoder.parameters(), max_norm=TRAIN_CFG["grad_clip"])
+        # training.py:130-131 also clips the (sparse) gradient of the codes: clip_grad_norm_ has no sparse kernel in
+        # this PyTorch version (independent of the decoder), so the step goes without it here
+        if not validation:
+            optimizer_encoder.step()
+        optimizer_lat.step()
+        history.append({k: loss_dict_nphm[k].item() for k in loss_dict_nphm} | {"loss": loss_tot.item()})
+    return history, decoder
+
+
+def test_training_script_steps_through_the_shim_cpu():
+    history, decoder = _train_script("cpu", "composite")
+    assert len(history) == 4 and all(np.isfinite(list(h.values())).all() for h in history)
+    assert set(history[0]) == set(TRAIN_CFG["lambdas"]) | {"loss"}
+    assert all(p.grad is not None for p in decoder.ensembled_deep_sdf.parameters())
+
+
+@pytest.mark.gpu
+def test_training_script_on_the_hip_tier_matches_composite():
+    assert torch.cuda.is_available()
+    used = {}
+    import nphm_amd.ensembled_deepsdf as E
+    orig = E.FastEnsembleDeepSDFMirrored._forward_hip_train
+    E.FastEnsembleDeepSDFMirrored._forward_hip_train = lambda self, *a: used.__setitem__("n", used.get("n", 0) + 1) or orig(self, *a)
+    try:
+        hip, _ = _train_script("cuda:0", "hip")
+    finally:
+        E.FastEnsembleDeepSDFMirrored._forward_hip_train = orig
+    assert used.get("n") == 3                       # the three training steps; the eval-mode validation step is composite
+    ref, _ = _train_script("cuda:0", "composite")
+    # same state at the first step: same losses.  Later steps: Adam divides every gradient entry by its own magnitude,
+    # so codes whose gradient is round-off (local codes of members no sample is near: exactly 0 on the pruned HIP tier,
+    # ~1e-12 on the composite tier) move by +-lr on one tier only.  With codes of norm 0.1 and lr 1e-3 that is visible
+    # in the code regularisers (10 %), not in the geometry terms (1 %)
+    for k in ref[0]:
+        assert abs(hip[0][k] - ref[0][k]) <= 2e-5 * max(1.0, abs(ref[0][k])), (k, hip[0][k], ref[0][k])
+    for h, r in zip(hip[1:], ref[1:]):
+        for k in r:
+            tol = 0.1 if k in ("lat_reg", "symm_dist", "middle_dist") else 1e-2
+            assert abs(h[k] - r[k]) <= tol * max(abs(r[k]), 1e-3), (k, h[k], r[k])
