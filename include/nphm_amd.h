@@ -201,6 +201,20 @@ int nphm_identity_train_backward(const void* packed, const void* packed_bwd, con
 int nphm_identity_train_weight_grads(const float* saved, const int* chunks, int n_chunks, float* const grad_weight[5],
                                      float* grad_bias1, float* grad_bias3, float* grad_bias4, void* stream);
 
+/* The Gaussian blend of the training tier WITH its spatial gradient, for callers that need both (compute_loss:
+ * decoder(...) followed by gradient(pred, x), loss_functions.py:36-49) without a graph-recording backward pass:
+ *   pred [n_rows,n_points] = sum_k what_k S_k,  grad [n_rows,n_points,3] = d pred / d xyz
+ * from the member values / gradients of nphm_identity_train_forward (EnsembledDeepSDF.py:129-150 for the weights; the
+ * anchors are the second forward output).  The backward takes dL/dpred and dL/dgrad (NULL: zero), WRITES
+ * grad_member_sdf / grad_member_grad (the seeds of nphm_identity_train_backward) and ACCUMULATES the blend's own
+ * terms into grad_xyz / grad_anchors. */
+int nphm_identity_blend_forward(const float* xyz, const float* anchors, const float* member_sdf, const float* member_grad,
+                                int n_rows, int64_t n_points, float* pred, float* grad, void* stream);
+int nphm_identity_blend_backward(const float* xyz, const float* anchors, const float* member_sdf, const float* member_grad,
+                                 const float* grad_pred, const float* grad_grad, int n_rows, int64_t n_points,
+                                 float* grad_member_sdf, float* grad_member_grad, float* grad_xyz, float* grad_anchors,
+                                 void* stream);
+
 /* Second stage of the two-stage evaluation get_logits_backward (src/NPHM/models/reconstruction.py:28-56):
  * the identity field at displaced lattice points.  xyz_slab [(ix1-ix0)*ry*rz, 3] holds the canonical
  * points x + F_ex(x) of the slab in flattened lattice order (nphm_mlp_eval_grid with add_input);

@@ -674,6 +674,125 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
   }
 }
 
+// ---- the Gaussian blend with its spatial gradient, and their backward ------------------------------------------
+// pred = sum_k what_k S_k (EnsembledDeepSDF.py:129-150: w_k = exp(-(|x - a_k| + 1e-5)^2 / 0.01), background weight
+// exp(-20), what = w / (sum w + 1e-6)) and  grad = d pred / d x = sum_k what_k G_k + sum_k (S_k - pred) what_k u_k,
+// u_k = d log w_k / d x = -2 (r_k + eps) / (sigma r_k) (x - a_k), for member values S and gradients G = dS/dx that
+// nphm_identity_train_forward produced.  The backward takes seeds (pbar, qbar) for (pred, grad) and returns
+//   Sbar_k = what_k (pbar + qbar . (u_k - m)),  m = sum_j what_j u_j          Gbar_k = what_k qbar
+//   dL/de_k = what_k u_k [pbar (S_k - pred) + qbar . (G_k - gt) + (S_k - pred)(t_k - tau) - theta]
+//             + (S_k - pred) what_k (c_k qbar + kappa_k (qbar . e_k) e_k),    e_k = x - a_k, t_k = qbar . u_k,
+//   xbar = sum_k dL/de_k,  abar_k = - sum over points dL/de_k
+// (S, G held fixed: their own dependence on x is nphm_identity_train_backward's business; tests/test_train_math.py
+// pins the formulas against float64 autograd).  One thread per point, the row's anchors in LDS.
+struct BlendArgs {
+  const float* xyz; const float* anchors; const float* S; const float* G;
+  int64_t n_points;
+  float* pred; float* grad;                      // forward
+  const float* g_pred; const float* g_grad;      // backward seeds (g_grad may be NULL)
+  float* gS; float* gG; float* gxyz; float* ganch;
+};
+
+constexpr float BL_SIGMA = 0.01f, BL_EPS = 1e-5f;
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void blend_kernel(BlendArgs p) {
+  __shared__ float anch[N_LOC * 3];
+  __shared__ float ga[N_LOC * 3];
+  const int row = blockIdx.y;
+  for (int i = threadIdx.x; i < N_LOC * 3; i += blockDim.x) { anch[i] = p.anchors[size_t(row) * N_LOC * 3 + i]; ga[i] = 0.f; }
+  __syncthreads();
+  const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool live = n < p.n_points;
+  const int64_t pt = int64_t(row) * p.n_points + (live ? n : 0);
+  const float qx = p.xyz[pt * 3], qy = p.xyz[pt * 3 + 1], qz = p.xyz[pt * 3 + 2];
+  const float* S = p.S + pt * N_MEMBERS;
+  const float* G = p.G + pt * N_MEMBERS * 3;
+  const float w_bg = expf(-0.2f / BL_SIGMA);
+
+  float w[N_MEMBERS];
+  float D = w_bg + 1e-6f;
+#pragma unroll
+  for (int k = 0; k < N_LOC; ++k) {
+    const float ex = qx - anch[3 * k], ey = qy - anch[3 * k + 1], ez = qz - anch[3 * k + 2];
+    const float rho = sqrtf(ex * ex + ey * ey + ez * ez) + BL_EPS;
+    w[k] = expf(-(rho * rho) / BL_SIGMA);
+    D += w[k];
+  }
+  w[N_LOC] = w_bg;
+  const float inv = 1.f / D;
+  float pr = 0.f, gtx = 0.f, gty = 0.f, gtz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;
+#pragma unroll
+  for (int k = 0; k < N_MEMBERS; ++k) {
+    w[k] *= inv;
+    pr = fmaf(w[k], S[k], pr);
+    gtx = fmaf(w[k], G[3 * k], gtx); gty = fmaf(w[k], G[3 * k + 1], gty); gtz = fmaf(w[k], G[3 * k + 2], gtz);
+  }
+  // u_k = c_k e_k ; q_w = sum (S_k - pred) what_k u_k ; m = sum what_k u_k
+  float qwx = 0.f, qwy = 0.f, qwz = 0.f;
+#pragma unroll
+  for (int k = 0; k < N_LOC; ++k) {
+    const float ex = qx - anch[3 * k], ey = qy - anch[3 * k + 1], ez = qz - anch[3 * k + 2];
+    const float r = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float c = r > 0.f ? -2.f * (r + BL_EPS) / (BL_SIGMA * r) : 0.f;
+    const float a = w[k] * c, b = (S[k] - pr) * a;
+    mx = fmaf(a, ex, mx); my = fmaf(a, ey, my); mz = fmaf(a, ez, mz);
+    qwx = fmaf(b, ex, qwx); qwy = fmaf(b, ey, qwy); qwz = fmaf(b, ez, qwz);
+  }
+  if (!BWD) {
+    if (live) {
+      p.pred[pt] = pr;
+      p.grad[pt * 3] = gtx + qwx; p.grad[pt * 3 + 1] = gty + qwy; p.grad[pt * 3 + 2] = gtz + qwz;
+    }
+    return;
+  }
+  const float pb = live ? p.g_pred[pt] : 0.f;
+  float bx = 0.f, by = 0.f, bz = 0.f;
+  if (live && p.g_grad) { bx = p.g_grad[pt * 3]; by = p.g_grad[pt * 3 + 1]; bz = p.g_grad[pt * 3 + 2]; }
+  const float tau = bx * mx + by * my + bz * mz;
+  const float theta = bx * qwx + by * qwy + bz * qwz;
+  const float qgt = bx * gtx + by * gty + bz * gtz;
+  float* gS = p.gS + pt * N_MEMBERS;
+  float* gG = p.gG + pt * N_MEMBERS * 3;
+  float xbx = 0.f, xby = 0.f, xbz = 0.f;
+#pragma unroll 1
+  for (int k = 0; k < N_MEMBERS; ++k) {
+    float t = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    const float dS = S[k] - pr;
+    if (k < N_LOC) {
+      const float ex = qx - anch[3 * k], ey = qy - anch[3 * k + 1], ez = qz - anch[3 * k + 2];
+      const float r = sqrtf(ex * ex + ey * ey + ez * ez);
+      if (r > 0.f) {
+        const float c = -2.f * (r + BL_EPS) / (BL_SIGMA * r);
+        const float kappa = 2.f * BL_EPS / (BL_SIGMA * r * r * r);
+        const float qe = bx * ex + by * ey + bz * ez;
+        t = c * qe;
+        const float qG = bx * G[3 * k] + by * G[3 * k + 1] + bz * G[3 * k + 2];
+        const float coef = w[k] * c * (pb * dS + (qG - qgt) + dS * (t - tau) - theta);
+        const float s2 = dS * w[k];
+        dx = coef * ex + s2 * (c * bx + kappa * qe * ex);
+        dy = coef * ey + s2 * (c * by + kappa * qe * ey);
+        dz = coef * ez + s2 * (c * bz + kappa * qe * ez);
+      }
+    }
+    if (live) {
+      gS[k] = w[k] * (pb + t - tau);
+      gG[3 * k] = w[k] * bx; gG[3 * k + 1] = w[k] * by; gG[3 * k + 2] = w[k] * bz;
+    }
+    if (k < N_LOC) {
+      xbx += dx; xby += dy; xbz += dz;
+      // anchor gradient: minus the sum over the block's points (wave reduction, then LDS, then one global atomic)
+      float sx = dx, sy = dy, sz = dz;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+      if ((threadIdx.x & 63) == 0) { atomicAdd(&ga[3 * k], -sx); atomicAdd(&ga[3 * k + 1], -sy); atomicAdd(&ga[3 * k + 2], -sz); }
+    }
+  }
+  if (live) { atomicAdd(p.gxyz + pt * 3, xbx); atomicAdd(p.gxyz + pt * 3 + 1, xby); atomicAdd(p.gxyz + pt * 3 + 2, xbz); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N_LOC * 3; i += blockDim.x) atomicAdd(p.ganch + size_t(row) * N_LOC * 3 + i, ga[i]);
+}
+
 }  // namespace train
 }  // namespace nphm
 
@@ -754,6 +873,42 @@ int nphm_identity_train_weight_grads(const float* saved, const int* chunks, int 
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_train_weight_grads launch", e);
+  return 0;
+}
+
+int nphm_identity_blend_forward(const float* xyz, const float* anchors, const float* member_sdf, const float* member_grad,
+                                int n_rows, int64_t n_points, float* pred, float* grad, void* stream) {
+  if (!xyz || !anchors || !member_sdf || !member_grad || !pred || !grad)
+    return nphm_fail_msg("nphm_identity_blend_forward: null pointer");
+  if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_identity_blend_forward: bad sizes");
+  nphm::train::BlendArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xyz = xyz; a.anchors = anchors; a.S = member_sdf; a.G = member_grad; a.n_points = n_points;
+  a.pred = pred; a.grad = grad;
+  hipLaunchKernelGGL(nphm::train::blend_kernel<false>, dim3(unsigned((n_points + 255) / 256), n_rows), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_blend_forward launch", e);
+  return 0;
+}
+
+int nphm_identity_blend_backward(const float* xyz, const float* anchors, const float* member_sdf, const float* member_grad,
+                                 const float* grad_pred, const float* grad_grad, int n_rows, int64_t n_points,
+                                 float* grad_member_sdf, float* grad_member_grad, float* grad_xyz, float* grad_anchors,
+                                 void* stream) {
+  if (!xyz || !anchors || !member_sdf || !member_grad || !grad_pred || !grad_member_sdf || !grad_member_grad || !grad_xyz ||
+      !grad_anchors)
+    return nphm_fail_msg("nphm_identity_blend_backward: null pointer");
+  if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_identity_blend_backward: bad sizes");
+  nphm::train::BlendArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xyz = xyz; a.anchors = anchors; a.S = member_sdf; a.G = member_grad; a.n_points = n_points;
+  a.g_pred = grad_pred; a.g_grad = grad_grad;
+  a.gS = grad_member_sdf; a.gG = grad_member_grad; a.gxyz = grad_xyz; a.ganch = grad_anchors;
+  hipLaunchKernelGGL(nphm::train::blend_kernel<true>, dim3(unsigned((n_points + 255) / 256), n_rows), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_blend_backward launch", e);
   return 0;
 }
 

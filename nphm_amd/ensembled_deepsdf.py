@@ -439,6 +439,47 @@ class _AttachGradientFn(torch.autograd.Function):
         return gc.sum(dim=2), -gc[:, :, :ctx.n_kps].sum(dim=1), gS, None
 
 
+class _BlendFn(torch.autograd.Function):
+    """(pred, d pred / d xyz) of the Gaussian blend from the member values S and gradients G = dS/dxyz of
+    ``_MemberFieldFn`` - one kernel forward, one backward (``nphm_identity_blend_forward/backward``).  With the spatial
+    gradient an OUTPUT, a loss on it needs no graph-recording backward pass: ``loss.backward()`` reaches the member
+    kernels with both seeds (dL/dS, dL/dG) through this function's first-order backward."""
+
+    @staticmethod
+    def forward(ctx, xyz, anchors, S, G):
+        lib = _lib.load()
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        xyz_c, anchors_c = xyz.detach().contiguous().float(), anchors.detach().contiguous().float()
+        S_c, G_c = S.detach().contiguous(), G.detach().contiguous()
+        pred = torch.empty(B, N, dtype=torch.float32, device=dev)
+        grad = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.nphm_identity_blend_forward(xyz_c.data_ptr(), anchors_c.data_ptr(), S_c.data_ptr(), G_c.data_ptr(), B, N,
+                                                   pred.data_ptr(), grad.data_ptr(), stream), "nphm_identity_blend_forward")
+        ctx.save_for_backward(xyz_c, anchors_c, S_c, G_c)
+        ctx.set_materialize_grads(False)
+        return pred, grad
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_pred, g_grad):
+        lib = _lib.load()
+        xyz, anchors, S, G = ctx.saved_tensors
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        gS, gG = torch.empty_like(S), torch.empty_like(G)
+        sizes = [B * N * 3, anchors.numel()]
+        gx, ga = torch.zeros(sum(sizes), dtype=torch.float32, device=dev).split(sizes)
+        gp = torch.zeros(B, N, dtype=torch.float32, device=dev) if g_pred is None else g_pred.contiguous().float()
+        gg = None if g_grad is None else g_grad.contiguous().float()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.nphm_identity_blend_backward(
+            xyz.data_ptr(), anchors.data_ptr(), S.data_ptr(), G.data_ptr(), gp.data_ptr(), None if gg is None else gg.data_ptr(),
+            B, N, gS.data_ptr(), gG.data_ptr(), gx.data_ptr(), ga.data_ptr(), stream), "nphm_identity_blend_backward")
+        return gx.view(B, N, 3), ga.view_as(anchors), gS, gG
+
+
 class FastEnsembleDeepSDFMirrored(nn.Module):
     """NPHM identity SDF: one small MLP per facial anchor (+ one background MLP), evaluated in
     anchor-local coordinates (odd member of each symmetric pair mirrored in x) and blended by a
@@ -632,11 +673,8 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         sdf = _IdentityFieldFn.apply(self, xyz, lat_rows, anchors)
         return sdf, anchors
 
-    def _forward_hip_train(self, xyz, lat_rows):
-        """Training tier: twice differentiable w.r.t. xyz, differentiable w.r.t. the latent rows and every
-        parameter.  Member MLPs (EnsembledDeepSDF.py:101-126) and their first / second-order backward on the
-        HIP kernels; anchors, the latent columns of lin0 / the skip layer and the Gaussian blend
-        (EnsembledDeepSDF.py:129-150) stay ordinary autograd (a few [B,N,40] elementwise ops)."""
+    def _train_members(self, xyz, lat_rows):
+        """(anchors, member values S [B,N,40], member gradients G = dS/dxyz [B,N,40,3]) on the training kernels."""
         B = xyz.shape[0]
         g, A = self.lat_dim_glob, self.num_kps + 1
         e = self.ensembled_deep_sdf
@@ -649,9 +687,42 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         b2f = torch.einsum("baf,aof->bao", cond, W2m[:, :, n1 + d_in:]) / _SQRT2 + e.lin2.member_bias()[None]
         S, G = _MemberFieldFn.apply(self, xyz, anchors, lat_rows, b0f, b2f, e.lin0.weight, e.lin1.weight, e.lin2.weight,
                                     e.lin3.weight, e.lin4.weight, e.lin1.bias, e.lin3.bias, e.lin4.bias)
+        return anchors, S, G
+
+    def _forward_hip_train(self, xyz, lat_rows):
+        """Training tier: twice differentiable w.r.t. xyz, differentiable w.r.t. the latent rows and every
+        parameter.  Member MLPs (EnsembledDeepSDF.py:101-126) and their first / second-order backward on the
+        HIP kernels; anchors, the latent columns of lin0 / the skip layer and the Gaussian blend
+        (EnsembledDeepSDF.py:129-150) stay ordinary autograd (a few [B,N,40] elementwise ops)."""
+        anchors, S, G = self._train_members(xyz, lat_rows)
         f = _AttachGradientFn.apply(xyz, anchors, S, G)
         pred = sample_point_feature(xyz[..., :3], anchors, f.unsqueeze(-1), background=True, var=0.1 ** 2)
         return pred, anchors
+
+    def _train_tier_serves(self, xyz, lat_rep):
+        """The HIP training tier's conditions: train mode, trainable parameters, ROCm fp32 tensors, the NPHM
+        architecture, one latent per batch row."""
+        if not (self.training and self.backend != "composite" and self.train_backend == "hip" and xyz.is_cuda
+                and xyz.dtype == torch.float32 and torch.is_grad_enabled() and self.hip_supported()):
+            return False
+        if self.assume_frozen_parameters or not any(p.requires_grad for p in self.parameters()):
+            return False
+        N = xyz.shape[1]
+        return lat_rep.shape[1] == 1 or (lat_rep.shape[1] == N and bool((lat_rep == lat_rep[:, :1]).all()))
+
+    def value_and_gradient(self, xyz: torch.Tensor, lat_rep: torch.Tensor):
+        """(sdf [B,N,1], d sdf / d xyz [B,N,3], anchors) in ONE differentiable evaluation - what ``compute_loss`` obtains
+        from ``decoder(...)`` followed by ``gradient(pred, x)`` (loss_functions.py:36-49) - or None when the HIP
+        training tier does not serve the call (the caller then does exactly that).  The spatial gradient is an output
+        of the fused blend kernel, so no graph-recording backward pass is needed: ``loss.backward()`` on terms of both
+        outputs differentiates through the member kernels' second-order backward."""
+        if xyz.dim() < 3:
+            xyz = xyz.unsqueeze(0)
+        if not self._train_tier_serves(xyz, lat_rep):
+            return None
+        anchors, S, G = self._train_members(xyz, lat_rep[:, 0, :])
+        pred, grad = _BlendFn.apply(xyz, anchors, S, G)
+        return pred.unsqueeze(-1), grad, anchors
 
     def predict_anchors(self, lat_rep: torch.Tensor) -> torch.Tensor:
         """Anchors of the identity codes ``lat_rep`` [B, L, lat_dim] (row 0 of every batch entry): the

@@ -32,8 +32,12 @@ def actual_compute_loss(batch_cuda, decoder, glob_cond):
     x = torch.cat([batch_cuda[k] for k in _POINT_SETS], dim=1).clone().detach().requires_grad_()
     # one code per subject: the decoders broadcast a [B,1,L] code over the points themselves (EnsembledDeepSDF.py:223,
     # deepSDF.py); the reference's glob_cond.repeat(1, N, 1) would only be compared back to one row by the HIP tiers
-    pred, anchors = decoder(x, glob_cond, batch_cuda["gt_anchors"] if has_anchors else None)
-    grad = gradient(pred, x)
+    fused = decoder.value_and_gradient(x, glob_cond) if hasattr(decoder, "value_and_gradient") else None
+    if fused is not None:              # HIP training tier: value and spatial gradient from one evaluation
+        pred, grad, anchors = fused
+    else:
+        pred, anchors = decoder(x, glob_cond, batch_cuda["gt_anchors"] if has_anchors else None)
+        grad = gradient(pred, x)
     # the point sets are consecutive slices of the batch: [face | non-face | near | far].  The reference's means over
     # concatenated per-set terms are means over slices of ONE tensor (same values, a fraction of the autograd nodes):
     n_face, n_non, n_near, n_far = sizes

@@ -62,8 +62,8 @@ def test_training_tier_matches_composite_double_backward(dev, prune_tol, tol):
     net.prune_tol = prune_tol
     lat, xyz, nrm = _batch(dev, B=4, N=1000)
     used = {}
-    orig = net._forward_hip_train
-    net._forward_hip_train = lambda *a, **k: used.setdefault("hip", True) and orig(*a, **k)
+    orig = net._train_members
+    net._train_members = lambda *a, **k: used.setdefault("hip", True) and orig(*a, **k)
     ref = _run(net, "composite", lat, xyz, nrm)
     assert not used
     out = _run(net, "hip", lat, xyz, nrm)
@@ -117,3 +117,34 @@ def test_training_step_moves_like_composite(dev):
             trace.append(float(loss))
         traces[backend] = np.array(trace)
     assert np.abs(traces["hip"] - traces["composite"]).max() < 1e-4 * np.abs(traces["composite"]).max()
+
+
+def test_value_and_gradient_matches_composite(dev):
+    """The fused entry (member kernels + blend kernel with its spatial gradient as an output) against the composite tier's
+    forward + gradient(pred, x): values, gradients, and the backward of a loss on both w.r.t. latents and parameters."""
+    net = U.build_identity(device=dev).train()
+    net.prune_tol = -1.0
+    lat0, xyz, nrm = _batch(dev, B=3, N=700, seed=9)
+
+    def loss_of(pred, grad, anchors, lat):
+        return (2.0 * pred.abs().mean() + 0.3 * (grad - nrm).norm(2, dim=-1).mean() + 0.1 * (grad.norm(dim=-1) - 1).abs().mean()
+                + 7.5 * anchors.square().mean() + 0.01 * (lat.norm(dim=-1) ** 2).mean())
+
+    res = {}
+    for mode in ("composite", "fused"):
+        net.zero_grad(set_to_none=True)
+        lat = lat0.clone().requires_grad_()
+        x = xyz.clone().requires_grad_()
+        if mode == "fused":
+            net.train_backend = "hip"
+            pred, grad, anchors = net.value_and_gradient(x, lat)
+        else:
+            net.train_backend = "composite"
+            assert net.value_and_gradient(x, lat) is None
+            pred, anchors = net(x, lat, None)
+            grad = gradient(pred, x)
+        loss_of(pred, grad, anchors, lat).backward()
+        res[mode] = {"pred": pred.detach(), "grad": grad.detach(), "lat": lat.grad.clone()}
+        res[mode].update({n: p.grad.clone() for n, p in net.named_parameters()})
+    worst = {k: _rel(res["fused"][k], res["composite"][k]) for k in res["composite"]}
+    assert all(v < 2e-4 for v in worst.values()), worst

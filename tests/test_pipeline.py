@@ -140,12 +140,12 @@ def test_training_script_on_the_hip_tier_matches_composite():
     assert torch.cuda.is_available()
     used = {}
     import nphm_amd.ensembled_deepsdf as E
-    orig = E.FastEnsembleDeepSDFMirrored._forward_hip_train
-    E.FastEnsembleDeepSDFMirrored._forward_hip_train = lambda self, *a: used.__setitem__("n", used.get("n", 0) + 1) or orig(self, *a)
+    orig = E.FastEnsembleDeepSDFMirrored._train_members
+    E.FastEnsembleDeepSDFMirrored._train_members = lambda self, *a: used.__setitem__("n", used.get("n", 0) + 1) or orig(self, *a)
     try:
         hip, _ = _train_script("cuda:0", "hip")
     finally:
-        E.FastEnsembleDeepSDFMirrored._forward_hip_train = orig
+        E.FastEnsembleDeepSDFMirrored._train_members = orig
     assert used.get("n") == 3                       # the three training steps; the eval-mode validation step is composite
     ref, _ = _train_script("cuda:0", "composite")
     # same state at the first step: same losses.  Later steps: Adam divides every gradient entry by its own magnitude,

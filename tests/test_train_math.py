@@ -105,3 +105,56 @@ def test_training_work_lists_cover_every_kept_pair_once(monkeypatch):
             assert (sets.numpy()[tiles[t0 + rel:t0 + rel + n, 1]] == s_).all()
             cover[t0 + rel:t0 + rel + n] += 1
     assert (cover == 1).all()
+
+
+def test_fused_blend_backward_formulas():
+    """nphm_identity_blend_backward (ident_train_kernel.hip): gradients of  L = pbar . pred + qbar . d pred/d x  w.r.t.
+    the member values S, their gradients G, the query point and the anchors, with pred the Gaussian blend of
+    EnsembledDeepSDF.py:129-150 - closed forms against float64 autograd."""
+    torch.manual_seed(0)
+    dt = torch.float64
+    P, K = 6, 5
+    sigma, eps = 0.01, 1e-5
+    x = (torch.randn(P, 3, dtype=dt) * 0.1).requires_grad_()
+    a = (torch.randn(K, 3, dtype=dt) * 0.1).requires_grad_()
+    S = torch.randn(P, K + 1, dtype=dt, requires_grad=True)
+    G = torch.randn(P, K + 1, 3, dtype=dt, requires_grad=True)
+    pbar, qbar = torch.randn(P, dtype=dt), torch.randn(P, 3, dtype=dt)
+    w_bg = math.exp(-0.2 / sigma)
+    x0 = x.detach().clone()
+
+    def field(xx):           # blend of member values that have gradient G at x0 (and no curvature)
+        d = (a[None] - xx[:, None]).norm(dim=2)
+        w = torch.exp(-((d + eps) ** 2) / sigma)
+        w = torch.cat([w, torch.full_like(w[:, :1], w_bg)], 1)
+        what = w / (w.sum(1, keepdim=True) + 1e-6)
+        return (what * (S + (G * (xx - x0)[:, None, :]).sum(-1))).sum(1)
+
+    p = field(x)
+    q = torch.autograd.grad(p.sum(), x, create_graph=True)[0]
+    gx, ga, gS, gG = torch.autograd.grad((pbar * p).sum() + (qbar * q).sum(), [x, a, S, G])
+    with torch.no_grad():
+        e = x0[:, None, :] - a[None]
+        r = e.norm(dim=2)
+        w = torch.exp(-(r + eps) ** 2 / sigma)
+        D = w.sum(1) + w_bg + 1e-6
+        wh = torch.cat([w, torch.full_like(w[:, :1], w_bg)], 1) / D[:, None]
+        c = -2 * (r + eps) / (sigma * r)
+        u = torch.cat([c[..., None] * e, torch.zeros(P, 1, 3, dtype=dt)], 1)
+        pred = (wh * S).sum(1)
+        m, gt = (wh[..., None] * u).sum(1), (wh[..., None] * G).sum(1)
+        dS = S - pred[:, None]
+        qw = ((dS * wh)[..., None] * u).sum(1)
+        assert (pred - p).abs().max() < 1e-12 and (gt + qw - q).abs().max() < 1e-11
+        t = (qbar[:, None, :] * u).sum(-1)
+        tau, theta = (wh * t).sum(1), (qbar * qw).sum(-1)
+        Sbar = wh * (pbar[:, None] + t - tau[:, None])
+        Gbar = wh[..., None] * qbar[:, None, :]
+        qG, qgt = (qbar[:, None, :] * G).sum(-1), (qbar * gt).sum(-1)
+        kappa, qe = 2 * eps / (sigma * r ** 3), (qbar[:, None, :] * e).sum(-1)
+        coef = pbar[:, None] * dS[:, :K] + (qG[:, :K] - qgt[:, None]) + dS[:, :K] * (t[:, :K] - tau[:, None]) - theta[:, None]
+        dLde = (wh[:, :K] * coef)[..., None] * u[:, :K] + (dS[:, :K] * wh[:, :K])[..., None] * (c[..., None] * qbar[:, None, :] + (kappa * qe)[..., None] * e)
+        rel = lambda A, B: float((A - B).abs().max() / B.abs().max())
+        assert rel(Sbar, gS) < 1e-12 and rel(Gbar, gG) < 1e-12 and rel(-dLde.sum(0), ga) < 1e-12
+        # autograd's d/dx also holds the member path sum_k Sbar_k G_k (the member kernels' share)
+        assert rel(dLde.sum(1) + (Sbar[..., None] * G).sum(1), gx) < 1e-12
