@@ -179,14 +179,16 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *   nphm_identity_train_forward : member_sdf [n_rows,n_points,40] = f_k, member_grad [n_rows,n_points,40,3] =
  *     d f_k / d xyz for the listed triples (others untouched).
  *   nphm_identity_train_backward : seeds grad_member_sdf = dL/df_k and grad_member_grad = dL/d(d f_k/d xyz) (NULL:
- *     zero) -> ACCUMULATES grad_xyz, grad_anchors, grad_b0, grad_b2 (as nphm_identity_backward, for
+ *     zero) -> ACCUMULATES grad_xyz, grad_anchors (as nphm_identity_backward, for
  *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k) and stores the operands of the weight gradients into
  *     saved (nphm_identity_train_saved_bytes(n_tiles) bytes; per tile [1409 rows][64 columns] fp32, column =
  *     32 * stream + point with stream 0 = value, 1 = tangent along the seed direction; rows = inputs of lin0..lin4
  *     followed by the adjoints of the pre-activations of lin0..lin3 and the output seeds, scaled domain).
  *   nphm_identity_train_weight_grads : contracts those operands over the columns, ADDING into parameter-shaped
  *     gradients grad_weight[l] (shape of lin<l>.weight; the latent columns of lin0 / lin2 are not touched - they
- *     receive theirs through grad_b0 / grad_b2) and grad_bias1/3/4.  chunks [n_chunks][4] = (weight set, first
+ *     receive theirs through grad_b0 / grad_b2), grad_bias1/3/4, and grad_b0 / grad_b2 [n_rows,40,200] =
+ *     dL/d(folded bias of lin0 / of the skip layer) per (row, member) as in nphm_identity_backward (row sums of the
+ *     stored adjoints; tiles = the backward kernel's tile table).  chunks [n_chunks][4] = (weight set, first
  *     tile, number of tiles, 0): consecutive tiles of ONE weight set each (the host cuts the member-ordered tile
  *     table; a few dozen tiles per chunk keeps the atomics negligible). */
 size_t nphm_identity_train_saved_bytes(int n_tiles);
@@ -196,10 +198,10 @@ int nphm_identity_train_forward(const void* packed, const void* packed_bwd, cons
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2,
-                                 float* saved, void* stream);
-int nphm_identity_train_weight_grads(const float* saved, const int* chunks, int n_chunks, float* const grad_weight[5],
-                                     float* grad_bias1, float* grad_bias3, float* grad_bias4, void* stream);
+                                 float* grad_xyz, float* grad_anchors, float* saved, void* stream);
+int nphm_identity_train_weight_grads(const float* saved, const int* tiles, const int* chunks, int n_chunks,
+                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_bias4,
+                                     float* grad_b0, float* grad_b2, void* stream);
 
 /* The Gaussian blend of the training tier WITH its spatial gradient, for callers that need both (compute_loss:
  * decoder(...) followed by gradient(pred, x), loss_functions.py:36-49) without a graph-recording backward pass:

@@ -53,8 +53,9 @@ SYMBOLS = {
     "nphm_identity_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
     "nphm_identity_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_void_p, c_int, _PtrArr5, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_int, _PtrArr5, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p]),
     "nphm_identity_blend_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_blend_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -85,8 +85,6 @@ struct TrainArgs {
   const float* g_grad;            // backward: [n_rows, n_points, 40, 3] or NULL (no second-order seed)
   float* gxyz;                    // [n_rows, n_points, 3]  (+=)
   float* ganch;                   // [n_rows, 39, 3]        (+=)
-  float* gb0;                     // [n_rows, 40, 200]      (+=)
-  float* gb2;                     // [n_rows, 40, 200]      (+=)
   float* save;                    // backward: [n_tiles][SV_ROWS][64]
 };
 
@@ -423,21 +421,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   }
   __syncthreads();
   copy_out(SV_D3, HID, 7);
-  // stage A: [H2 | U2] = lin3^T [D3 | T3] ; bias gradient of the skip layer = k sum D2
+  // stage A: [H2 | U2] = lin3^T [D3 | T3]   (bias gradients: row sums of the stored adjoints, taken by wgrad_kernel)
   if (wave < 7) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero16;
     gemm_tile(acc, bw + OFF_A, wave, std::integral_constant<int, A_KS>{});
     deactivate(acc, s2, q2, val);
-    if (SECOND) {
-      float* gb = p.gb2 + (size_t(row) * N_MEMBERS + k) * HID;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float sum = half_wave_sum(val[0][r]);
-        const int f = feat_of(wave, r, h);
-        if (j == 0 && f < HID) atomicAdd(gb + f, sum * SP_SCALE);
-      }
-    }
   }
   __syncthreads();
   if (wave < 7) { store_tile(wave, val); save_tile(val); }
@@ -460,21 +449,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   if (wave < B_OB) { store_tile(wave, val); save_tile(val); }
   __syncthreads();
   copy_out(SV_D1, L1_OUT, B_OB);
-  // stage C: [H0 | U0] = lin1^T [D1 | T1] ; bias gradient of lin0 = k sum D0
+  // stage C: [H0 | U0] = lin1^T [D1 | T1]
   if (wave < 7) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero16;
     gemm_tile(acc, bw + OFF_C, wave, std::integral_constant<int, C_KS>{});
     deactivate(acc, s0, q0, val);
-    if (SECOND) {
-      float* gb = p.gb0 + (size_t(row) * N_MEMBERS + k) * HID;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float sum = half_wave_sum(val[0][r]);
-        const int f = feat_of(wave, r, h);
-        if (j == 0 && f < HID) atomicAdd(gb + f, sum * SP_SCALE);
-      }
-    }
   }
   __syncthreads();
   if (wave < 7) { store_tile(wave, val); save_tile(val); }
@@ -533,8 +513,10 @@ namespace train {
 struct WgradArgs {
   const float* saved;         // [n_tiles][SV_ROWS][64]
   const int* chunks;          // [n_chunks][4] = weight set, first tile, number of tiles, -
+  const int* tiles;           // the backward kernel's tile table of this piece (row, member of every tile)
   float* gW[5];               // parameter-shaped gradients of lin0..lin4.weight  (+=)
   float* gb1; float* gb3; float* gb4;    // of lin1/lin3/lin4.bias  (+=)
+  float* gb0; float* gb2;     // of the folded biases of lin0 / the skip layer [n_rows, 40, 200]  (+=)
 };
 
 constexpr int WG_ROW_BYTES = 64 * 2 + 16;            // bf16 row of 64 columns, padded against bank conflicts
@@ -608,8 +590,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
     }
   };
 
+  // bias gradients = k * row sums of the adjoints' value columns: per weight set for lin1 / lin3, per (batch row,
+  // member) for the folded biases of lin0 / the skip layer - the tile table is ordered by (member, row), so a chunk
+  // crosses few pairs: the running sum is flushed whenever the pair changes
+  float* const gb_pair = layer == 0 ? p.gb0 : layer == 2 ? p.gb2 : nullptr;
+  int pair = -1;
+  auto flush_pair = [&]() __attribute__((always_inline)) {
+    const float total = bsum + __shfl_xor(bsum, 32);
+    if (pair >= 0 && h == 0 && row_ok) atomicAdd(gb_pair + size_t(pair) * HID + orow, total * SP_SCALE);
+    bsum = 0.f;
+  };
   if (n_tiles > 0) fetch(0);
   for (int t = 0; t < n_tiles; ++t) {
+    if (gb_pair) {
+      const int* tl = p.tiles + 4 * (tile0 + t);
+      const int pr = tl[0] * N_MEMBERS + tl[1];
+      if (pr != pair) { flush_pair(); pair = pr; }
+    }
     __syncthreads();                                   // the previous tile's LDS operand has been consumed
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
@@ -649,6 +646,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
       }
     }
   }
+  if (gb_pair) flush_pair();
   if (!active) return;
 
   // scaled-domain products -> parameter gradients
@@ -838,17 +836,16 @@ int nphm_identity_train_forward(const void* packed, const void* packed_bwd, cons
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2,
-                                 float* saved, void* stream) {
+                                 float* grad_xyz, float* grad_anchors, float* saved, void* stream) {
   nphm::train::TrainArgs a;
   if (train_common(a, packed, packed_bwd, latent_state, xyz, n_points, tiles, n_tiles, point_list,
                    "nphm_identity_train_backward: null pointer or bad sizes")) return 1;
-  if (!grad_member_sdf || !grad_xyz || !grad_anchors || !grad_b0 || !grad_b2 || !saved)
+  if (!grad_member_sdf || !grad_xyz || !grad_anchors || !saved)
     return nphm_fail_msg("nphm_identity_train_backward: null pointer");
   if (n_tiles == 0) return 0;
   a.save = saved;
   a.g_sdf = grad_member_sdf; a.g_grad = grad_member_grad;
-  a.gxyz = grad_xyz; a.ganch = grad_anchors; a.gb0 = grad_b0; a.gb2 = grad_b2;
+  a.gxyz = grad_xyz; a.ganch = grad_anchors;
   hipLaunchKernelGGL(nphm::train::train_kernel<true>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
@@ -856,14 +853,16 @@ int nphm_identity_train_backward(const void* packed, const void* packed_bwd, con
   return 0;
 }
 
-int nphm_identity_train_weight_grads(const float* saved, const int* chunks, int n_chunks, float* const grad_weight[5],
-                                     float* grad_bias1, float* grad_bias3, float* grad_bias4, void* stream) {
-  if (!saved || !chunks || !grad_weight || !grad_bias1 || !grad_bias3 || !grad_bias4)
+int nphm_identity_train_weight_grads(const float* saved, const int* tiles, const int* chunks, int n_chunks,
+                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_bias4,
+                                     float* grad_b0, float* grad_b2, void* stream) {
+  if (!saved || !tiles || !chunks || !grad_weight || !grad_bias1 || !grad_bias3 || !grad_bias4 || !grad_b0 || !grad_b2)
     return nphm_fail_msg("nphm_identity_train_weight_grads: null pointer");
   if (n_chunks < 0) return nphm_fail_msg("nphm_identity_train_weight_grads: bad sizes");
   if (n_chunks == 0) return 0;
   nphm::train::WgradArgs a;
-  a.saved = saved; a.chunks = chunks;
+  a.saved = saved; a.chunks = chunks; a.tiles = tiles;
+  a.gb0 = grad_b0; a.gb2 = grad_b2;
   for (int i = 0; i < 5; ++i) {
     if (!grad_weight[i]) return nphm_fail_msg("nphm_identity_train_weight_grads: null gradient pointer");
     a.gW[i] = grad_weight[i];

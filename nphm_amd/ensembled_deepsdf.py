@@ -410,11 +410,11 @@ class _MemberFieldFn(torch.autograd.Function):
                 _lib.check(lib.nphm_identity_train_backward(
                     packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N,
                     tiles.data_ptr() + 16 * t0, nt, plist.data_ptr(), gS_c.data_ptr(),
-                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), ga.data_ptr(), gb0.data_ptr(),
-                    gb2.data_ptr(), saved.data_ptr(), stream), "nphm_identity_train_backward")
+                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), ga.data_ptr(), saved.data_ptr(), stream),
+                    "nphm_identity_train_backward")
                 _lib.check(lib.nphm_identity_train_weight_grads(
-                    saved.data_ptr(), chunks.data_ptr() + 16 * c0, nc, gws, gb1.data_ptr(), gb3.data_ptr(),
-                    gb4.data_ptr(), stream), "nphm_identity_train_weight_grads")
+                    saved.data_ptr(), tiles.data_ptr() + 16 * t0, chunks.data_ptr() + 16 * c0, nc, gws, gb1.data_ptr(),
+                    gb3.data_ptr(), gb4.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_train_weight_grads")
         return (None, gx, ga, None, gb0, gb2, gW0, gW1, gW2, gW3, gW4, gb1, gb3, gb4)
 
 
