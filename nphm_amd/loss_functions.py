@@ -29,15 +29,27 @@ def actual_compute_loss(batch_cuda, decoder, glob_cond):
     anchors - anchors, symm_dist, middle_dist."""
     has_anchors = hasattr(decoder, "anchors")
     sizes = [batch_cuda[k].shape[1] for k in _POINT_SETS]
-    x = torch.cat([batch_cuda[k] for k in _POINT_SETS], dim=1).clone().detach().requires_grad_()
-    # one code per subject: the decoders broadcast a [B,1,L] code over the points themselves (EnsembledDeepSDF.py:223,
-    # deepSDF.py); the reference's glob_cond.repeat(1, N, 1) would only be compared back to one row by the HIP tiers
-    fused = decoder.value_and_gradient(x, glob_cond) if hasattr(decoder, "value_and_gradient") else None
-    if fused is not None:              # HIP training tier: value and spatial gradient from one evaluation
-        pred, grad, anchors = fused
+    anchors_gt = batch_cuda["gt_anchors"] if has_anchors else None
+    if decoder.training or not hasattr(decoder, "num_kps"):
+        x = torch.cat([batch_cuda[k] for k in _POINT_SETS], dim=1).clone().detach().requires_grad_()
+        # one code per subject: the decoders broadcast a [B,1,L] code over the points themselves (EnsembledDeepSDF.py:223,
+        # deepSDF.py); the reference's glob_cond.repeat(1, N, 1) would only be compared back to one row by the HIP tiers
+        fused = decoder.value_and_gradient(x, glob_cond) if hasattr(decoder, "value_and_gradient") else None
+        if fused is not None:              # HIP training tier: value and spatial gradient from one evaluation
+            pred, grad, anchors = fused
+        else:
+            pred, anchors = decoder(x, glob_cond, anchors_gt)
+            grad = gradient(pred, x)
     else:
-        pred, anchors = decoder(x, glob_cond, batch_cuda["gt_anchors"] if has_anchors else None)
-        grad = gradient(pred, x)
+        # eval mode (validation, training.py:250-268): the NPHM decoder overwrites the member values of the LAST point of
+        # every call (EnsembledDeepSDF.py:260-261) - four calls, four overwritten points, as in the reference
+        preds, grads = [], []
+        for k in _POINT_SETS:
+            x = batch_cuda[k].clone().detach().requires_grad_()
+            p_k, anchors = decoder(x, glob_cond, anchors_gt)
+            preds.append(p_k)
+            grads.append(gradient(p_k, x))
+        pred, grad = torch.cat(preds, dim=1), torch.cat(grads, dim=1)
     # the point sets are consecutive slices of the batch: [face | non-face | near | far].  The reference's means over
     # concatenated per-set terms are means over slices of ONE tensor (same values, a fraction of the autograd nodes):
     n_face, n_non, n_near, n_far = sizes

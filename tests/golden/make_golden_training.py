@@ -8,7 +8,7 @@ Batch of 3 subjects with the point-set layout of face_dataset.py:93-123 at reduc
 dataset here), latents with the reference's sampling statistics, the seeded random-init decoder of make_golden.py
 in train mode.  Stored: the batch, the loss dictionary, the total loss with nphm.yaml's lambdas and - after
 loss.backward() (training.py:119-124) - the gradients of the latents, of ensemble tensors (the large ones for three weight sets) and of mlp_pos,
-plus the norm of every parameter gradient."""
+plus the norm of every parameter gradient; and the loss dictionary / code gradient of the validation step (eval mode)."""
 import os
 import sys
 import types
@@ -67,10 +67,19 @@ def main():
     for k, v in losses.items():
         out["loss_" + k] = v.detach().numpy()
     for n in ("ensembled_deep_sdf.lin0.weight", "ensembled_deep_sdf.lin2.weight", "ensembled_deep_sdf.lin3.weight"):
-        out["grad_" + n] = grads[n][SETS].numpy()                 # a symmetric, a mid-line and the background set
+        out["grad_" + n] = grads[n][SETS].numpy().copy()          # a symmetric, a mid-line and the background set
     for n in ("ensembled_deep_sdf.lin4.weight", "ensembled_deep_sdf.lin1.bias", "mlp_pos.4.weight"):
-        out["grad_" + n] = grads[n].numpy()
+        out["grad_" + n] = grads[n].numpy().copy()
     out["sets"] = np.array(SETS)
+    # the validation step (training.py:250-268): the same loss in eval mode - the decoder overwrites the last point of
+    # each of its four calls (EnsembledDeepSDF.py:260-261) - differentiated w.r.t. the codes
+    net.eval()
+    lat_val = lat.detach().clone().requires_grad_()
+    losses_val = actual_compute_loss({k: v.clone() for k, v in batch.items()}, net, lat_val)
+    sum(LAMBDAS[k] * losses_val[k] for k in losses_val).backward()
+    for k, v in losses_val.items():
+        out["val_loss_" + k] = v.detach().numpy()
+    out["val_grad_lat"] = lat_val.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "training.npz"), **out)
     print({k: float(v) for k, v in losses.items()}, float(total))
 

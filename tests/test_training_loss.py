@@ -56,6 +56,23 @@ def test_loss_and_gradients_match_reference_cpu():
     _check(net, g, losses, total, lat, 1e-6, 1e-5)
 
 
+def test_validation_step_matches_reference_cpu():
+    """training.py:250-268: compute_loss in eval mode (the decoder overwrites the last point of each of its four calls),
+    backward to the codes only."""
+    g = U.golden("training")
+    net = U.build_identity().eval()
+    net.backend = "composite"
+    batch = {k[6:]: torch.from_numpy(g[k]) for k in g if k.startswith("batch_")}
+    lat = torch.from_numpy(g["lat"]).requires_grad_()
+    losses = actual_compute_loss(batch, net, lat)
+    sum(LAMBDAS[k] * losses[k] for k in losses).backward()
+    for k, v in losses.items():
+        assert abs(float(v.detach()) - float(g["val_loss_" + k])) <= 1e-6 * max(1.0, abs(float(g["val_loss_" + k]))), k
+    assert float(np.abs(lat.grad.numpy() - g["val_grad_lat"]).max()) <= 1e-5 * float(np.abs(g["val_grad_lat"]).max())
+    # ... and differs from the train-mode value (the overwritten points are on the surface sets)
+    assert abs(float(g["val_loss_surf_sdf"]) - float(g["loss_surf_sdf"])) > 1e-4
+
+
 @pytest.mark.gpu
 def test_loss_and_gradients_match_reference_hip():
     dev = torch.device("cuda:0")
