@@ -114,7 +114,7 @@ def test_training_step_moves_like_composite(dev):
             loss.backward()
             torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=0.1)
             opt.step(); opt_lat.step()
-            trace.append(float(loss))
+            trace.append(float(loss.detach()))
         traces[backend] = np.array(trace)
     assert np.abs(traces["hip"] - traces["composite"]).max() < 1e-4 * np.abs(traces["composite"]).max()
 
@@ -148,3 +148,32 @@ def test_value_and_gradient_matches_composite(dev):
         res[mode].update({n: p.grad.clone() for n, p in net.named_parameters()})
     worst = {k: _rel(res["fused"][k], res["composite"][k]) for k in res["composite"]}
     assert all(v < 2e-4 for v in worst.values()), worst
+
+
+@pytest.mark.parametrize("B,N,far", [(1, 1, False), (1, 33, False), (2, 65, False), (3, 129, True), (2, 64, True)])
+def test_training_tier_ragged_shapes(dev, B, N, far):
+    """Tile edges (1 point, 32/64-point boundaries +- 1), and batches whose points are far from every anchor (almost
+    every member pruned; some (row, member) lists empty): both entries of the tier against the composite tier."""
+    net = U.build_identity(device=dev).train()
+    lat0, xyz, nrm = _batch(dev, B=B, N=N, seed=B * 100 + N)
+    if far:
+        xyz = xyz + torch.tensor([0.0, 0.0, 0.9], device=dev) * (torch.arange(N, device=dev) % 2)[None, :, None]   # every other point off the head
+    res = {}
+    for mode in ("composite", "hip", "fused"):
+        net.train_backend = "composite" if mode == "composite" else "hip"
+        net.zero_grad(set_to_none=True)
+        lat = lat0.clone().requires_grad_()
+        x = xyz.clone().requires_grad_()
+        if mode == "fused":
+            pred, grad, anchors = net.value_and_gradient(x, lat)
+        else:
+            pred, anchors = net(x, lat, None)
+            grad = gradient(pred, x)
+        (2.0 * pred.abs().mean() + 0.3 * (grad - nrm).norm(2, dim=-1).mean() + 0.1 * (grad.norm(dim=-1) - 1).abs().mean()
+         + 7.5 * anchors.square().mean()).backward()
+        res[mode] = {"pred": pred.detach(), "grad": grad.detach(), "lat": lat.grad.clone(),
+                     "w3": net.ensembled_deep_sdf.lin3.weight.grad.clone(), "w0": net.ensembled_deep_sdf.lin0.weight.grad.clone(),
+                     "b4": net.ensembled_deep_sdf.lin4.bias.grad.clone(), "pos": net.mlp_pos[4].weight.grad.clone()}
+    for mode in ("hip", "fused"):
+        worst = {k: _rel(res[mode][k], res["composite"][k]) for k in res["composite"]}
+        assert all(v < 1e-3 for v in worst.values()), (mode, worst)
