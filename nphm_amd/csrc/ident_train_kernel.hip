@@ -271,15 +271,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
       for (int t = 0; t < NT; ++t) base[((r & 3) + 8 * (r >> 2)) * 64 + 32 * t] = v[t][r];
     }
   };
-  // wavefront 7: blocks 0..n_blocks-1 of the staging buffer -> rows 0..rows-1 of a saved operand (contiguous in HBM)
-  auto copy_out = [&](int which, int rows, int n_blocks) __attribute__((always_inline)) {
+  // wavefront 7: blocks 0..NB-1 of the staging buffer -> rows 0..ROWS-1 of a saved operand (contiguous in HBM).  All
+  // of a block's LDS reads are issued before its stores (fully unrolled, compile-time extents): a read-wait-store loop
+  // takes longer than the GEMM stage it is meant to hide behind, and the next barrier then waits for this wavefront.
+  auto copy_out = [&](int which, auto rows_c, auto nb_c) __attribute__((always_inline)) {
     if (!SECOND || wave != 7) return;
-    char* dst = reinterpret_cast<char*>(save + sv_offset(which) * 64);
-    const char* src = reinterpret_cast<const char*>(stage_buf);
-    for (int n = 0; n < n_blocks; ++n) {
-      const int valid = rows - 32 * n < 32 ? rows - 32 * n : 32;
-      for (int o = lane * 16; o < valid * 256; o += 1024)
-        *reinterpret_cast<f32x4*>(dst + n * 8192 + o) = *reinterpret_cast<const f32x4*>(src + n * 8192 + o);
+    constexpr int ROWS = decltype(rows_c)::value, NB = decltype(nb_c)::value;
+    char* dst = reinterpret_cast<char*>(save + sv_offset(which) * 64) + lane * 16;
+    const char* src = reinterpret_cast<const char*>(stage_buf) + lane * 16;
+    static_assert(NB <= 7, "staging blocks");
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int bytes = (ROWS - 32 * n < 32 ? ROWS - 32 * n : 32) * 256;     // of this block, a multiple of 256
+      f32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i * 1024 < bytes) v[i] = *reinterpret_cast<const f32x4*>(src + n * 8192 + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i * 1024 + lane * 16 < bytes) *reinterpret_cast<f32x4*>(dst + n * 8192 + i * 1024) = v[i];
     }
   };
   // activation: h' = softplus2(d') (backward, tile 1: u' = s tau); keeps the state of the reverse sweep
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     save_tile(val);
   }
   __syncthreads();
-  copy_out(SV_IN1, HID, 7);
+  copy_out(SV_IN1, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   // L1: 200 -> 101 (4 tiles); the skip coordinates (tangent: the direction) join tile 3 as features 101..103
   if (wave < L1_OB) {
     acc[0] = load_frag16(tails + wave * TAIL_FLOATS + h * 16);
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   __syncthreads();                       // every wavefront has read a0
   if (wave < L1_OB) { store_tile(wave, val); save_tile(val); }
   __syncthreads();
-  copy_out(SV_IN2, L2_IN, L1_OB);
+  copy_out(SV_IN2, std::integral_constant<int, L2_IN>{}, std::integral_constant<int, L1_OB>{});
   // L2: 104 -> 200
   if (wave < 7) {
     acc[0] = load_frag16(tails + (L1_OB + wave) * TAIL_FLOATS + h * 16);
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   __syncthreads();
   if (wave < 7) { store_tile(wave, val); save_tile(val); }
   __syncthreads();
-  copy_out(SV_IN3, HID, 7);
+  copy_out(SV_IN3, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   // L3: 200 -> 200, lin4 fused: f = sum h3' * w4 / k + b4
   f32x16 w4v = zero16;
   if (wave < 7) {
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     if (wave < 7) save_tile(val);
   }
   __syncthreads();
-  copy_out(SV_IN4, HID, 7);
+  copy_out(SV_IN4, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   if (!SECOND && threadIdx.x < 64) {
     const int m = threadIdx.x;
     float f = p.packed_f32[size_t(set) * SET_STRIDE + OFF_L4B];
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     if (wave < 7) save_tile(val);
   }
   __syncthreads();
-  copy_out(SV_D3, HID, 7);
+  copy_out(SV_D3, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   // stage A: [H2 | U2] = lin3^T [D3 | T3]   (bias gradients: row sums of the stored adjoints, taken by wgrad_kernel)
   if (wave < 7) {
 #pragma unroll
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   __syncthreads();
   if (wave < 7) { store_tile(wave, val); save_tile(val); }
   __syncthreads();
-  copy_out(SV_D2, HID, 7);
+  copy_out(SV_D2, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   // stage B: rows 0..100: [H1 | U1] = (lin2a / sqrt2)^T [D2 | T2]; rows 101..103: d phi / d coords (skip path)
   if (wave < B_OB) {
 #pragma unroll
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   __syncthreads();
   if (wave < B_OB) { store_tile(wave, val); save_tile(val); }
   __syncthreads();
-  copy_out(SV_D1, L1_OUT, B_OB);
+  copy_out(SV_D1, std::integral_constant<int, L1_OUT>{}, std::integral_constant<int, B_OB>{});
   // stage C: [H0 | U0] = lin1^T [D1 | T1]
   if (wave < 7) {
 #pragma unroll
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   __syncthreads();
   if (wave < 7) { store_tile(wave, val); save_tile(val); }
   __syncthreads();
-  copy_out(SV_D0, HID, 7);
+  copy_out(SV_D0, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   // stage D: d phi / d coords (lin0 path) = (k lin0[:, :3])^T D0 ; one tile, wavefront 0
   if (wave == 0) {
 #pragma unroll
