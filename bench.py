@@ -437,9 +437,10 @@ def training_record(args, dev, with_composite=True, steps=8):
     lat0 = torch.stack([U.sample_latent(10 + b) for b in range(B)])[:, None, :].to(dev)
     n_pts = sum(batch[k].shape[1] for k in ("points_face", "points_non_face", "sup_grad_near", "sup_grad_far"))
 
-    def run(backend):
+    def run(backend, operands="f32"):
         net = U.build_identity(device=dev).train()
         net.train_backend = backend
+        net.train_operands = operands
         lat = lat0.clone().requires_grad_()
         opt = torch.optim.AdamW(list(net.parameters()) + [lat], lr=5e-4, weight_decay=0.01)
         torch.cuda.reset_peak_memory_stats()
@@ -460,6 +461,11 @@ def training_record(args, dev, with_composite=True, steps=8):
                                   "loss terms of loss_functions.py:20-110 with create_graph gradients, all decoder weights + latent codes trainable "
                                   "(SURVEY 8 f4)", "prune_tol": ours["prune_tol"]},
            "first_loss": ours["first_loss"], "last_loss": ours["last_loss"], "peak_mem_gb": ours["peak_mem_gb"], "roofline": None}
+    o16 = run("hip", "bf16")
+    out["operands_bf16"] = {"ms_per_step": o16["ms_per_step"], "steps_per_s": o16["steps_per_s"], "last_loss": o16["last_loss"],
+                            "peak_mem_gb": o16["peak_mem_gb"],
+                            "note": "opt-in (decoder.train_operands = 'bf16'): the operands of the weight gradients cross HBM as bf16; parameter "
+                                    "gradients within 2.2e-4 of the default's largest entry per tensor on this batch (DESIGN.md section 12)"}
     if with_composite:
         ref = run("composite")
         out["composite_same_gpu"] = dict(ref, note="the same step with the decoder on the composite PyTorch tier (fp32 autograd double "

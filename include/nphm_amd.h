@@ -181,7 +181,9 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *   nphm_identity_train_backward : seeds grad_member_sdf = dL/df_k and grad_member_grad = dL/d(d f_k/d xyz) (NULL:
  *     zero) -> ACCUMULATES grad_xyz, grad_anchors (as nphm_identity_backward, for
  *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k) and stores the operands of the weight gradients into
- *     saved (nphm_identity_train_saved_bytes(n_tiles) bytes; per tile [1409 rows][64 columns] fp32, column =
+ *     saved (nphm_identity_train_saved_bytes(n_tiles, operands_bf16) bytes; per tile [1409 rows][64 columns] fp32 - or,
+ *     with operands_bf16 != 0, bf16: half the operand traffic of both kernels, the weight-gradient products then
+ *     carry 8-bit mantissas (opt-in; same flag in all three calls) -, column =
  *     32 * stream + point with stream 0 = value, 1 = tangent along the seed direction; rows = inputs of lin0..lin4
  *     followed by the adjoints of the pre-activations of lin0..lin3 and the output seeds, scaled domain).
  *   nphm_identity_train_weight_grads : contracts those operands over the columns, ADDING into parameter-shaped
@@ -191,15 +193,15 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *     stored adjoints; tiles = the backward kernel's tile table).  chunks [n_chunks][4] = (weight set, first
  *     tile, number of tiles, 0): consecutive tiles of ONE weight set each (the host cuts the member-ordered tile
  *     table; a few dozen tiles per chunk keeps the atomics negligible). */
-size_t nphm_identity_train_saved_bytes(int n_tiles);
+size_t nphm_identity_train_saved_bytes(int n_tiles, int operands_bf16);
 int nphm_identity_train_forward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                 int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                 float* member_sdf, float* member_grad, void* stream);
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, float* grad_anchors, float* saved, void* stream);
-int nphm_identity_train_weight_grads(const float* saved, const int* tiles, const int* chunks, int n_chunks,
+                                 float* grad_xyz, float* grad_anchors, void* saved, int operands_bf16, void* stream);
+int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* tiles, const int* chunks, int n_chunks,
                                      float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_bias4,
                                      float* grad_b0, float* grad_b2, void* stream);
 

@@ -49,12 +49,12 @@ SYMBOLS = {
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nphm_identity_train_saved_bytes": (c_size_t, [c_int]),
+    "nphm_identity_train_saved_bytes": (c_size_t, [c_int, c_int]),
     "nphm_identity_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
     "nphm_identity_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_int, _PtrArr5, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, _PtrArr5, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_void_p, c_void_p]),
     "nphm_identity_blend_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_blend_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,

@@ -118,9 +118,12 @@ __device__ __forceinline__ bf16x8 tangent_operand(float x, float y, float z, int
 // One workgroup per tile, tiles in table order.  Measured alternatives (32 x 1693-point batch, 28.6 k backward tiles):
 // persistent workgroups striding over the table +35 %; XCD-aware order (XCD x walks the x-th eighth of the
 // member-ordered table) +6 %; a fully unrolled K loop with 4..12 weight fragments in flight +10..30 %.
-template <bool SECOND>
+// O16: the stored operands of the weight gradients as bf16 instead of fp32 (opt-in: half the operand traffic of the
+// reverse and the weight-gradient kernel; the products of the weight gradients then carry 8-bit mantissas).
+template <bool SECOND, bool O16 = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   constexpr int NT = 2;
+  constexpr int ES = O16 ? 2 : 4;                    // bytes per stored operand element
   constexpr int PTS = SECOND ? 32 : 64;              // points per tile
   __shared__ __attribute__((aligned(16))) char act_hi[PLANE_BYTES];
   __shared__ __attribute__((aligned(16))) char act_lo[PLANE_BYTES];
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   // as their weight-fragment loads (every stage would begin by waiting for the previous stage's stores to be
   // acknowledged), and 1600 dword stores per tile become 350 16-byte ones.  Measured: -2 % on the kernel (2.73 ->
   // 2.68 ms per 14.3 k tiles) - the stores were not what a stage waits for.
-  __shared__ __attribute__((aligned(16))) float stage_buf[SECOND ? 7 * 32 * 64 : 4];
+  __shared__ __attribute__((aligned(16))) char stage_buf[SECOND ? 7 * 32 * 64 * ES : 16];
 
   const int tile_index = blockIdx.x;
   const int lane = threadIdx.x & 63;
@@ -147,7 +150,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   const int set = member_set(k);
   const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
   const float sign_x = (k < 2 * N_SYMM && (k & 1)) ? -1.f : 1.f;
-  float* const save = SECOND ? p.save + size_t(tile_index) * SV_ROWS * 64 : nullptr;
+  char* const save = SECOND ? reinterpret_cast<char*>(p.save) + size_t(tile_index) * SV_ROWS * 64 * ES : nullptr;
+  auto put = [&](char* at, float v) __attribute__((always_inline)) {
+    if (O16) *reinterpret_cast<__bf16*>(at) = (__bf16)v; else *reinterpret_cast<float*>(at) = v;
+  };
 
   if (threadIdx.x < 64) {
     const int m = threadIdx.x;
@@ -264,11 +270,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   // D tile of this wavefront -> its block of the staging buffer, row = feature - 32 * wave
   auto save_tile = [&](const f32x16 (&v)[NT]) __attribute__((always_inline)) {
     if (!SECOND) return;
-    float* base = stage_buf + wave * (32 * 64) + (4 * h) * 64 + j;
+    char* base = stage_buf + (wave * (32 * 64) + (4 * h) * 64 + j) * ES;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) base[((r & 3) + 8 * (r >> 2)) * 64 + 32 * t] = v[t][r];
+      for (int t = 0; t < NT; ++t) put(base + (((r & 3) + 8 * (r >> 2)) * 64 + 32 * t) * ES, v[t][r]);
     }
   };
   // wavefront 7: blocks 0..NB-1 of the staging buffer -> rows 0..ROWS-1 of a saved operand (contiguous in HBM).  All
@@ -277,19 +283,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   auto copy_out = [&](int which, auto rows_c, auto nb_c) __attribute__((always_inline)) {
     if (!SECOND || wave != 7) return;
     constexpr int ROWS = decltype(rows_c)::value, NB = decltype(nb_c)::value;
-    char* dst = reinterpret_cast<char*>(save + sv_offset(which) * 64) + lane * 16;
-    const char* src = reinterpret_cast<const char*>(stage_buf) + lane * 16;
+    char* dst = save + sv_offset(which) * 64 * ES + lane * 16;
+    const char* src = stage_buf + lane * 16;
+    constexpr int BLK = 32 * 64 * ES;                                        // bytes of a staging block
     static_assert(NB <= 7, "staging blocks");
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      const int bytes = (ROWS - 32 * n < 32 ? ROWS - 32 * n : 32) * 256;     // of this block, a multiple of 256
-      f32x4 v[8];
+      const int bytes = (ROWS - 32 * n < 32 ? ROWS - 32 * n : 32) * 64 * ES;  // of this block, a multiple of 128
+      f32x4 v[BLK / 1024];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i * 1024 < bytes) v[i] = *reinterpret_cast<const f32x4*>(src + n * 8192 + i * 1024);
+      for (int i = 0; i < BLK / 1024; ++i)
+        if (i * 1024 < bytes) v[i] = *reinterpret_cast<const f32x4*>(src + n * BLK + i * 1024);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i * 1024 + lane * 16 < bytes) *reinterpret_cast<f32x4*>(dst + n * 8192 + i * 1024) = v[i];
+      for (int i = 0; i < BLK / 1024; ++i)
+        if (i * 1024 + lane * 16 < bytes) *reinterpret_cast<f32x4*>(dst + n * BLK + i * 1024) = v[i];
     }
   };
   // activation: h' = softplus2(d') (backward, tile 1: u' = s tau); keeps the state of the reverse sweep
@@ -328,11 +335,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
 
   if (SECOND && wave == 7) {                       // lin0's own inputs and the output seeds, as saved operands
     if (h == 0) {
-      float* b = save + sv_offset(SV_IN0) * 64 + j;
-      b[0] = cx; b[64] = cy; b[128] = cz;
-      b[32] = vx; b[64 + 32] = vy; b[128 + 32] = vz;
-      float* sd = save + sv_offset(SV_SEED) * 64 + j;
-      sd[0] = seed; sd[32] = valid;
+      char* b = save + (sv_offset(SV_IN0) * 64 + j) * ES;
+      put(b, cx); put(b + 64 * ES, cy); put(b + 128 * ES, cz);
+      put(b + 32 * ES, vx); put(b + (64 + 32) * ES, vy); put(b + (128 + 32) * ES, vz);
+      char* sd = save + (sv_offset(SV_SEED) * 64 + j) * ES;
+      put(sd, seed); put(sd + 32 * ES, valid);
     }
   }
 
@@ -537,9 +544,15 @@ __device__ __forceinline__ Split8 split8v(const f32x4& a, const f32x4& b) {
   return split8(x);
 }
 
+template <bool O16>
 __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
+  constexpr int ES = O16 ? 2 : 4;
   __shared__ __attribute__((aligned(16))) char in_hi[WG_PLANE];
-  __shared__ __attribute__((aligned(16))) char in_lo[WG_PLANE];
+  __shared__ __attribute__((aligned(16))) char in_lo[O16 ? 16 : WG_PLANE];
+  const char* const saved = reinterpret_cast<const char*>(p.saved);
+  auto get = [&](const char* at) __attribute__((always_inline)) -> float {
+    return O16 ? (float)*reinterpret_cast<const __bf16*>(at) : *reinterpret_cast<const float*>(at);
+  };
   const int* ch = p.chunks + 4 * blockIdx.x;
   const int set = ch[0], tile0 = ch[1], n_tiles = ch[2];
   const int layer = blockIdx.y;
@@ -551,13 +564,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
     if (tid <= HID) {
       float acc = 0.f;
       for (int t = 0; t < n_tiles; ++t) {
-        const float* blk = p.saved + size_t(tile0 + t) * SV_ROWS * 64;
-        const float* sd = blk + sv_offset(SV_SEED) * 64;
+        const char* blk = saved + size_t(tile0 + t) * SV_ROWS * 64 * ES;
+        const char* sd = blk + sv_offset(SV_SEED) * 64 * ES;
         if (tid < HID) {
-          const float* r = blk + (sv_offset(SV_IN4) + tid) * 64;
-          for (int c = 0; c < 64; ++c) acc = fmaf(r[c], sd[c], acc);
+          const char* r = blk + (sv_offset(SV_IN4) + tid) * 64 * ES;
+          for (int c = 0; c < 64; ++c) acc = fmaf(get(r + c * ES), get(sd + c * ES), acc);
         } else {
-          for (int c = 0; c < 32; ++c) acc += sd[c];
+          for (int c = 0; c < 32; ++c) acc += get(sd + c * ES);
         }
       }
       if (tid < HID) atomicAdd(p.gW[4] + size_t(set) * HID + tid, acc / SP_SCALE);
@@ -583,20 +596,30 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
   float bsum = 0.f;
 
   // staging registers: the tile's input operand (7 passes of 32 rows x 16 float4) and this lane's adjoint row
-  f32x4 in_reg[7], d_reg[8];
+  // (bf16 operands: 4 columns = 8 bytes per thread of the input operand, 8 columns = one 16-byte A fragment per K-step)
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  f32x4 in_reg[O16 ? 1 : 7], d_reg[O16 ? 1 : 8];
+  bf16x4 in_reg16[O16 ? 7 : 1];
+  bf16x8 d_reg16[O16 ? 4 : 1];
   const int srow = tid >> 4, sc4 = tid & 15;
   auto fetch = [&](int t) __attribute__((always_inline)) {
-    const float* blk = p.saved + size_t(tile0 + t) * SV_ROWS * 64;
+    const char* blk = saved + size_t(tile0 + t) * SV_ROWS * 64 * ES;
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
       const int r = 32 * q + srow;
-      in_reg[q] = r < rows_in ? *reinterpret_cast<const f32x4*>(blk + (sv_offset(i_which) + r) * 64 + 4 * sc4) : f32x4{};
+      const char* at = blk + ((sv_offset(i_which) + r) * 64 + 4 * sc4) * ES;
+      if (O16) in_reg16[q] = r < rows_in ? *reinterpret_cast<const bf16x4*>(at) : bf16x4{};
+      else in_reg[q] = r < rows_in ? *reinterpret_cast<const f32x4*>(at) : f32x4{};
     }
-    const float* dr = blk + (sv_offset(d_which) + (row_ok ? orow : 0)) * 64 + 8 * h;
+    const char* dr = blk + ((sv_offset(d_which) + (row_ok ? orow : 0)) * 64 + 8 * h) * ES;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      d_reg[2 * s] = row_ok ? *reinterpret_cast<const f32x4*>(dr + 16 * s) : f32x4{};
-      d_reg[2 * s + 1] = row_ok ? *reinterpret_cast<const f32x4*>(dr + 16 * s + 4) : f32x4{};
+      if (O16) {
+        d_reg16[s] = row_ok ? *reinterpret_cast<const bf16x8*>(dr + 16 * s * ES) : bf16x8{};
+      } else {
+        d_reg[2 * s] = row_ok ? *reinterpret_cast<const f32x4*>(dr + 16 * s * ES) : f32x4{};
+        d_reg[2 * s + 1] = row_ok ? *reinterpret_cast<const f32x4*>(dr + (16 * s + 4) * ES) : f32x4{};
+      }
     }
   };
 
@@ -621,20 +644,31 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
       const int r = 32 * q + srow;
-      __bf16 hi[4], lo[4];
+      if (O16) {
+        *reinterpret_cast<bf16x4*>(in_hi + r * WG_ROW_BYTES + 8 * sc4) = in_reg16[q];
+      } else {
+        __bf16 hi[4], lo[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)in_reg[q][e]; lo[e] = (__bf16)(in_reg[q][e] - (float)hi[e]); }
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-      *reinterpret_cast<bf16x4*>(in_hi + r * WG_ROW_BYTES + 8 * sc4) = bf16x4{hi[0], hi[1], hi[2], hi[3]};
-      *reinterpret_cast<bf16x4*>(in_lo + r * WG_ROW_BYTES + 8 * sc4) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+        for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)in_reg[q][e]; lo[e] = (__bf16)(in_reg[q][e] - (float)hi[e]); }
+        *reinterpret_cast<bf16x4*>(in_hi + r * WG_ROW_BYTES + 8 * sc4) = bf16x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<bf16x4*>(in_lo + r * WG_ROW_BYTES + 8 * sc4) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+      }
     }
     Split8 a[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      a[s] = split8v(d_reg[2 * s], d_reg[2 * s + 1]);
-      if (s < 2) {                                     // bias gradient: the value columns are columns 0..31
+      if (O16) {
+        a[s].hi = d_reg16[s];
+        if (s < 2) {                                   // bias gradient: the value columns are columns 0..31
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bsum += d_reg[2 * s][e] + d_reg[2 * s + 1][e];
+          for (int e = 0; e < 8; ++e) bsum += (float)d_reg16[s][e];
+        }
+      } else {
+        a[s] = split8v(d_reg[2 * s], d_reg[2 * s + 1]);
+        if (s < 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum += d_reg[2 * s][e] + d_reg[2 * s + 1][e];
+        }
       }
     }
     __syncthreads();
@@ -647,10 +681,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
           for (int s = 0; s < 4; ++s) {
             const int o = (32 * b + j) * WG_ROW_BYTES + (16 * s + 8 * h) * 2;
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(in_hi + o);
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(in_lo + o);
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].hi, bh, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].hi, bl, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].lo, bh, acc[b], 0, 0, 0);
+            if (!O16) {
+              const bf16x8 bl = *reinterpret_cast<const bf16x8*>(in_lo + o);
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].hi, bl, acc[b], 0, 0, 0);
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].lo, bh, acc[b], 0, 0, 0);
+            }
           }
         }
       }
@@ -809,8 +845,8 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs p) {
 // ============================================================================================
 extern "C" {
 
-size_t nphm_identity_train_saved_bytes(int n_tiles) {
-  return n_tiles <= 0 ? 0 : size_t(n_tiles) * nphm::train::SV_ROWS * 64 * sizeof(float);
+size_t nphm_identity_train_saved_bytes(int n_tiles, int operands_bf16) {
+  return n_tiles <= 0 ? 0 : size_t(n_tiles) * nphm::train::SV_ROWS * 64 * (operands_bf16 ? 2 : 4);
 }
 
 static int train_common(nphm::train::TrainArgs& a, const void* packed, const void* packed_bwd, const void* latent_state,
@@ -846,24 +882,28 @@ int nphm_identity_train_forward(const void* packed, const void* packed_bwd, cons
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, float* grad_anchors, float* saved, void* stream) {
+                                 float* grad_xyz, float* grad_anchors, void* saved, int operands_bf16, void* stream) {
   nphm::train::TrainArgs a;
   if (train_common(a, packed, packed_bwd, latent_state, xyz, n_points, tiles, n_tiles, point_list,
                    "nphm_identity_train_backward: null pointer or bad sizes")) return 1;
   if (!grad_member_sdf || !grad_xyz || !grad_anchors || !saved)
     return nphm_fail_msg("nphm_identity_train_backward: null pointer");
   if (n_tiles == 0) return 0;
-  a.save = saved;
+  a.save = static_cast<float*>(saved);
   a.g_sdf = grad_member_sdf; a.g_grad = grad_member_grad;
   a.gxyz = grad_xyz; a.ganch = grad_anchors;
-  hipLaunchKernelGGL(nphm::train::train_kernel<true>, dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (operands_bf16)
+    hipLaunchKernelGGL((nphm::train::train_kernel<true, true>), dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL((nphm::train::train_kernel<true, false>), dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+                       static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_train_backward launch", e);
   return 0;
 }
 
-int nphm_identity_train_weight_grads(const float* saved, const int* tiles, const int* chunks, int n_chunks,
+int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* tiles, const int* chunks, int n_chunks,
                                      float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_bias4,
                                      float* grad_b0, float* grad_b2, void* stream) {
   if (!saved || !tiles || !chunks || !grad_weight || !grad_bias1 || !grad_bias3 || !grad_bias4 || !grad_b0 || !grad_b2)
@@ -871,15 +911,19 @@ int nphm_identity_train_weight_grads(const float* saved, const int* tiles, const
   if (n_chunks < 0) return nphm_fail_msg("nphm_identity_train_weight_grads: bad sizes");
   if (n_chunks == 0) return 0;
   nphm::train::WgradArgs a;
-  a.saved = saved; a.chunks = chunks; a.tiles = tiles;
+  a.saved = static_cast<const float*>(saved); a.chunks = chunks; a.tiles = tiles;
   a.gb0 = grad_b0; a.gb2 = grad_b2;
   for (int i = 0; i < 5; ++i) {
     if (!grad_weight[i]) return nphm_fail_msg("nphm_identity_train_weight_grads: null gradient pointer");
     a.gW[i] = grad_weight[i];
   }
   a.gb1 = grad_bias1; a.gb3 = grad_bias3; a.gb4 = grad_bias4;
-  hipLaunchKernelGGL(nphm::train::wgrad_kernel, dim3(n_chunks, 5), dim3(64 * nphm::bwd::WAVES), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (operands_bf16)
+    hipLaunchKernelGGL(nphm::train::wgrad_kernel<true>, dim3(n_chunks, 5), dim3(64 * nphm::bwd::WAVES), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(nphm::train::wgrad_kernel<false>, dim3(n_chunks, 5), dim3(64 * nphm::bwd::WAVES), 0,
+                       static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_train_weight_grads launch", e);
   return 0;

@@ -402,7 +402,8 @@ class _MemberFieldFn(torch.autograd.Function):
         if T and (gS is not None or gG is not None):
             gS_c = torch.zeros(B, N, A, dtype=torch.float32, device=dev) if gS is None else gS.detach().contiguous().float()
             gG_c = None if gG is None else gG.detach().contiguous().float()
-            saved = torch.empty(lib.nphm_identity_train_saved_bytes(max(n for _, n, _, _ in ctx.pieces)),
+            o16 = {"f32": 0, "bf16": 1}[module.train_operands]
+            saved = torch.empty(lib.nphm_identity_train_saved_bytes(max(n for _, n, _, _ in ctx.pieces), o16),
                                 dtype=torch.uint8, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             gws = _lib.ptr_array5([gW0, gW1, gW2, gW3, gW4])
@@ -410,10 +411,10 @@ class _MemberFieldFn(torch.autograd.Function):
                 _lib.check(lib.nphm_identity_train_backward(
                     packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N,
                     tiles.data_ptr() + 16 * t0, nt, plist.data_ptr(), gS_c.data_ptr(),
-                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), ga.data_ptr(), saved.data_ptr(), stream),
+                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), ga.data_ptr(), saved.data_ptr(), o16, stream),
                     "nphm_identity_train_backward")
                 _lib.check(lib.nphm_identity_train_weight_grads(
-                    saved.data_ptr(), tiles.data_ptr() + 16 * t0, chunks.data_ptr() + 16 * c0, nc, gws, gb1.data_ptr(),
+                    saved.data_ptr(), o16, tiles.data_ptr() + 16 * t0, chunks.data_ptr() + 16 * c0, nc, gws, gb1.data_ptr(),
                     gb3.data_ptr(), gb4.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_train_weight_grads")
         return (None, gx, ga, None, gb0, gb2, gW0, gW1, gW2, gW3, gW4, gb1, gb3, gb4)
 
@@ -532,6 +533,10 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         # pairs: 16.6 per point at 1e-7 on near-surface training samples
         self.train_prune_tol = (float(os.environ["NPHM_AMD_TRAIN_PRUNE_TOL"])
                                 if "NPHM_AMD_TRAIN_PRUNE_TOL" in os.environ else None)
+        # storage of the weight-gradient operands between the reverse and the weight-gradient kernel: "f32" (default,
+        # fp32-equivalent products end to end) | "bf16" (half the traffic that bounds both kernels; the weight gradients
+        # are then sums of bf16 x bf16 products: ~1e-3 of their largest entry, everything else unchanged)
+        self.train_operands = os.environ.get("NPHM_AMD_TRAIN_OPERANDS", "f32")
 
     # ------------------------------------------------------------------------------------------
     def invalidate_pack(self):
