@@ -120,3 +120,60 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
             raise _lib.NphmAmdError(msg)
         warnings.warn(msg)
     return worst
+
+
+def validate_training_numerics(decoder, latents: torch.Tensor, n: int = 2048, *, tol: float = 1e-3, strict: bool = False,
+                               seed: int = 0) -> dict:
+    """The same guard for the HIP training tier (pruned member lists, split-bf16 sweeps, optionally bf16 operand
+    storage): one training-style loss (SDF, eikonal and normal-like terms on the spatial gradient) on ``n`` sample points
+    per latent, evaluated through ``decoder.value_and_gradient`` and through the composite PyTorch tier (fp32 autograd
+    double backward, all 40 members) for the weights and latents at hand.  Returns the largest deviation of the SDF, of
+    its spatial gradient and - relative to each tensor's largest entry - of the latent and parameter gradients; warns
+    (raises with ``strict=True``) when a gradient deviates by more than ``tol``.  Leaves ``.grad`` of the parameters
+    untouched and needs a ROCm device."""
+    from .diff_operators import gradient
+    lat0 = latents.detach().reshape(-1, 1, decoder.lat_dim).float()
+    params = [p for p in decoder.parameters() if p.requires_grad]
+    if not params:
+        raise ValueError("validate_training_numerics: the decoder has no trainable parameter")
+    was_training, backend0 = decoder.training, decoder.train_backend
+    decoder.train()
+    try:
+        with torch.no_grad():
+            anchors = decoder.predict_anchors(lat0)
+        xyz = torch.stack([_sample_points(anchors[b], n, seed + b)[:n] for b in range(lat0.shape[0])])
+        g = torch.Generator().manual_seed(seed)
+        nrm = torch.nn.functional.normalize(torch.randn(xyz.shape, generator=g), dim=-1).to(xyz.device)
+        res = {}
+        for mode in ("composite", "hip"):
+            decoder.train_backend = mode
+            lat = lat0.clone().requires_grad_()
+            x = xyz.clone().requires_grad_()
+            fused = decoder.value_and_gradient(x, lat) if mode == "hip" else None
+            if mode == "hip" and fused is None:
+                raise _lib.NphmAmdError("validate_training_numerics: the HIP training tier does not serve this decoder / device")
+            if fused is not None:
+                pred, grad, _ = fused
+            else:
+                pred, _ = decoder(x, lat, None)
+                grad = gradient(pred, x)
+            loss = pred.abs().mean() + 0.1 * (grad.norm(dim=-1) - 1).abs().mean() + 0.3 * (grad - nrm).norm(dim=-1).mean()
+            grads = torch.autograd.grad(loss, [lat] + params)
+            res[mode] = (pred.detach(), grad.detach(), grads)
+    finally:
+        decoder.train_backend = backend0
+        decoder.train(was_training)
+    (p_c, g_c, gr_c), (p_h, g_h, gr_h) = res["composite"], res["hip"]
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    out = {"max_abs_diff_sdf": float((p_h - p_c).abs().max()), "max_abs_diff_gradient": float((g_h - g_c).abs().max()),
+           "max_rel_diff_latent_grad": rel(gr_h[0], gr_c[0]),
+           "max_rel_diff_param_grad": max(rel(a, b) for a, b in zip(gr_h[1:], gr_c[1:])),
+           "n_points": int(xyz.shape[0] * xyz.shape[1]), "operands": decoder.train_operands,
+           "prune_tol": decoder.prune_tol if decoder.train_prune_tol is None else decoder.train_prune_tol}
+    worst = max(out["max_rel_diff_latent_grad"], out["max_rel_diff_param_grad"])
+    if worst > tol or out["max_abs_diff_sdf"] > 1e-4:
+        msg = f"nphm_amd training tier deviates from the composite tier: {out}"
+        if strict:
+            raise _lib.NphmAmdError(msg)
+        warnings.warn(msg)
+    return out

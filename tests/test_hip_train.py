@@ -193,3 +193,16 @@ def test_bf16_operand_storage_is_opt_in_and_close(dev):
     worst = {k: _rel(out[k], ref[k]) for k in ref if k not in ("pred", "grad", "loss")}
     assert all(v < 5e-3 for v in worst.values()), worst
     assert max(worst.values()) > 0            # the option does something
+
+
+def test_validate_training_numerics(dev):
+    import nphm_amd
+    net = U.build_identity(device=dev).eval()
+    lat = torch.stack([U.sample_latent(31), U.sample_latent(32)]).to(dev)
+    before = [p.grad for p in net.parameters()]
+    rep = nphm_amd.validate_training_numerics(net, lat, n=1500, strict=True)
+    assert rep["max_abs_diff_sdf"] < 2e-5 and rep["max_rel_diff_param_grad"] < 5e-4 and rep["max_rel_diff_latent_grad"] < 5e-4
+    assert [p.grad for p in net.parameters()] == before and not net.training       # state restored, .grad untouched
+    net.train_operands = "bf16"
+    rep16 = nphm_amd.validate_training_numerics(net, lat, n=1500)
+    assert rep16["operands"] == "bf16" and rep16["max_rel_diff_param_grad"] < 5e-3
