@@ -318,7 +318,9 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             jac_posed = jac(decoder_expr, p_corresp, glob_cond, anchors_b)
         grad_inv = _inverse3x3(jac_posed)
         correction = preds_posed - preds_posed.detach()
-        correction = torch.einsum("bnij,bnj->bni", -grad_inv.detach(), correction)
+        # 3x3 matrix-vector products per point, elementwise: as an einsum this is a rocBLAS batched GEMM of 5000 3x3
+        # problems (69 us forward + 40 us backward per step)
+        correction = -(grad_inv.detach() * correction.unsqueeze(-2)).sum(dim=-1)
         xc = p_corresp + correction
 
         shape_cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
