@@ -446,11 +446,23 @@ def training_record(args, dev, with_composite=True, steps=8):
         torch.cuda.reset_peak_memory_stats()
         losses = [float(BT.step(net, lat, batch, opt)) for _ in range(2)]
         torch.cuda.synchronize()
+        net._train_backward_events = events = []          # HIP events around the reverse + weight-gradient kernels
         t0 = time.perf_counter()
         losses += [BT.step(net, lat, batch, opt) for _ in range(steps)]
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        return {"ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "first_loss": losses[0], "last_loss": float(losses[-1]),
+        net._train_backward_events = None
+        hbm = None
+        if events:
+            ms = float(np.mean([a.elapsed_time(b) for a, b, _ in events]))
+            nbytes = float(np.mean([n for _, _, n in events]))
+            hbm = {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / ms / 1e6 / 8000.0,
+                   "traffic": nbytes, "kernel_ms": ms,
+                   "note": "reverse kernel (train_kernel<true>) + weight-gradient kernel of one step, HIP events on the launch stream; "
+                           "achieved = the stored operands of the weight gradients, written once and read once (the algorithmic bytes of this "
+                           "two-kernel design; they match the PMC counters - WRITE_SIZE of the reverse kernel, 2 x FETCH_SIZE of the "
+                           "weight-gradient kernel, profiles/r02_g_training_summary.txt) / the time of the two kernels"}
+        return {"ms_per_step": dt * 1e3, "roofline": hbm, "steps_per_s": 1.0 / dt, "first_loss": losses[0], "last_loss": float(losses[-1]),
                 "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "prune_tol": net.prune_tol}
 
     ours = run("hip")
@@ -460,14 +472,16 @@ def training_record(args, dev, with_composite=True, steps=8):
            "config": {"workload": f"training step, batch {B} x {n_pts} points (nphm.yaml: 750 face + 50 non-face + 800 near + 93 far), "
                                   "loss terms of loss_functions.py:20-110 with create_graph gradients, all decoder weights + latent codes trainable "
                                   "(SURVEY 8 f4)", "prune_tol": ours["prune_tol"]},
-           "first_loss": ours["first_loss"], "last_loss": ours["last_loss"], "peak_mem_gb": ours["peak_mem_gb"], "roofline": None}
+           "first_loss": ours["first_loss"], "last_loss": ours["last_loss"], "peak_mem_gb": ours["peak_mem_gb"],
+           "roofline": ours["roofline"]}
     o16 = run("hip", "bf16")
-    out["operands_bf16"] = {"ms_per_step": o16["ms_per_step"], "steps_per_s": o16["steps_per_s"], "last_loss": o16["last_loss"],
+    out["operands_bf16"] = {"ms_per_step": o16["ms_per_step"], "roofline": o16["roofline"], "steps_per_s": o16["steps_per_s"], "last_loss": o16["last_loss"],
                             "peak_mem_gb": o16["peak_mem_gb"],
                             "note": "opt-in (decoder.train_operands = 'bf16'): the operands of the weight gradients cross HBM as bf16; parameter "
                                     "gradients within 2.2e-4 of the default's largest entry per tensor on this batch (DESIGN.md section 12)"}
     if with_composite:
         ref = run("composite")
+        ref.pop("roofline", None)
         out["composite_same_gpu"] = dict(ref, note="the same step with the decoder on the composite PyTorch tier (fp32 autograd double "
                                                    "backward, the four point sets as one batch) on this GPU")
         out["speedup_vs_composite"] = ref["ms_per_step"] / ours["ms_per_step"]
