@@ -209,3 +209,29 @@ def test_validate_training_numerics(dev):
         warnings.simplefilter("ignore")        # 3000 points: the bf16 rounding averages over fewer columns than a real batch
         rep16 = nphm_amd.validate_training_numerics(net, lat, n=1500)
     assert rep16["operands"] == "bf16" and rep16["max_rel_diff_param_grad"] < 5e-3
+
+
+def test_training_tier_stress_weights(dev):
+    """Weights x2 and latents at 3 sigma (larger pre-activations, steeper softplus transitions, larger member values):
+    the kernels' scaled-domain arithmetic against the composite tier."""
+    net = U.build_identity(device=dev).train()
+    net.prune_tol = -1.0
+    with torch.no_grad():
+        for i in range(5):
+            getattr(net.ensembled_deep_sdf, f"lin{i}").weight.mul_(2.0 if i < 4 else 1.0)
+    lat0 = torch.stack([U.sample_latent(70 + b, scale=3.0) for b in range(2)])[:, None, :].to(dev)
+    _, xyz, nrm = _batch(dev, B=2, N=600, seed=44)
+    res = {}
+    for mode in ("composite", "hip"):
+        net.train_backend = mode
+        net.zero_grad(set_to_none=True)
+        lat = lat0.clone().requires_grad_()
+        x = xyz.clone().requires_grad_()
+        pred, anchors = net(x, lat, None)
+        grad = gradient(pred, x)
+        (pred.abs().mean() + 0.1 * (grad.norm(dim=-1) - 1).abs().mean() + 0.3 * (grad - nrm).norm(2, dim=-1).mean()).backward()
+        res[mode] = {"pred": pred.detach(), "grad": grad.detach(), "lat": lat.grad.clone(),
+                     **{n: p.grad.clone() for n, p in net.ensembled_deep_sdf.named_parameters()}}
+    assert float(res["composite"]["pred"].abs().max()) > 0.1            # the stress does something
+    worst = {k: _rel(res["hip"][k], res["composite"][k]) for k in res["composite"]}
+    assert all(v < 1e-3 for v in worst.values()), worst
