@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "layout.h"
 
 namespace nphm {
@@ -90,11 +92,27 @@ __device__ __forceinline__ f32x16 load_frag16(const float* p) {
   return o;
 }
 
-// sum over the 32 lanes of a half-wave (all lanes of the half end up with the total)
+// sum over the 32 lanes of a half-wave (all lanes of the half end up with the total).  Four DPP steps inside each
+// row of 16 lanes (VALU operand modifiers: no LDS crossbar traffic) and ONE cross-row exchange, instead of five
+// ds_bpermute round trips (__shfl_xor): the reductions of the bias gradients are 32 of these per wavefront and tile.
+#ifndef NPHM_DPP_REDUCE
+#define NPHM_DPP_REDUCE 1
+#endif
 __device__ __forceinline__ float half_wave_sum(float v) {
+#if NPHM_DPP_REDUCE
+  auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror: quads 0 <-> 1, 2 <-> 3 (every lane then holds its 8-lane sum)
+  v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror: the two halves of the 16-lane row
+  return v + __shfl_xor(v, 16);                          // the two rows of the half-wave
+#else
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
+#endif
 }
 
 }  // namespace bwd
