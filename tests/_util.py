@@ -74,3 +74,45 @@ def sample_latent(seed, scale=0.85):
 
 def maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def stratified_voxels(axes, anchors, n_each, seed=0, exclude=None, pool=400_000):
+    """Flat indices of 3 * n_each lattice voxels, stratified by where the NPHM blend puts them: near an anchor
+    (< 0.05 from the closest one: several members with sizeable weights), mid-field (sum of blend weights >= 1e-6,
+    not near) and far field (sum of blend weights < 1e-6: the epsilon of the normaliser dominates,
+    EnsembledDeepSDF.py:147).  ``anchors`` [39,3] are the PREDICTED anchors of the latent at hand."""
+    rng = np.random.default_rng(seed)
+    ax, ay, az = [np.asarray(a) for a in axes]
+    ny, nz = len(ay), len(az)
+    total = len(ax) * ny * nz
+    cand = rng.choice(total, min(pool, total), replace=False)
+    if exclude is not None:
+        cand = np.setdiff1d(cand, exclude)
+    q = np.stack([ax[cand // (ny * nz)], ay[(cand // nz) % ny], az[cand % nz]], -1).astype(np.float32)
+    d = np.linalg.norm(q[:, None] - np.asarray(anchors, np.float32)[None], axis=-1) + np.float32(1e-5)
+    s_w = np.exp(-(d * d) / np.float32(0.01)).sum(-1) + np.exp(np.float32(-20.0))
+    near = d.min(-1) < 0.05
+    far = s_w < 1e-6
+    mid = ~near & ~far
+    picks = []
+    for m in (near, mid, far):
+        ids = cand[m]
+        assert len(ids) >= n_each, (int(near.sum()), int(mid.sum()), int(far.sum()))
+        picks.append(rng.choice(ids, n_each, replace=False))
+    return np.concatenate(picks)
+
+
+def trained_checkpoint():
+    """(state_dict as torch tensors, codes [64,1344]) of the trained-like checkpoint (tests/golden/trained_state.npz:
+    5 000 steps on analytic head-like surfaces, tools/train_synthetic_heads.py; the reference outputs on it are in
+    tests/golden/trained.npz, make_golden_trained.py)."""
+    ck = np.load(os.path.join(GOLDEN, "trained_state.npz"))
+    sd = {k[3:]: torch.from_numpy(ck[k]) for k in ck.files if k.startswith("sd.")}
+    return sd, torch.from_numpy(ck["codes"]).float()
+
+
+def build_trained_identity(device="cpu"):
+    net = build_identity(device=device)
+    sd, codes = trained_checkpoint()
+    net.load_state_dict(sd, strict=True)
+    return net, codes.to(device)

@@ -376,20 +376,23 @@ def test_two_stage_full_size_256_cubed_properties(dnet, dev):
     assert vol.shape == (res ** 3,) and can.shape == (res ** 3, 3) and bool(torch.isfinite(vol).all())
     slab = R.evaluate_grid_two_stage(inet, dnet, lat_id, lat_ex, axes, hack_chunk=0, x_range=(96, 104))
     assert torch.equal(slab, vol.view(res, -1)[96:104].reshape(-1))
-    rng = np.random.default_rng(1)
-    keep = rng.choice(res ** 3, 2048, replace=False)
+    anchors = inet.prepare_latent(lat_id[None])[2]
+    # 4 608 voxels stratified by the identity field's blend regime AT THE LATTICE POINT (near an anchor / mid-field /
+    # far field; the canonical points are displaced by the deformation): all of them against the numpy oracle
+    keep = U.stratified_voxels(axes, anchors[0].cpu().numpy(), 1536, seed=1)
     ax, ay, az = axes
     pts = np.stack([ax[keep // (res * res)], ay[(keep // res) % res], az[keep % res]], -1).astype(np.float32)
-    anchors = inet.prepare_latent(lat_id[None])[2]
     with torch.no_grad():
         off, _ = dnet(_t(pts[None], dev), lat_ex[None, None], anchors)
     k = torch.from_numpy(keep).to(dev)
     assert U.maxdiff(can[k].cpu().numpy(), pts + off[0].cpu().numpy()) < 1e-6
-    sub = slice(0, 128)
-    off_o, _ = O.deformation_forward(U.np_state(dnet), pts[None, sub], g["lat"], anchors.cpu().numpy())
-    ref, _ = O.nphm_identity_forward(U.np_state(inet), U.anchors_mean(), (pts[None, sub] + off_o).astype(np.float32),
+    off_o, _ = O.deformation_forward(U.np_state(dnet), pts[None], g["lat"], anchors.cpu().numpy())
+    ref, _ = O.nphm_identity_forward(U.np_state(inet), U.anchors_mean(), (pts[None] + off_o).astype(np.float32),
                                      g["lat"][:, :, :1344], training=True)
-    assert U.maxdiff(vol[k][sub].cpu().numpy(), ref.reshape(-1)) < TOL_BAR
+    err = np.abs(vol[k].cpu().numpy() - ref.reshape(-1))
+    print("two-stage 256^3 vs oracle, max |err| near-anchor / mid-field / far-field: %.2e / %.2e / %.2e"
+          % (err[:1536].max(), err[1536:3072].max(), err[3072:].max()))
+    assert float(err.max()) < 1e-5
 
 
 def test_npm_full_size_64_cubed_vs_reference_sequence(npm, dev):

@@ -1,0 +1,120 @@
+"""Parity on a TRAINED-LIKE checkpoint (tests/golden/trained_state.npz: the identity decoder after 5 000 training
+steps on analytic head-like surfaces - weights up to 1.25 against 0.07 at the seeded init, |sdf| up to 0.35 in the
+extraction box, a real zero level set).  tests/golden/trained.npz holds the REFERENCE's outputs on that state_dict
+(make_golden_trained.py: FastEnsembleDeepSDFMirrored of /root/reference on the CPU, strict load).
+
+CPU tests pin the numpy oracle and the composite tier to those outputs; GPU tests pin every precision mode of the HIP
+kernels - the default (adaptive split-bf16, prune_tol 1e-7) at a tenth of the 1e-4 bar - and report the guard's
+verdict (nphm_amd.validate_numerics) and the member statistics of the checkpoint."""
+import numpy as np
+import pytest
+import torch
+
+import _util as U
+import nphm_amd
+from nphm_amd import reconstruction as R
+from oracle import nphm_oracle as O
+
+TOL_BAR = 1e-4
+CODES = (0, 1, 2, 17)
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return U.golden("trained")
+
+
+def _voxel_points(fx, c, res=256):
+    axes = R.grid_axes(U.MINI, U.MAXI, res)
+    keep = fx[f"c{c}_voxels"]
+    return np.stack([axes[0][keep // (res * res)], axes[1][(keep // res) % res], axes[2][keep % res]], -1).astype(np.float32)
+
+
+def test_checkpoint_is_the_one_the_reference_evaluated(fx):
+    net, codes = U.build_trained_identity()
+    assert U.state_hash(net) == str(fx["state_sha256"])
+    assert codes.shape == (64, 1344) and float(codes.norm(dim=-1).max()) <= 1.0 + 1e-5
+    w = net.state_dict()["ensembled_deep_sdf.lin2.weight"]
+    assert float(w.abs().max()) > 1.0          # trained sharpness: the seeded init is bounded by 1 / sqrt(200)
+
+
+def test_oracle_and_composite_match_the_reference_on_trained_weights(fx):
+    net, codes = U.build_trained_identity()
+    net.backend = "composite"
+    net.train()
+    params, amean = U.np_state(net), U.anchors_mean()
+    for c in CODES[:2]:
+        lat = codes[c].numpy()[None, None]
+        pts = np.concatenate([_voxel_points(fx, c)[::6], fx[f"c{c}_near"][::4]])[None]        # 768 + 512 points
+        ref = np.concatenate([fx[f"c{c}_sdf_voxels"][::6], fx[f"c{c}_sdf_near"][::4]])
+        got_o, anc_o = O.nphm_identity_forward(params, amean, pts, lat, training=True)
+        assert U.maxdiff(anc_o[0], fx[f"c{c}_anchors"]) < 1e-6
+        assert U.maxdiff(got_o.reshape(-1), ref) < 2e-6
+        with torch.no_grad():
+            got_c, _ = net(torch.from_numpy(pts), codes[c][None, None], None)
+        assert U.maxdiff(got_c.reshape(-1).numpy(), ref) < 2e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,prune,tol", [("f32", -1.0, 2e-5), ("bf16x3", -1.0, 1e-5), ("bf16x3", 1e-7, 1e-5),
+                                                 ("bf16x3a", 1e-7, 1e-5), ("bf16x3a2", 1e-7, 1e-5)])
+def test_hip_modes_on_trained_weights(fx, dev, precision, prune, tol):
+    """every precision mode against the reference fixture: 4 codes x (4 608 stratified voxels + 2 048 near-surface points)"""
+    net, codes = U.build_trained_identity(device=dev)
+    net.train()                                  # the fixture's point sets are train-mode values (no last-point overwrite)
+    net.precision, net.prune_tol = precision, prune
+    worst = {}
+    for c in CODES:
+        with torch.no_grad():
+            for name, pts, ref in (("voxels", _voxel_points(fx, c), fx[f"c{c}_sdf_voxels"]),
+                                   ("near", fx[f"c{c}_near"], fx[f"c{c}_sdf_near"])):
+                got, anc = net(torch.from_numpy(pts)[None].to(dev), codes[c][None, None], None)
+                err = np.abs(got.reshape(-1).cpu().numpy() - ref)
+                if name == "voxels":
+                    for i, reg in enumerate(("near_anchor", "mid_field", "far_field")):
+                        worst[reg] = max(worst.get(reg, 0.0), float(err[1536 * i:1536 * (i + 1)].max()))
+                else:
+                    worst["near_surface"] = max(worst.get("near_surface", 0.0), float(err.max()))
+            assert U.maxdiff(anc[0].cpu().numpy(), fx[f"c{c}_anchors"]) < 1e-6
+    print(f"trained checkpoint, {precision}, prune_tol {prune:g}: max |hip - reference| " +
+          ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    assert max(worst.values()) < tol
+
+
+@pytest.mark.gpu
+def test_get_logits_eval_mode_lattice_on_trained_weights(fx, dev):
+    """the reference's get_logits (eval mode, chunk 9 000: overwrite voxels included) on a 40^3 lattice"""
+    net, codes = U.build_trained_identity(device=dev)
+    net.eval()
+    res, chunk = int(fx["lattice_res"]), int(fx["lattice_chunk"])
+    grid = torch.from_numpy(R.create_grid_points_from_bounds(U.MINI, U.MAXI, res)).float()[None].to(dev)
+    vol = R.get_logits(net, codes[CODES[0]], grid, nbatch_points=chunk)
+    ref = fx["lattice_volume"]
+    hacked = O.hack_indices(res ** 3, chunk)
+    assert U.maxdiff(vol[hacked], ref[hacked]) < 1e-6 and float(np.abs(ref[hacked] - 1).max()) < 1e-3
+    err = np.abs(vol - ref)
+    print(f"trained checkpoint, 40^3 get_logits: max |err| {err.max():.2e}, sign flips {int(((vol < 0) != (ref < 0)).sum())}")
+    assert float(err.max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_validate_numerics_and_member_statistics_on_trained_weights(dev):
+    net, codes = U.build_trained_identity(device=dev)
+    net.eval()
+    rep = nphm_amd.validate_numerics(net, codes[list(CODES)], n=1 << 15)
+    print("validate_numerics on the trained checkpoint:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in rep.items()})
+    assert rep["max_abs_diff"] < TOL_BAR and rep["max_abs_sdf"] > 0.2
+    # member statistics of the default mode on the 128^3 lattice (what the throughput depends on)
+    axes = R.grid_axes(U.MINI, U.MAXI, 128)
+    stats = torch.zeros(16, dtype=torch.int64, device=dev)
+    R.evaluate_grid(net, codes[0], axes, hack_chunk=0, stats=stats)
+    s = stats.cpu().numpy()
+    n = 128 ** 3
+    print(f"trained checkpoint 128^3: members per wavefront {s[0] / n:.2f} (single-pass {s[15] / n:.2f}, two-pass {s[14] / n:.2f})")
+    assert 2.0 < s[0] / n < 20.0
