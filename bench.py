@@ -64,19 +64,23 @@ def parse():
     ap.add_argument("--no-mesh", action="store_true", help="skip the mesh-extract leg (kernel timing experiments)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="lattice points of the PyTorch-CPU baseline (prefix)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0 = min(cores, 32): the fastest of 8..256 on the 256-core GPU box)")
-    ap.add_argument("--fit-steps", type=int, default=1000, help="n_steps of the fitting config (run at step_scale 1/4)")
+    ap.add_argument("--fit-steps", type=int, default=1000, help="n_steps of the fitting config (HIP tier: step_scale 1; composite comparison: 1/4)")
     return ap.parse_args()
 
 
 def measured_traffic(kernel, n_points):
-    """HBM bytes per launch of a kernel, from the committed rocprofv3 PMC passes (profiles/traffic.json;
-    the counters cannot be read live from inside the process), scaled to this launch's point count.
-    None if no profile covers the kernel."""
+    """HBM bytes per launch of a kernel, from the COMMITTED rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/pmc_traffic.sh on the GPU box: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections of
+    MI355X_MICROARCH.md; hardware counters cannot be read from inside the timed process), scaled to this launch's
+    point count.  None if no profile covers the kernel.  `traffic_source` of the roofline object says so."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
         return t["traffic_bytes"] * n_points / t["points_per_launch"]
     except Exception:
         return None
+
+
+TRAFFIC_SOURCE = "profiles/traffic.json (committed rocprofv3 --pmc passes, tools/pmc_traffic.sh), not measured in this run"
 
 
 def _timed(fn, steps, warmup):
@@ -129,6 +133,8 @@ class IdentityBench:
         self.gather_done = [None, None]
         self.k = 0
         self.full = None
+        self.collective_events = []      # (start, all-gather done, reorder done) on the side stream, timed steps only
+        self.rank_report = None
 
     def step(self, precision, binned, stats=None, ev=None):
         net, R = self.net, self.R
@@ -159,8 +165,16 @@ class IdentityBench:
             ready.record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
+                cev = None if ev is None else [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                if cev:
+                    cev[0].record(self.side)
                 dist.all_gather_into_tensor(self.gathered[i], self.shard)
+                if cev:
+                    cev[1].record(self.side)
                 self.full = R.reorder_gathered(self.gathered[i], self.rx, self.plane, self.world)
+                if cev:
+                    cev[2].record(self.side)
+                    self.collective_events.append(cev)
                 done = torch.cuda.Event()
                 done.record(self.side)
                 self.gather_done[i] = done
@@ -184,11 +198,25 @@ class IdentityBench:
         self.barrier()
         dt = time.perf_counter() - t0
         k_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        self.rank_report = None
         if self.distributed:
             import torch.distributed as dist
-            tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+            ag = [a.elapsed_time(b) for a, b, _ in self.collective_events]
+            ro = [b.elapsed_time(c) for _, b, c in self.collective_events]
+            self.collective_events = []
+            # per-rank figures of the timed region: what makes an N > 1 line diagnosable (load balance, how much of the
+            # all-gather + reorder stays exposed behind the next step's kernel)
+            mine = torch.tensor([dt, k_ms, float(np.mean(ag)) if ag else 0.0, float(np.mean(ro)) if ro else 0.0,
+                                 float(self.n_planes)], dtype=torch.float64, device=self.dev)
+            allr = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(allr, mine)
+            allr = torch.stack(allr).cpu().numpy()
+            dt = float(allr[:, 0].max())
+            self.rank_report = {"step_ms": [round(v / steps * 1e3, 3) for v in allr[:, 0]], "kernel_ms": [round(v, 3) for v in allr[:, 1]],
+                                "allgather_ms": [round(v, 3) for v in allr[:, 2]], "reorder_ms": [round(v, 3) for v in allr[:, 3]],
+                                "planes": [int(v) for v in allr[:, 4]],
+                                "kernel_max_over_mean": float(allr[:, 1].max() / max(allr[:, 1].mean(), 1e-12)),
+                                "exposed_ms_per_step": float(dt / steps * 1e3 - allr[:, 1].max())}
         return dt, k_ms, stats.cpu().numpy()
 
     def record(self, precision, steps, warmup, binned=True):
@@ -216,8 +244,8 @@ class IdentityBench:
             "value": n_total * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "dtype": DTYPE[precision],
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": measured_traffic(tkey, n_local), "algorithmic_bytes": 4 * n_local,
-                         "kernel": kname, "rank0_planes": self.n_planes, "binned_tiles": binned,
+                         "traffic": measured_traffic(tkey, n_local), "traffic_source": TRAFFIC_SOURCE,
+                         "algorithmic_bytes": 4 * n_local, "kernel": kname, "rank0_planes": self.n_planes, "binned_tiles": binned,
                          "kernel_ms": k_ms, "points_per_launch": n_local,
                          "executed_flops_per_point": exec_flops / n_local, "mean_single_pass_members": mean_light,
                          "mean_two_pass_members": mean_mid,
@@ -260,12 +288,10 @@ class IdentityBench:
         return {"wall_ms": (t_m1 - t_m0) * 1e3 + (t_d1 - t_d0) * 1e3, "volume_ms": (t_m1 - t_m0) * 1e3,
                 "device_marching_cubes_ms": (t_d1 - t_d0) * 1e3, "device_marching_cubes_first_call_ms": cold_ms,
                 "n_vertices": int(len(vd_h)), "n_faces": int(len(fd_h)),
+                # reference order: get_logits -> numpy volume on the host -> mesh_from_logits (host marching cubes)
                 "reference_order": {"wall_ms": (t_m3 - t_m0) * 1e3, "d2h_ms": (t_m2 - t_m1) * 1e3,
-                                    "host_marching_cubes_ms": (t_m3 - t_m2) * 1e3,
-                                    "note": "get_logits -> numpy volume on the host -> mesh_from_logits (host marching cubes, <= 16 threads)"},
-                "same_mesh": bool(len(vd_h) == len(m.vertices) and np.array_equal(fd_h, np.asarray(m.faces))),
-                "note": "wall = latent -> SDF volume (all ranks, all-gathered) -> marching cubes on the GPU -> vertices/faces on the host; "
-                        "PyMCubes of the reference is absent, both extractors are this repo's (bit-identical meshes)"}
+                                    "host_marching_cubes_ms": (t_m3 - t_m2) * 1e3},
+                "same_mesh": bool(len(vd_h) == len(m.vertices) and np.array_equal(fd_h, np.asarray(m.faces)))}
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -342,6 +368,7 @@ def npm_record(args, dev, steps, warmup, cpu):
     return out
 
 
+FIT_LAUNCHES_PER_STEP = 212      # kernel launches of one replayed step (profiles/r02_h_fitting_kernel_stats.csv; refreshed per round)
 FIT_LAMBDAS = {"surface": 2.0, "reg_expr": 0.01, "reg_global": 0.25, "reg_unobserved": 10, "reg_loc": 0.05,
                "symm_dist": 5.0}                                                   # fitting_pointclouds.py:253-259
 FIT_SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 500: 9999},
@@ -364,24 +391,48 @@ def grid512_record(args, dev, steps=2):
                                    "its per-rank launch is timed below)", "res": 512},
             "roofline": full["roofline"],
             "rank0_of_8": {"planes": share.n_planes, "points": n_share, "kernel_ms": k_ms,
-                           "projected_8gpu_mpoints_per_s_without_allgather": 512 ** 3 / (k_ms * 1e-3) / 1e6,
-                           "note": "cyclic 8-plane slabs of rank 0 in one launch on this GPU; every rank's share costs the same "
-                                   "within 2 % (tools/slab_balance.py)"}}
+                           "projected_8gpu_mpoints_per_s_without_allgather": 512 ** 3 / (k_ms * 1e-3) / 1e6}}
+
+
+def trained_record(args, dev, steps=3):
+    """configs[1] on the TRAINED-LIKE checkpoint (tests/golden/trained_state.npz: 5 000 steps on analytic head-like
+    surfaces, weights up to 1.25) with one of its trained codes: throughput and member statistics where the blend
+    fields and the SDF have trained sharpness, next to its max |error| against the dense exact-fp32 kernel on a
+    64^3 sub-lattice."""
+    import _util as U
+    from nphm_amd import reconstruction as R
+    ib = IdentityBench(args, dev, 1, 0)
+    ib.net, codes = U.build_trained_identity(device=dev)
+    ib.net.eval()
+    ib.lat = codes[0]
+    rec = ib.record(args.precision, steps, 1)
+    axes = R.grid_axes(U.MINI, U.MAXI, 64)
+    fast = R.evaluate_grid(ib.net, ib.lat, axes, hack_chunk=0)
+    ib.net.precision, ib.net.prune_tol, keep = "f32", -1.0, (ib.net.precision, ib.net.prune_tol)
+    exact = R.evaluate_grid(ib.net, ib.lat, axes, hack_chunk=0)
+    ib.net.precision, ib.net.prune_tol = keep
+    r = rec["roofline"]
+    return {"metric": "SDF query throughput, NPHM identity field, trained-like checkpoint", "value": rec["value"], "unit": "Mpoints/s",
+            "ms_per_step": rec["ms_per_step"], "steps": steps, "dtype": rec["dtype"],
+            "config": {"workload": f"NPHM identity net, trained-like checkpoint (tests/golden/trained_state.npz), code 0, {args.res}^3", "res": args.res},
+            "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms", "mean_active_members",
+                                           "mean_single_pass_members", "mean_two_pass_members", "executed_flops_per_point")},
+            "max_abs_err_vs_dense_f32_64cubed": float((fast - exact).abs().max()), "max_abs_sdf": float(exact.abs().max())}
 
 
 def fitting_record(args, dev, with_reference_loop=True):
-    """configs[4]: latent fitting (fitting_pointclouds.py:253-276: n_steps 1000, the published schedule) at the
-    reference's own step_scale 1/4 = 250 Adam steps through every transition of the schedule; synthetic
-    observations on the level set of a seeded ground-truth identity.  Final loss next to the SAME loop on the
-    all-composite PyTorch-ROCm tier (the reference's arithmetic on this GPU)."""
+    """configs[4]: latent fitting at its stated horizon (fitting_pointclouds.py:269-276: step_scale 1, n_steps 1000,
+    the published schedule) on the HIP tier; synthetic observations on the level set of a seeded ground-truth
+    identity.  Comparison: the SAME loop on the all-composite PyTorch-ROCm tier (the reference's arithmetic on this
+    GPU) at step_scale 1/4 (250 steps through the same schedule transitions; 1000 composite steps would take 13 s).
+    Bound of the record: the share of a step the GPU is busy replaying the captured graph (HIP events around the
+    replay), next to the launch count per step of the committed kernel trace."""
     import _util as U
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_fitting as BF
     from nphm_amd import fitting as F
-    step_scale = 0.25
-    n_iter = int(args.fit_steps * step_scale)
 
-    def run(backend):
+    def run(backend, step_scale):
         shape_net = U.build_identity(device=dev)
         expr_net = U.build_deformation(device=dev).eval()
         obs = BF.synthetic_observations(shape_net, dev)
@@ -393,33 +444,38 @@ def fitting_record(args, dev, with_reference_loop=True):
         torch.manual_seed(0)
         F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(FIT_LAMBDAS), 8, cfg(), verbose=False)   # warm-up
         torch.cuda.synchronize()
-        hist = []
+        hist, timing = [], {}
         torch.manual_seed(0)
         t0 = time.perf_counter()
         F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(FIT_LAMBDAS), args.fit_steps, cfg(),
-                                                 step_scale=step_scale, verbose=False, history=hist)
+                                                 step_scale=step_scale, verbose=False, history=hist, timing=timing)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         tail = hist[-20:]
-        return {"steps_per_s": len(hist) / dt, "ms_per_step": dt / len(hist) * 1e3, "steps": len(hist),
+        return {"steps_per_s": len(hist) / dt, "ms_per_step": dt / len(hist) * 1e3, "steps": len(hist), "step_scale": step_scale,
                 "first_surface_loss": hist[0]["surface"], "final_surface_loss": float(np.mean([h["surface"] for h in tail])),
                 "final_total_loss": float(np.mean([h["loss"] for h in tail])),
-                "final_valid_correspondences": float(np.mean([h["n_valid"] for h in tail]))}
+                "final_valid_correspondences": float(np.mean([h["n_valid"] for h in tail])),
+                "graph_ms": timing.get("graph_ms"), "graph_steps": timing.get("graph_steps")}
 
-    ours = run(None)
+    ours = run(None, 1.0)
+    busy = None if not ours["graph_ms"] else ours["graph_ms"] / ours["ms_per_step"]
     out = {"metric": "latent-code fitting steps/s (inference_iterative_root_finding_joint)", "value": ours["steps_per_s"],
            "unit": "steps/s", "ms_per_step": ours["ms_per_step"], "steps": ours["steps"],
            "dtype": "bf16x3 kernels + fp32 PyTorch ops",
            "config": {"workload": "latent fitting, 3 synthetic observations x 2500 points, 5 x 1000 points per step, Adam on "
-                                  f"identity + expression codes, n_steps {args.fit_steps} at step_scale 1/4 = {n_iter} steps through "
-                                  "the whole published schedule (BASELINE.json configs[4])"},
+                                  f"identity + expression codes, n_steps {args.fit_steps} at step_scale 1 = {ours['steps']} steps, "
+                                  "the published schedule (BASELINE.json configs[4])"},
            "first_surface_loss": ours["first_surface_loss"], "final_surface_loss": ours["final_surface_loss"],
            "final_total_loss": ours["final_total_loss"], "final_valid_correspondences": ours["final_valid_correspondences"],
-           "roofline": None, "note": "surface losses = mean over the last 20 steps; the step is host-latency bound (DESIGN.md section 9)"}
+           # surface losses = mean over the last 20 steps
+           "roofline": {"bound": "latency (launch-bound GPU stream)", "graph_replay_ms": ours["graph_ms"],
+                        "gpu_busy_frac_of_step": busy, "graph_steps_timed": ours["graph_steps"],
+                        "host_ms_per_step_outside_graph": None if busy is None else ours["ms_per_step"] - ours["graph_ms"],
+                        "launches_per_step": FIT_LAUNCHES_PER_STEP, "launches_source": "profiles (rocprofv3 --kernel-trace of --workload fitting)"}}
     if with_reference_loop:
-        ref = run("composite")
-        out["reference_loop_same_gpu"] = dict(ref, note="the same loop with every field on the composite tier = the reference's "
-                                                        "PyTorch arithmetic on this GPU (eager PyTorch-ROCm, fp32)")
+        ref = run("composite", 0.25)
+        out["reference_loop_same_gpu"] = ref          # every field on the composite tier = eager PyTorch-ROCm fp32, 250 steps
         out["final_surface_loss_ratio"] = ours["final_surface_loss"] / max(ref["final_surface_loss"], 1e-30)
     return out
 
@@ -457,11 +513,9 @@ def training_record(args, dev, with_composite=True, steps=8):
             ms = float(np.mean([a.elapsed_time(b) for a, b, _ in events]))
             nbytes = float(np.mean([n for _, _, n in events]))
             hbm = {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / ms / 1e6 / 8000.0,
-                   "traffic": nbytes, "kernel_ms": ms,
-                   "note": "reverse kernel (train_kernel<true>) + weight-gradient kernel of one step, HIP events on the launch stream; "
-                           "achieved = the stored operands of the weight gradients, written once and read once (the algorithmic bytes of this "
-                           "two-kernel design; they match the PMC counters - WRITE_SIZE of the reverse kernel, 2 x FETCH_SIZE of the "
-                           "weight-gradient kernel, profiles/r02_g_training_summary.txt) / the time of the two kernels"}
+                   # reverse + weight-gradient kernels of one step (HIP events on the launch stream); achieved = the stored
+                   # operands of the weight gradients written once and read once / the time of the two kernels
+                   "traffic": nbytes, "kernel_ms": ms}
         return {"ms_per_step": dt * 1e3, "roofline": hbm, "steps_per_s": 1.0 / dt, "first_loss": losses[0], "last_loss": float(losses[-1]),
                 "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "prune_tol": net.prune_tol}
 
@@ -476,14 +530,11 @@ def training_record(args, dev, with_composite=True, steps=8):
            "roofline": ours["roofline"]}
     o16 = run("hip", "bf16")
     out["operands_bf16"] = {"ms_per_step": o16["ms_per_step"], "roofline": o16["roofline"], "steps_per_s": o16["steps_per_s"], "last_loss": o16["last_loss"],
-                            "peak_mem_gb": o16["peak_mem_gb"],
-                            "note": "opt-in (decoder.train_operands = 'bf16'): the operands of the weight gradients cross HBM as bf16; parameter "
-                                    "gradients within 2.2e-4 of the default's largest entry per tensor on this batch (DESIGN.md section 12)"}
+                            "peak_mem_gb": o16["peak_mem_gb"]}      # opt-in: decoder.train_operands = 'bf16' 
     if with_composite:
         ref = run("composite")
         ref.pop("roofline", None)
-        out["composite_same_gpu"] = dict(ref, note="the same step with the decoder on the composite PyTorch tier (fp32 autograd double "
-                                                   "backward, the four point sets as one batch) on this GPU")
+        out["composite_same_gpu"] = ref               # the same step on the composite PyTorch tier (fp32 autograd double backward)
         out["speedup_vs_composite"] = ref["ms_per_step"] / ours["ms_per_step"]
         out["last_loss_diff"] = abs(ours["last_loss"] - ref["last_loss"])
     return out
@@ -594,8 +645,7 @@ def mfma_sustained(dev):
     stream = torch.cuda.current_stream(dev).cuda_stream
     for _ in range(2):
         _lib.check(lib.nphm_probe_mfma_rate(ctypes.byref(tf), ctypes.byref(ghz), stream), "nphm_probe_mfma_rate")
-    out = {"tflops": tf.value, "clock_ghz": ghz.value, "frac_of_peak": tf.value / 2500.0,
-           "note": "bf16 32x32x16 MFMA only, 2 wavefronts per SIMD, A fragments re-read from LDS, pseudo-random operands"}
+    out = {"tflops": tf.value, "clock_ghz": ghz.value, "frac_of_peak": tf.value / 2500.0}
     # an independent reference on the same box: the vendor library's bf16 GEMM (torch.matmul -> hipBLASLt) at a size that
     # is MFMA-bound, on normally distributed operands - the rate a tuned dense kernel reaches under the same power limit
     try:
@@ -613,10 +663,10 @@ def mfma_sustained(dev):
         e1.record()
         torch.cuda.synchronize()
         out["library_gemm_bf16_tflops"] = 2.0 * n ** 3 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
-        out["library_gemm_note"] = f"torch.matmul bf16 {n}^3 (hipBLASLt), randn operands, {reps} calls"
+        out["library_gemm_shape"] = f"torch.matmul bf16 {n}^3 randn"
     except Exception as e:            # noqa: BLE001 - a reference figure only
         out["library_gemm_bf16_tflops"] = None
-        out["library_gemm_note"] = repr(e)
+        out["library_gemm_shape"] = repr(e)
     return out
 
 
@@ -639,12 +689,103 @@ def single_workload(args):
     print(json.dumps(dict(base, **rec)))
 
 
+def summary_of(out):
+    """Headline numbers of every sub-record in < 1 500 characters, printed as the LAST key of the line (a driver that
+    keeps only the tail of a long line still sees mesh_extract and configs[0] / [2] / [4])."""
+    r3 = lambda v: None if v is None else float(f"{v:.4g}")
+    s = {"value": r3(out["value"]), "frac": r3(out["roofline"]["frac"]), "kernel_ms": r3(out["roofline"]["kernel_ms"])}
+    m = out.get("mesh_extract")
+    if m:
+        s["mesh_extract_ms"] = {"wall": r3(m["wall_ms"]), "volume": r3(m["volume_ms"]), "gpu_mc": r3(m["device_marching_cubes_ms"]),
+                                "reference_order_wall": r3(m["reference_order"]["wall_ms"]), "same_mesh": m["same_mesh"]}
+    if out.get("mfma_sustained"):
+        s["mfma_sustained_tflops"] = r3(out["mfma_sustained"]["tflops"])
+        s["library_gemm_bf16_tflops"] = r3(out["mfma_sustained"].get("library_gemm_bf16_tflops"))
+    for k, v in (out.get("precisions") or {}).items():
+        s["prec_" + k] = [r3(v["value"]), r3(v["roofline"]["frac"])]
+    c = out.get("configs") or {}
+    if "npm_64" in c:
+        s["cfg0_npm_64"] = {"mpts": r3(c["npm_64"]["value"]), "frac": r3(c["npm_64"]["roofline"]["frac"]),
+                            "cpu_mpts": r3((c["npm_64"].get("cpu_baseline") or {}).get("value"))}
+    if "two_stage_256" in c:
+        s["cfg2_two_stage_256"] = {"mpts": r3(c["two_stage_256"]["value"]), "frac": r3(c["two_stage_256"]["roofline"]["frac"])}
+    if "grid512_one_gpu" in c:
+        s["cfg3_512_one_gpu"] = {"mpts": r3(c["grid512_one_gpu"]["value"]), "rank0_of_8_ms": r3(c["grid512_one_gpu"]["rank0_of_8"]["kernel_ms"])}
+    if "fitting" in c:
+        f = c["fitting"]
+        s["cfg4_fitting"] = {"steps_per_s": r3(f["value"]), "steps": f["steps"], "final_surface_loss": r3(f["final_surface_loss"]),
+                             "gpu_busy": r3(f["roofline"]["gpu_busy_frac_of_step"]),
+                             "composite_steps_per_s": r3((f.get("reference_loop_same_gpu") or {}).get("steps_per_s")),
+                             "loss_ratio": r3(f.get("final_surface_loss_ratio"))}
+    if "training" in c:
+        t = c["training"]
+        s["f4_training"] = {"steps_per_s": r3(t["value"]), "ms": r3(t["ms_per_step"]),
+                            "composite_ms": r3((t.get("composite_same_gpu") or {}).get("ms_per_step")),
+                            "hbm_frac": r3((t.get("roofline") or {}).get("frac"))}
+    if "trained_checkpoint_256" in c:
+        t = c["trained_checkpoint_256"]
+        s["trained_ckpt"] = {"mpts": r3(t["value"]), "frac": r3(t["roofline"]["frac"]), "members": r3(t["roofline"]["mean_active_members"]),
+                             "max_err": r3(t["max_abs_err_vs_dense_f32_64cubed"])}
+    if out.get("cpu_baseline"):
+        s["cpu_mpts"] = [r3(out["cpu_baseline"]["value"]), out["cpu_baseline"]["cores"]]
+    if out.get("pytorch_rocm_baseline"):
+        s["pytorch_rocm_mpts"] = r3(out["pytorch_rocm_baseline"]["value"])
+    return s
+
+
+def two_stage_sharded(args, world):
+    """--workload two_stage under torch.distributed.run: configs[2] sharded like configs[3] (cyclic 8-plane slabs,
+    deformation + identity kernels per slab, one all-gather + reorder), max over ranks, one line on rank 0."""
+    import torch.distributed as dist
+    import _util as U
+    from nphm_amd import reconstruction as R
+    rank, local_rank = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = int(os.environ.get("NPHM_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("NPHM_BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    g = U.golden("deformation")
+    inet, dnet = U.build_identity(device=dev).eval(), U.build_deformation(device=dev).eval()
+    lat_id = torch.from_numpy(g["lat"].reshape(-1)[:1344]).to(dev)
+    lat_ex = torch.from_numpy(g["lat"].reshape(-1)).to(dev)
+    axes = [torch.from_numpy(a).to(dev) for a in R.grid_axes(U.MINI, U.MAXI, args.res)]
+    fn = lambda: R.evaluate_grid_two_stage_sharded(inet, dnet, lat_id, lat_ex, axes, hack_chunk=args.chunk)
+    for _ in range(args.warmup):
+        fn()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fn()
+    dist.barrier(); torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    allt = [float(x.item()) for x in allt]
+    if rank == 0:
+        n, dt = args.res ** 3, max(allt)
+        print(json.dumps({"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice", "value": n * args.steps / dt / 1e6,
+                          "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "bf16x3(split-bf16 MFMA) deformation + " + inet.precision + " identity", "data": "synthetic (seeded random-init weights)",
+                          "config": {"workload": f"NPHM identity + forward-deformation field, {args.res}^3 (BASELINE.json configs[2]), sharded",
+                                     "res": args.res, "parallelism": f"cyclic 8-plane x-slabs x{world} + all_gather"},
+                          "ranks": {"step_ms": [round(x / args.steps * 1e3, 3) for x in allt]}, "roofline": None, "cpu_baseline": None}))
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload == "two_stage" and world > 1:
+        return two_stage_sharded(args, world)
     if args.workload not in ("all", "identity"):
         if world != 1:
-            raise SystemExit("--workload other than all / identity runs on one GPU")
+            raise SystemExit("--workload other than all / identity / two_stage runs on one GPU")
         return single_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -682,13 +823,13 @@ def main():
                        "res": args.res, "prune_tol": ib.net.prune_tol, "precision": args.precision,
                        "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather (of step k, on a side stream, under the "
                                        "kernel of step k+1)" if distributed else "single GPU")},
-            "roofline": dict(rec["roofline"], note=(
-                "achieved counts EXECUTED matrix FLOPs (tile padding excluded): the adaptive default issues one pass instead "
-                "of three for ~46% of the evaluated members and two for ~17%, so it is faster at a lower FLOP rate; `peak` is the datasheet figure - "
-                "an MFMA-only loop sustains `mfma_sustained.tflops` on this box (power-limited clock, tools/micro/chain.hip), "
-                "which with the kernel's 17.6% tile padding bounds `frac` at about 0.5 (DESIGN.md section 4.1)")),
+            # achieved counts EXECUTED matrix FLOPs (tile padding excluded); peak is the datasheet figure - an MFMA-only loop
+            # sustains `mfma_sustained.tflops` on this box (power-limited clock), DESIGN.md section 4.1
+            "roofline": rec["roofline"],
             "mesh_extract": mesh,
         }
+        if ib.rank_report is not None:
+            out["ranks"] = ib.rank_report
         if world == 1 and args.workload == "all" and not args.no_sub:
             sub_steps = max(2, min(args.steps, 5))
             out["mfma_sustained"] = mfma_sustained(dev)
@@ -700,6 +841,7 @@ def main():
                 "fitting": fitting_record(args, dev, with_reference_loop=not args.no_cpu_baseline),
                 "grid512_one_gpu": grid512_record(args, dev),
                 "training": training_record(args, dev, with_composite=not args.no_cpu_baseline),
+                "trained_checkpoint_256": trained_record(args, dev),
             }
             ib.net.precision = args.precision
         if not args.no_cpu_baseline and world == 1:
@@ -708,6 +850,7 @@ def main():
             out["cpu_baseline_port"] = cpu_baseline_port(ib.net, ib.lat, ib.axes)
         else:
             out["cpu_baseline"] = None
+        out["summary"] = summary_of(out)          # LAST key: the sub-records' headline numbers survive a truncated tail
         print(json.dumps(out))
     if distributed:
         import torch.distributed as dist

@@ -194,11 +194,39 @@ __device__ __forceinline__ void static_range(F&& f) {
 // slot s runs the units [unit_begin(s), unit_begin(s + 1))
 __host__ __device__ constexpr int unit_begin(int s, int ns, int nu) { return (s * nu + ns - 1) / ns; }
 
+#ifndef NPHM_F16_EPI
+#define NPHM_F16_EPI 0   // TIMING EXPERIMENT (garbage results): 1 = the epilogue instruction sequences of a split-f16 path
+#endif
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // registers R, R+1 of an activation block -> their split-bf16 operand slots (one packed convert each
 // for hi and lo); LIGHT members carry no lo part
 template <int R, bool LIGHT>
 __device__ __forceinline__ void pack_pair(const f32x16& a, ActB& o) {
   constexpr int s = R >> 3, q = (R & 7) >> 1;
+#if NPHM_F16_EPI
+  if constexpr (!LIGHT) {
+    unsigned ph, pl;
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(a[R]), "v"(a[R + 1]));
+    asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(pl) : "v"(ph), "v"(a[R]));
+    asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(pl) : "v"(ph), "v"(a[R + 1]));
+    o.hi[s][q] = ph & 0x3fff3fffu;      // keep the bf16 reading of the bits small (no inf / nan into the MFMA)
+    o.lo[s][q] = pl & 0x3fff3fffu;
+  } else {
+    const f32x2 v = {a[R], a[R + 1]};
+    const f16x2 d = __builtin_convertvector(v, f16x2);
+    const f16x2 ad = __builtin_elementwise_max(d, -d);
+    const f16x2 c1 = {(_Float16)-0.18805397f, (_Float16)-0.18805397f}, c0 = {(_Float16)0.9767937f, (_Float16)0.9767937f};
+    const f16x2 z = {(_Float16)0.f, (_Float16)0.f};
+    const f16x2 qq = __builtin_elementwise_max(ad * c1 + c0, z);
+    const f16x2 r = qq * qq + __builtin_elementwise_max(d, z);
+    o.hi[s][q] = __builtin_bit_cast(unsigned, r) & 0x3fff3fffu;
+  }
+  if constexpr (q == 3) {
+    asm volatile("" : "+v"(o.hi[s]));
+    if constexpr (!LIGHT) asm volatile("" : "+v"(o.lo[s]));
+  }
+  return;
+#endif
   // hi pair: one packed convert; its two halves widened back with a shift / a mask; lo pair: the residuals
   // through a second packed convert - 6 VALU per pair (written out: the generic __bf16 casts made hipcc
   // convert every value twice and shuffle the packed registers)
@@ -905,7 +933,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       constexpr int g = P - 1;
       constexpr bool last_block = P == 0 || g == L1_OB - 1 || g == L1_OB + L2_OB - 1 || P == CHUNKS_PER_MEMBER - 1;
       (void)last_block;
-      float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
+      float x = (LIGHT && NPHM_LIGHT_POLY) ? ((NPHM_F16_EPI && P < 1 + L1_OB + L2_OB) ? a[r] : softplus2_light(a[r])) : softplus2(a[r]);
       if constexpr (P >= 1 + L1_OB + L2_OB) {
         // lin3 block: lin4 (200 -> 1) fused; its 16 weights sit in the chunk's ring-slot tail
         if constexpr (r % 4 == 0) {
@@ -951,7 +979,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       constexpr bool LIGHT = decltype(LL)::value == 1;
       constexpr int NR = B == 6 ? LAST_BLOCK_REGS : 16;
       f32x16& a = l0_acc(BB);
-      const float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
+      const float x = (LIGHT && NPHM_LIGHT_POLY) ? (NPHM_F16_EPI ? a[r] : softplus2_light(a[r])) : softplus2(a[r]);
       if constexpr (PREC == 0) {
         H[B][r] = x;
         asm volatile("" : "+v"(H[B][r]));

@@ -3,7 +3,18 @@ src/NPHM/models/diff_operators.py (``jac`` :26-54, ``gradient`` :69-79).  They a
 hot path: the fields' differentiable (composite) tier serves them."""
 from __future__ import annotations
 
+import threading
+
 import torch
+
+# set while ``gradient`` runs its graph-recording backward pass: the HIP training tier's autograd functions
+# (ensembled_deepsdf._MemberFieldFn / _AttachGradientFn) serve a create_graph pass ONLY when nothing but the spatial
+# gradient is requested - they check this flag and raise otherwise instead of returning partial gradients
+_graph_pass = threading.local()
+
+
+def spatial_graph_pass_active() -> bool:
+    return bool(getattr(_graph_pass, "depth", 0))
 
 
 def jac(decoder_expr, xc, cond, anchors):
@@ -32,15 +43,26 @@ def gradient(outputs, inputs):
     """d outputs / d inputs[..., -3:] with an all-ones cotangent, graph retained and extended
     (diff_operators.py:69-79) — the SDF normal direction used by the losses."""
     ones = torch.ones_like(outputs)
-    g = torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=ones, create_graph=True,
-                            retain_graph=True, only_inputs=True, allow_unused=True)[0]
+    _graph_pass.depth = getattr(_graph_pass, "depth", 0) + 1
+    try:
+        g = torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=ones, create_graph=True,
+                                retain_graph=True, only_inputs=True, allow_unused=True)[0]
+    finally:
+        _graph_pass.depth -= 1
     return g[:, :, -3:]
 
 
 def inverse3x3(J):
-    """Batched 3x3 inverse.  The reference's ``Tensor.inverse()`` (= linalg.inv) is an LU factorisation followed
-    by a blocking read of its error flag; on a ROCm device the adjugate formula runs in one small kernel
-    (``nphm_inverse3x3``: no host sync, no library workspace - capturable in a hipGraph), elsewhere inv_ex."""
+    """Batched 3x3 inverse of a CONSTANT: the result never carries a graph (both callers - the root finder's initial
+    inverse Jacobian and the implicit-differentiation correction of the fitting loop - detach it; the reference's
+    ``Tensor.inverse()`` would be differentiable).  A Jacobian that requires grad is refused rather than silently cut
+    from the graph.  The reference's inverse (= linalg.inv) is an LU factorisation followed by a blocking read of
+    its error flag; on a ROCm device the adjugate formula runs in one small kernel (``nphm_inverse3x3``: no host sync,
+    no library workspace - capturable in a hipGraph; a singular matrix yields inf / nan entries instead of the
+    reference's exception), elsewhere inv_ex."""
+    if J.requires_grad:
+        raise RuntimeError("nphm_amd.diff_operators.inverse3x3 is not differentiable: pass J.detach() "
+                           "(use torch.linalg.inv for a differentiable inverse)")
     if J.is_cuda and J.dtype == torch.float32:
         from . import _lib
         lib = _lib.load()

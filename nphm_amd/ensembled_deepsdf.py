@@ -383,6 +383,13 @@ class _MemberFieldFn(torch.autograd.Function):
         n_in = 14
         if torch.is_grad_enabled():
             # graph-recording pass (gradient(pred, x), create_graph=True): _AttachGradientFn supplies d/dxyz
+            from .diff_operators import spatial_graph_pass_active
+            if not spatial_graph_pass_active():
+                # torch.autograd.grad(pred, [x, lat, ...], create_graph=True) / loss.backward(create_graph=True): this
+                # pass would have to return latent and parameter gradients as differentiable ops - it cannot
+                raise RuntimeError("nphm_amd training tier: a graph-recording backward pass is served only through "
+                                   "diff_operators.gradient(pred, x) (spatial gradient alone); for create_graph=True "
+                                   "w.r.t. latents or parameters set module.train_backend = 'composite'")
             if gG is not None:
                 raise RuntimeError("nphm_amd training tier: third-order derivatives are not implemented "
                                    "(set module.train_backend = 'composite')")

@@ -204,7 +204,7 @@ def _masked_surface_loss(sdf, thr, valid=None):
     keep = l < thr
     if valid is not None:
         keep = keep & valid.reshape(valid.shape + (1,) * (l.dim() - valid.dim()))
-    return (l * keep).sum() / keep.sum()
+    return torch.where(keep, l, torch.zeros_like(l)).sum() / keep.sum()
 
 
 class _GraphedStep:
@@ -222,6 +222,16 @@ class _GraphedStep:
         if self.graph is None:                       # once captured, backward REWRITES the static .grad buffers
             for p in self.params:
                 p.grad = None
+
+    def eager(self):
+        """one step outside the graph (a draw whose shape differs from the graph's static input): after the capture
+        backward ACCUMULATES into the graph's static .grad buffers, so they are cleared first"""
+        for p in self.params:
+            if self.graph is None:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+        return self.body()
 
     def __call__(self):
         if not self.enabled or (self.graph is None and self.calls < self.warm):
@@ -246,6 +256,43 @@ class _GraphedStep:
         return self.out
 
 
+def _run_step(step, sampler, drawn_static, drawn_cur):
+    """Draw this step's sample (host RNG, reference order) and run the step on it.  The graph reads the static index
+    tensor; observations of different sizes below n_points can yield a draw of another length (every row of a draw
+    has the length of ITS observation, fitting.py:64-70, and the reference needs them equal within a step only): such
+    a step runs eagerly on its own index tensor."""
+    drawn = sampler.draw()
+    if drawn.shape == drawn_static.shape:
+        sampler.upload(drawn, out=drawn_static)
+        drawn_cur[0] = drawn_static
+        return step()
+    drawn_cur[0] = sampler.upload(drawn)
+    try:
+        return step.eager()
+    finally:
+        drawn_cur[0] = drawn_static
+
+
+def _step_events(timing, step):
+    """HIP events around a REPLAYED step (eager steps are host-bound and not what ``timing`` reports)"""
+    if timing is None or step.graph is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    timing.setdefault("_events", []).append(ev)
+    return ev
+
+
+def _flush_timing(timing):
+    if timing is None:
+        return
+    evs = timing.pop("_events", [])
+    if evs:
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in evs]
+        timing["graph_ms"], timing["graph_steps"] = float(sum(ms) / len(ms)), len(ms)
+
+
 def _graph_default(device, verbose, *decoders):
     """hipGraph replay of the step: on by default for HIP-backed decoders on a ROCm device when nothing has to be
     printed per step (NPHM_AMD_FIT_GRAPH=0 turns it off)."""
@@ -258,7 +305,7 @@ def _graph_default(device, verbose, *decoders):
 def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[torch.Tensor], lambdas, n_steps,
                                            schedule_cfg: Dict, step_scale=1, lr_scale=1, *, verbose: bool = True,
                                            history: Optional[list] = None, compute_unused_sdf_grad: bool = False,
-                                           use_graph: Optional[bool] = None):
+                                           use_graph: Optional[bool] = None, timing: Optional[dict] = None):
     """Joint fit of one identity code and one expression code per observation (fitting.py:14-177).
     Returns (lat_rep [n_obs,1,lat_dim_expr], lat_rep_shape [1,1,lat_dim], anchors).
 
@@ -271,7 +318,9 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     point), the sampled points are gathered on the device, the surface loss over the converged correspondences is
     a masked mean, loss weights / the loss clamp are device scalars, the loss trace stays on the device until the
     loop ends (``verbose`` printing reads it every step, like the reference).  On a ROCm device the whole step
-    (forward, backward, every fused kernel) is then recorded once into a hipGraph and replayed (``use_graph``)."""
+    (forward, backward, every fused kernel) is then recorded once into a hipGraph and replayed (``use_graph``).
+    ``timing`` (a dict) receives ``graph_ms`` = mean device time of one replayed step between two HIP events on the
+    launch stream, and ``graph_steps`` (bench.py: the share of a step the GPU is busy)."""
     device = all_obs[0].device
     n_obs = len(all_obs)
     n_batch, n_points = 5, 1000
@@ -287,7 +336,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     n_iter = int(n_steps * step_scale)
     hist = _History(history, lambdas.keys(), n_iter, device, extra=("n_valid",))
     ctl = _StepControls(lambdas, device)
-    drawn_dev = sampler.upload(sampler.draw_like())          # static input of the step: the sampled indices
+    drawn_static = sampler.upload(sampler.draw_like())       # static input of the step: the sampled indices
+    drawn_cur = [drawn_static]                               # what the step reads (another tensor for odd-shaped draws)
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder, decoder_expr) and not compute_unused_sdf_grad
 
@@ -298,7 +348,7 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     def body_in_scope():
         # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
         anchors = _anchors_of(decoder, lat_rep_shape, device)
-        obs_idx, obs = sampler.gather(drawn_dev)
+        obs_idx, obs = sampler.gather(drawn_cur[0])
         glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), lat_rep[obs_idx, :, :]], dim=-1)   # [B,1,L]
         anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
 
@@ -316,7 +366,7 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
             preds_posed = preds_posed + p_corresp
             jac_posed = jac(decoder_expr, p_corresp, glob_cond, anchors_b)
-        grad_inv = _inverse3x3(jac_posed)
+        grad_inv = _inverse3x3(jac_posed.detach())
         correction = preds_posed - preds_posed.detach()
         # 3x3 matrix-vector products per point, elementwise: as an einsum this is a rocBLAS batched GEMM of 5000 3x3
         # problems (69 us forward + 40 us backward per step)
@@ -343,8 +393,10 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt, opt_expr), True)
             ctl.refresh(lambdas, j, step_scale)
             step.zero_grad()
-            sampler.upload(sampler.draw(), out=drawn_dev)
-            row, anchors = step()
+            ev = _step_events(timing, step)
+            row, anchors = _run_step(step, sampler, drawn_static, drawn_cur)
+            if ev is not None:
+                ev[1].record()
             opt.step()
             opt_expr.step()
             hist.record(j, row)
@@ -353,6 +405,7 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
                 r = row.cpu().numpy()
                 _report(j, lambdas, dict(zip(ctl.keys, r)), int(round(float(r[-1]))))
     hist.flush(done)
+    _flush_timing(timing)
     if anchors is not None:
         anchors = anchors.clone()                              # out of the graph's memory pool
 
@@ -374,13 +427,14 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
     n_iter = int(n_steps * step_scale)
     hist = _History(history, lambdas.keys(), n_iter, device)
     ctl = _StepControls(lambdas, device)
-    drawn_dev = sampler.upload(sampler.draw_like())
+    drawn_static = sampler.upload(sampler.draw_like())
+    drawn_cur = [drawn_static]
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder)
 
     def body():
         anchors = _anchors_of(decoder, lat_rep_shape, device)
-        _, obs = sampler.gather(drawn_dev)
+        _, obs = sampler.gather(drawn_cur[0])
         cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
         sdf, _ = decoder(obs, cond, None)
         loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr)}
@@ -397,8 +451,7 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
             _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt,), False)
             ctl.refresh(lambdas, j, step_scale)
             step.zero_grad()
-            sampler.upload(sampler.draw(), out=drawn_dev)
-            row, anchors = step()
+            row, anchors = _run_step(step, sampler, drawn_static, drawn_cur)
             opt.step()
             hist.record(j, row)
             done = j + 1

@@ -82,7 +82,7 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
     else:
         xc_init = obs.detach().clone()
 
-    J_inv_init = inverse3x3(jac(decoder_expr, xc_init, cond, anchors)).flatten(0, 1)    # the reference: `.inverse()`
+    J_inv_init = inverse3x3(jac(decoder_expr, xc_init, cond, anchors).detach()).flatten(0, 1)    # the reference: `.inverse()`
     x0 = xc_init.reshape(-1, 3, 1)
     # conditioning may come as one row per batch entry (cond [B,1,L], anchors [B,K,3]: what the mirrored fitting
     # loop passes); the python solver below wants the reference's per-point tensors

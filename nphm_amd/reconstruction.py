@@ -338,6 +338,8 @@ def evaluate_grid_two_stage(decoder_shape: FastEnsembleDeepSDFMirrored, decoder_
     n = (ix1 - ix0) * ry * rz
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=device)
+    elif out.numel() != n or out.dtype != torch.float32 or not out.is_contiguous() or out.device != canonical.device:
+        raise ValueError("out must be a contiguous fp32 device tensor with (ix1-ix0)*ry*rz elements")
     stream = torch.cuda.current_stream(device).cuda_stream
     ws = grid_workspace(device, ix1 - ix0, ry, rz)
     _lib.check(lib.nphm_identity_eval_grid_points(
@@ -415,6 +417,18 @@ def reorder_gathered(gathered: torch.Tensor, rx: int, plane: int, world_size: in
     return gathered.view(world_size * depth, plane).index_select(0, index).reshape(-1)
 
 
+def _takes_output(fn) -> bool:
+    """does the injected per-rank evaluator have the ``(planes, out)`` form (>= 2 positional parameters)?"""
+    import inspect
+    try:
+        params = list(inspect.signature(fn).parameters.values())
+    except (TypeError, ValueError):
+        return True
+    if any(p.kind == p.VAR_POSITIONAL for p in params):
+        return True
+    return sum(p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) for p in params) >= 2
+
+
 def evaluate_grid_sharded(decoder, encoding, axes, *, hack_chunk: Optional[int] = None, group=None,
                           evaluate=None, unit: int = 8):
     """Multi-GPU lattice evaluation: every rank evaluates its cyclic set of x-planes
@@ -422,7 +436,8 @@ def evaluate_grid_sharded(decoder, encoding, axes, *, hack_chunk: Optional[int] 
     all-gather + reorder reassembles the full volume on every rank (``gather_planes``).  The chunk
     overwrite uses global indices, so the result is bit-identical to the single-GPU volume.
     ``evaluate(planes: int32 ndarray, out: tensor)`` can be injected (CPU/gloo tests, other fields): it fills
-    ``out`` [len(planes)*ry*rz] with the values of those planes."""
+    ``out`` [len(planes)*ry*rz] with the values of those planes.  The round-1 form ``evaluate(planes) -> tensor``
+    is still accepted (its result is copied into the shard)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -436,7 +451,9 @@ def evaluate_grid_sharded(decoder, encoding, axes, *, hack_chunk: Optional[int] 
     shard = torch.empty(shard_depth(rx, world, unit) * plane, dtype=torch.float32, device=encoding.device)
     n = len(planes) * plane
     if n:
-        evaluate(planes, shard[:n])
+        res = evaluate(planes, shard[:n]) if _takes_output(evaluate) else evaluate(planes)
+        if res is not None and torch.is_tensor(res) and res.data_ptr() != shard.data_ptr():
+            shard[:n].copy_(res.reshape(-1))
     shard[n:].zero_()                           # padding of the ranks with fewer planes
     return gather_planes(shard, rx, plane, group, unit)
 

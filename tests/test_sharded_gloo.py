@@ -35,10 +35,16 @@ def _worker(rank, world, port, shape, q):
             p = torch.from_numpy(planes.astype(np.int64))
             out.copy_((p[:, None] * plane + torch.arange(plane)[None, :]).reshape(-1).float())
 
+        def evaluate_returning(planes):            # the round-1 callback form: returns the values instead of filling `out`
+            p = torch.from_numpy(planes.astype(np.int64))
+            return (p[:, None] * plane + torch.arange(plane)[None, :]).reshape(-1).float()
+
         ok = True
         for unit in (8, 2):
             full = R.evaluate_grid_sharded(None, torch.zeros(1), axes, evaluate=evaluate, unit=unit)
             ok = ok and torch.equal(full, torch.arange(rx * plane, dtype=torch.float32))
+        full = R.evaluate_grid_sharded(None, torch.zeros(1), axes, evaluate=evaluate_returning)
+        ok = ok and torch.equal(full, torch.arange(rx * plane, dtype=torch.float32))
         # the two-stage sharding cuts a rank's plane set into contiguous runs and evaluates run by run
         calls = []
         orig = R.evaluate_grid_two_stage
@@ -62,9 +68,11 @@ def _worker(rank, world, port, shape, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape", [(40, 3, 5), (21, 4, 3), (5, 4, 3), (1, 2, 2)])
-def test_all_gather_reassembles_the_volume(shape):
-    world = 2
+@pytest.mark.parametrize("shape,world", [((40, 3, 5), 2), ((21, 4, 3), 2), ((5, 4, 3), 2), ((1, 2, 2), 2),
+                                         ((512, 2, 3), 8), ((100, 1, 2), 8)])
+def test_all_gather_reassembles_the_volume(shape, world):
+    """world 2, and the 8-rank layout of BASELINE.json configs[3]: 512 x-planes as cyclic 8-plane slabs (64 planes per
+    rank), plus a ragged 100-plane case where ranks hold 16 / 12 / 8 planes and pad their shards"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -77,7 +85,7 @@ def test_all_gather_reassembles_the_volume(shape):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     planes = dict((r, b) for r, _, b in res)
-    assert sorted(planes[0] + planes[1]) == list(range(shape[0]))
+    assert sorted(sum((planes[r] for r in range(world)), [])) == list(range(shape[0]))
 
 
 def test_partitions_cover_without_overlap():

@@ -100,9 +100,11 @@ __global__ __launch_bounds__(512, 2) void chunk_body(float* out, int iters) {
   for (int q = 0; q < 4; ++q) { wh[q] = 0x2c002c00u + lane * 3; wl[q] = 0x10001000u + lane; }
   Act dst;
   const long long t0 = clock64();
-  for (int it = 0; it < iters; ++it) {
-    f32x16& acc = accs[it & 1];
-    f32x16& a = accs[(it & 1) ^ 1];
+  // two chunks per trip with STATIC register indices (a run-time index into accs / in would go through scratch)
+  auto chunk = [&](auto PAR) __attribute__((always_inline)) {
+    constexpr int par = decltype(PAR)::value;
+    f32x16& acc = accs[par];
+    f32x16& a = accs[par ^ 1];
     constexpr int NS = NKS * NPASS, NU = VARIANT == 4 ? 0 : 16;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -168,17 +170,21 @@ __global__ __launch_bounds__(512, 2) void chunk_body(float* out, int iters) {
       }
     }
     if constexpr (VARIANT != 4) {
-      // the finished operands feed the next chunk's GEMM (keeps them alive, as in the kernel)
+      // the finished operands feed the next chunks' GEMMs (keeps them alive, as in the kernel)
       asm volatile("" : "+v"(dst.hi[0]), "+v"(dst.hi[1]));
-      in[it % 7].hi[0] = dst.hi[0]; in[it % 7].hi[1] = dst.hi[1];
+      in[par].hi[0] = dst.hi[0]; in[par].hi[1] = dst.hi[1];
       if constexpr (VARIANT == 0 || VARIANT == 1 || VARIANT == 5) {
         asm volatile("" : "+v"(dst.lo[0]), "+v"(dst.lo[1]));
-        in[it % 7].lo[0] = dst.lo[0]; in[it % 7].lo[1] = dst.lo[1];
+        in[par].lo[0] = dst.lo[0]; in[par].lo[1] = dst.lo[1];
       }
-      // fresh pre-activations for the next epilogue (values that exercise exp / log, not inf)
+      // fresh pre-activations for the next epilogue: a cheap, exact-ish rescale that keeps exp / log busy with finite values
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = a[r] * 0.03125f - 0.4f;
+      for (int r = 0; r < 16; ++r) a[r] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, acc[r]) & 0x807fffffu) | 0x3e800000u);
     }
+  };
+  for (int it = 0; it < iters; it += 2) {
+    chunk(std::integral_constant<int, 0>{});
+    chunk(std::integral_constant<int, 1>{});
   }
   const long long t1 = clock64();
   float s = pad[(threadIdx.x * 7) & 511];
