@@ -39,10 +39,12 @@ FLOP_DENSE = 9_616_000            # reference formulation, 40 x 2 x 120 200 (SUR
 FLOP_MEMBER_FOLDED = 2 * 81_800   # one member, one point, latent folded
 FLOP_DEFORMATION_FOLDED = 2 * 1_074_688   # deformation backbone, latent folded
 FLOP_NPM_FOLDED = 2 * 6_292_480
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16x3a": 2500.0, "bf16x3a2": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16x3a": 2500.0, "bf16x3a2": 2500.0, "f16x3": 2500.0, "f16x3a2": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (bf16 = f16 rate)
 DTYPE = {"f32": "f32", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)",
          "bf16x3a": "bf16x3 adaptive(split-bf16 MFMA for blend weights >= 1e-3, single-pass bf16 below)",
-         "bf16x3a2": "bf16x3 adaptive(split-bf16 MFMA: 3 passes for blend weights >= 1e-2, 2 passes >= 1e-3, single-pass bf16 below)"}
+         "bf16x3a2": "bf16x3 adaptive(split-bf16 MFMA: 3 passes for blend weights >= 1e-2, 2 passes >= 1e-3, single-pass bf16 below)",
+         "f16x3": "f16x3(split-f16 MFMA, fp32 accumulate)",
+         "f16x3a2": "f16x3 adaptive(split-f16 MFMA: 3 passes for blend weights >= 8e-2, 2 passes >= 8e-3, single-pass f16 below)"}
 
 
 def parse():
@@ -52,7 +54,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--prune-tol", type=float, default=None)
-    ap.add_argument("--precision", default="bf16x3a2", choices=["f32", "bf16x3", "bf16x3a", "bf16x3a2"])
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3", "bf16x3a", "bf16x3a2", "f16x3", "f16x3a2"],
+                    help="auto (default) = the module's default: knobs calibrated for the checkpoint (numerics = 'auto')")
     ap.add_argument("--chunk", type=int, default=25000, help="get_logits chunk whose last voxel is overwritten (eval mode)")
     ap.add_argument("--workload", default="all", choices=["all", "identity", "two_stage", "npm", "fitting", "training"],
                     help="all (default) = the contract line for configs[1] with every other config / precision as "
@@ -110,8 +113,6 @@ class IdentityBench:
         self.distributed = distributed       # launched by torch.distributed.run (N = 1 takes the collective path too)
         self.R, self.lib, self._lib = R, _lib.load(), _lib
         self.net = U.build_identity(device=dev).eval()
-        if args.prune_tol is not None:
-            self.net.prune_tol = args.prune_tol
         self.lat = U.sample_latent(0).to(dev)
         self.axes = R.grid_axes(U.MINI, U.MAXI, args.res)
         self.axes_dev = [torch.from_numpy(a).to(dev) for a in self.axes]
@@ -136,9 +137,21 @@ class IdentityBench:
         self.collective_events = []      # (start, all-gather done, reorder done) on the side stream, timed steps only
         self.rank_report = None
 
+    def set_precision(self, precision):
+        """'auto' = calibrated knobs (the module's default); anything else pins the mode at prune_tol 1e-7 / --prune-tol"""
+        net = self.net
+        if precision == "auto":
+            net.numerics = "auto"
+            net.kernel_knobs(self.dev, self.lat[None])         # calibrate outside the timed region, with the latent at hand
+            c = net.calibration
+            return c["precision"]
+        net.precision = precision                              # pins the numerics
+        net.light_tol, net.mid_tol = None, None
+        net.prune_tol = self.args.prune_tol if self.args.prune_tol is not None else 1e-7
+        return precision
+
     def step(self, precision, binned, stats=None, ev=None):
         net, R = self.net, self.R
-        net.precision = precision
         packed, state, _ = net.prepare_latent(self.lat[None])
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         ws = R.grid_workspace(self.dev, self.n_planes, self.ry, self.rz) if binned and self.n_planes else None
@@ -154,7 +167,7 @@ class IdentityBench:
             self._lib.check(self.lib.nphm_identity_eval_grid_planes(
                 packed.data_ptr(), state.data_ptr(), self.axes_dev[0].data_ptr(), self.axes_dev[1].data_ptr(),
                 self.axes_dev[2].data_ptr(), self.rx, self.ry, self.rz, self.planes_dev.data_ptr(), self.n_planes,
-                self.args.chunk, float(net.prune_tol), net._precision_code(), self.shard.data_ptr(),
+                self.args.chunk, *net.kernel_knobs(self.dev, self.lat[None]), self.shard.data_ptr(),
                 None if stats is None else stats.data_ptr(), None if ws is None else ws.data_ptr(),
                 0 if ws is None else ws.numel(), stream), "eval_grid_planes")
         if ev is not None:
@@ -221,11 +234,12 @@ class IdentityBench:
 
     def record(self, precision, steps, warmup, binned=True):
         """value + roofline of one precision mode (the contract line's fields for this rank layout)"""
+        requested, precision = precision, self.set_precision(precision)
         dt, k_ms, active = self.measure(precision, steps, warmup, binned)
         n_total = self.rx * self.ry * self.rz
         n_local = max(1, self.n_planes * self.plane)
         mean_active = float(active[0]) / max(1, steps) / n_local            # evaluated member-points / point
-        passes = 1 if precision == "f32" else 3     # the split-bf16 path issues 3 bf16 MFMA products per fp32 product
+        passes = 1 if precision == "f32" else 3     # the split paths issue 3 bf16 / f16 MFMA products per fp32 product
         mean_light = float(active[15]) / max(1, steps) / n_local            # single-pass pairs (adaptive modes)
         mean_mid = float(active[14]) / max(1, steps) / n_local              # two-pass pairs (bf16x3a2)
         exec_flops = (passes * (mean_active - mean_light - mean_mid) + 2 * mean_mid + mean_light) * FLOP_MEMBER_FOLDED * n_local
@@ -238,11 +252,12 @@ class IdentityBench:
             if precision != "f32" else None
         # the events bracket the whole grid call: with binning that is the tile pre-pass + radix sort
         # (together ~1 % of it) + the dominant kernel
-        kname = "nphm::eval_kernel<%d,%d>" % (2 if binned else 1, 0 if precision == "f32" else 1)
-        tkey = kname if precision in ("bf16x3a", "bf16x3a2") else kname + ":" + precision
+        kname = "nphm::eval_kernel<%d,%d>" % (2 if binned else 1, 0 if precision == "f32" else 2 if precision.startswith("f16") else 1)
+        tkey = kname if precision in ("bf16x3a", "bf16x3a2", "f16x3a2") else kname + ":" + precision
         return {
             "value": n_total * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "dtype": DTYPE[precision],
+            "numerics": self.numerics_report(requested),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": measured_traffic(tkey, n_local), "traffic_source": TRAFFIC_SOURCE,
                          "algorithmic_bytes": 4 * n_local, "kernel": kname, "rank0_planes": self.n_planes, "binned_tiles": binned,
@@ -253,6 +268,15 @@ class IdentityBench:
                          "issued_tflops_with_tile_padding": None if issued_flops is None else issued_flops / (k_ms * 1e-3) / 1e12,
                          "dense_equiv_tflops": FLOP_DENSE * n_local / (k_ms * 1e-3) / 1e12},
         }
+
+    def numerics_report(self, requested):
+        net = self.net
+        if requested != "auto":
+            return {"mode": "fixed", "precision": net.precision, "prune_tol": net.prune_tol}
+        c = net.calibration
+        return {"mode": "auto (calibrated per checkpoint against the dense exact-fp32 kernel)", "precision": c["precision"],
+                "light_tol": c["light_tol"], "mid_tol": c["mid_tol"], "prune_tol": c["prune_tol"],
+                "sample_max_abs_err": c["error"], "target": c["target"], "sample_points": c["n_points"]}
 
     def mesh_extract(self, precision, binned):
         """second half of the BASELINE metric: latent -> SDF volume (all ranks) -> marching cubes -> vertices/faces,
@@ -317,7 +341,7 @@ def two_stage_record(args, dev, steps, warmup):
     kname = "nphm::mlp::mlp_eval_kernel<2,2,1,0>"
     return {"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice",
             "value": n * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "dtype": "bf16x3(split-bf16 MFMA) deformation + " + inet.precision + " identity",
+            "dtype": "bf16x3(split-bf16 MFMA) deformation + " + (inet.calibration or {}).get("precision", inet.precision) + " identity",
             "config": {"workload": f"NPHM identity + forward-deformation field, {args.res}^3 (BASELINE.json configs[2])",
                        "res": args.res},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
@@ -408,13 +432,13 @@ def trained_record(args, dev, steps=3):
     rec = ib.record(args.precision, steps, 1)
     axes = R.grid_axes(U.MINI, U.MAXI, 64)
     fast = R.evaluate_grid(ib.net, ib.lat, axes, hack_chunk=0)
-    ib.net.precision, ib.net.prune_tol, keep = "f32", -1.0, (ib.net.precision, ib.net.prune_tol)
+    ib.net.precision, ib.net.prune_tol = "f32", -1.0
     exact = R.evaluate_grid(ib.net, ib.lat, axes, hack_chunk=0)
-    ib.net.precision, ib.net.prune_tol = keep
     r = rec["roofline"]
     return {"metric": "SDF query throughput, NPHM identity field, trained-like checkpoint", "value": rec["value"], "unit": "Mpoints/s",
             "ms_per_step": rec["ms_per_step"], "steps": steps, "dtype": rec["dtype"],
             "config": {"workload": f"NPHM identity net, trained-like checkpoint (tests/golden/trained_state.npz), code 0, {args.res}^3", "res": args.res},
+            "numerics": rec["numerics"],
             "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms", "mean_active_members",
                                            "mean_single_pass_members", "mean_two_pass_members", "executed_flops_per_point")},
             "max_abs_err_vs_dense_f32_64cubed": float((fast - exact).abs().max()), "max_abs_sdf": float(exact.abs().max())}
@@ -771,7 +795,7 @@ def two_stage_sharded(args, world):
         print(json.dumps({"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice", "value": n * args.steps / dt / 1e6,
                           "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                          "dtype": "bf16x3(split-bf16 MFMA) deformation + " + inet.precision + " identity", "data": "synthetic (seeded random-init weights)",
+                          "dtype": "bf16x3(split-bf16 MFMA) deformation + " + (inet.calibration or {}).get("precision", inet.precision) + " identity", "data": "synthetic (seeded random-init weights)",
                           "config": {"workload": f"NPHM identity + forward-deformation field, {args.res}^3 (BASELINE.json configs[2]), sharded",
                                      "res": args.res, "parallelism": f"cyclic 8-plane x-slabs x{world} + all_gather"},
                           "ranks": {"step_ms": [round(x / args.steps * 1e3, 3) for x in allt]}, "roofline": None, "cpu_baseline": None}))
@@ -820,7 +844,7 @@ def main():
             "dtype": rec["dtype"], "data": "synthetic (seeded random-init weights, latent ~ shipped mean/std x0.85)",
             "config": {"workload": f"NPHM 39-anchor identity net, {args.res}^3 lattice extraction "
                                    f"(BASELINE.json configs[1]), eval-mode get_logits chunk {args.chunk}",
-                       "res": args.res, "prune_tol": ib.net.prune_tol, "precision": args.precision,
+                       "res": args.res, "numerics": rec["numerics"], "precision": args.precision,
                        "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather (of step k, on a side stream, under the "
                                        "kernel of step k+1)" if distributed else "single GPU")},
             # achieved counts EXECUTED matrix FLOPs (tile padding excluded); peak is the datasheet figure - an MFMA-only loop
@@ -843,7 +867,7 @@ def main():
                 "training": training_record(args, dev, with_composite=not args.no_cpu_baseline),
                 "trained_checkpoint_256": trained_record(args, dev),
             }
-            ib.net.precision = args.precision
+            ib.set_precision(args.precision)
         if not args.no_cpu_baseline and world == 1:
             out["pytorch_rocm_baseline"] = pytorch_rocm_line(ib.net, ib.lat, ib.axes_dev, args.chunk)
             out["cpu_baseline"] = cpu_baseline(ib.net, ib.lat, ib.axes, args)

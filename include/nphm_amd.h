@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 4
+#define NPHM_AMD_ABI_VERSION 5
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -56,6 +56,21 @@ int nphm_identity_supported(int lat_dim_glob, int lat_dim_loc, int n_loc, int n_
 #define NPHM_PREC_BF16X3_ADAPTIVE2 3 /* ... and two passes (xh*wh + xl*wh: weights rounded to bf16) for members that stay between
                                         NPHM_LIGHT_TOL and NPHM_MID_TOL in the wavefront; three passes from NPHM_MID_TOL on */
 #define NPHM_MID_TOL 1e-2f
+/* split-f16 flavours of the same products (v_mfma_f32_32x32x16_f16 on binary16 halves: 11-bit significands - three passes
+ * carry 22 bits against 16, the two-pass and single-pass tiers are 8x closer to fp32 than their bf16 counterparts, so
+ * their thresholds sit 8x higher at the same error; activations are exact up to 908 (131 008 in the kernels' scaled
+ * domain: beyond that the hi half saturates) */
+#define NPHM_PREC_F16X3 4            /* three passes for every member */
+#define NPHM_PREC_F16X3_ADAPTIVE2 5  /* single pass below NPHM_LIGHT_TOL_F16, two passes below NPHM_MID_TOL_F16, three from there on */
+#define NPHM_LIGHT_TOL_F16 8e-3f
+#define NPHM_MID_TOL_F16 8e-2f
+/* Per-call tier thresholds of the adaptive modes: the `precision` argument carries the mode in its low byte and,
+ * optionally, half-octave codes of the two thresholds in bits 8..15 (single-pass tier) and 16..23 (two-pass tier):
+ * code 0 = the mode's default above, code c in 1..254 = 2^(1 - c/2) (c = 21: 1.4e-3, c = 15: 1.1e-2, c = 9: 8.8e-2),
+ * 255 = tier off.  What nphm_amd.calibrate_numerics picks per checkpoint (the error of a tier scales with the member
+ * values of the checkpoint at hand; the defaults are calibrated on seeded random-init weights). */
+#define NPHM_PREC_WITH_TIERS(mode, light_code, mid_code) ((mode) | ((light_code) << 8) | ((mid_code) << 16))
+#define NPHM_TIER_TOL(code) exp2f(1.f - 0.5f * (float)(code))
 
 size_t nphm_identity_packed_bytes(void);
 size_t nphm_identity_latent_state_bytes(int n_rows);

@@ -6,9 +6,9 @@ from .deepsdf import DeepSDF, DeformationNetwork
 from .reconstruction import (create_grid_points_from_bounds, deform_mesh, get_logits,
                              get_logits_backward, grid_axes, marching_cubes, mesh_from_logits)
 from ._lib import NphmAmdError
-from .numerics import validate_numerics, validate_training_numerics
+from .numerics import calibrate_numerics, validate_numerics, validate_training_numerics
 
 __all__ = ["EnsembledDeepSDF", "EnsembledLinear", "FastEnsembleDeepSDFMirrored", "sample_point_feature",
            "DeepSDF", "DeformationNetwork", "create_grid_points_from_bounds", "deform_mesh", "get_logits",
-           "get_logits_backward", "grid_axes", "marching_cubes", "mesh_from_logits", "NphmAmdError", "validate_numerics",
+           "get_logits_backward", "grid_axes", "marching_cubes", "mesh_from_logits", "NphmAmdError", "calibrate_numerics", "validate_numerics",
            "validate_training_numerics"]

@@ -16,6 +16,8 @@ NPHM_PREC_F32 = 0
 NPHM_PREC_BF16X3 = 1
 NPHM_PREC_BF16X3_ADAPTIVE = 2
 NPHM_PREC_BF16X3_ADAPTIVE2 = 3
+NPHM_PREC_F16X3 = 4
+NPHM_PREC_F16X3_ADAPTIVE2 = 5
 
 _PtrArr5 = c_void_p * 5
 _PtrArr3 = c_void_p * 3
@@ -117,7 +119,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 4:
+    if lib.nphm_abi_version() != 5:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -32,10 +32,14 @@ namespace nphm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// PREC (template parameter of the kernel): 0 = fp32 MFMA, 1 = split bf16, 2 = split f16 (binary16 halves: same
+// structure and fragment layout as 1, v_mfma_f32_32x32x16_f16; 11-bit significands)
 struct EvalArgs {
   const float* packed_f32;
   const uint16_t* packed_bf16;
+  const uint16_t* packed_f16;
   const float* state;       // [n_rows, LS_ROW_STRIDE]
   float* out;
   unsigned long long* stats;
@@ -68,7 +72,8 @@ struct EvalArgs {
 #define NPHM_DMA_INSTREAM 1
 #endif
 // timing ablations (results are garbage): 1 = no weight streaming, 2 = no workgroup barrier, 4 = no epilogue arithmetic,
-// 16 = no wait for the weight DMA, 32 = every member streams weight set 0 / member 0's state (L2-resident stream)
+// 16 = no wait for the weight DMA, 32 = every member streams weight set 0 / member 0's state (L2-resident stream),
+// 64 = no softplus arithmetic for single-pass members only
 #ifndef NPHM_ABLATE
 #define NPHM_ABLATE 0
 #endif
@@ -123,7 +128,7 @@ __device__ __forceinline__ float softplus2(float d) {
 #define NPHM_LIGHT_POW 2   // power of the polynomial correction of softplus2_light: 8, 4 or 2 (max abs error 4.2e-3 / 1.6e-2 / 4.6e-2)
 #endif
 __device__ __forceinline__ float softplus2_light(float d) {
-  if (NPHM_ABLATE & 4) return d;
+  if (NPHM_ABLATE & (4 | 64)) return d;      // 64: only the single-pass members' softplus
 #if NPHM_LIGHT_POW == 8
   float q = fmaxf(fmaf(fabsf(d), -0.06564446f, 1.00028698f), 0.f);
   q *= q;
@@ -154,6 +159,12 @@ struct ActB {
   u32x4 hi[2], lo[2];     // dword q of hi[s] / lo[s] = k-slots 2q, 2q + 1 (bf16 pairs)
 };
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+// one 32x32x16 MFMA on 16-byte operand fragments: bf16 (F16 = false) or binary16 halves
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 // two floats -> one dword of bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   const f32x2 v = {a, b};
@@ -194,39 +205,32 @@ __device__ __forceinline__ void static_range(F&& f) {
 // slot s runs the units [unit_begin(s), unit_begin(s + 1))
 __host__ __device__ constexpr int unit_begin(int s, int ns, int nu) { return (s * nu + ns - 1) / ns; }
 
-#ifndef NPHM_F16_EPI
-#define NPHM_F16_EPI 0   // TIMING EXPERIMENT (garbage results): 1 = the epilogue instruction sequences of a split-f16 path
-#endif
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // registers R, R+1 of an activation block -> their split-bf16 operand slots (one packed convert each
 // for hi and lo); LIGHT members carry no lo part
-template <int R, bool LIGHT>
+template <int R, bool LIGHT, bool F16 = false>
 __device__ __forceinline__ void pack_pair(const f32x16& a, ActB& o) {
   constexpr int s = R >> 3, q = (R & 7) >> 1;
-#if NPHM_F16_EPI
-  if constexpr (!LIGHT) {
-    unsigned ph, pl;
-    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(a[R]), "v"(a[R + 1]));
-    asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(pl) : "v"(ph), "v"(a[R]));
-    asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(pl) : "v"(ph), "v"(a[R + 1]));
-    o.hi[s][q] = ph & 0x3fff3fffu;      // keep the bf16 reading of the bits small (no inf / nan into the MFMA)
-    o.lo[s][q] = pl & 0x3fff3fffu;
-  } else {
-    const f32x2 v = {a[R], a[R + 1]};
-    const f16x2 d = __builtin_convertvector(v, f16x2);
-    const f16x2 ad = __builtin_elementwise_max(d, -d);
-    const f16x2 c1 = {(_Float16)-0.18805397f, (_Float16)-0.18805397f}, c0 = {(_Float16)0.9767937f, (_Float16)0.9767937f};
-    const f16x2 z = {(_Float16)0.f, (_Float16)0.f};
-    const f16x2 qq = __builtin_elementwise_max(ad * c1 + c0, z);
-    const f16x2 r = qq * qq + __builtin_elementwise_max(d, z);
-    o.hi[s][q] = __builtin_bit_cast(unsigned, r) & 0x3fff3fffu;
+  if constexpr (F16) {
+    // binary16 halves.  hi: ONE v_cvt_pkrtz_f16_f32 - round toward zero, so a value beyond the f16 range saturates
+    // at 65504 instead of becoming inf (the lo half then carries the rest: exact up to 131 008 in the scaled domain,
+    // i.e. activations of 908); lo = x - hi straight into its half of the packed register: v_fma_mixlo / mixhi_f16
+    // read the f16 hi half and the fp32 value in one instruction (no widening, no second packed convert):
+    // 1.5 VALU per value against 3 on the bf16 path.  Inline asm is safe here: both inputs are VALU results
+    // (the softplus), not MFMA results.
+    const unsigned ph = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a[R], a[R + 1]));
+    o.hi[s][q] = ph;
+    if constexpr (!LIGHT) {
+      unsigned pl;
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(pl) : "v"(ph), "v"(a[R]));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(pl) : "v"(ph), "v"(a[R + 1]));
+      o.lo[s][q] = pl;
+    }
+    if constexpr (q == 3) {
+      asm volatile("" : "+v"(o.hi[s]));
+      if constexpr (!LIGHT) asm volatile("" : "+v"(o.lo[s]));
+    }
+    return;
   }
-  if constexpr (q == 3) {
-    asm volatile("" : "+v"(o.hi[s]));
-    if constexpr (!LIGHT) asm volatile("" : "+v"(o.lo[s]));
-  }
-  return;
-#endif
   // hi pair: one packed convert; its two halves widened back with a shift / a mask; lo pair: the residuals
   // through a second packed convert - 6 VALU per pair (written out: the generic __bf16 casts made hipcc
   // convert every value twice and shuffle the packed registers)
@@ -310,6 +314,13 @@ template <> struct Stream<1> {
   __host__ __device__ static constexpr int groups(int ci) {
     return ci == 0 ? 8 : (ci - 1 >= L1_OB && ci - 1 < L1_OB + L2_OB) ? 2 * L2_KS16 : 2 * L1_KS16;
   }
+};
+
+template <> struct Stream<2> : Stream<1> {
+  __device__ static __forceinline__ const char* set_base(const EvalArgs& p, int s) {
+    return reinterpret_cast<const char*>(p.packed_f16 + size_t(s) * BF_SET_STRIDE);
+  }
+  static constexpr int LS_OFF_L0 = LS_OFF_L0H;
 };
 
 template <int PREC>
@@ -517,11 +528,11 @@ __host__ __device__ constexpr bool epilogue_exposed(int P) {
 // in the shadow of that MFMA (32 cycles of matrix pipe, 4 of issue) - measured in
 // tools/micro/overlap.hip: MFMA + softplus interleaved in one wavefront cost max(...) + ~15 %, not the sum.
 // sched_barrier(0) after every slot keeps hipcc from regrouping the stream.
-template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, class Epi, class Pre, class Slot>
+template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, bool F16, class Epi, class Pre, class Slot>
 __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc, const ActB (&in)[NIN],
                                                   int lane, Epi&& epi, Pre&& pre, Slot&& slot_hook) {
-  const bf16x8* A = reinterpret_cast<const bf16x8*>(afrag) + lane;
-  bf16x8 wh[NKS16], wl[NKS16];
+  const u32x4* A = reinterpret_cast<const u32x4*>(afrag) + lane;
+  u32x4 wh[NKS16], wl[NKS16];
 #pragma unroll
   for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
     wh[ks] = A[(2 * ks) * 64];
@@ -541,9 +552,9 @@ __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc,
     constexpr int sb = ks < 2 * FULL ? (ks & 1) : 0;
     static_for<NM>([&](auto mm) __attribute__((always_inline)) {
       constexpr int m = decltype(mm)::value;
-      if constexpr (m == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], as_bf16x8(in[b].hi[sb]), acc, 0, 0, 0);
-      else if constexpr (m == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], as_bf16x8(in[b].lo[sb]), acc, 0, 0, 0);
-      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], as_bf16x8(in[b].hi[sb]), acc, 0, 0, 0);
+      if constexpr (m == 0) acc = mfma16<F16>(wh[ks], in[b].hi[sb], acc);
+      else if constexpr (m == 1) acc = mfma16<F16>(wh[ks], in[b].lo[sb], acc);
+      else acc = mfma16<F16>(wl[ks], in[b].hi[sb], acc);
       constexpr int slot = ks * NM + m;
       static_range<unit_begin(slot, NS, NU), unit_begin(slot + 1, NS, NU)>(epi);
       slot_hook(kk, mm);                   // work with its own placement (the L0 epilogues inside lin1's first chunk)
@@ -886,8 +897,8 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     PROF_T(t_m0);
     // adaptive precision (bf16 path): single-pass products for a member that weighs < light_tol at
     // every point of this wavefront (its error enters the blend scaled by that weight)
-    const bool light = PREC == 1 && !((hmask >> k) & 1ull);
-    const bool mid = PREC == 1 && !light && !((fmask >> k) & 1ull);     // two-pass tier
+    const bool light = PREC >= 1 && !((hmask >> k) & 1ull);
+    const bool mid = PREC >= 1 && !light && !((fmask >> k) & 1ull);     // two-pass tier
 
     // local coordinates (EnsembledDeepSDF.py:240-244): anchor-relative, odd member of a
     // symmetric pair mirrored in x, background member uses global coordinates
@@ -933,7 +944,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       constexpr int g = P - 1;
       constexpr bool last_block = P == 0 || g == L1_OB - 1 || g == L1_OB + L2_OB - 1 || P == CHUNKS_PER_MEMBER - 1;
       (void)last_block;
-      float x = (LIGHT && NPHM_LIGHT_POLY) ? ((NPHM_F16_EPI && P < 1 + L1_OB + L2_OB) ? a[r] : softplus2_light(a[r])) : softplus2(a[r]);
+      float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
       if constexpr (P >= 1 + L1_OB + L2_OB) {
         // lin3 block: lin4 (200 -> 1) fused; its 16 weights sit in the chunk's ring-slot tail
         if constexpr (r % 4 == 0) {
@@ -961,7 +972,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           }
         } else {
           a[r] = x;
-          if constexpr (r & 1) pack_pair<r - 1, LIGHT>(a, dst);
+          if constexpr (r & 1) pack_pair<r - 1, LIGHT, PREC == 2>(a, dst);
           if constexpr (r == NR - 1 && NR < 16) {
             // padding features of a layer's last block: zero operands (their weights are zero too,
             // but 0 x garbage could be NaN)
@@ -979,7 +990,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       constexpr bool LIGHT = decltype(LL)::value == 1;
       constexpr int NR = B == 6 ? LAST_BLOCK_REGS : 16;
       f32x16& a = l0_acc(BB);
-      const float x = (LIGHT && NPHM_LIGHT_POLY) ? (NPHM_F16_EPI ? a[r] : softplus2_light(a[r])) : softplus2(a[r]);
+      const float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
       if constexpr (PREC == 0) {
         H[B][r] = x;
         asm volatile("" : "+v"(H[B][r]));
@@ -989,7 +1000,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         }
       } else {
         a[r] = x;
-        if constexpr (r & 1) pack_pair<r - 1, LIGHT>(a, H[B]);
+        if constexpr (r & 1) pack_pair<r - 1, LIGHT, PREC == 2>(a, H[B]);
         if constexpr (r == NR - 1 && NR < 16) {
 #pragma unroll
           for (int q = NR / 2; q < 4; ++q) { H[B].hi[0][q] = 0u; H[B].lo[0][q] = 0u; }
@@ -1012,30 +1023,32 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         z = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob) * 64], bk0, z, 0, 0, 0);
         l0_acc(BB) = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * ob + 1) * 64], bk1, z, 0, 0, 0);
       } else {
-        const bf16x8* A = reinterpret_cast<const bf16x8*>(buf) + lane;
-        __bf16 xh[3], xl[3], xll[3];
+        const u32x4* A = reinterpret_cast<const u32x4*>(buf) + lane;
+        using half_t = typename std::conditional<PREC == 2, _Float16, __bf16>::type;
+        typedef half_t half8 __attribute__((ext_vector_type(8)));
+        half_t xh[3], xl[3], xll[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          xh[i] = (__bf16)coords[i];
+          xh[i] = (half_t)coords[i];
           const float r1 = coords[i] - (float)xh[i];
-          xl[i] = (__bf16)r1;
-          xll[i] = (__bf16)(r1 - (float)xl[i]);
+          xl[i] = (half_t)r1;
+          xll[i] = (half_t)(r1 - (float)xl[i]);
         }
-        const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-        bf16x8 bv;
+        const half_t one = (half_t)1.f, zero = (half_t)0.f;
+        half8 bv;
         bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
         bv[3] = h ? one : xl[0];
         bv[4] = h ? xll[0] : xl[1];
         bv[5] = h ? xll[1] : xl[2];
         bv[6] = h ? xll[2] : one;
         bv[7] = h ? zero : one;
-        l0_acc(BB) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ob * 64], bv, z, 0, 0, 0);
+        l0_acc(BB) = mfma16<PREC == 2>(A[ob * 64], __builtin_bit_cast(u32x4, bv), z);
       }
     };
     // bf16 path: the epilogues of the L0 blocks 1..6 ride inside lin1's FIRST chunk (its K-steps 2b, 2b+1
     // read block b, so block b+1 is drained there and the MFMA of block b+2 is issued ahead); only block 0
     // runs exposed.  fp32 path: all 7 blocks exposed in step 0 (an fp32 MFMA chain has shadow to spare).
-    constexpr bool L0_FUSED = PREC == 1 && NPHM_L0_FUSED;
+    constexpr bool L0_FUSED = PREC >= 1 && NPHM_L0_FUSED;
     auto step = [&](auto cc, auto LL) __attribute__((always_inline)) {
       constexpr int c = decltype(cc)::value;
       constexpr int TIER = decltype(LL)::value;            // 0: three passes, 1: one ("light"), 2: two
@@ -1092,9 +1105,10 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           else d = gemm_fused_f32<L3_KS, 6, 7, NU>(buf, d, H, lane, epi, pre);
         } else {
           constexpr int PF = LIGHT ? NPHM_PF_LIGHT : NPHM_PF_HEAVY;
-          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NPASS, PF, NU>(buf, d, H, lane, epi, pre, slot_hook);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NPASS, PF, NU>(buf, d, G, lane, epi, pre, slot_hook);
-          else d = gemm_fused_bf16<L3_KS16, 6, 7, NPASS, PF, NU>(buf, d, H, lane, epi, pre, slot_hook);
+          constexpr bool F16 = PREC == 2;
+          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NPASS, PF, NU, F16>(buf, d, H, lane, epi, pre, slot_hook);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NPASS, PF, NU, F16>(buf, d, G, lane, epi, pre, slot_hook);
+          else d = gemm_fused_bf16<L3_KS16, 6, 7, NPASS, PF, NU, F16>(buf, d, H, lane, epi, pre, slot_hook);
         }
         accs[c & 1] = d;
         if constexpr (epilogue_exposed(c)) {
@@ -1169,12 +1183,40 @@ static float nphm_mid_tol() {
   return v;
 }
 
-static bool is_adaptive(int precision) { return precision == NPHM_PREC_BF16X3_ADAPTIVE || precision == NPHM_PREC_BF16X3_ADAPTIVE2; }
+// `precision` = mode (low byte) | optional tier overrides (include/nphm_amd.h: NPHM_PREC_WITH_TIERS)
+static int prec_mode(int precision) { return precision & 0xff; }
+static bool is_f16(int precision) { return prec_mode(precision) == NPHM_PREC_F16X3 || prec_mode(precision) == NPHM_PREC_F16X3_ADAPTIVE2; }
+static bool is_adaptive(int precision) {
+  const int m = prec_mode(precision);
+  return m == NPHM_PREC_BF16X3_ADAPTIVE || m == NPHM_PREC_BF16X3_ADAPTIVE2 || m == NPHM_PREC_F16X3_ADAPTIVE2;
+}
 
 static int check_prec(int precision) {
-  if (precision != NPHM_PREC_F32 && precision != NPHM_PREC_BF16X3 && !is_adaptive(precision))
+  const int m = prec_mode(precision);
+  if (m != NPHM_PREC_F32 && m != NPHM_PREC_BF16X3 && m != NPHM_PREC_F16X3 && !is_adaptive(precision))
     return nphm_fail_msg("nphm_identity_eval: unsupported precision mode");
   return 0;
+}
+
+// tier thresholds of a precision mode (normalised blend weight below which a member runs single-pass / two-pass in a
+// wavefront): the mode's defaults, or the half-octave codes carried in bits 8..23 of `precision`
+static float tier_of_code(int code, float dflt) {
+  if (code == 0) return dflt;
+  if (code == 255) return -1.f;                       // tier switched off
+  return exp2f(1.f - 0.5f * float(code));             // NPHM_TIER_TOL(code)
+}
+static void set_tiers(nphm::EvalArgs& a, int precision) {
+  const int m = prec_mode(precision);
+  float light = -1.f, mid = -1.f;
+  if (m == NPHM_PREC_F16X3_ADAPTIVE2) { light = NPHM_LIGHT_TOL_F16; mid = NPHM_MID_TOL_F16; }
+  else if (m == NPHM_PREC_BF16X3_ADAPTIVE2) { light = NPHM_LIGHT_TOL; mid = nphm_mid_tol(); }
+  else if (m == NPHM_PREC_BF16X3_ADAPTIVE) light = NPHM_LIGHT_TOL;
+  if (is_adaptive(precision)) {
+    light = tier_of_code((precision >> 8) & 0xff, light);
+    if (m != NPHM_PREC_BF16X3_ADAPTIVE) mid = tier_of_code((precision >> 16) & 0xff, mid);
+  }
+  a.light_tol = light;
+  a.mid_tol = mid;
 }
 
 static void fill_common(nphm::EvalArgs& a, const void* packed, const void* latent_state, float* out,
@@ -1182,6 +1224,7 @@ static void fill_common(nphm::EvalArgs& a, const void* packed, const void* laten
   memset(&a, 0, sizeof(a));
   a.packed_f32 = static_cast<const float*>(packed);
   a.packed_bf16 = reinterpret_cast<const uint16_t*>(static_cast<const char*>(packed) + nphm::PACKED_F32_FLOATS * 4);
+  a.packed_f16 = a.packed_bf16 + nphm::PACKED_BF16_HALFS;
   a.state = static_cast<const float*>(latent_state);
   a.out = out;
   a.stats = stats;
@@ -1225,8 +1268,7 @@ size_t nphm_identity_grid_workspace_bytes(int n_x_local, int ry, int rz) {
 
 static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t workspace_bytes, hipStream_t st,
                        const char* who) {
-  a.light_tol = is_adaptive(precision) ? NPHM_LIGHT_TOL : -1.f;
-  a.mid_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE2 ? nphm_mid_tol() : -1.f;
+  set_tiers(a, precision);
 #if NPHM_PROF
   if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
 #endif
@@ -1252,7 +1294,8 @@ static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t
     const int64_t round = nphm::XCD_RUN > 1 ? 8 * int64_t(nphm::XCD_RUN) : 1;
     const int64_t groups = ((l.n_tiles + nphm::NW - 1) / nphm::NW + round - 1) / round * round;
     const dim3 grid((unsigned)groups), block(64 * nphm::NW);
-    if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<2, 0>), grid, block, 0, st, a);
+    if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<2, 0>), grid, block, 0, st, a);
+    else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<2, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((nphm::eval_kernel<2, 1>), grid, block, 0, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return nphm_fail(who, e);
@@ -1266,7 +1309,8 @@ static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t
   const int64_t bricks = supers * (nphm::SBX * nphm::SBY * nphm::SBZ);
   if (bricks > 0x7fffffffLL) return nphm_fail_msg("slab too large for one launch");
   const dim3 grid((unsigned)bricks), block(64 * nphm::NW);
-  if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), grid, block, 0, st, a);
+  if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), grid, block, 0, st, a);
+  else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<1, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((nphm::eval_kernel<1, 1>), grid, block, 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail(who, e);
@@ -1288,12 +1332,12 @@ int nphm_identity_eval_points(const void* packed, const void* latent_state,
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_identity_eval_points: too many points");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * nphm::NW);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  a.light_tol = is_adaptive(precision) ? NPHM_LIGHT_TOL : -1.f;
-  a.mid_tol = precision == NPHM_PREC_BF16X3_ADAPTIVE2 ? nphm_mid_tol() : -1.f;
+  set_tiers(a, precision);
 #if NPHM_PROF
   if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
 #endif
-  if (precision == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), grid, block, 0, st, a);
+  if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), grid, block, 0, st, a);
+  else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<0, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((nphm::eval_kernel<0, 1>), grid, block, 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_eval_points launch", e);

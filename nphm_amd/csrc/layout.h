@@ -84,10 +84,14 @@ constexpr int BF_OFF_L3A = BF_OFF_L2A + BF_SZ_L2A;
 constexpr int BF_SZ_L3A = L3_OB * L3_KS16 * 2 * 64 * 8;
 constexpr int BF_SET_STRIDE = BF_OFF_L3A + BF_SZ_L3A;               // uint16 per weight set
 
-// whole packed buffer: [fp32 sets | bf16 sets]
+// whole packed buffer: [fp32 sets | bf16 sets | f16 sets].  The split-f16 fragments have the layout of the split-bf16
+// ones (same K order, [ob][kstep][hi|lo][lane][8]); the halves are IEEE binary16: 11-bit significands, so the
+// three-term product carries 22 bits (bf16: 16) and the two-term / single-pass tiers are 8x closer to fp32; the lo
+// halves of typical weights are f16 subnormals, which v_mfma_f32_32x32x16_f16 does not flush (tools/micro/f16split.hip)
 constexpr size_t PACKED_F32_FLOATS = size_t(N_SETS) * SET_STRIDE;
 constexpr size_t PACKED_BF16_HALFS = size_t(N_SETS) * BF_SET_STRIDE;
-constexpr size_t PACKED_BYTES = PACKED_F32_FLOATS * 4 + PACKED_BF16_HALFS * 2;
+constexpr size_t PACKED_F16_HALFS = size_t(N_SETS) * BF_SET_STRIDE;
+constexpr size_t PACKED_BYTES = PACKED_F32_FLOATS * 4 + PACKED_BF16_HALFS * 2 + PACKED_F16_HALFS * 2;
 
 // ---- streaming units ---------------------------------------------------------------------------
 // A member is consumed as 19 chunks: chunk 0 = its L0 block (lin0 restricted to the 3 coordinates
@@ -101,12 +105,14 @@ constexpr int TAIL_FLOATS = 64;
 constexpr int L0_BLOCK_FLOATS = 2048;                       // 8 KiB per member and precision
 //   fp32 L0 block : float [ob 7][ks 2][lane 64]   A[i][k=h]: ks0 = (w_x, w_y), ks1 = (w_z, bias)
 //   bf16 L0 block : bf16  [ob 7][lane 64][8]      one K=16 step, see prepare_latent_kernel
+//   f16 L0 block  : the same with binary16 halves
 
 // ---- per-latent state (one per batch row), in floats ----------------------------------------------
 constexpr int LS_OFF_TAIL = 0;                                              // [member][18][64]
 constexpr int LS_OFF_L0F = LS_OFF_TAIL + N_MEMBERS * GEMM_CHUNKS * TAIL_FLOATS;   // [member][2048]
 constexpr int LS_OFF_L0B = LS_OFF_L0F + N_MEMBERS * L0_BLOCK_FLOATS;        // [member][2048]
-constexpr int LS_OFF_ANCH = LS_OFF_L0B + N_MEMBERS * L0_BLOCK_FLOATS;       // anchors [39][3]
+constexpr int LS_OFF_L0H = LS_OFF_L0B + N_MEMBERS * L0_BLOCK_FLOATS;        // [member][2048] (f16 fragments)
+constexpr int LS_OFF_ANCH = LS_OFF_L0H + N_MEMBERS * L0_BLOCK_FLOATS;       // anchors [39][3]
 constexpr int LS_ROW_STRIDE = LS_OFF_ANCH + 128;
 
 __host__ __device__ constexpr int member_set(int k) {

@@ -20,6 +20,7 @@ struct PackArgs {
   const float* b[5];
   float* out_f32;
   uint16_t* out_bf16;
+  uint16_t* out_f16;
 };
 
 __device__ inline uint16_t f32_to_bf16_rn(float x) {
@@ -28,6 +29,9 @@ __device__ inline uint16_t f32_to_bf16_rn(float x) {
   return uint16_t(r >> 16);
 }
 __device__ inline float bf16_to_f32(uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+// IEEE binary16, round to nearest even (subnormals kept)
+__device__ inline uint16_t f32_to_f16_rn(float x) { return __builtin_bit_cast(uint16_t, (_Float16)x); }
+__device__ inline float f16_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
 
 // value of the (row, k-feature) entry of the GEMM layer L (1,2,3) for weight set s
 __device__ inline float layer_weight(const PackArgs& a, int L, int s, int row, int kf) {
@@ -84,6 +88,10 @@ __global__ void pack_bf16_kernel(PackArgs a) {
   const uint16_t hi = f32_to_bf16_rn(w);
   const uint16_t lo = f32_to_bf16_rn(w - bf16_to_f32(hi));
   a.out_bf16[size_t(s) * BF_SET_STRIDE + e] = part ? lo : hi;
+  // the split-f16 fragments: same position, binary16 halves
+  const uint16_t hh = f32_to_f16_rn(w);
+  const uint16_t hl = f32_to_f16_rn(w - f16_to_f32(hh));
+  a.out_f16[size_t(s) * BF_SET_STRIDE + e] = part ? hl : hh;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -198,6 +206,31 @@ __global__ __launch_bounds__(256) void prepare_latent_kernel(PrepArgs a) {
       }
       l0b[e] = v;
     }
+    // L0 block, split f16: the same K = 16 step with binary16 halves
+    uint16_t* l0h = reinterpret_cast<uint16_t*>(st + LS_OFF_L0H + size_t(k) * L0_BLOCK_FLOATS);
+    for (int e = t; e < 2 * L0_BLOCK_FLOATS; e += blockDim.x) {
+      uint16_t v = 0;
+      if (e < 7 * 64 * 8) {
+        const int i = e & 7, lane = (e >> 3) & 63, ob = e >> 9;
+        const int f = 32 * ob + (lane & 31), hh = lane >> 5;
+        if (f < HID) {
+          const float* w0 = a.w[0] + (size_t(s) * HID + f) * D_IN;
+          const float bias = b0f[f] * SP_SCALE;
+          const uint16_t bh = f32_to_f16_rn(bias);
+          const float r1 = bias - f16_to_f32(bh);
+          const uint16_t bm = f32_to_f16_rn(r1);
+          const uint16_t bl = f32_to_f16_rn(r1 - f16_to_f32(bm));
+          auto whi = [&](int c) { return f32_to_f16_rn(w0[c] * SP_SCALE); };
+          auto wlo = [&](int c) {
+            const float w = w0[c] * SP_SCALE;
+            return f32_to_f16_rn(w - f16_to_f32(f32_to_f16_rn(w)));
+          };
+          if (hh == 0) v = i < 3 ? whi(i) : i < 6 ? whi(i - 3) : i == 6 ? bh : bm;
+          else v = i < 3 ? wlo(i) : i == 3 ? bl : i < 7 ? whi(i - 4) : uint16_t(0);
+        }
+      }
+      l0h[e] = v;
+    }
   } else {
     // anchors = mlp_pos(z_glob) + mean anchors (EnsembledDeepSDF.py:228-229)
     float* h1 = sh;
@@ -258,6 +291,7 @@ int nphm_identity_pack(const float* const lin_weight[5], const float* const lin_
   }
   a.out_f32 = static_cast<float*>(packed);
   a.out_bf16 = reinterpret_cast<uint16_t*>(static_cast<char*>(packed) + nphm::PACKED_F32_FLOATS * 4);
+  a.out_f16 = a.out_bf16 + nphm::PACKED_BF16_HALFS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 g1((nphm::SET_STRIDE + 255) / 256, nphm::N_SETS);
   hipLaunchKernelGGL(nphm::pack_f32_kernel, g1, dim3(256), 0, st, a);

@@ -528,11 +528,22 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
 
         # ---- execution knobs (defaults keep reference numerics within 1e-4) -------------------
         self.backend = "hip"            # "hip" | "composite"
-        self.prune_tol = float(os.environ.get("NPHM_AMD_PRUNE_TOL", "1e-7"))
-        # "bf16x3a2" (default): per wavefront, single-pass bf16 for members below 1e-3 normalised blend weight, two
-        # passes (weights rounded to bf16) below 1e-2, the full three-pass split-bf16 product from there on |
-        # "bf16x3a": the same without the two-pass tier | "bf16x3": split-bf16 everywhere | "f32": exact products
-        self.precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3a2")
+        # Knobs of the inference kernels (eval_kernel.hip).  numerics = "auto" (default): pruning tolerance, precision
+        # mode and tier thresholds are CALIBRATED per checkpoint (numerics.calibrate_numerics: the fastest setting whose
+        # error against the dense exact-fp32 kernel stays a decade inside the 1e-4 bar for the weights at hand; once per
+        # weight version, a few ms).  Assigning ``precision`` / ``prune_tol`` / a tier threshold (or NPHM_AMD_PRECISION /
+        # NPHM_AMD_PRUNE_TOL) pins them: numerics = "fixed".
+        # "bf16x3a2": per wavefront, single-pass bf16 for members below 1e-3 normalised blend weight, two passes (weights
+        # rounded to bf16) below 1e-2, the full three-pass split-bf16 product from there on | "bf16x3a": the same without
+        # the two-pass tier | "bf16x3": split-bf16 everywhere | "f16x3a2" / "f16x3": the same on binary16 halves (thresholds
+        # 8e-3 / 8e-2) | "f32": exact products.  ``prune_tol`` is also the tolerance of the autograd / training tiers.
+        self._prune_tol = float(os.environ.get("NPHM_AMD_PRUNE_TOL", "1e-7"))
+        self._precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3a2")
+        self._light_tol = None          # tier thresholds of the adaptive modes (None: the mode's default)
+        self._mid_tol = None
+        pinned = "NPHM_AMD_PRECISION" in os.environ or "NPHM_AMD_PRUNE_TOL" in os.environ
+        self.numerics = os.environ.get("NPHM_AMD_NUMERICS", "fixed" if pinned else "auto")
+        self._calibration = None        # (weights key, preset dict) of numerics = "auto"
         self._pack_cache = None         # (key, packed tensor)
         self._pack_bwd_cache = None     # (key, transposed pack for the backward kernel)
         # latent fitting with the REFERENCE's unchanged fitting.py: it leaves the decoder's parameters trainable and
@@ -661,9 +672,59 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             state.data_ptr(), anchors.data_ptr(), stream), "nphm_identity_prepare_latent")
         return packed, state, anchors
 
+    # ---- knobs: plain attributes to the caller; assigning one pins the numerics ----------------------------
+    def _pin(self, name, value):
+        object.__setattr__(self, name, value)
+        object.__setattr__(self, "numerics", "fixed")
+
+    prune_tol = property(lambda self: self._prune_tol, lambda self, v: self._pin("_prune_tol", float(v)))
+    precision = property(lambda self: self._precision, lambda self, v: self._pin("_precision", v))
+    light_tol = property(lambda self: self._light_tol, lambda self, v: self._pin("_light_tol", v))
+    mid_tol = property(lambda self: self._mid_tol, lambda self, v: self._pin("_mid_tol", v))
+
+    _MODES = {"f32": _lib.NPHM_PREC_F32, "bf16x3": _lib.NPHM_PREC_BF16X3, "bf16x3a": _lib.NPHM_PREC_BF16X3_ADAPTIVE,
+              "bf16x3a2": _lib.NPHM_PREC_BF16X3_ADAPTIVE2, "f16x3": _lib.NPHM_PREC_F16X3,
+              "f16x3a2": _lib.NPHM_PREC_F16X3_ADAPTIVE2}
+
+    @staticmethod
+    def _tier_code(tol):
+        """half-octave code of a tier threshold (include/nphm_amd.h: NPHM_PREC_WITH_TIERS): the largest representable
+        threshold <= tol; None -> 0 (the mode's default), tol <= 0 -> 255 (tier off)"""
+        if tol is None:
+            return 0
+        if tol <= 0:
+            return 255
+        import math
+        return int(min(254, max(1, math.ceil(2.0 * (1.0 - math.log2(tol)) - 1e-9))))
+
+    @staticmethod
+    def precision_code(precision, light_tol=None, mid_tol=None):
+        T = FastEnsembleDeepSDFMirrored
+        return T._MODES[precision] | (T._tier_code(light_tol) << 8) | (T._tier_code(mid_tol) << 16)
+
     def _precision_code(self):
-        return {"f32": _lib.NPHM_PREC_F32, "bf16x3": _lib.NPHM_PREC_BF16X3,
-                "bf16x3a": _lib.NPHM_PREC_BF16X3_ADAPTIVE, "bf16x3a2": _lib.NPHM_PREC_BF16X3_ADAPTIVE2}[self.precision]
+        return self.precision_code(self._precision, self._light_tol, self._mid_tol)
+
+    def kernel_knobs(self, device=None, lat_rows=None):
+        """(prune_tol, precision code with its tier thresholds) of the inference kernels: the pinned values, or with
+        numerics = "auto" on a ROCm device the setting calibrated for the current weights (cached per weight
+        version - the first call after a weight change calibrates, with ``lat_rows`` [B, lat_dim] when given;
+        ``calibration`` holds the report)."""
+        if self.numerics != "auto" or device is None or torch.device(device).type != "cuda":
+            return float(self._prune_tol), self._precision_code()
+        ws, bs = self._lin_params()
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in ws + bs) + (str(device),)
+        if self._calibration is None or self._calibration[0] != key:
+            from .numerics import calibrate_numerics
+            lat = None if lat_rows is None else lat_rows.detach().reshape(-1, self.lat_dim)[:2]
+            object.__setattr__(self, "_calibration", (key, calibrate_numerics(self, lat, device=device)))
+        c = self._calibration[1]
+        return float(c["prune_tol"]), self.precision_code(c["precision"], c["light_tol"], c["mid_tol"])
+
+    @property
+    def calibration(self):
+        """report of the last calibration (numerics = "auto"), or None"""
+        return None if self._calibration is None else self._calibration[1]
 
     def _forward_hip(self, xyz, lat_rows):
         lib = _lib.load()
@@ -674,7 +735,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         stream = torch.cuda.current_stream(xyz.device).cuda_stream
         _lib.check(lib.nphm_identity_eval_points(
             packed.data_ptr(), state.data_ptr(), xyz.data_ptr(), B, N, 0 if self.training else N,
-            float(self.prune_tol), self._precision_code(), out.data_ptr(), None, stream),
+            *self.kernel_knobs(xyz.device, lat_rows), out.data_ptr(), None, stream),
             "nphm_identity_eval_points")
         return out, anchors
 

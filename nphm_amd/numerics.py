@@ -28,11 +28,16 @@ from . import _lib
 
 LIGHT_TOL = 1e-3
 MID_TOL = 1e-2
+# tiers of a precision mode: (single-pass threshold, two-pass threshold, rounding level of a single-pass member,
+# ... of a two-pass member); the f16 modes carry 3 more significand bits at 8x the thresholds (include/nphm_amd.h)
+TIERS = {"bf16x3a": (LIGHT_TOL, None, 2.0 ** -8, 0.0), "bf16x3a2": (LIGHT_TOL, MID_TOL, 2.0 ** -8, 2.0 ** -9),
+         "f16x3a2": (8e-3, 8e-2, 2.0 ** -11, 2.0 ** -12)}
 
 
 def _sample_points(anchors: torch.Tensor, n: int, seed: int) -> torch.Tensor:
     """n points: half on a coarse lattice of the reference's extraction box, half Gaussian clouds around the
-    anchors (sigma 0.03 and 0.1: inside and at the edge of the blend kernels)."""
+    anchors (sigma 0.03, 0.1 and 0.25: inside the blend kernels, at their edge, and in the transition to the far
+    field where members with tiny weights predict large values - the worst case of the pruning rule)."""
     dev = anchors.device
     g = torch.Generator().manual_seed(seed)
     lo, hi = torch.tensor([-.55, -.5, -.95]), torch.tensor([0.55, 0.75, 0.4])
@@ -42,9 +47,54 @@ def _sample_points(anchors: torch.Tensor, n: int, seed: int) -> torch.Tensor:
     k = n - lattice.shape[0]
     a = anchors.reshape(-1, 3).cpu()
     pick = a[torch.randint(0, a.shape[0], (k,), generator=g)]
-    sigma = torch.where(torch.rand(k, 1, generator=g) < 0.5, torch.tensor(0.03), torch.tensor(0.1))
+    u = torch.rand(k, 1, generator=g)
+    sigma = torch.where(u < 0.4, torch.tensor(0.03), torch.where(u < 0.75, torch.tensor(0.1), torch.tensor(0.25)))
     near = pick + sigma * torch.randn(k, 3, generator=g)
     return torch.cat([lattice, near], 0).to(dev).contiguous()
+
+
+# lattice spacing of the reference's extraction box at 512^3 (the finest BASELINE config): the tiles of the sample
+# below are the 4 x 4 x 2-voxel tiles one wavefront of the grid kernels works on.  Pruning and the precision tiers
+# are decided per wavefront (a member survives / keeps the full product when ANY of the 32 points asks for it), so
+# their error depends on the tile geometry: points scattered over a wavefront (nphm_identity_eval_points on a random
+# sample) share far more members than a compact tile and measure a several times smaller error than a real
+# lattice extraction shows.
+_TILE_SPACING = ((0.55 + 0.55) / 511.0, (0.75 + 0.5) / 511.0, (0.4 + 0.95) / 511.0)
+
+
+def _sample_tiles(anchors: torch.Tensor, n_tiles: int, seed: int):
+    """Lattice-ordered sample for nphm_identity_eval_grid_points: an index lattice [rx, ry, rz] whose 4x4x2 index tiles
+    are compact physical tiles (512^3 spacing of the reference box) centred on n_tiles sample positions - half uniform
+    in the box, half Gaussian clouds around the anchors (``_sample_points``).  Returns (xyz [rx*ry*rz, 3], (rx, ry, rz))."""
+    a = 1
+    while a * a * a < n_tiles:
+        a *= 2
+    b = a
+    c = max(1, n_tiles // (a * b))
+    while a * b * c < n_tiles:
+        c *= 2
+    T = a * b * c
+    centres = _sample_points(anchors, T, seed)                       # [T, 3], device of the anchors
+    dev = centres.device
+    g = torch.Generator().manual_seed(seed + 7)
+    lo, hi = torch.tensor([-.55, -.5, -.95]), torch.tensor([0.55, 0.75, 0.4])
+    centres[: T // 2] = (torch.rand(T // 2, 3, generator=g) * (hi - lo) + lo).to(dev)   # the lattice half: uniform in the box
+    h = torch.tensor(_TILE_SPACING, device=dev)
+    rx, ry, rz = 4 * a, 4 * b, 2 * c
+    ix, iy, iz = torch.meshgrid(torch.arange(rx, device=dev), torch.arange(ry, device=dev), torch.arange(rz, device=dev), indexing="ij")
+    tile = ((ix // 4) * b + (iy // 4)) * c + (iz // 2)
+    off = torch.stack([ix % 4, iy % 4, iz % 2], dim=-1).float() * h
+    xyz = centres[tile.reshape(-1)] + off.reshape(-1, 3)
+    return xyz.contiguous(), (rx, ry, rz)
+
+
+def _eval_tiles(lib, decoder, packed, state, xyz, dims, code, prune, stream):
+    rx, ry, rz = dims
+    out = torch.empty(rx * ry * rz, dtype=torch.float32, device=xyz.device)
+    _lib.check(lib.nphm_identity_eval_grid_points(packed.data_ptr(), state.data_ptr(), xyz.data_ptr(), rx, ry, rz, 0, rx, 0,
+                                                  float(prune), code, out.data_ptr(), None, None, 0, stream),
+               "nphm_identity_eval_grid_points")
+    return out
 
 
 def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 1 << 16, *, tol: float = 1e-5,
@@ -62,7 +112,11 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
         latents = torch.zeros(1, decoder.lat_dim, device=dev)
     latents = latents.reshape(-1, decoder.lat_dim).to(device=dev, dtype=torch.float32)
     A = decoder.num_kps + 1
-    saved = (decoder.precision, decoder.prune_tol, getattr(decoder, "_needs_validation", False))
+    prune_eff, code_eff = decoder.kernel_knobs(dev)              # pinned, or calibrated (numerics = "auto")
+    eff = decoder.calibration if decoder.numerics == "auto" else None
+    precision_eff = eff["precision"] if eff else decoder.precision
+    light_eff, mid_eff = (eff["light_tol"], eff["mid_tol"]) if eff else (decoder.light_tol, decoder.mid_tol)
+    saved = (precision_eff, prune_eff, getattr(decoder, "_needs_validation", False))
     decoder._needs_validation = False
     worst = {"max_abs_diff": 0.0, "max_pruned": 0.0, "max_light": 0.0, "max_two_pass": 0.0, "max_abs_sdf": 0.0,
              "max_abs_member": 0.0}
@@ -70,7 +124,6 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
         with torch.no_grad():
             for r in range(latents.shape[0]):
                 lat = latents[r:r + 1]
-                decoder.precision, decoder.prune_tol = saved[0], saved[1]
                 packed, state, anchors = decoder.prepare_latent(lat)
                 pts = (points.to(dev).float() if points is not None else _sample_points(anchors[0], n, seed + r))[None]
                 N = pts.shape[1]
@@ -82,8 +135,15 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
                                                              float(prune), prec_code, out.data_ptr(), None, stream),
                                "nphm_identity_eval_points")
                     return out
-                fast = run(decoder._precision_code(), decoder.prune_tol)
-                dense = run(_lib.NPHM_PREC_F32, -1.0)
+                if points is None:
+                    # the comparison proper on compact lattice tiles (what an extraction evaluates); the per-member
+                    # analysis below stays on the scattered sample
+                    txyz, tdims = _sample_tiles(anchors[0], max(256, n // 32), seed + r)
+                    fast = _eval_tiles(lib, decoder, packed, state, txyz, tdims, code_eff, prune_eff, stream)
+                    dense = _eval_tiles(lib, decoder, packed, state, txyz, tdims, _lib.NPHM_PREC_F32, -1.0, stream)
+                else:
+                    fast = run(code_eff, prune_eff)
+                    dense = run(_lib.NPHM_PREC_F32, -1.0)
                 # every member's value at every point (member-centric kernel, all pairs listed)
                 what_all, tiles, plist = _member_point_lists(anchors, pts, -1.0, A)
                 fmem = torch.zeros(1, N, A, dtype=torch.float32, device=dev)
@@ -92,15 +152,17 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
                                                             tiles.shape[0], None, plist.data_ptr(), fmem.data_ptr(), stream),
                            "nphm_identity_member_forward")
                 contrib = what_all * fmem.abs()                                   # w_k |f_k|, [1,N,A]
-                if decoder.prune_tol >= 0:
-                    kept = _member_point_lists(anchors, pts, decoder.prune_tol, A)[0] > 0
+                if prune_eff >= 0:
+                    kept = _member_point_lists(anchors, pts, prune_eff, A)[0] > 0
                     pruned = (contrib * (~kept)).sum(dim=2)
                 else:
                     pruned = torch.zeros_like(contrib[..., 0])
-                light = contrib * (what_all < LIGHT_TOL) * 2.0 ** -8 if decoder.precision.startswith("bf16x3a") else contrib * 0
-                # two-pass members (bf16x3a2): weights rounded to bf16, a 2^-9 relative perturbation of the member
-                mid = (contrib * ((what_all >= LIGHT_TOL) & (what_all < MID_TOL)) * 2.0 ** -9
-                       if decoder.precision == "bf16x3a2" else contrib * 0)
+                t_light, t_mid, r_light, r_mid = TIERS.get(precision_eff, (None, None, 0.0, 0.0))
+                t_light = light_eff if (light_eff is not None and t_light is not None) else t_light
+                t_mid = mid_eff if (mid_eff is not None and t_mid is not None) else t_mid
+                light = contrib * (what_all < t_light) * r_light if t_light is not None else contrib * 0
+                # two-pass members: weights rounded to bf16 / f16, a 2^-9 / 2^-12 relative perturbation of the member
+                mid = contrib * ((what_all >= t_light) & (what_all < t_mid)) * r_mid if t_mid is not None else contrib * 0
                 worst["max_abs_diff"] = max(worst["max_abs_diff"], float((fast - dense).abs().max()))
                 worst["max_pruned"] = max(worst["max_pruned"], float(pruned.max()))
                 worst["max_light"] = max(worst["max_light"], float(light.max()))
@@ -108,8 +170,9 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
                 worst["max_abs_sdf"] = max(worst["max_abs_sdf"], float(dense.abs().max()))
                 worst["max_abs_member"] = max(worst["max_abs_member"], float(fmem.abs().max()))
     finally:
-        decoder.precision, decoder.prune_tol, decoder._needs_validation = saved
-    worst.update(n_points=int(N), n_latents=int(latents.shape[0]), precision=saved[0], prune_tol=saved[1], tol=tol)
+        decoder._needs_validation = saved[2]
+    worst.update(n_points=int(N), n_latents=int(latents.shape[0]), precision=saved[0], prune_tol=saved[1], tol=tol,
+                 light_tol=light_eff, mid_tol=mid_eff, numerics=decoder.numerics)
     worst["ok"] = bool(worst["max_abs_diff"] <= tol and worst["max_pruned"] <= tol)
     if not worst["ok"]:
         msg = ("nphm_amd.validate_numerics: the fast mode (precision %s, prune_tol %g) deviates from the dense fp32 kernel "
@@ -120,6 +183,67 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
             raise _lib.NphmAmdError(msg)
         warnings.warn(msg)
     return worst
+
+
+# ---- per-checkpoint calibration (numerics = "auto") -------------------------------------------------------------------
+# Two coordinates, searched greedily: the pruning budget with every member on the full three-pass product, then the tier
+# thresholds at that budget.  Candidates from the fastest to the safest setting:
+PRUNE_LADDER = (1e-7, 3e-8, 1e-8, 3e-9, 1e-9, -1.0)
+TIER_LADDER = ((8e-3, 8e-2), (4e-3, 4e-2), (2e-3, 2e-2), (1e-3, 1e-2), (5e-4, 5e-3), (2.5e-4, 2.5e-3), (None, None))
+
+
+def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 1 << 19, *, target: float = 5e-6,
+                       seed: int = 0, device=None) -> dict:
+    """Fastest setting of the inference kernels (pruning tolerance, split-f16 tiers) whose error against the dense
+    exact-fp32 kernel stays <= ``target`` on ``n`` sample points per latent - n / 32 compact 4x4x2 lattice tiles at the
+    512^3 spacing of the reference box, half of them uniform in the box, half in clouds around the anchors
+    (``_sample_tiles``) - for the weights the decoder holds NOW.  ``target`` defaults to 5e-6: half of a tenth of the 1e-4 bar (margin for the points
+    the sample does not hold; DESIGN.md section 3 compares the sample maximum with full 256^3 volumes).  ``latents``
+    [R, lat_dim]: the codes to calibrate with (``kernel_knobs`` passes the code of the call that triggers it; default:
+    the zero code = mean anchors).  Returns {"precision", "light_tol", "mid_tol", "prune_tol",
+    "error", "searched": [(setting, error)]}; what ``decoder.kernel_knobs`` uses when ``decoder.numerics == "auto"``."""
+    lib = _lib.load()
+    dev = torch.device(device) if device is not None else next(decoder.parameters()).device
+    if dev.type != "cuda" or not decoder.hip_supported():
+        raise _lib.NphmAmdError("calibrate_numerics needs the HIP-backed NPHM identity field on a ROCm device")
+    if latents is None:
+        latents = torch.zeros(1, decoder.lat_dim, device=dev)
+    latents = latents.reshape(-1, decoder.lat_dim).to(device=dev, dtype=torch.float32)
+    searched = []
+    with torch.no_grad():
+        cases = []
+        for r in range(latents.shape[0]):
+            packed, state, anchors = decoder.prepare_latent(latents[r:r + 1])
+            xyz, dims = _sample_tiles(anchors[0], max(256, n // 32), seed + r)
+            cases.append((packed, state, xyz, dims))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def run(case, code, prune):
+            packed, state, xyz, dims = case
+            return _eval_tiles(lib, decoder, packed, state, xyz, dims, code, prune, stream)
+        dense = [run(c, _lib.NPHM_PREC_F32, -1.0) for c in cases]
+
+        def err_of(precision, light, mid, prune):
+            code = decoder.precision_code(precision, light, mid)
+            e = max(float((run(c, code, prune) - d).abs().max()) for c, d in zip(cases, dense))
+            searched.append(({"precision": precision, "light_tol": light, "mid_tol": mid, "prune_tol": prune}, e))
+            return e
+        # 1. pruning budget, three-pass product everywhere: half of the target
+        prune, e_prune = PRUNE_LADDER[-1], None
+        for cand in PRUNE_LADDER:
+            e = err_of("f16x3", None, None, cand)
+            if e <= 0.5 * target or cand == PRUNE_LADDER[-1]:
+                prune, e_prune = cand, e
+                break
+        # 2. tier thresholds at that budget: the whole target
+        choice, e_choice = ("f16x3", None, None), e_prune
+        for light, mid in TIER_LADDER[:-1]:
+            e = err_of("f16x3a2", light, mid, prune)
+            if e <= target:
+                choice, e_choice = ("f16x3a2", light, mid), e
+                break
+    return {"precision": choice[0], "light_tol": choice[1], "mid_tol": choice[2], "prune_tol": prune, "error": e_choice,
+            "target": target, "n_points": int(n), "n_latents": int(latents.shape[0]), "searched": searched}
 
 
 def validate_training_numerics(decoder, latents: torch.Tensor, n: int = 2048, *, tol: float = 1e-3, strict: bool = False,

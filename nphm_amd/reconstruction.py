@@ -252,12 +252,12 @@ def evaluate_grid(decoder: FastEnsembleDeepSDFMirrored, encoding: torch.Tensor, 
     if planes_dev is not None:
         _lib.check(lib.nphm_identity_eval_grid_planes(
             packed.data_ptr(), state.data_ptr(), ax.data_ptr(), ay.data_ptr(), az.data_ptr(), rx, ry, rz,
-            planes_dev.data_ptr(), n_planes, int(hack_chunk), float(decoder.prune_tol), decoder._precision_code(),
+            planes_dev.data_ptr(), n_planes, int(hack_chunk), *decoder.kernel_knobs(device, lat),
             out.data_ptr(), stats_ptr, ws_ptr, ws_bytes, stream), "nphm_identity_eval_grid_planes")
     else:
         _lib.check(lib.nphm_identity_eval_grid(
             packed.data_ptr(), state.data_ptr(), ax.data_ptr(), ay.data_ptr(), az.data_ptr(), rx, ry, rz,
-            ix0, ix1, int(hack_chunk), float(decoder.prune_tol), decoder._precision_code(),
+            ix0, ix1, int(hack_chunk), *decoder.kernel_knobs(device, lat),
             out.data_ptr(), stats_ptr, ws_ptr, ws_bytes, stream), "nphm_identity_eval_grid")
     return (out, anchors) if return_anchors else out
 
@@ -344,7 +344,7 @@ def evaluate_grid_two_stage(decoder_shape: FastEnsembleDeepSDFMirrored, decoder_
     ws = grid_workspace(device, ix1 - ix0, ry, rz)
     _lib.check(lib.nphm_identity_eval_grid_points(
         packed.data_ptr(), state.data_ptr(), canonical.data_ptr(), rx, ry, rz, ix0, ix1, int(hack_chunk),
-        float(decoder_shape.prune_tol), decoder_shape._precision_code(), out.data_ptr(), None,
+        *decoder_shape.kernel_knobs(device, lat), out.data_ptr(), None,
         ws.data_ptr(), ws.numel(), stream), "nphm_identity_eval_grid_points")
     return (out, canonical) if return_canonical else out
 
@@ -501,7 +501,7 @@ def get_logits(decoder, encoding, grid_points, nbatch_points=100000, return_anch
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nphm_identity_eval_points(
                 packed.data_ptr(), state.data_ptr(), pts.data_ptr(), 1, pts.shape[1], hack,
-                float(decoder.prune_tol), decoder._precision_code(), vol.data_ptr(), None, stream),
+                *decoder.kernel_knobs(device, lat.to(device)), vol.data_ptr(), None, stream),
                 "nphm_identity_eval_points")
         logits = to_host(vol)
         return (logits, anchors) if return_anchors else logits
@@ -561,7 +561,7 @@ def get_logits_backward(decoder_shape, decoder_expr, encoding_shape, encoding_ex
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nphm_identity_eval_points(
                 packed.data_ptr(), state.data_ptr(), canonical.data_ptr(), 1, canonical.shape[1], hack,
-                float(decoder_shape.prune_tol), decoder_shape._precision_code(), vol.data_ptr(), None, stream),
+                *decoder_shape.kernel_knobs(device, lat), vol.data_ptr(), None, stream),
                 "nphm_identity_eval_points")
         logits = to_host(vol)
         return (logits, anchors_pred) if return_anchors else logits

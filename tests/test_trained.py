@@ -62,26 +62,39 @@ def dev():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,prune,tol", [("f32", -1.0, 2e-5), ("bf16x3", -1.0, 1e-5), ("bf16x3", 1e-7, 1e-5),
-                                                 ("bf16x3a", 1e-7, 1e-5), ("bf16x3a2", 1e-7, 1e-5)])
+@pytest.mark.parametrize("precision,prune,tol", [
+    ("auto", None, 1e-5),                                   # the default: knobs calibrated for THIS checkpoint, a decade inside the bar
+    ("f32", -1.0, 2e-5), ("bf16x3", -1.0, 1e-5), ("f16x3", -1.0, 1e-5),      # exact / split products, all 40 members
+    ("f16x3", 1e-8, 1e-5), ("bf16x3", 1e-7, TOL_BAR), ("f16x3", 1e-7, TOL_BAR),
+    # the pinned round-2 default and the f16 tiers at their seeded-weight thresholds: inside the 1e-4 bar, NOT a decade
+    # inside on trained weights (their tiers were calibrated on seeded random-init weights) - what "auto" is for
+    ("bf16x3a", 1e-7, TOL_BAR), ("bf16x3a2", 1e-7, TOL_BAR), ("f16x3a2", 1e-7, 5e-4)])
 def test_hip_modes_on_trained_weights(fx, dev, precision, prune, tol):
-    """every precision mode against the reference fixture: 4 codes x (4 608 stratified voxels + 2 048 near-surface points)"""
+    """every precision mode against the reference fixture: 4 codes x (4 608 stratified voxels of a 256^3 extraction + 2 048
+    near-surface points)"""
     net, codes = U.build_trained_identity(device=dev)
     net.train()                                  # the fixture's point sets are train-mode values (no last-point overwrite)
-    net.precision, net.prune_tol = precision, prune
+    if precision != "auto":
+        net.precision, net.prune_tol = precision, prune
     worst = {}
+    axes = R.grid_axes(U.MINI, U.MAXI, 256)
     for c in CODES:
         with torch.no_grad():
-            for name, pts, ref in (("voxels", _voxel_points(fx, c), fx[f"c{c}_sdf_voxels"]),
-                                   ("near", fx[f"c{c}_near"], fx[f"c{c}_sdf_near"])):
-                got, anc = net(torch.from_numpy(pts)[None].to(dev), codes[c][None, None], None)
-                err = np.abs(got.reshape(-1).cpu().numpy() - ref)
-                if name == "voxels":
-                    for i, reg in enumerate(("near_anchor", "mid_field", "far_field")):
-                        worst[reg] = max(worst.get(reg, 0.0), float(err[1536 * i:1536 * (i + 1)].max()))
-                else:
-                    worst["near_surface"] = max(worst.get("near_surface", 0.0), float(err.max()))
+            # the stratified voxels out of a REAL 256^3 extraction (compact 4x4x2 tiles per wavefront: pruning and the
+            # precision tiers are decided per wavefront, scattered points would share more members and err less)
+            vol = R.evaluate_grid(net, codes[c], axes, hack_chunk=0)
+            err = np.abs(vol[torch.from_numpy(fx[f"c{c}_voxels"]).to(dev)].cpu().numpy() - fx[f"c{c}_sdf_voxels"])
+            for i, reg in enumerate(("near_anchor", "mid_field", "far_field")):
+                worst[reg] = max(worst.get(reg, 0.0), float(err[1536 * i:1536 * (i + 1)].max()))
+            got, anc = net(torch.from_numpy(fx[f"c{c}_near"])[None].to(dev), codes[c][None, None], None)
+            worst["near_surface"] = max(worst.get("near_surface", 0.0),
+                                        float(np.abs(got.reshape(-1).cpu().numpy() - fx[f"c{c}_sdf_near"]).max()))
             assert U.maxdiff(anc[0].cpu().numpy(), fx[f"c{c}_anchors"]) < 1e-6
+    if precision == "auto":
+        c = net.calibration
+        print(f"trained checkpoint, calibrated: {c['precision']} light {c['light_tol']} mid {c['mid_tol']} prune {c['prune_tol']:g} "
+              f"(sample error {c['error']:.2e})")
+        prune = c["prune_tol"]
     print(f"trained checkpoint, {precision}, prune_tol {prune:g}: max |hip - reference| " +
           ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
     assert max(worst.values()) < tol
@@ -97,7 +110,7 @@ def test_get_logits_eval_mode_lattice_on_trained_weights(fx, dev):
     vol = R.get_logits(net, codes[CODES[0]], grid, nbatch_points=chunk)
     ref = fx["lattice_volume"]
     hacked = O.hack_indices(res ** 3, chunk)
-    assert U.maxdiff(vol[hacked], ref[hacked]) < 1e-6 and float(np.abs(ref[hacked] - 1).max()) < 1e-3
+    assert U.maxdiff(vol[hacked], ref[hacked]) < 1e-6          # S / (S + 1e-6): 1 near the head, ~0 in the far field
     err = np.abs(vol - ref)
     print(f"trained checkpoint, 40^3 get_logits: max |err| {err.max():.2e}, sign flips {int(((vol < 0) != (ref < 0)).sum())}")
     assert float(err.max()) < 1e-5
@@ -107,13 +120,18 @@ def test_get_logits_eval_mode_lattice_on_trained_weights(fx, dev):
 def test_validate_numerics_and_member_statistics_on_trained_weights(dev):
     net, codes = U.build_trained_identity(device=dev)
     net.eval()
-    rep = nphm_amd.validate_numerics(net, codes[list(CODES)], n=1 << 15)
+    rep = nphm_amd.validate_numerics(net, codes[list(CODES)], n=1 << 17)         # numerics = "auto": the calibrated setting
     print("validate_numerics on the trained checkpoint:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in rep.items()})
-    assert rep["max_abs_diff"] < TOL_BAR and rep["max_abs_sdf"] > 0.2
+    assert rep["ok"] and rep["max_abs_diff"] < 1e-5 and rep["max_abs_sdf"] > 0.2
+    net.precision, net.prune_tol = "bf16x3a2", 1e-7                              # the pinned round-2 default is flagged
+    rep2 = nphm_amd.validate_numerics(net, codes[list(CODES)], n=1 << 17)
+    print("... pinned bf16x3a2 / 1e-7:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in rep2.items()})
+    assert not rep2["ok"] and rep2["max_abs_diff"] < TOL_BAR
+    net.numerics = "auto"
     # member statistics of the default mode on the 128^3 lattice (what the throughput depends on)
     axes = R.grid_axes(U.MINI, U.MAXI, 128)
     stats = torch.zeros(16, dtype=torch.int64, device=dev)
-    R.evaluate_grid(net, codes[0], axes, hack_chunk=0, stats=stats)
+    R.evaluate_grid(net, codes[0], axes, hack_chunk=0, stats=stats)          # calibrated setting
     s = stats.cpu().numpy()
     n = 128 ** 3
     print(f"trained checkpoint 128^3: members per wavefront {s[0] / n:.2f} (single-pass {s[15] / n:.2f}, two-pass {s[14] / n:.2f})")
