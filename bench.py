@@ -146,13 +146,13 @@ class IdentityBench:
             c = net.calibration
             return c["precision"]
         net.precision = precision                              # pins the numerics
-        net.light_tol, net.mid_tol = None, None
+        net.light_tol, net.mid_tol, net.refine_band = None, None, None
         net.prune_tol = self.args.prune_tol if self.args.prune_tol is not None else 1e-7
         return precision
 
     def step(self, precision, binned, stats=None, ev=None):
         net, R = self.net, self.R
-        packed, state, _ = net.prepare_latent(self.lat[None])
+        packed, state, _ = net.prepare_latent(self.lat[None], inference=True)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         ws = R.grid_workspace(self.dev, self.n_planes, self.ry, self.rz) if binned and self.n_planes else None
         i = self.k & 1
@@ -275,7 +275,8 @@ class IdentityBench:
             return {"mode": "fixed", "precision": net.precision, "prune_tol": net.prune_tol}
         c = net.calibration
         return {"mode": "auto (calibrated per checkpoint against the dense exact-fp32 kernel)", "precision": c["precision"],
-                "light_tol": c["light_tol"], "mid_tol": c["mid_tol"], "prune_tol": c["prune_tol"],
+                "light_tol": c["light_tol"], "mid_tol": c["mid_tol"], "prune_tol": c["prune_tol"], "refine_band": c["refine_band"],
+                "member_bounds": c["bounds"] is not None,
                 "sample_max_abs_err": c["error"], "target": c["target"], "sample_points": c["n_points"]}
 
     def mesh_extract(self, precision, binned):

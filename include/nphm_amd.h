@@ -96,6 +96,14 @@ int nphm_identity_prepare_latent(const void* packed,
                                  const float* lat_rows, int n_rows,
                                  void* latent_state, float* anchors_out, void* stream);
 
+/* Magnitude bounds of the ensemble members for the pruning rule and the precision tiers of the inference kernels
+ * (nphm_identity_eval_*): bounds [40][4] = (b0, b1, b2, unused) per member with B_k(d) = b0 + b1 d + b2 d^2 >= |f_k| at
+ * distance d from anchor k (member 39, the background member: d = 0).  With bounds installed, "weight" in the rules of
+ * prune_tol / NPHM_LIGHT_TOL / NPHM_MID_TOL reads w_k B_k(d_k): what a member's term can contribute in SDF units, so
+ * 40 * prune_tol bounds the pruning error itself.  NULL (and every freshly prepared state) = (1, 0, 0): the bare weights.
+ * Device pointer; the latent_state of nphm_identity_prepare_latent is updated in place for all n_rows. */
+int nphm_identity_set_member_bounds(void* latent_state, int n_rows, const float* bounds, void* stream);
+
 /* FastEnsembleDeepSDFMirrored.forward for latents that are constant along the point axis
  * (EnsembledDeepSDF.py:203-267):  sdf_out[b,n] for xyz[b,n,:].
  *   hack_chunk > 0 reproduces the eval-mode overwrite (EnsembledDeepSDF.py:260-261) of the last

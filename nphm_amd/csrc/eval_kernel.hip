@@ -44,6 +44,8 @@ struct EvalArgs {
   float* out;
   unsigned long long* stats;
   float prune_tol;
+  float refine_band;        // > 0: sign-safe refinement - a wavefront whose blended value lands within this band of zero at any
+  float refine_prune_tol;   // of its points re-evaluates its tile with every member on the three-pass product at this budget
   float light_tol;          // bf16 path: members below this normalised weight in a wavefront run single-pass
   float mid_tol;            // ... members below THIS one (and >= light_tol) two-pass: xh wh + xl wh, weights rounded to bf16
   // MODE 0 (points)
@@ -621,8 +623,12 @@ __device__ __forceinline__ GridPoint grid_point(const EvalArgs& p, int lx, int i
 // division by the scalar 0.01 is on a GPU) and exp(t) = 2^hi (1 + lo ln2) with t log2(e) = hi + lo carried in
 // two floats, instead of the IEEE sqrt / divide / expf expansions of hipcc: 12 instead of 45 VALU
 // operations, to the same ulp - 39 of them per lattice point in the binning pre-pass.
-__device__ __forceinline__ float blend_weight(float dx, float dy, float dz) {
+__device__ __forceinline__ float blend_weight(float dx, float dy, float dz, float* dist = nullptr) {
+  // no implicit fma contraction here and in blend_masks: the binning pre-pass and the in-kernel form of the rule must
+  // produce the same bits (the binned traversal is bitwise the brick traversal), whatever surrounds the inlined code
+#pragma clang fp contract(off)
   const float d = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
+  if (dist) *dist = d;
   const float t = -(d * d) * 100.0f;
   const float hi = t * 1.44269504f;                                          // log2(e) = 1.44269504 + 1.925963e-8
   const float lo = fmaf(t, 1.44269504f, -hi) + t * 1.925963033e-8f;
@@ -641,18 +647,24 @@ template <bool SPLIT>
 __device__ __forceinline__ void blend_masks(const float* anch, float qx, float qy, float qz, bool valid, bool hack,
                                             float prune_tol, float light_tol, float mid_tol, float& S_out, float& denom_out,
                                             uint64_t (&wmask)[2], uint64_t (&hmask)[2], uint64_t (&fmask)[2]) {
+#pragma clang fp contract(off)
   // the 39 anchor weights of this lane's point are computed ONCE and kept in registers: the three
-  // passes below index them statically (unrolled)
+  // passes below index them statically (unrolled).  The rules act on wv[k] = w_k B_k(d_k), the size member k's term
+  // can have (layout.h: LS_OFF_BND; B = 1 unless bounds were installed); the blend sum S on the bare weights.
+  const float* bnd = anch + (LS_OFF_BND - LS_OFF_ANCH);
   float wv[N_LOC];
   float S = 0.f;
 #pragma unroll
   for (int k = 0; k < N_LOC; ++k) {
     const float dx = anch[3 * k] - qx, dy = anch[3 * k + 1] - qy, dz = anch[3 * k + 2] - qz;
-    wv[k] = blend_weight(dx, dy, dz);
-    S += wv[k];
+    float d;
+    const float w = blend_weight(dx, dy, dz, &d);
+    S += w;
+    wv[k] = w * fmaf(fmaf(bnd[4 * k + 2], d, bnd[4 * k + 1]), d, bnd[4 * k]);
   }
-  const float w_bg = expf(-0.2f / 0.01f);
-  S += w_bg;
+  const float w_bg_raw = expf(-0.2f / 0.01f);
+  S += w_bg_raw;
+  const float w_bg = w_bg_raw * bnd[4 * N_LOC];
   const float denom = S + 1e-6f;
   S_out = S;
   denom_out = denom;
@@ -852,6 +864,14 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     atomicAdd(p.stats + 14, nv * __popcll(wmask & hmask & ~fmask));   // two-pass pairs
   }
 
+  float acc = 0.f;
+  // Two passes at most.  Pass 0 is the evaluation proper.  Pass 1 (refine_band > 0, rare) is the sign-safe refinement:
+  // where the blended value of pass 0 lands within refine_band of zero, an error of the fast setting could flip its sign
+  // - and with it the topology of the extracted mesh.  Such a wavefront re-evaluates its tile with every member on the
+  // full three-pass product under a tighter pruning budget; the workgroup streams those members once more (the other
+  // wavefronts idle through the pass).  ~1e-5 of the tiles of a 256^3 extraction.
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
   // ---- union over the workgroup: the members whose weights get streamed ----------------------
   if (threadIdx.x < 2) wg_mask[threadIdx.x] = 0u;
   __syncthreads();
@@ -872,7 +892,6 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   ws.issue(false, 0);
   ws.issue(false, 1);
 
-  float acc = 0.f;
 #if NPHM_PROF
   long long prof[6] = {0, 0, 0, 0, 0, 0};   // L0 gemm, sync, gemm, epilogue, member total, kernel total
   const long long t_kernel = clock64();
@@ -1160,6 +1179,30 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     atomicAdd(p.stats + 11, 1ull);
   }
 #endif
+    if (pass == 1 || !(p.refine_band > 0.f)) break;
+    // ---- does any wavefront of the workgroup sit on the zero level set? -------------------------------------------
+    const bool wave_near = __ballot(valid && !hack && fabsf(acc) < p.refine_band) != 0ull;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) wg_mask[0] = 0u;
+    __syncthreads();
+    if (lane == 0 && wave_near) atomicOr(&wg_mask[0], 1u);
+    __syncthreads();
+    const bool wg_near = wg_mask[0] != 0u;
+    __syncthreads();                                  // wg_mask is reused at the top of the next pass
+    if (!wg_near) break;
+    if (wave_near) {
+      float S2, denom2;
+      uint64_t wm[2], hm[2], fm[2];
+      blend_masks<false>(anch, qx, qy, qz, valid, hack, p.refine_prune_tol, -1.f, -1.f, S2, denom2, wm, hm, fm);
+      wmask = wm[0];
+      acc = 0.f;
+      if (p.stats && lane == 0) atomicAdd(p.stats + 13, (unsigned long long)(nv * __popcll(wmask)));   // refined pairs
+    } else {
+      wmask = 0ull;
+    }
+    hmask = fmask = ~0ull;                            // three passes for everything in the refinement
+  }
 
   // eval-mode overwrite (EnsembledDeepSDF.py:260-261): every member predicts 1 for this point
   if (hack) acc = S / denom;
@@ -1217,6 +1260,12 @@ static void set_tiers(nphm::EvalArgs& a, int precision) {
   }
   a.light_tol = light;
   a.mid_tol = mid;
+  // sign-safe refinement band (bits 24..30 of `precision`, half-octave code like the tiers; 0 = off): tiles with a value
+  // inside the band are re-evaluated with all members on the three-pass product at 1/32 of the pruning budget
+  const int rc = (precision >> 24) & 0x7f;
+  a.refine_band = rc ? exp2f(1.f - 0.5f * float(rc)) : 0.f;
+  a.refine_prune_tol = a.prune_tol >= 0.f ? a.prune_tol * (1.f / 32.f) : -1.f;
+  if (a.prune_tol < 0.f && !is_adaptive(precision)) a.refine_band = 0.f;     // nothing to refine: already the exact setting
 }
 
 static void fill_common(nphm::EvalArgs& a, const void* packed, const void* latent_state, float* out,

@@ -113,7 +113,12 @@ constexpr int LS_OFF_L0F = LS_OFF_TAIL + N_MEMBERS * GEMM_CHUNKS * TAIL_FLOATS; 
 constexpr int LS_OFF_L0B = LS_OFF_L0F + N_MEMBERS * L0_BLOCK_FLOATS;        // [member][2048]
 constexpr int LS_OFF_L0H = LS_OFF_L0B + N_MEMBERS * L0_BLOCK_FLOATS;        // [member][2048] (f16 fragments)
 constexpr int LS_OFF_ANCH = LS_OFF_L0H + N_MEMBERS * L0_BLOCK_FLOATS;       // anchors [39][3]
-constexpr int LS_ROW_STRIDE = LS_OFF_ANCH + 128;
+// magnitude bounds of the members, [member][4] = (b0, b1, b2, -): B_k(d) = b0 + b1 d + b2 d^2 >= |f_k| at distance d from
+// anchor k.  The pruning rule and the precision tiers of the inference kernels act on w_k B_k(d_k) - the size a member's
+// term can have - instead of the bare blend weight w_k; (1, 0, 0) (what prepare_latent writes) is the plain-weight rule.
+// Fitted per checkpoint by numerics.calibrate_numerics, installed with nphm_identity_set_member_bounds.
+constexpr int LS_OFF_BND = LS_OFF_ANCH + 128;
+constexpr int LS_ROW_STRIDE = LS_OFF_BND + N_MEMBERS * 4;
 
 __host__ __device__ constexpr int member_set(int k) {
   return k < 2 * N_SYMM ? (k >> 1) : N_SYMM + (k - 2 * N_SYMM);

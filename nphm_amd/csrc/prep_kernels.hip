@@ -255,7 +255,16 @@ __global__ __launch_bounds__(256) void prepare_latent_kernel(PrepArgs a) {
       st[LS_OFF_ANCH + o] = v;
       if (a.anchors_out) a.anchors_out[size_t(row) * N_LOC * 3 + o] = v;
     }
+    // member magnitude bounds: the plain-weight rule until nphm_identity_set_member_bounds installs fitted ones
+    for (int o = t; o < N_MEMBERS * 4; o += blockDim.x) st[LS_OFF_BND + o] = (o & 3) == 0 ? 1.f : 0.f;
   }
+}
+
+__global__ void set_bounds_kernel(float* state, const float* bounds, int n_rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows * N_MEMBERS * 4) return;
+  const int row = i / (N_MEMBERS * 4), o = i % (N_MEMBERS * 4);
+  state[size_t(row) * LS_ROW_STRIDE + LS_OFF_BND + o] = bounds ? bounds[o] : ((o & 3) == 0 ? 1.f : 0.f);
 }
 
 }  // namespace nphm
@@ -326,6 +335,16 @@ int nphm_identity_prepare_latent(const void* packed,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_prepare_latent launch", e);
+  return 0;
+}
+
+int nphm_identity_set_member_bounds(void* latent_state, int n_rows, const float* bounds, void* stream) {
+  if (!latent_state || n_rows <= 0) return nphm_fail_msg("nphm_identity_set_member_bounds: bad arguments");
+  const int n = n_rows * nphm::N_MEMBERS * 4;
+  hipLaunchKernelGGL(nphm::set_bounds_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<float*>(latent_state), bounds, n_rows);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_set_member_bounds launch", e);
   return 0;
 }
 

@@ -541,6 +541,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         self._precision = os.environ.get("NPHM_AMD_PRECISION", "bf16x3a2")
         self._light_tol = None          # tier thresholds of the adaptive modes (None: the mode's default)
         self._mid_tol = None
+        self._refine_band = None        # sign-safe refinement band (None / 0: off)
         pinned = "NPHM_AMD_PRECISION" in os.environ or "NPHM_AMD_PRUNE_TOL" in os.environ
         self.numerics = os.environ.get("NPHM_AMD_NUMERICS", "fixed" if pinned else "auto")
         self._calibration = None        # (weights key, preset dict) of numerics = "auto"
@@ -645,14 +646,23 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         self._pack_bwd_cache = (key, packed)
         return packed
 
-    def prepare_latent(self, lat_rows: torch.Tensor):
-        """lat_rows [B, lat_dim] -> (latent_state, anchors [B,n_loc,3]) via the HIP prologue kernel."""
+    def prepare_latent(self, lat_rows: torch.Tensor, inference: bool = False, bounds="auto"):
+        """lat_rows [B, lat_dim] -> (packed weights, latent_state, anchors [B,n_loc,3]) via the HIP prologue kernel.
+        ``inference``: the state feeds the inference kernels (eval_kernel.hip) - with numerics = "auto" the knobs are
+        calibrated for the current weights first (once per weight version) and the fitted member magnitude bounds are
+        installed into the state.  ``bounds``: "auto" (the calibrated bounds when they belong to the current weights,
+        else the plain-weight rule), None, or a [40,4] device tensor."""
         lib = _lib.load()
         device = lat_rows.device
         if getattr(self, "_needs_validation", False):
             from .numerics import validate_numerics
             self._needs_validation = False
             validate_numerics(self, lat_rows[:1].detach(), n=1 << 14)
+        if inference:
+            self.kernel_knobs(device, lat_rows)          # numerics = "auto": calibrate for these weights if needed
+        if isinstance(bounds, str):
+            c = self._calibration
+            bounds = c[1].get("bounds") if (self.numerics == "auto" and c is not None and c[0] == self._weights_key(device)) else None
         packed = self._packed(device)
         B = lat_rows.shape[0]
         lat_rows = lat_rows.contiguous().float()
@@ -670,7 +680,14 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             packed.data_ptr(), _lib.ptr_array5(ws), _lib.ptr_array5(bs), _lib.ptr_array3(pw),
             _lib.ptr_array3(pb), self.pos_mlp_dim, mean.data_ptr(), lat_rows.data_ptr(), B,
             state.data_ptr(), anchors.data_ptr(), stream), "nphm_identity_prepare_latent")
+        if bounds is not None:
+            _lib.check(lib.nphm_identity_set_member_bounds(state.data_ptr(), B, bounds.data_ptr(), stream),
+                       "nphm_identity_set_member_bounds")
         return packed, state, anchors
+
+    def _weights_key(self, device):
+        ws, bs = self._lin_params()
+        return tuple((t.data_ptr(), t._version, str(t.device)) for t in ws + bs) + (str(device),)
 
     # ---- knobs: plain attributes to the caller; assigning one pins the numerics ----------------------------
     def _pin(self, name, value):
@@ -681,6 +698,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     precision = property(lambda self: self._precision, lambda self, v: self._pin("_precision", v))
     light_tol = property(lambda self: self._light_tol, lambda self, v: self._pin("_light_tol", v))
     mid_tol = property(lambda self: self._mid_tol, lambda self, v: self._pin("_mid_tol", v))
+    refine_band = property(lambda self: self._refine_band, lambda self, v: self._pin("_refine_band", v))
 
     _MODES = {"f32": _lib.NPHM_PREC_F32, "bf16x3": _lib.NPHM_PREC_BF16X3, "bf16x3a": _lib.NPHM_PREC_BF16X3_ADAPTIVE,
               "bf16x3a2": _lib.NPHM_PREC_BF16X3_ADAPTIVE2, "f16x3": _lib.NPHM_PREC_F16X3,
@@ -698,12 +716,19 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         return int(min(254, max(1, math.ceil(2.0 * (1.0 - math.log2(tol)) - 1e-9))))
 
     @staticmethod
-    def precision_code(precision, light_tol=None, mid_tol=None):
+    def precision_code(precision, light_tol=None, mid_tol=None, refine_band=None):
+        """``refine_band``: sign-safe refinement (eval_kernel.hip) - tiles with a value within the band of zero are
+        re-evaluated with every member on the three-pass product at 1/32 of the pruning budget; coded in bits 24..30 as the
+        smallest half-octave step >= the band"""
         T = FastEnsembleDeepSDFMirrored
-        return T._MODES[precision] | (T._tier_code(light_tol) << 8) | (T._tier_code(mid_tol) << 16)
+        rc = 0
+        if refine_band is not None and refine_band > 0:
+            import math
+            rc = int(min(127, max(1, math.floor(2.0 * (1.0 - math.log2(refine_band)) + 1e-9))))
+        return T._MODES[precision] | (T._tier_code(light_tol) << 8) | (T._tier_code(mid_tol) << 16) | (rc << 24)
 
     def _precision_code(self):
-        return self.precision_code(self._precision, self._light_tol, self._mid_tol)
+        return self.precision_code(self._precision, self._light_tol, self._mid_tol, self._refine_band)
 
     def kernel_knobs(self, device=None, lat_rows=None):
         """(prune_tol, precision code with its tier thresholds) of the inference kernels: the pinned values, or with
@@ -712,14 +737,13 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         ``calibration`` holds the report)."""
         if self.numerics != "auto" or device is None or torch.device(device).type != "cuda":
             return float(self._prune_tol), self._precision_code()
-        ws, bs = self._lin_params()
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in ws + bs) + (str(device),)
+        key = self._weights_key(device)
         if self._calibration is None or self._calibration[0] != key:
             from .numerics import calibrate_numerics
             lat = None if lat_rows is None else lat_rows.detach().reshape(-1, self.lat_dim)[:2]
             object.__setattr__(self, "_calibration", (key, calibrate_numerics(self, lat, device=device)))
         c = self._calibration[1]
-        return float(c["prune_tol"]), self.precision_code(c["precision"], c["light_tol"], c["mid_tol"])
+        return float(c["prune_tol"]), self.precision_code(c["precision"], c["light_tol"], c["mid_tol"], c.get("refine_band"))
 
     @property
     def calibration(self):
@@ -729,7 +753,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     def _forward_hip(self, xyz, lat_rows):
         lib = _lib.load()
         B, N, _ = xyz.shape
-        packed, state, anchors = self.prepare_latent(lat_rows)
+        packed, state, anchors = self.prepare_latent(lat_rows, inference=True)
         xyz = xyz.contiguous().float()
         out = torch.empty(B, N, 1, dtype=torch.float32, device=xyz.device)
         stream = torch.cuda.current_stream(xyz.device).cuda_stream

@@ -88,6 +88,24 @@ def _sample_tiles(anchors: torch.Tensor, n_tiles: int, seed: int):
     return xyz.contiguous(), (rx, ry, rz)
 
 
+def _tile_surface_weights(dense: torch.Tensor, dims):
+    """(mask of the sample points within ~1.5 lattice spacings of the zero level set, 1 / |grad f|) from the dense values
+    on the compact tiles of ``_sample_tiles``: one-sided differences inside every 4x4x2 tile.  An SDF error e moves the
+    extracted surface by e / |grad f| there - what the north star's mesh criterion (Chamfer within 1e-5) measures; a
+    trained field has |grad f| ~ 1, a seeded one ~ 0.1."""
+    rx, ry, rz = dims
+    f = dense.view(rx // 4, 4, ry // 4, 4, rz // 2, 2)
+    hx, hy, hz = _TILE_SPACING
+
+    def one_sided(t, axis, h):
+        d = torch.diff(t, dim=axis) / h
+        last = d.narrow(axis, d.shape[axis] - 1, 1)
+        return torch.cat([d, last], dim=axis)
+    g = torch.sqrt(one_sided(f, 1, hx) ** 2 + one_sided(f, 3, hy) ** 2 + one_sided(f, 5, hz) ** 2).reshape(-1)
+    near = dense.abs() <= 1.5 * max(hx, hy, hz) * g
+    return near, 1.0 / g.clamp_min(1e-3)
+
+
 def _eval_tiles(lib, decoder, packed, state, xyz, dims, code, prune, stream):
     rx, ry, rz = dims
     out = torch.empty(rx * ry * rz, dtype=torch.float32, device=xyz.device)
@@ -95,6 +113,17 @@ def _eval_tiles(lib, decoder, packed, state, xyz, dims, code, prune, stream):
                                                   float(prune), code, out.data_ptr(), None, None, 0, stream),
                "nphm_identity_eval_grid_points")
     return out
+
+
+def _kept_mask(rule: torch.Tensor, prune_tol: float) -> torch.Tensor:
+    """The pruning rule of the kernels (eval_kernel.hip: blend_masks) per point on normalised rule weights [..., A]: the
+    cut is the largest of the candidates {1, 2, 4, 8, 16, 40} x prune_tol whose not-larger weights sum to <= 40 prune_tol."""
+    budget = 40.0 * prune_tol
+    cut = torch.full(rule.shape[:-1], prune_tol, dtype=rule.dtype, device=rule.device)
+    for c in (2.0, 4.0, 8.0, 16.0, 40.0):
+        ok = torch.where(rule <= c * prune_tol, rule, torch.zeros_like(rule)).sum(dim=-1) <= budget
+        cut = torch.where(ok, torch.full_like(cut, c * prune_tol), cut)
+    return rule > cut[..., None]
 
 
 def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 1 << 16, *, tol: float = 1e-5,
@@ -116,6 +145,7 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
     eff = decoder.calibration if decoder.numerics == "auto" else None
     precision_eff = eff["precision"] if eff else decoder.precision
     light_eff, mid_eff = (eff["light_tol"], eff["mid_tol"]) if eff else (decoder.light_tol, decoder.mid_tol)
+    bounds_eff = eff.get("bounds") if eff else None
     saved = (precision_eff, prune_eff, getattr(decoder, "_needs_validation", False))
     decoder._needs_validation = False
     worst = {"max_abs_diff": 0.0, "max_pruned": 0.0, "max_light": 0.0, "max_two_pass": 0.0, "max_abs_sdf": 0.0,
@@ -152,17 +182,22 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
                                                             tiles.shape[0], None, plist.data_ptr(), fmem.data_ptr(), stream),
                            "nphm_identity_member_forward")
                 contrib = what_all * fmem.abs()                                   # w_k |f_k|, [1,N,A]
+                # what the rules of the kernels see: the normalised weight times the member's magnitude bound
+                rule = what_all
+                if bounds_eff is not None:
+                    dk = torch.cat([(pts[0][:, None, :] - anchors[0][None]).norm(dim=-1) + 1e-5,
+                                    torch.zeros(N, 1, device=dev)], dim=1)[None]
+                    rule = what_all * (bounds_eff[:, 0] + bounds_eff[:, 1] * dk + bounds_eff[:, 2] * dk * dk)
                 if prune_eff >= 0:
-                    kept = _member_point_lists(anchors, pts, prune_eff, A)[0] > 0
-                    pruned = (contrib * (~kept)).sum(dim=2)
+                    pruned = (contrib * (~_kept_mask(rule, prune_eff))).sum(dim=2)
                 else:
                     pruned = torch.zeros_like(contrib[..., 0])
                 t_light, t_mid, r_light, r_mid = TIERS.get(precision_eff, (None, None, 0.0, 0.0))
                 t_light = light_eff if (light_eff is not None and t_light is not None) else t_light
                 t_mid = mid_eff if (mid_eff is not None and t_mid is not None) else t_mid
-                light = contrib * (what_all < t_light) * r_light if t_light is not None else contrib * 0
+                light = contrib * (rule < t_light) * r_light if t_light is not None else contrib * 0
                 # two-pass members: weights rounded to bf16 / f16, a 2^-9 / 2^-12 relative perturbation of the member
-                mid = contrib * ((what_all >= t_light) & (what_all < t_mid)) * r_mid if t_mid is not None else contrib * 0
+                mid = contrib * ((rule >= t_light) & (rule < t_mid)) * r_mid if t_mid is not None else contrib * 0
                 worst["max_abs_diff"] = max(worst["max_abs_diff"], float((fast - dense).abs().max()))
                 worst["max_pruned"] = max(worst["max_pruned"], float(pruned.max()))
                 worst["max_light"] = max(worst["max_light"], float(light.max()))
@@ -172,7 +207,7 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
     finally:
         decoder._needs_validation = saved[2]
     worst.update(n_points=int(N), n_latents=int(latents.shape[0]), precision=saved[0], prune_tol=saved[1], tol=tol,
-                 light_tol=light_eff, mid_tol=mid_eff, numerics=decoder.numerics)
+                 light_tol=light_eff, mid_tol=mid_eff, numerics=decoder.numerics, member_bounds=bounds_eff is not None)
     worst["ok"] = bool(worst["max_abs_diff"] <= tol and worst["max_pruned"] <= tol)
     if not worst["ok"]:
         msg = ("nphm_amd.validate_numerics: the fast mode (precision %s, prune_tol %g) deviates from the dense fp32 kernel "
@@ -186,22 +221,76 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
 
 
 # ---- per-checkpoint calibration (numerics = "auto") -------------------------------------------------------------------
-# Two coordinates, searched greedily: the pruning budget with every member on the full three-pass product, then the tier
-# thresholds at that budget.  Candidates from the fastest to the safest setting:
-PRUNE_LADDER = (1e-7, 3e-8, 1e-8, 3e-9, 1e-9, -1.0)
-TIER_LADDER = ((8e-3, 8e-2), (4e-3, 4e-2), (2e-3, 2e-2), (1e-3, 1e-2), (5e-4, 5e-3), (2.5e-4, 2.5e-3), (None, None))
+# 1. member magnitude bounds B_k(d) >= |f_k| (quadratic upper envelopes in the distance to the anchor, fitted on a sample of
+#    member values, x BOUND_SAFETY): the pruning rule and the tiers then act on w_k B_k(d_k) - the size of a member's
+#    term in SDF units - so that 40 * prune_tol bounds the pruning error of ANY checkpoint, whatever its members do far
+#    from their anchors (a trained member predicts tens of SDF units there, a seeded one 0.1);
+# 2. two coordinates searched greedily from the fastest to the safest candidate: the pruning budget with every member on
+#    the three-pass product, then the tier thresholds at that budget.
+BOUND_SAFETY = 2.0
+PRUNE_LADDER = (1e-6, 3e-7, 1e-7, 3e-8, 1e-8, 3e-9, 1e-9, -1.0)
+TIER_LADDER = ((3e-2, 3e-1), (1.6e-2, 1.6e-1), (8e-3, 8e-2), (4e-3, 4e-2), (2e-3, 2e-2), (1e-3, 1e-2), (5e-4, 5e-3),
+               (2.5e-4, 2.5e-3), (1.2e-4, 1.2e-3), (6e-5, 6e-4), (None, None))
+
+
+def fit_member_bounds(decoder, lat: torch.Tensor, n: int = 1 << 16, seed: int = 0) -> torch.Tensor:
+    """[40,4] device tensor (b0, b1, b2, 0) per member: b0 + b1 d + b2 d^2 >= BOUND_SAFETY * |f_k(x)| for the sampled
+    points x at distance d from anchor k (background member: constant), non-negative coefficients.  Member values by
+    the member-centric kernel on lattice + near-anchor sample points of the latent ``lat`` [1, lat_dim]."""
+    from .ensembled_deepsdf import _member_point_lists
+    lib = _lib.load()
+    dev = lat.device
+    A = decoder.num_kps + 1
+    with torch.no_grad():
+        packed, state, anchors = decoder.prepare_latent(lat, bounds=None)
+        pts = _sample_points(anchors[0], n, seed)[None]
+        N = pts.shape[1]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _, tiles, plist = _member_point_lists(anchors, pts, -1.0, A)
+        fmem = torch.zeros(1, N, A, dtype=torch.float32, device=dev)
+        _lib.check(lib.nphm_identity_member_forward(packed.data_ptr(), decoder._packed_bwd(dev).data_ptr(), state.data_ptr(),
+                                                    pts.data_ptr(), N, tiles.data_ptr(), tiles.shape[0], None, plist.data_ptr(),
+                                                    fmem.data_ptr(), stream), "nphm_identity_member_forward")
+        f = fmem[0].abs().cpu().numpy()                                               # [N, 40]
+        d = (pts[0][:, None, :] - anchors[0][None]).norm(dim=-1).cpu().numpy()       # [N, 39]
+    out = np.zeros((A, 4), np.float32)
+    edges = np.linspace(0.0, 2.4, 25)
+    for k in range(A - 1):
+        b = np.clip(np.digitize(d[:, k], edges) - 1, 0, 23)
+        m = np.zeros(24)
+        np.maximum.at(m, b, f[:, k])
+        m = np.maximum.accumulate(m)                         # non-decreasing envelope of the bin maxima
+        x = edges[1:]                                        # evaluated at the far edge of a bin
+        # non-negative least squares on (1, d, d^2), then lifted onto the envelope
+        from scipy.optimize import nnls
+        Amat = np.stack([np.ones_like(x), x, x * x], 1)
+        c, _ = nnls(Amat, m)
+        lift = float(np.max(m - Amat @ c))
+        c[0] += max(lift, 0.0)
+        out[k, :3] = BOUND_SAFETY * c
+    out[A - 1, 0] = BOUND_SAFETY * float(f[:, A - 1].max())
+    out[:, 0] = np.maximum(out[:, 0], 1e-6)
+    return torch.from_numpy(out).to(dev)
 
 
 def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 1 << 19, *, target: float = 5e-6,
-                       seed: int = 0, device=None) -> dict:
-    """Fastest setting of the inference kernels (pruning tolerance, split-f16 tiers) whose error against the dense
-    exact-fp32 kernel stays <= ``target`` on ``n`` sample points per latent - n / 32 compact 4x4x2 lattice tiles at the
-    512^3 spacing of the reference box, half of them uniform in the box, half in clouds around the anchors
-    (``_sample_tiles``) - for the weights the decoder holds NOW.  ``target`` defaults to 5e-6: half of a tenth of the 1e-4 bar (margin for the points
-    the sample does not hold; DESIGN.md section 3 compares the sample maximum with full 256^3 volumes).  ``latents``
-    [R, lat_dim]: the codes to calibrate with (``kernel_knobs`` passes the code of the call that triggers it; default:
-    the zero code = mean anchors).  Returns {"precision", "light_tol", "mid_tol", "prune_tol",
-    "error", "searched": [(setting, error)]}; what ``decoder.kernel_knobs`` uses when ``decoder.numerics == "auto"``."""
+                       target_surface: float = 5e-6, seed: int = 0, device=None, member_bounds: bool = True,
+                       refine_band: Optional[float] = None) -> dict:
+    """Fastest setting of the inference kernels (member magnitude bounds, pruning budget, split-f16 tiers) whose error
+    against the dense exact-fp32 kernel stays <= ``target`` on ``n`` sample points per latent - n / 32 compact 4x4x2
+    lattice tiles at the 512^3 spacing of the reference box, half of them uniform in the box, half in clouds around the
+    anchors (``_sample_tiles``: the tile geometry of an extraction at its finest BASELINE resolution, where a
+    wavefront's points share the fewest members - the worst case of the per-wavefront rules) - for the weights the
+    decoder holds NOW.  ``target`` defaults to 5e-6: full 256^3 extractions then stay below 1e-5, a decade inside the 1e-4
+    bar (their maximum over 16.7 M voxels is up to twice the sample's).  ``target_surface`` bounds the
+    MEAN displacement of the zero level set, |error| / |grad f| over the sample points next to it (the mesh criterion of
+    the north star: Chamfer within 1e-5; only binding for fields with small gradients, e.g. seeded weights).
+    ``refine_band`` (default: target): the sign-safe refinement band every candidate runs with - values that close to
+    zero are re-evaluated at full precision, so the fast setting cannot flip the sign of a voxel (mesh topology).
+    ``latents`` [R, lat_dim]: the codes to
+    calibrate with (``kernel_knobs`` passes the code of the call that triggers it; default: the zero code = mean
+    anchors).  Returns {"precision", "light_tol", "mid_tol", "prune_tol", "bounds" [40,4] or None, "error",
+    "searched": [(setting, error)]}; what the inference entry points use when ``decoder.numerics == "auto"``."""
     lib = _lib.load()
     dev = torch.device(device) if device is not None else next(decoder.parameters()).device
     if dev.type != "cuda" or not decoder.hip_supported():
@@ -211,9 +300,13 @@ def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int =
     latents = latents.reshape(-1, decoder.lat_dim).to(device=dev, dtype=torch.float32)
     searched = []
     with torch.no_grad():
+        bounds = None
+        if member_bounds:
+            fits = torch.stack([fit_member_bounds(decoder, latents[r:r + 1], seed=seed + r) for r in range(latents.shape[0])])
+            bounds = fits.max(dim=0).values.contiguous()
         cases = []
         for r in range(latents.shape[0]):
-            packed, state, anchors = decoder.prepare_latent(latents[r:r + 1])
+            packed, state, anchors = decoder.prepare_latent(latents[r:r + 1], bounds=bounds)
             xyz, dims = _sample_tiles(anchors[0], max(256, n // 32), seed + r)
             cases.append((packed, state, xyz, dims))
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -222,10 +315,19 @@ def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int =
             packed, state, xyz, dims = case
             return _eval_tiles(lib, decoder, packed, state, xyz, dims, code, prune, stream)
         dense = [run(c, _lib.NPHM_PREC_F32, -1.0) for c in cases]
+        surf = [_tile_surface_weights(d, c[3]) for c, d in zip(cases, dense)]
+        scale = target / target_surface          # errors are compared in units of `target`
+
+        band = target if refine_band is None else refine_band
 
         def err_of(precision, light, mid, prune):
-            code = decoder.precision_code(precision, light, mid)
-            e = max(float((run(c, code, prune) - d).abs().max()) for c, d in zip(cases, dense))
+            code = decoder.precision_code(precision, light, mid, band)
+            e = 0.0
+            for c, d, (near, inv_g) in zip(cases, dense, surf):
+                diff = (run(c, code, prune) - d).abs()
+                e = max(e, float(diff.max()))
+                if int(near.sum()) >= 64:
+                    e = max(e, scale * float((diff * inv_g)[near].mean()))
             searched.append(({"precision": precision, "light_tol": light, "mid_tol": mid, "prune_tol": prune}, e))
             return e
         # 1. pruning budget, three-pass product everywhere: half of the target
@@ -242,8 +344,9 @@ def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int =
             if e <= target:
                 choice, e_choice = ("f16x3a2", light, mid), e
                 break
-    return {"precision": choice[0], "light_tol": choice[1], "mid_tol": choice[2], "prune_tol": prune, "error": e_choice,
-            "target": target, "n_points": int(n), "n_latents": int(latents.shape[0]), "searched": searched}
+    return {"precision": choice[0], "light_tol": choice[1], "mid_tol": choice[2], "prune_tol": prune, "bounds": bounds,
+            "refine_band": band,
+            "error": e_choice, "target": target, "n_points": int(n), "n_latents": int(latents.shape[0]), "searched": searched}
 
 
 def validate_training_numerics(decoder, latents: torch.Tensor, n: int = 2048, *, tol: float = 1e-3, strict: bool = False,

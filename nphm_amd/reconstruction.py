@@ -229,7 +229,7 @@ def evaluate_grid(decoder: FastEnsembleDeepSDFMirrored, encoding: torch.Tensor, 
     if hack_chunk is None:
         hack_chunk = 0 if decoder.training else rx * ry * rz
     lat = _as_lat_row(encoding.to(device=device, dtype=torch.float32), decoder.lat_dim)
-    packed, state, anchors = decoder.prepare_latent(lat)
+    packed, state, anchors = decoder.prepare_latent(lat, inference=True)
     planes_dev = None
     if x_planes is not None:
         planes_dev = torch.as_tensor(np.ascontiguousarray(x_planes, dtype=np.int32)).to(device) \
@@ -328,7 +328,7 @@ def evaluate_grid_two_stage(decoder_shape: FastEnsembleDeepSDFMirrored, decoder_
     if hack_chunk is None:
         hack_chunk = 0 if decoder_shape.training else rx * ry * rz
     lat = _as_lat_row(encoding_shape.to(device=device, dtype=torch.float32), decoder_shape.lat_dim)
-    packed, state, anchors_pred = decoder_shape.prepare_latent(lat)
+    packed, state, anchors_pred = decoder_shape.prepare_latent(lat, inference=True)
     if anchors is None:
         anchors = anchors_pred
     mlp, cond = _expr_condition(decoder_expr, encoding_expr, anchors, device)
@@ -495,7 +495,7 @@ def get_logits(decoder, encoding, grid_points, nbatch_points=100000, return_anch
             vol, anchors = evaluate_grid(decoder, lat, lattice, hack_chunk=hack, return_anchors=True)
         else:
             lib = _lib.load()
-            packed, state, anchors = decoder.prepare_latent(lat.to(device))
+            packed, state, anchors = decoder.prepare_latent(lat.to(device), inference=True)
             pts = grid_points.contiguous()
             vol = torch.empty(pts.shape[1], dtype=torch.float32, device=device)
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -556,7 +556,7 @@ def get_logits_backward(decoder_shape, decoder_expr, encoding_shape, encoding_ex
         else:
             mlp, cond = _expr_condition(decoder_expr, encoding_expr, anchors, device)
             canonical = mlp.forward_hip(grid_points, cond, add_input=True)[..., :3].contiguous()
-            packed, state, anchors_pred = decoder_shape.prepare_latent(lat)
+            packed, state, anchors_pred = decoder_shape.prepare_latent(lat, inference=True)
             vol = torch.empty(canonical.shape[1], dtype=torch.float32, device=device)
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nphm_identity_eval_points(
