@@ -3,18 +3,7 @@ src/NPHM/models/diff_operators.py (``jac`` :26-54, ``gradient`` :69-79).  They a
 hot path: the fields' differentiable (composite) tier serves them."""
 from __future__ import annotations
 
-import threading
-
 import torch
-
-# set while ``gradient`` runs its graph-recording backward pass: the HIP training tier's autograd functions
-# (ensembled_deepsdf._MemberFieldFn / _AttachGradientFn) serve a create_graph pass ONLY when nothing but the spatial
-# gradient is requested - they check this flag and raise otherwise instead of returning partial gradients
-_graph_pass = threading.local()
-
-
-def spatial_graph_pass_active() -> bool:
-    return bool(getattr(_graph_pass, "depth", 0))
 
 
 def jac(decoder_expr, xc, cond, anchors):
@@ -43,12 +32,8 @@ def gradient(outputs, inputs):
     """d outputs / d inputs[..., -3:] with an all-ones cotangent, graph retained and extended
     (diff_operators.py:69-79) — the SDF normal direction used by the losses."""
     ones = torch.ones_like(outputs)
-    _graph_pass.depth = getattr(_graph_pass, "depth", 0) + 1
-    try:
-        g = torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=ones, create_graph=True,
-                                retain_graph=True, only_inputs=True, allow_unused=True)[0]
-    finally:
-        _graph_pass.depth -= 1
+    g = torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=ones, create_graph=True,
+                            retain_graph=True, only_inputs=True, allow_unused=True)[0]
     return g[:, :, -3:]
 
 

@@ -383,17 +383,40 @@ class _MemberFieldFn(torch.autograd.Function):
         n_in = 14
         if torch.is_grad_enabled():
             # graph-recording pass (gradient(pred, x), create_graph=True): _AttachGradientFn supplies d/dxyz
-            from .diff_operators import spatial_graph_pass_active
-            if not spatial_graph_pass_active():
-                # torch.autograd.grad(pred, [x, lat, ...], create_graph=True) / loss.backward(create_graph=True): this
-                # pass would have to return latent and parameter gradients as differentiable ops - it cannot
-                raise RuntimeError("nphm_amd training tier: a graph-recording backward pass is served only through "
-                                   "diff_operators.gradient(pred, x) (spatial gradient alone); for create_graph=True "
-                                   "w.r.t. latents or parameters set module.train_backend = 'composite'")
+            # - and only d/dxyz, d/danchors.  A graph-recording pass that ALSO asks for latent or parameter gradients
+            # (torch.autograd.grad(pred, [x, lat], create_graph=True), loss.backward(create_graph=True)) would have to
+            # return them as differentiable ops, which this function cannot: refuse instead of returning nothing for them.
+            # ctx is this function's node: next_functions[i] is where the gradient of input i would flow.
+            # Where the engine can tell that such a gradient is wanted this raises; where it cannot (leaf inputs under
+            # torch.autograd.grad) the gradient is returned NaN-filled: discarded by the engine when nobody asked for it,
+            # unmistakable otherwise.
+            wanted, unknown = [], []
+            for i, (node, _) in enumerate(ctx.next_functions):
+                if i in (1, 2) or node is None or not ctx.needs_input_grad[i]:     # xyz, anchors: _AttachGradientFn
+                    continue
+                try:
+                    if torch._C._will_engine_execute_node(node):
+                        wanted.append(i)
+                except Exception:                         # noqa: BLE001 - leaf under autograd.grad / API missing
+                    unknown.append(i)
+            if wanted:
+                raise RuntimeError("nphm_amd training tier: a graph-recording backward pass (create_graph=True) can only "
+                                   "deliver the spatial gradient d/dxyz (diff_operators.gradient); latent / parameter "
+                                   "gradients of such a pass need module.train_backend = 'composite' "
+                                   f"(requested inputs {wanted} of _MemberFieldFn)")
             if gG is not None:
                 raise RuntimeError("nphm_amd training tier: third-order derivatives are not implemented "
                                    "(set module.train_backend = 'composite')")
-            return (None,) * n_in
+            out = [None] * n_in
+            if unknown:
+                xyz_s = ctx.saved_tensors[0]
+                B = xyz_s.shape[0]
+                A, H = ctx.module.num_kps + 1, ctx.module.hidden_dim
+                shapes = {3: (B, ctx.module.lat_dim), 4: (B, A, H), 5: (B, A, H)}
+                shapes.update({6 + j: tuple(sh) for j, sh in enumerate(ctx.shapes)})
+                for i in unknown:
+                    out[i] = torch.full(shapes[i], float("nan"), dtype=torch.float32, device=xyz_s.device)
+            return tuple(out)
         lib = _lib.load()
         module = ctx.module
         xyz, packed, packed_bwd, state, tiles, plist, chunks = ctx.saved_tensors

@@ -235,3 +235,24 @@ def test_training_tier_stress_weights(dev):
     assert float(res["composite"]["pred"].abs().max()) > 0.1            # the stress does something
     worst = {k: _rel(res["hip"][k], res["composite"][k]) for k in res["composite"]}
     assert all(v < 1e-3 for v in worst.values()), worst
+
+
+def test_graph_recording_pass_refuses_latent_and_parameter_gradients(dev):
+    """create_graph=True is served for the spatial gradient alone (what ``gradient(pred, x)`` asks for); a graph-recording
+    pass that also wants latent / parameter gradients raises (or, where the engine cannot tell, returns NaN) instead of
+    silently handing back nothing for them."""
+    net = U.build_identity(device=dev).train()
+    lat0, xyz, _ = _batch(dev, 1, 96)
+    x = xyz.clone().requires_grad_()
+    lat = lat0.clone().requires_grad_()
+    pred, _ = net(x, lat, None)
+    g = gradient(pred, x)                                   # fine: the reference's own pattern
+    assert g.shape == x.shape and bool(torch.isfinite(g).all()) and g.requires_grad
+    with pytest.raises(RuntimeError, match="graph-recording"):
+        torch.autograd.grad(pred.sum(), [x, lat], create_graph=True)
+    w = net.ensembled_deep_sdf.lin3.weight                   # a leaf under autograd.grad: the engine cannot be asked
+    try:
+        gw = torch.autograd.grad(pred.sum(), [w], create_graph=True, allow_unused=True)[0]
+        assert gw is None or bool(torch.isnan(gw).all())
+    except RuntimeError as e:
+        assert "graph-recording" in str(e)
