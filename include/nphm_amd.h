@@ -252,6 +252,29 @@ int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
                                    float* sdf_out, unsigned long long* stats,
                                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the non-field pieces of one latent-fitting step, fused (src/NPHM/models/fitting.py:99-167) -------------------
+ * nphm_fit_loss: the loss terms of one step in ONE launch - clamped surface loss, mean |sdf| over the valid points below the
+ *   device scalar `thr` (fitting.py:115-132); reg_expr = mean over the n_rows drawn observations of |z_ex|^2 (:136);
+ *   reg_global / reg_loc / reg_unobserved / symm_dist of the identity code (:139-166) - and their weighted total.
+ *   row [8] = surface, reg_expr, reg_global, reg_unobserved, reg_loc, symm_dist, total (lam in that order), number of valid points.
+ *   valid [n_points] bytes (torch.bool) or NULL; z_expr NULL for the identity-only loop (fitting.py:180-288).
+ * nphm_fit_loss_backward: gradients of the total (times the device scalar *g_out, NULL = 1) w.r.t. sdf, the identity
+ *   code [1344] and the expression codes [n_obs, expr_dim] (rows drawn several times collect every draw).
+ * nphm_fit_root_backward: g_posed[p] = -J^-T[p] g_xc[p] - the implicit-function correction of the correspondence root
+ *   (fitting.py:99-106) as one launch instead of an einsum chain.
+ * nphm_identity_latent_grad: bias gradients of lin0 / the skip layer [n_rows,40,200] (nphm_identity_backward) -> gradient of
+ *   the latent rows [n_rows,1344], through the latent columns of lin0.weight [24,200,99] / lin2.weight [24,200,200]
+ *   (what the cond tensor of EnsembledDeepSDF.py:247-255 transports). */
+int nphm_fit_loss(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                  const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                  float* row, void* stream);
+int nphm_fit_loss_backward(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                           const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                           const float* g_out, float* g_sdf, float* g_shape, float* g_expr, void* stream);
+int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g_posed, int64_t n, void* stream);
+int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight, const float* g_bias0, const float* g_bias2,
+                              int n_rows, float* g_lat, void* stream);
+
 /* ---- dense skip-MLP: DeepSDF (NPM global SDF, backbone of DeformationNetwork) ----------- */
 /* Architecture (src/NPHM/models/deepSDF.py:7-62): dims = [3 + lat_dim] + [hidden_dim]*nlayers + [out_dim],
  * input re-injected (concat, / sqrt 2) before layer nlayers/2, Softplus(beta) activations.

@@ -1,0 +1,255 @@
+// fit_kernels.hip — the small pieces of one latent-fitting step (src/NPHM/models/fitting.py:99-167 of the reference)
+// that are NOT field evaluations, fused: in the reference (and in rounds 1-2 of this repo) they are ~150 elementwise /
+// reduction / tiny-GEMM launches per step, half of the step's time once the fields run on their fused kernels.
+//
+//   fit_loss_kernel      clamped surface loss over the converged correspondences + every code regulariser + the weighted
+//                        total (fitting.py:115-166): the loss terms, and in a second mode their gradients
+//   root_bwd_kernel      implicit differentiation of the correspondence root (fitting.py:99-106): g_posed = -J^-T g_xc
+//   latent_blocks_kernel bias gradients of lin0 / the skip layer of the identity field -> gradient of the latent row
+//                        (what a batched GEMM over the 40 members' latent column blocks did)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "capi_common.h"
+#include "layout.h"
+
+namespace nphm {
+namespace fit {
+
+constexpr int N_TERMS = 6;     // surface, reg_expr, reg_global, reg_unobserved, reg_loc, symm_dist (the lambdas' order)
+
+struct LossArgs {
+  const float* sdf;            // [P]
+  const unsigned char* valid;  // [P] or null (torch.bool)
+  const float* thr;            // device scalar: clamp of the surface loss
+  const float* lam;            // [6] device: loss weights in the order above
+  const float* z_shape;        // [1344] identity code
+  const float* z_expr;         // [n_obs, 200] expression codes (null: identity-only loop)
+  const int64_t* obs_idx;      // [B] observation of every batch row (null with z_expr)
+  int P, B, n_obs, expr_dim;
+  const float* g_out;          // backward: device scalar dL/dloss (null = 1)
+  float* row;                  // forward: [8] = 6 terms, total, number of valid correspondences
+  float* g_sdf;                // backward: [P]
+  float* g_shape;              // backward: [1344]
+  float* g_expr;               // backward: [n_obs, 200]
+};
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  // sum over the 1024 threads of the block, result in every thread
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < int(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+
+// one workgroup.  BWD = false: the loss terms (row).  BWD = true: the gradients of the weighted total.
+template <bool BWD>
+__global__ __launch_bounds__(1024) void fit_loss_kernel(LossArgs a) {
+  __shared__ float sh[16];
+  __shared__ float pair_norm[N_SYMM];
+  const int t = threadIdx.x;
+  const float thr = *a.thr;
+  // ---- surface: mean |sdf| over the valid points below the clamp (fitting.py:115-132) ----
+  float s = 0.f, c = 0.f, nv = 0.f;
+  for (int i = t; i < a.P; i += blockDim.x) {
+    const float l = fabsf(a.sdf[i]);
+    const bool ok = a.valid ? a.valid[i] != 0 : true;
+    const bool keep = ok && l < thr;
+    s += keep ? l : 0.f;
+    c += keep ? 1.f : 0.f;
+    nv += ok ? 1.f : 0.f;
+  }
+  s = block_sum(s, sh);
+  c = block_sum(c, sh);
+  nv = block_sum(nv, sh);
+  const float surface = s / c;                         // 0 / 0 = nan when nothing is kept, like the reference's empty mean
+  // ---- regularisers of the identity code (fitting.py:139-166) ----
+  const float* z = a.z_shape;
+  float g2 = 0.f, l2 = 0.f, u2 = 0.f;
+  for (int i = t; i < LAT_DIM; i += blockDim.x) {
+    const float v = z[i] * z[i];
+    if (i < LAT_GLOB) g2 += v; else l2 += v;
+    const int k = (i - LAT_GLOB) / LAT_LOC;
+    if (i >= LAT_GLOB && (k == 30 || k == 31 || k == 39)) u2 += v;
+  }
+  g2 = block_sum(g2, sh);
+  l2 = block_sum(l2, sh);
+  u2 = block_sum(u2, sh);
+  // symmetric pairs: mean over the 16 pairs of |z_2i - z_2i+1|
+  if (t < N_SYMM * 64) {
+    const int p = t >> 6, j = t & 63;
+    float d = 0.f;
+    if (j < LAT_LOC) {
+      const float x = z[LAT_GLOB + (2 * p) * LAT_LOC + j] - z[LAT_GLOB + (2 * p + 1) * LAT_LOC + j];
+      d = x * x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if (j == 0) pair_norm[p] = sqrtf(d);
+  }
+  __syncthreads();
+  float symm = 0.f;
+  for (int p = 0; p < N_SYMM; ++p) symm += pair_norm[p];
+  symm *= 1.f / N_SYMM;
+  // expression codes of the batch rows: mean over the rows of |z_ex|^2
+  float e2 = 0.f;
+  if (a.z_expr)
+    for (int i = t; i < a.B * a.expr_dim; i += blockDim.x) {
+      const float v = a.z_expr[a.obs_idx[i / a.expr_dim] * a.expr_dim + i % a.expr_dim];
+      e2 += v * v;
+    }
+  e2 = block_sum(e2, sh) / float(max(a.B, 1));
+  const float terms[N_TERMS] = {surface, e2, g2, u2, l2, symm};
+  if (!BWD) {
+    if (t == 0) {
+      float total = 0.f;
+      for (int i = 0; i < N_TERMS; ++i) {
+        a.row[i] = terms[i];
+        if (i != 1 || a.z_expr) total += a.lam[i] * terms[i];
+      }
+      a.row[N_TERMS] = total;
+      a.row[N_TERMS + 1] = nv;
+    }
+    return;
+  }
+  const float go = a.g_out ? *a.g_out : 1.f;
+  // d surface / d sdf_i = sign(sdf_i) keep_i / count
+  const float ws = go * a.lam[0] / c;
+  for (int i = t; i < a.P; i += blockDim.x) {
+    const float v = a.sdf[i];
+    const bool keep = (a.valid ? a.valid[i] != 0 : true) && fabsf(v) < thr;
+    a.g_sdf[i] = keep ? (v > 0.f ? ws : v < 0.f ? -ws : 0.f) : 0.f;
+  }
+  // identity code: 2 z on the squared norms; unit vectors on the pair distances (0 where a pair coincides, like torch)
+  for (int i = t; i < LAT_DIM; i += blockDim.x) {
+    float g;
+    if (i < LAT_GLOB) {
+      g = 2.f * a.lam[2] * z[i];
+    } else {
+      const int k = (i - LAT_GLOB) / LAT_LOC, j = (i - LAT_GLOB) % LAT_LOC;
+      g = 2.f * a.lam[4] * z[i];
+      if (k == 30 || k == 31 || k == 39) g += 2.f * a.lam[3] * z[i];
+      if (k < 2 * N_SYMM) {
+        const int p = k >> 1;
+        const float n = pair_norm[p];
+        if (n > 0.f) {
+          const float x = z[LAT_GLOB + (2 * p) * LAT_LOC + j] - z[LAT_GLOB + (2 * p + 1) * LAT_LOC + j];
+          g += ((k & 1) ? -1.f : 1.f) * a.lam[5] * x / (n * N_SYMM);
+        }
+      }
+    }
+    a.g_shape[i] = go * g;
+  }
+  // expression codes: rows that were drawn more than once collect every draw
+  if (a.z_expr) {
+    const float we = go * a.lam[1] * 2.f / float(max(a.B, 1));
+    for (int i = t; i < a.n_obs * a.expr_dim; i += blockDim.x) {
+      const int o = i / a.expr_dim;
+      int cnt = 0;
+      for (int b = 0; b < a.B; ++b) cnt += a.obs_idx[b] == o;
+      a.g_expr[i] = we * float(cnt) * a.z_expr[i];
+    }
+  }
+}
+
+// g_posed[p][i] = - sum_j Jinv[p][j][i] g_xc[p][j]: the gradient the implicit-function correction x_c = root - J^-1 (F - F.detach())
+// sends to the posed points (fitting.py:99-106; the reference builds it with an einsum on a detached inverse Jacobian)
+__global__ void root_bwd_kernel(const float* jinv, const float* g_xc, float* g_posed, int64_t n) {
+  const int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (p >= n) return;
+  const float* J = jinv + 9 * p;
+  const float gx = g_xc[3 * p], gy = g_xc[3 * p + 1], gz = g_xc[3 * p + 2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g_posed[3 * p + i] = -(J[i] * gx + J[3 + i] * gy + J[6 + i] * gz);
+}
+
+// g_lat[b][:] from the bias gradients gb0 / gb2 [B][40][200] of lin0 and of the skip layer: the folded bias of member k is
+// W0[set(k)][:, 3:] cond_k + b (lin0) and W2[set(k)][:, 104:] cond_k / sqrt2 + b (skip layer), cond_k = [z_glob | z_k]
+// (EnsembledDeepSDF.py:247-255), so d/dcond_k = gb0_k W0_lat + gb2_k W2_lat / sqrt2.  One workgroup per (member, row):
+// the global part is accumulated over the members with atomics (g_lat zeroed by the caller), the local part written.
+__global__ __launch_bounds__(128) void latent_blocks_kernel(const float* w0, const float* w2, const float* gb0, const float* gb2,
+                                                             float* g_lat, int B) {
+  const int k = blockIdx.x, b = blockIdx.y, j = threadIdx.x;           // j: conditioning column 0..95
+  if (j >= LAT_COND) return;
+  const int s = member_set(k);
+  const float* g0 = gb0 + (size_t(b) * N_MEMBERS + k) * HID;
+  const float* g2 = gb2 + (size_t(b) * N_MEMBERS + k) * HID;
+  const float* W0 = w0 + size_t(s) * HID * D_IN + 3 + j;               // [200][99]: column 3 + j
+  const float* W2 = w2 + size_t(s) * HID * HID + L2_IN + j;            // [200][200]: column 104 + j
+  float acc0 = 0.f, acc2 = 0.f;
+  for (int f = 0; f < HID; ++f) {
+    acc0 = fmaf(g0[f], W0[size_t(f) * D_IN], acc0);
+    acc2 = fmaf(g2[f], W2[size_t(f) * HID], acc2);
+  }
+  const float v = acc0 + acc2 / INV_SQRT2_DIV;
+  float* out = g_lat + size_t(b) * LAT_DIM;
+  if (j < LAT_GLOB) atomicAdd(out + j, v);
+  else out[LAT_GLOB + k * LAT_LOC + (j - LAT_GLOB)] = v;
+}
+
+__global__ void zero_kernel(float* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+}  // namespace fit
+}  // namespace nphm
+
+extern "C" {
+
+int nphm_fit_loss(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                  const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                  float* row, void* stream) {
+  if (!sdf || !thr || !lam || !z_shape || !row || n_points <= 0) return nphm_fail_msg("nphm_fit_loss: bad arguments");
+  if (z_expr && (!obs_idx || n_rows <= 0 || n_obs <= 0 || expr_dim <= 0)) return nphm_fail_msg("nphm_fit_loss: bad expression-code arguments");
+  nphm::fit::LossArgs a{sdf, valid, thr, lam, z_shape, z_expr, obs_idx, int(n_points), n_rows, n_obs, expr_dim, nullptr, row,
+                        nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(nphm::fit::fit_loss_kernel<false>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_fit_loss launch", e);
+}
+
+int nphm_fit_loss_backward(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                           const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                           const float* g_out, float* g_sdf, float* g_shape, float* g_expr, void* stream) {
+  if (!sdf || !thr || !lam || !z_shape || !g_sdf || !g_shape || n_points <= 0) return nphm_fail_msg("nphm_fit_loss_backward: bad arguments");
+  if (z_expr && (!obs_idx || !g_expr || n_rows <= 0 || n_obs <= 0 || expr_dim <= 0))
+    return nphm_fail_msg("nphm_fit_loss_backward: bad expression-code arguments");
+  nphm::fit::LossArgs a{sdf, valid, thr, lam, z_shape, z_expr, obs_idx, int(n_points), n_rows, n_obs, expr_dim, g_out, nullptr,
+                        g_sdf, g_shape, g_expr};
+  hipLaunchKernelGGL(nphm::fit::fit_loss_kernel<true>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_fit_loss_backward launch", e);
+}
+
+int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g_posed, int64_t n, void* stream) {
+  if (!jac_inverse || !g_xc || !g_posed) return nphm_fail_msg("nphm_fit_root_backward: null pointer");
+  if (n <= 0) return n == 0 ? 0 : nphm_fail_msg("nphm_fit_root_backward: negative count");
+  hipLaunchKernelGGL(nphm::fit::root_bwd_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     jac_inverse, g_xc, g_posed, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_fit_root_backward launch", e);
+}
+
+int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight, const float* g_bias0, const float* g_bias2,
+                              int n_rows, float* g_lat, void* stream) {
+  if (!lin0_weight || !lin2_weight || !g_bias0 || !g_bias2 || !g_lat || n_rows <= 0)
+    return nphm_fail_msg("nphm_identity_latent_grad: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // (a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node was not replayed reliably - the atomics below then
+  // accumulated onto the previous replay's values)
+  const int n = n_rows * nphm::LAT_DIM;
+  hipLaunchKernelGGL(nphm::fit::zero_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g_lat, n);
+  hipError_t e;
+  hipLaunchKernelGGL(nphm::fit::latent_blocks_kernel, dim3(nphm::N_MEMBERS, n_rows), dim3(128), 0, st, lin0_weight, lin2_weight,
+                     g_bias0, g_bias2, g_lat, n_rows);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_identity_latent_grad launch", e);
+}
+
+}  // extern "C"

@@ -323,9 +323,12 @@ class _IdentityFieldFn(torch.autograd.Function):
                 ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_backward")
         # folded bias of member k: W0[k][:, lat] cond_k + b (lin0), W2[k][:, lat] cond_k / sqrt2 + b (skip layer), with
         # cond_k = [z_glob | z_k]: d/dcond_k = gb0_k W0_lat[k] + gb2_k W2_lat[k] / sqrt2, then back onto the latent layout
-        g_cond = torch.bmm(torch.cat([gb0, gb2], dim=2).transpose(0, 1), module._latent_blocks(dev)).transpose(0, 1)   # [B,A,96]
-        g = module.lat_dim_glob
-        g_lat = torch.cat([g_cond[..., :g].sum(dim=1), g_cond[..., g:].reshape(B, -1)], dim=-1)
+        # (one launch through the latent columns of lin0 / lin2 in place of a batched GEMM over the 40 members + cat / sum)
+        e = module.ensembled_deep_sdf
+        w0, w2 = e.lin0.weight.detach(), e.lin2.weight.detach()
+        g_lat = torch.empty(B, module.lat_dim, dtype=torch.float32, device=dev)
+        _lib.check(lib.nphm_identity_latent_grad(w0.data_ptr(), w2.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), B, g_lat.data_ptr(),
+                                                 torch.cuda.current_stream(dev).cuda_stream), "nphm_identity_latent_grad")
         return None, gx, g_lat, ga
 
 

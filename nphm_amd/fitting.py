@@ -177,6 +177,7 @@ class _StepControls:
         self.keys = list(lambdas.keys())
         self.lam = torch.zeros(len(self.keys), dtype=torch.float32, device=device)
         self.thr = torch.zeros((), dtype=torch.float32, device=device)
+        self.lam6 = torch.zeros(6, dtype=torch.float32, device=device)       # the weights in the fused kernel's term order
         self._lam_host, self._thr_host = None, None
 
     def refresh(self, lambdas, j, step_scale):
@@ -184,16 +185,113 @@ class _StepControls:
         thr = 0.0075 if j > int(500 * step_scale) else (0.05 if j > int(250 * step_scale) else 0.1)
         if lam != self._lam_host:
             self.lam.copy_(torch.tensor(lam, dtype=torch.float32))
+            l6 = [0.0] * 6
+            for k, v in zip(self.keys, lam):
+                if k in _LOSS_SLOTS:
+                    l6[_LOSS_SLOTS[k]] = v
+            self.lam6.copy_(torch.tensor(l6, dtype=torch.float32))
             self._lam_host = lam
         if thr != self._thr_host:
             self.thr.fill_(thr)
             self._thr_host = thr
+
+    def fused_row(self, row8, extra=()):
+        """history row (lambdas order, total, extras) out of the fused kernel's row"""
+        if getattr(self, "_perm", None) is None or self._perm_n != len(extra):
+            idx = [_LOSS_SLOTS[k] for k in self.keys] + [6] + [7] * len(extra)
+            self._perm, self._perm_n = torch.tensor(idx, dtype=torch.long, device=row8.device), len(extra)
+        return row8.index_select(0, self._perm)
 
     def total(self, loss_dict):
         loss = 0
         for i, k in enumerate(self.keys):
             loss = loss + loss_dict[k] * self.lam[i]
         return loss
+
+
+_LOSS_SLOTS = {"surface": 0, "reg_expr": 1, "reg_global": 2, "reg_unobserved": 3, "reg_loc": 4, "symm_dist": 5}
+
+
+class _FitLossFn(torch.autograd.Function):
+    """Every loss term of a fitting step and their weighted total in ONE launch (``nphm_fit_loss``), the gradients
+    w.r.t. the SDF values, the identity code and the expression codes in a second one (fitting.py:115-166; ~100
+    elementwise / reduction launches of the PyTorch formulation).  Returns (total, row [8] = the six terms in
+    ``_LOSS_SLOTS`` order, the total, the number of valid correspondences)."""
+
+    @staticmethod
+    def forward(ctx, sdf, valid, z_shape, z_expr, obs_idx, thr, lam6):
+        from . import _lib
+        lib = _lib.load()
+        dev = sdf.device
+        sdf_c = sdf.detach().reshape(-1).contiguous()
+        valid_c = None if valid is None else valid.reshape(-1).contiguous()
+        zs = z_shape.detach().reshape(-1).contiguous()
+        ze = None if z_expr is None else z_expr.detach().contiguous()
+        obs_idx = None if obs_idx is None else obs_idx.to(torch.int64).contiguous()       # a strided column of the draw
+        row = torch.empty(8, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        n_obs, expr_dim = (ze.shape[0], ze.shape[-1]) if ze is not None else (0, 0)
+        _lib.check(lib.nphm_fit_loss(sdf_c.data_ptr(), None if valid_c is None else valid_c.data_ptr(), sdf_c.numel(), thr.data_ptr(),
+                                     lam6.data_ptr(), zs.data_ptr(), None if ze is None else ze.data_ptr(),
+                                     None if ze is None else obs_idx.data_ptr(), 0 if ze is None else obs_idx.numel(), n_obs, expr_dim,
+                                     row.data_ptr(), stream), "nphm_fit_loss")
+        ctx.save_for_backward(sdf_c, valid_c, zs, ze, obs_idx, thr, lam6)
+        ctx.shapes = (sdf.shape, z_shape.shape, None if z_expr is None else z_expr.shape)
+        ctx.mark_non_differentiable(row)
+        return row[6].clone(), row
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_total, _g_row):
+        from . import _lib
+        lib = _lib.load()
+        sdf_c, valid_c, zs, ze, obs_idx, thr, lam6 = ctx.saved_tensors
+        dev = sdf_c.device
+        g_sdf = torch.empty_like(sdf_c)
+        g_shape = torch.empty_like(zs)
+        g_expr = None if ze is None else torch.empty_like(ze)
+        go = g_total.detach().reshape(1).float().contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        n_obs, expr_dim = (ze.shape[0], ze.shape[-1]) if ze is not None else (0, 0)
+        _lib.check(lib.nphm_fit_loss_backward(sdf_c.data_ptr(), None if valid_c is None else valid_c.data_ptr(), sdf_c.numel(),
+                                              thr.data_ptr(), lam6.data_ptr(), zs.data_ptr(), None if ze is None else ze.data_ptr(),
+                                              None if ze is None else obs_idx.data_ptr(), 0 if ze is None else obs_idx.numel(), n_obs,
+                                              expr_dim, go.data_ptr(), g_sdf.data_ptr(), g_shape.data_ptr(),
+                                              None if g_expr is None else g_expr.data_ptr(), stream), "nphm_fit_loss_backward")
+        s_sdf, s_shape, s_expr = ctx.shapes
+        return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None)
+
+
+class _ImplicitRootFn(torch.autograd.Function):
+    """x_c = root - J^-1 (F(root) - F(root).detach()) (fitting.py:99-106): the value is the root itself, the gradient
+    g_posed = -J^-T g_xc flows to the posed points F(root) - one small launch each way instead of the einsum chain."""
+
+    @staticmethod
+    def forward(ctx, root, posed, jac_inverse):
+        ctx.save_for_backward(jac_inverse)
+        return root.detach().clone()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_xc):
+        from . import _lib
+        lib = _lib.load()
+        (jinv,) = ctx.saved_tensors
+        g = g_xc.contiguous().float()
+        out = torch.empty_like(g)
+        _lib.check(lib.nphm_fit_root_backward(jinv.data_ptr(), g.data_ptr(), out.data_ptr(), g.numel() // 3,
+                                              torch.cuda.current_stream(g.device).cuda_stream), "nphm_fit_root_backward")
+        return None, out, None
+
+
+def _fused_losses_ok(decoder, lambdas, device) -> bool:
+    """the fused loss kernels cover the NPHM identity code layout (64 + 40 x 32) and the published loss terms"""
+    import os
+    if os.environ.get("NPHM_AMD_FIT_FUSED", "1") in ("0", ""):
+        return False
+    return (device.type == "cuda" and hasattr(decoder, "lat_dim_glob") and getattr(decoder, "backend", "hip") == "hip"
+            and getattr(decoder, "lat_dim", 0) == 1344 and getattr(decoder, "num_symm_pairs", 0) == 16
+            and all(k in _LOSS_SLOTS for k in lambdas))
 
 
 def _masked_surface_loss(sdf, thr, valid=None):
@@ -338,6 +436,7 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     ctl = _StepControls(lambdas, device)
     drawn_static = sampler.upload(sampler.draw_like())       # static input of the step: the sampled indices
     drawn_cur = [drawn_static]                               # what the step reads (another tensor for odd-shaped draws)
+    fused = _fused_losses_ok(decoder, lambdas, device) and "reg_expr" in lambdas
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder, decoder_expr) and not compute_unused_sdf_grad
 
@@ -367,17 +466,24 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             preds_posed = preds_posed + p_corresp
             jac_posed = jac(decoder_expr, p_corresp, glob_cond, anchors_b)
         grad_inv = _inverse3x3(jac_posed.detach())
-        correction = preds_posed - preds_posed.detach()
-        # 3x3 matrix-vector products per point, elementwise: as an einsum this is a rocBLAS batched GEMM of 5000 3x3
-        # problems (69 us forward + 40 us backward per step)
-        correction = -(grad_inv.detach() * correction.unsqueeze(-2)).sum(dim=-1)
-        xc = p_corresp + correction
+        if fused:
+            xc = _ImplicitRootFn.apply(p_corresp, preds_posed, grad_inv)
+        else:
+            correction = preds_posed - preds_posed.detach()
+            # 3x3 matrix-vector products per point, elementwise: as an einsum this is a rocBLAS batched GEMM of 5000 3x3
+            # problems (69 us forward + 40 us backward per step)
+            correction = -(grad_inv.detach() * correction.unsqueeze(-2)).sum(dim=-1)
+            xc = p_corresp + correction
 
         shape_cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
         sdf, _ = decoder(xc, shape_cond, None)
         if compute_unused_sdf_grad:
             _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
 
+        if fused:                          # every loss term, the total and (backward) their gradients: two launches
+            loss, row8 = _FitLossFn.apply(sdf, valid, lat_rep_shape, lat_rep, obs_idx, ctl.thr, ctl.lam6)
+            loss.backward()
+            return ctl.fused_row(row8, extra=("n_valid",)), anchors.detach()
         loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr, valid),
                      "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
         _shape_regularisers(decoder, lat_rep_shape, loss_dict)
@@ -429,6 +535,7 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
     ctl = _StepControls(lambdas, device)
     drawn_static = sampler.upload(sampler.draw_like())
     drawn_cur = [drawn_static]
+    fused = _fused_losses_ok(decoder, lambdas, device) and "reg_expr" not in lambdas
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder)
 
@@ -437,6 +544,10 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
         _, obs = sampler.gather(drawn_cur[0])
         cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
         sdf, _ = decoder(obs, cond, None)
+        if fused:
+            loss, row8 = _FitLossFn.apply(sdf, None, lat_rep_shape, None, None, ctl.thr, ctl.lam6)
+            loss.backward()
+            return ctl.fused_row(row8), anchors.detach()
         loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr)}
         _shape_regularisers(decoder, lat_rep_shape, loss_dict)
         loss = ctl.total(loss_dict)

@@ -201,3 +201,70 @@ def test_joint_fit_matches_reference_loop_gpu():
     assert np.abs(table[:, -1] - g["history"][:, -1]).max() <= 2
     _check_trace(table, g, tight=2e-5, loose=5e-4)
     _check_latents(lat_s, lat_e, anc, g, typical=1e-5, worst=5e-3)
+
+
+@pytest.mark.gpu
+def test_fused_step_pieces_match_the_pytorch_formulation():
+    """The fused loss / regulariser kernels, the implicit-root backward and the latent-block kernel of the fitting step
+    against the PyTorch formulation they replace (fitting.py:99-166), values and gradients."""
+    from nphm_amd import fitting as F
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    net = U.build_identity(device=dev).train()
+    P, B, n_obs = 5000, 5, 3
+    sdf0 = (torch.randn(B, P // B, 1, generator=g) * 0.04).to(dev)
+    valid = (torch.rand(B, P // B, generator=g) < 0.9).to(dev)
+    zs0 = (torch.randn(1, 1, 1344, generator=g) * 0.05).to(dev)
+    ze0 = (torch.randn(n_obs, 1, 200, generator=g) * 0.05).to(dev)
+    obs_idx = torch.tensor([2, 0, 2, 1, 2], device=dev)
+    lambdas = {"surface": 2.0, "reg_expr": 0.01, "reg_global": 0.25, "reg_unobserved": 10, "reg_loc": 0.05, "symm_dist": 5.0}
+    ctl = F._StepControls(lambdas, dev)
+    ctl.refresh(lambdas, 300, 1)                        # clamp 0.05
+
+    def reference(sdf, zs, ze):
+        ld = {"surface": F._masked_surface_loss(sdf, ctl.thr, valid), "reg_expr": (torch.norm(ze[obs_idx, :, :], dim=-1) ** 2).mean()}
+        F._shape_regularisers(net, zs, ld)
+        return ctl.total(ld), ld
+
+    a = [t.clone().requires_grad_() for t in (sdf0, zs0, ze0)]
+    b = [t.clone().requires_grad_() for t in (sdf0, zs0, ze0)]
+    loss_r, ld = reference(*a)
+    loss_r.backward()
+    loss_f, row = F._FitLossFn.apply(b[0], valid, b[1], b[2], obs_idx, ctl.thr, ctl.lam6)
+    loss_f.backward()
+    assert abs(float(loss_f) - float(loss_r)) < 1e-6 * max(1.0, abs(float(loss_r)))
+    for k, i in F._LOSS_SLOTS.items():
+        assert abs(float(row[i]) - float(ld[k])) < 1e-6 * max(1.0, abs(float(ld[k]))), k
+    assert int(row[7]) == int(valid.sum())
+    for x, y, name in zip(a, b, ("sdf", "identity code", "expression codes")):
+        assert float((x.grad - y.grad).abs().max()) < 1e-6 * max(1.0, float(x.grad.abs().max())), name
+    # zero code: the pair distances have the subgradient 0 (torch.norm's backward), not nan
+    z0 = torch.zeros(1, 1, 1344, device=dev, requires_grad=True)
+    l0, _ = F._FitLossFn.apply(sdf0, valid, z0, ze0, obs_idx, ctl.thr, ctl.lam6)
+    l0.backward()
+    assert bool(torch.isfinite(z0.grad).all()) and float(z0.grad.abs().max()) == 0.0
+    # implicit root: value = the root, gradient = -J^-T g
+    n = 777
+    root = torch.randn(1, n, 3, generator=g).to(dev)
+    posed = torch.randn(1, n, 3, generator=g).to(dev).requires_grad_()
+    jinv = torch.randn(1, n, 3, 3, generator=g).to(dev)
+    seed = torch.randn(1, n, 3, generator=g).to(dev)
+    xc = F._ImplicitRootFn.apply(root, posed, jinv)
+    assert torch.equal(xc, root)
+    (gp,) = torch.autograd.grad(xc, posed, seed)
+    p2 = posed.detach().clone().requires_grad_()
+    corr = -(jinv * (p2 - p2.detach()).unsqueeze(-2)).sum(dim=-1)
+    (gr,) = torch.autograd.grad(root + corr, p2, seed)
+    assert float((gp - gr).abs().max()) < 1e-6
+    # latent-block kernel vs the batched product over the members' latent column blocks
+    from nphm_amd import _lib
+    lib = _lib.load()
+    gb0 = torch.randn(B, 40, 200, generator=g).to(dev)
+    gb2 = torch.randn(B, 40, 200, generator=g).to(dev)
+    e = net.ensembled_deep_sdf
+    out = torch.empty(B, 1344, device=dev)
+    _lib.check(lib.nphm_identity_latent_grad(e.lin0.weight.data_ptr(), e.lin2.weight.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), B,
+                                             out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "latent_grad")
+    g_cond = torch.bmm(torch.cat([gb0, gb2], dim=2).transpose(0, 1), net._latent_blocks(dev)).transpose(0, 1)
+    ref = torch.cat([g_cond[..., :64].sum(dim=1), g_cond[..., 64:].reshape(B, -1)], dim=-1)
+    assert float((out - ref).abs().max()) < 2e-4 * float(ref.abs().max())

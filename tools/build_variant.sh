@@ -8,7 +8,7 @@ NAME=$1; shift
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -fno-honor-nans -I include"
 mkdir -p gpurun_tmp/obj
 V=${VARIANT_SRC:-eval_kernel}
-ALL="prep_kernels eval_kernel mlp_kernel mlp_bwd_kernel ident_bwd_kernel ident_train_kernel mc_device probe"
+ALL="prep_kernels eval_kernel mlp_kernel mlp_bwd_kernel ident_bwd_kernel ident_train_kernel fit_kernels mc_device probe"
 for f in $ALL; do
   [ $f = $V ] && continue
   if [ ! -f gpurun_tmp/obj/$f.o ] || [ nphm_amd/csrc/$f.hip -nt gpurun_tmp/obj/$f.o ]; then hipcc $FLAGS -c nphm_amd/csrc/$f.hip -o gpurun_tmp/obj/$f.o & fi
