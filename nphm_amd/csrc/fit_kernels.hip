@@ -192,6 +192,111 @@ __global__ __launch_bounds__(128) void latent_blocks_kernel(const float* w0, con
   else out[LAT_GLOB + k * LAT_LOC + (j - LAT_GLOB)] = v;
 }
 
+// ---- small dense heads with frozen weights: mlp_pos (64 -> 256 -> 256 -> 117, ReLU; EnsembledDeepSDF.py:194-200) and the
+// compressor of the deformation field (1461 -> 32; deepSDF.py:212-223) on a handful of rows: one workgroup per row, the
+// whole chain in one launch (the PyTorch formulation: a rocBLAS GEMM + bias + ReLU launch per layer and direction).
+struct HeadArgs {
+  const float* w[3];
+  const float* b[3];
+  int dims[4];                 // in, (hidden ...), out
+  int n_layers;
+  const float* x;              // [rows, dims[0]]
+  float* y;                    // [rows, dims[n_layers]]
+  float* hidden;               // [rows, dims[1] + dims[2]] post-ReLU activations (saved for the backward pass)
+  const float* g_y;            // backward: [rows, out]
+  float* g_x;                  // backward: [rows, in]
+};
+constexpr int HEAD_MAX = 1536;   // widest layer input / output held in LDS
+
+// forward: a wavefront takes 8 output features at a time (lanes split the input: coalesced weight rows, 8 x din / 64 loads
+// in flight per lane - the kernel is one workgroup per row and therefore latency-bound), ReLU between the layers
+__global__ __launch_bounds__(1024) void head_fwd_kernel(HeadArgs a) {
+  __shared__ float cur[HEAD_MAX], nxt[HEAD_MAX];
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+  for (int i = t; i < a.dims[0]; i += blockDim.x) cur[i] = a.x[size_t(row) * a.dims[0] + i];
+  __syncthreads();
+  int hoff = 0;
+  const int hstride = a.dims[1] + (a.n_layers > 2 ? a.dims[2] : 0);
+  for (int l = 0; l < a.n_layers; ++l) {
+    const int din = a.dims[l], dout = a.dims[l + 1];
+    const bool last = l == a.n_layers - 1;
+    constexpr int U = 8;
+    for (int o0 = wave * U; o0 < dout; o0 += nw * U) {
+      float acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = 0.f;
+      for (int i = lane; i < din; i += 64) {
+        const float x = cur[i];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int o = min(o0 + u, dout - 1);
+          acc[u] = fmaf(a.w[l][size_t(o) * din + i], x, acc[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v = acc[u];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+        if (lane == 0 && o0 + u < dout) {
+          v += a.b[l][o0 + u];
+          nxt[o0 + u] = last ? v : fmaxf(v, 0.f);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < dout; i += blockDim.x) {
+      const float v = nxt[i];
+      cur[i] = v;
+      if (last) a.y[size_t(row) * dout + i] = v;
+      else if (a.hidden) a.hidden[size_t(row) * hstride + hoff + i] = v;
+    }
+    if (!last) hoff += dout;
+    __syncthreads();
+  }
+}
+
+// backward w.r.t. the input only (the weights are constants here): g_in = W^T (g_out * relu').  Thread (i, s) sums segment s
+// of the output features for input feature i (coalesced over i, 16 loads in flight per thread), the segments meet in LDS.
+__global__ __launch_bounds__(1024) void head_bwd_kernel(HeadArgs a) {
+  __shared__ float cur[HEAD_MAX], part[4096];
+  const int row = blockIdx.x, t = threadIdx.x;
+  const int dout_last = a.dims[a.n_layers];
+  for (int i = t; i < dout_last; i += blockDim.x) cur[i] = a.g_y[size_t(row) * dout_last + i];
+  __syncthreads();
+  const int hstride = a.dims[1] + (a.n_layers > 2 ? a.dims[2] : 0);
+  for (int l = a.n_layers - 1; l >= 0; --l) {
+    const int din = a.dims[l], dout = a.dims[l + 1];
+    int hoff = 0;
+    for (int q = 1; q < l; ++q) hoff += a.dims[q];          // offset of this layer's INPUT activation (layer l - 1's output)
+    // segments: as many as fit 1024 threads and the 4096-float scratch (input features beyond one pass loop)
+    int S = 1;
+    while (S * 2 * min(din, 1024) <= 1024 && S * 2 <= dout) S *= 2;
+    const int per = (dout + S - 1) / S;
+    for (int i0 = 0; i0 < din; i0 += 1024 / S) {
+      const int i = i0 + t % (1024 / S), sgm = t / (1024 / S);
+      float acc = 0.f;
+      if (i < din && sgm < S) {
+        const int o1 = min(dout, (sgm + 1) * per);
+#pragma unroll 16
+        for (int o = sgm * per; o < o1; ++o) acc = fmaf(a.w[l][size_t(o) * din + i], cur[o], acc);
+      }
+      part[t] = acc;
+      __syncthreads();
+      if (t < 1024 / S && i0 + t < din) {
+        float v = 0.f;
+        for (int q = 0; q < S; ++q) v += part[q * (1024 / S) + t];
+        if (l > 0) v = a.hidden[size_t(row) * hstride + hoff + i0 + t] > 0.f ? v : 0.f;       // ReLU of the previous layer
+        if (l == 0) a.g_x[size_t(row) * din + i0 + t] = v;
+        part[2048 + ((i0 + t) & 2047)] = v;          // next layer's cotangent, staged (din <= HEAD_MAX <= 2048)
+      }
+      __syncthreads();
+    }
+    for (int i = t; i < din; i += blockDim.x) cur[i] = part[2048 + i];
+    __syncthreads();
+  }
+}
+
 __global__ void zero_kernel(float* p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0.f;
@@ -234,6 +339,40 @@ int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g
                      jac_inverse, g_xc, g_posed, n);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_fit_root_backward launch", e);
+}
+
+static int head_args(nphm::fit::HeadArgs& a, const float* const w[3], const float* const b[3], const int dims[4], int n_layers,
+                     const char* who) {
+  if (n_layers < 1 || n_layers > 3) return nphm_fail_msg(who);
+  for (int l = 0; l <= n_layers; ++l)
+    if (dims[l] <= 0 || dims[l] > nphm::fit::HEAD_MAX) return nphm_fail_msg(who);
+  for (int l = 0; l < 3; ++l) { a.w[l] = l < n_layers ? w[l] : nullptr; a.b[l] = l < n_layers ? b[l] : nullptr; }
+  for (int l = 0; l < 4; ++l) a.dims[l] = l <= n_layers ? dims[l] : 0;
+  a.n_layers = n_layers;
+  for (int l = 0; l < n_layers; ++l) if (!a.w[l] || !a.b[l]) return nphm_fail_msg(who);
+  return 0;
+}
+
+int nphm_head_forward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* x,
+                      int n_rows, float* y, float* hidden, void* stream) {
+  nphm::fit::HeadArgs a{};
+  if (!x || !y || n_rows <= 0 || (n_layers > 1 && !hidden)) return nphm_fail_msg("nphm_head_forward: bad arguments");
+  if (head_args(a, weight, bias, dims, n_layers, "nphm_head_forward: unsupported head (1..3 layers, widths <= 1536)")) return -2;
+  a.x = x; a.y = y; a.hidden = hidden;
+  hipLaunchKernelGGL(nphm::fit::head_fwd_kernel, dim3(n_rows), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_head_forward launch", e);
+}
+
+int nphm_head_backward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* hidden,
+                       const float* g_y, int n_rows, float* g_x, void* stream) {
+  nphm::fit::HeadArgs a{};
+  if (!g_y || !g_x || n_rows <= 0 || (n_layers > 1 && !hidden)) return nphm_fail_msg("nphm_head_backward: bad arguments");
+  if (head_args(a, weight, bias, dims, n_layers, "nphm_head_backward: unsupported head (1..3 layers, widths <= 1536)")) return -2;
+  a.hidden = const_cast<float*>(hidden); a.g_y = g_y; a.g_x = g_x;
+  hipLaunchKernelGGL(nphm::fit::head_bwd_kernel, dim3(n_rows), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_head_backward launch", e);
 }
 
 int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight, const float* g_bias0, const float* g_bias2,

@@ -444,7 +444,8 @@ class DeformationNetwork(nn.Module):
         if self.mode == "compress":
             a0 = anchors[:, 0] if anchors.dim() == 4 else anchors              # row 0 only
             packed = torch.cat([lat_rep[:, 0, :-e], a0.reshape(B, -1)], dim=-1)
-            comp = self.compressor(packed).unsqueeze(1)                         # [B,1,32]
+            from .ensembled_deepsdf import frozen_head
+            comp = frozen_head(self.compressor, packed, False).unsqueeze(1)     # [B,1,32]; one launch when the weights are frozen
             if self.training:
                 comp = comp + torch.randn(B, N, comp.shape[-1], device=comp.device) / 200
             Lr = max(comp.shape[1], lat_rep.shape[1])

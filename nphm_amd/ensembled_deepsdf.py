@@ -267,6 +267,65 @@ def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
     return what, tiles[: B * n_members * T], n_used, plist
 
 
+class _FrozenHeadFn(torch.autograd.Function):
+    """y = head(x) for a small nn.Sequential of Linear / ReLU layers whose parameters are CONSTANTS (latent fitting:
+    ``mlp_pos``, the deformation field's compressor): the whole chain in one launch, the gradient w.r.t. x in one launch
+    (``nphm_head_forward / _backward``) - the PyTorch formulation is a GEMM + bias + ReLU launch per layer and direction."""
+
+    @staticmethod
+    def forward(ctx, x, n_layers, *wb):
+        lib = _lib.load()
+        ws, bs = list(wb[0::2]), list(wb[1::2])
+        rows = x.shape[0]
+        dims = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        xc = x.detach().contiguous().float()
+        y = torch.empty(rows, dims[-1], dtype=torch.float32, device=x.device)
+        hidden = torch.empty(rows, max(1, sum(dims[1:-1])), dtype=torch.float32, device=x.device)
+        import ctypes
+        cdims = (ctypes.c_int * 4)(*(dims + [0] * (4 - len(dims))))
+        pad = lambda ts: _lib.ptr_array3([t.detach() for t in ts] + [ts[0].detach()] * (3 - len(ts)))
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.nphm_head_forward(pad(ws), pad(bs), cdims, n_layers, xc.data_ptr(), rows, y.data_ptr(), hidden.data_ptr(), stream),
+                   "nphm_head_forward")
+        ctx.save_for_backward(hidden, *[t.detach() for t in wb])
+        ctx.meta = (n_layers, dims)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_y):
+        lib = _lib.load()
+        hidden, *wb = ctx.saved_tensors
+        n_layers, dims = ctx.meta
+        ws, bs = list(wb[0::2]), list(wb[1::2])
+        g = g_y.contiguous().float()
+        rows = g.shape[0]
+        g_x = torch.empty(rows, dims[0], dtype=torch.float32, device=g.device)
+        import ctypes
+        cdims = (ctypes.c_int * 4)(*(dims + [0] * (4 - len(dims))))
+        pad = lambda ts: _lib.ptr_array3(list(ts) + [ts[0]] * (3 - len(ts)))
+        stream = torch.cuda.current_stream(g.device).cuda_stream
+        _lib.check(lib.nphm_head_backward(pad(ws), pad(bs), cdims, n_layers, hidden.data_ptr(), g.data_ptr(), rows, g_x.data_ptr(), stream),
+                   "nphm_head_backward")
+        return (g_x, None) + (None,) * len(wb)
+
+
+def frozen_head(seq, x, frozen: bool):
+    """``seq(x)`` for an nn.Sequential of Linear (+ ReLU between) layers; on a ROCm device, with parameters that do not
+    require grad (or ``frozen``), fp32 rows and <= 3 linear layers of width <= 1536 through the fused kernels."""
+    lins = [m for m in seq if isinstance(m, nn.Linear)]
+    others = [m for m in seq if not isinstance(m, nn.Linear)]
+    ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= len(lins) <= 3 and len(others) == len(lins) - 1
+          and all(isinstance(m, nn.ReLU) for m in others)
+          and all(max(l.in_features, l.out_features) <= 1536 and l.bias is not None for l in lins)
+          and (frozen or not any(p.requires_grad for l in lins for p in l.parameters()))
+          and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", ""))
+    if not ok:
+        return seq(x)
+    wb = [t for l in lins for t in (l.weight, l.bias)]
+    return _FrozenHeadFn.apply(x, len(lins), *wb)
+
+
 class _IdentityFieldFn(torch.autograd.Function):
     """sdf = field(xyz; latent rows, anchors) with hand-written forward and first-order backward kernels
     (member-centric: one workgroup = one member x 64 of the points that member matters for).  The kernels work on
@@ -687,8 +746,11 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         if inference:
             self.kernel_knobs(device, lat_rows)          # numerics = "auto": calibrate for these weights if needed
         if isinstance(bounds, str):
+            # the bounds only matter to the inference kernels; the autograd / training tiers build their member lists with
+            # the plain rule
             c = self._calibration
-            bounds = c[1].get("bounds") if (self.numerics == "auto" and c is not None and c[0] == self._weights_key(device)) else None
+            bounds = c[1].get("bounds") if (inference and self.numerics == "auto" and c is not None
+                                            and c[0] == self._weights_key(device)) else None
         packed = self._packed(device)
         B = lat_rows.shape[0]
         lat_rows = lat_rows.contiguous().float()
@@ -794,12 +856,11 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         B = xyz.shape[0]
         g, A = self.lat_dim_glob, self.num_kps + 1
         # parameters enter as constants here when they are (treated as) frozen: no .grad is produced for them
-        const = (lambda t: t.detach()) if self.assume_frozen_parameters else (lambda t: t)
-        h = lat_rows[:, :g]
-        for i, lin in enumerate(self.mlp_pos):
-            h = torch.nn.functional.linear(h, const(lin.weight), const(lin.bias)) if isinstance(lin, nn.Linear) else lin(h)
-        anchors = h.view(B, self.num_kps, 3)
-        anchors = anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
+        if self.assume_frozen_parameters or not any(p.requires_grad for p in self.mlp_pos.parameters()):
+            anchors = self._anchors_of_rows(lat_rows)          # fused head, shared inside an anchor_scope
+        else:
+            anchors = self.mlp_pos(lat_rows[:, :g]).view(B, self.num_kps, 3)
+            anchors = anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
         sdf = _IdentityFieldFn.apply(self, xyz, lat_rows, anchors)
         return sdf, anchors
 
@@ -859,9 +920,39 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         second return value of ``forward`` (EnsembledDeepSDF.py:228-229) without evaluating any SDF -
         differentiable w.r.t. the global code.  The fitting loops call it instead of the reference's
         one-point ``decoder(zeros, lat, None)`` whose SDF value they discard (fitting.py:58, :208)."""
-        B = lat_rep.shape[0]
-        anchors = self.mlp_pos(lat_rep[:, 0, :self.lat_dim_glob]).view(B, self.num_kps, 3)
-        return anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
+        return self._anchors_of_rows(lat_rep[:, 0, :])
+
+    def _anchors_of_rows(self, lat_rows):
+        """anchors [B,39,3] of latent rows [B, lat_dim] (differentiable w.r.t. the global code).  Inside ``anchor_scope()``
+        the rows of one code tensor - also as an expanded view of it - are evaluated once: a fitting step needs the anchors
+        of its identity code for the deformation field's conditioning AND inside the identity field."""
+        B = lat_rows.shape[0]
+        scope = getattr(self, "_anchor_scope", None)
+        key = None
+        if scope is not None:
+            key = (lat_rows.data_ptr(), lat_rows._version, lat_rows.shape[1], str(lat_rows.device))
+            hit = scope.get(key)
+            if hit is not None and (hit[0].shape[0] == B or (hit[0].shape[0] == 1 and (B == 1 or lat_rows.stride(0) == 0))):
+                return hit[0] if hit[0].shape[0] == B else hit[0].expand(B, -1, -1)
+            if B > 1 and lat_rows.stride(0) == 0:
+                lat_rows = lat_rows[:1]                      # identical rows (an expanded code): evaluate one
+        frozen = self.assume_frozen_parameters
+        a = frozen_head(self.mlp_pos, lat_rows[:, :self.lat_dim_glob], frozen).view(lat_rows.shape[0], self.num_kps, 3)
+        a = a + self.anchors.reshape(1, self.num_kps, 3).to(a)
+        if key is not None:
+            scope[key] = (a, lat_rows)
+        return a if a.shape[0] == B else a.expand(B, -1, -1)
+
+    from contextlib import contextmanager as _cm
+
+    @_cm
+    def anchor_scope(self):
+        """see ``_anchors_of_rows``; the scope holds the tensors, so an address cannot be recycled under it"""
+        self._anchor_scope = {}
+        try:
+            yield self
+        finally:
+            self._anchor_scope = None
 
     def _forward_composite(self, xyz, lat_rep):
         B, N, _ = xyz.shape

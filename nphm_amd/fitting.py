@@ -441,7 +441,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         use_graph = _graph_default(device, verbose, decoder, decoder_expr) and not compute_unused_sdf_grad
 
     def body():
-        with (decoder_expr.condition_scope() if hasattr(decoder_expr, "condition_scope") else nullcontext()):
+        with (decoder_expr.condition_scope() if hasattr(decoder_expr, "condition_scope") else nullcontext()), \
+                (decoder.anchor_scope() if hasattr(decoder, "anchor_scope") else nullcontext()):
             return body_in_scope()
 
     def body_in_scope():

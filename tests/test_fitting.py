@@ -268,3 +268,31 @@ def test_fused_step_pieces_match_the_pytorch_formulation():
     g_cond = torch.bmm(torch.cat([gb0, gb2], dim=2).transpose(0, 1), net._latent_blocks(dev)).transpose(0, 1)
     ref = torch.cat([g_cond[..., :64].sum(dim=1), g_cond[..., 64:].reshape(B, -1)], dim=-1)
     assert float((out - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_frozen_heads_match_the_linear_layers():
+    """mlp_pos and the deformation field's compressor through the fused head kernels (frozen weights) against the
+    nn.Linear / ReLU layers: values and input gradients; the per-step anchor cache returns the same tensor."""
+    from nphm_amd.ensembled_deepsdf import frozen_head
+    dev = torch.device("cuda:0")
+    net = U.build_identity(device=dev)
+    dnet = U.build_deformation(device=dev).eval()
+    g = torch.Generator().manual_seed(5)
+    for seq, rows in ((net.mlp_pos, 1), (net.mlp_pos, 5), (dnet.compressor, 5)):
+        for p in seq.parameters():
+            p.requires_grad_(False)
+        n_in = [m for m in seq if isinstance(m, torch.nn.Linear)][0].in_features
+        x0 = (torch.randn(rows, n_in, generator=g) * 0.3).to(dev)
+        a, b = x0.clone().requires_grad_(), x0.clone().requires_grad_()
+        ya, yb = frozen_head(seq, a, False), seq(b)
+        assert ya.grad_fn is not None and "FrozenHead" in type(ya.grad_fn).__name__
+        assert float((ya - yb).abs().max()) < 1e-5 * max(1.0, float(yb.abs().max()))
+        seed = torch.randn(yb.shape, generator=g).to(dev)
+        (ga,), (gb,) = torch.autograd.grad(ya, a, seed), torch.autograd.grad(yb, b, seed)
+        assert float((ga - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
+    lat = torch.zeros(1, 1, 1344, device=dev, requires_grad=True)
+    with net.anchor_scope():
+        a1 = net.predict_anchors(lat)
+        a5 = net._anchors_of_rows(lat.expand(5, -1, -1)[:, 0, :])
+        assert a5.shape == (5, 39, 3) and a5.data_ptr() == a1.data_ptr()
