@@ -256,7 +256,10 @@ class IdentityBench:
         tkey = kname if precision in ("bf16x3a", "bf16x3a2", "f16x3a2") else kname + ":" + precision
         return {
             "value": n_total * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "dtype": DTYPE[precision],
+            "dtype": (DTYPE[precision] if requested != "auto" else
+                      {"f16x3a2": "f16x3 adaptive(split-f16 MFMA, fp32 accumulate: 3 / 2 / 1 passes per member by the size of its blend term, "
+                                  "thresholds calibrated per checkpoint - config.numerics)",
+                       "f16x3": "f16x3(split-f16 MFMA, fp32 accumulate; calibrated: no cheaper tier met the target - config.numerics)"}[precision]),
             "numerics": self.numerics_report(requested),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": measured_traffic(tkey, n_local), "traffic_source": TRAFFIC_SOURCE,
