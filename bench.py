@@ -13,7 +13,7 @@ fused grid kernel (+ all-gather of the x-slabs when N > 1), output resident in H
 
 Prints ONE JSON line on rank 0 (contract in the task statement): the contract fields describe configs[1]
 in the default precision; at N = 1 the line also carries
-  "precisions"  the same workload with --precision bf16x3 and f32 (value + roofline each),
+  "precisions"  the same workload with the numerics pinned: bf16x3a2 (the round-2 default), f16x3, bf16x3, f32 (value + roofline each),
   "configs"     configs[0] (NPM 64^3), configs[2] (two-stage 256^3), configs[4] (latent fitting, 250 steps,
                 final loss next to the all-composite PyTorch-ROCm loop), 512^3 on one GPU and one training step of the
                 identity decoder at nphm.yaml's sizes next to the composite tier,
@@ -396,7 +396,7 @@ def npm_record(args, dev, steps, warmup, cpu):
     return out
 
 
-FIT_LAUNCHES_PER_STEP = 212      # kernel launches of one replayed step (profiles/r02_h_fitting_kernel_stats.csv; refreshed per round)
+FIT_LAUNCHES_PER_STEP = 105      # kernel launches of one replayed step (profiles/r03_c_fitting_kernel_stats.csv; refreshed per round)
 FIT_LAMBDAS = {"surface": 2.0, "reg_expr": 0.01, "reg_global": 0.25, "reg_unobserved": 10, "reg_loc": 0.05,
                "symm_dist": 5.0}                                                   # fitting_pointclouds.py:253-259
 FIT_SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 500: 9999},
@@ -862,7 +862,7 @@ def main():
             sub_steps = max(2, min(args.steps, 5))
             out["mfma_sustained"] = mfma_sustained(dev)
             out["precisions"] = {p: ib.record(p, sub_steps if p != "f32" else 2, 1, binned)
-                                 for p in ("bf16x3a", "bf16x3", "f32") if p != args.precision}
+                                 for p in ("bf16x3a2", "f16x3", "bf16x3", "f32") if p != args.precision}
             out["configs"] = {
                 "npm_64": npm_record(args, dev, max(sub_steps, 5), 2, not args.no_cpu_baseline),
                 "two_stage_256": two_stage_record(args, dev, sub_steps, 1),
