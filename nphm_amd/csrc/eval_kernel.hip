@@ -731,7 +731,7 @@ __device__ __forceinline__ void blend_masks(const float* anch, float qx, float q
 // change of member set along the list (brick order: 5.4 GB of L2 fills per 256^3 launch, binned without
 // runs: 18.7 GB).  Grids are padded to whole rounds of 8 runs.
 #ifndef NPHM_XCD_RUN
-#define NPHM_XCD_RUN 64
+#define NPHM_XCD_RUN 32   // round 3 (calibrated f16 default, ~5 members per wavefront): 16 / 32 are 2-3 % ahead of 64 on two boxes, 128 -4 %
 #endif
 constexpr unsigned XCD_RUN = NPHM_XCD_RUN;
 __device__ __forceinline__ unsigned binned_group(unsigned b) {

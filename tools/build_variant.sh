@@ -11,7 +11,8 @@ V=${VARIANT_SRC:-eval_kernel}
 ALL="prep_kernels eval_kernel mlp_kernel mlp_bwd_kernel ident_bwd_kernel ident_train_kernel fit_kernels mc_device probe"
 for f in $ALL; do
   [ $f = $V ] && continue
-  if [ ! -f gpurun_tmp/obj/$f.o ] || [ nphm_amd/csrc/$f.hip -nt gpurun_tmp/obj/$f.o ]; then hipcc $FLAGS -c nphm_amd/csrc/$f.hip -o gpurun_tmp/obj/$f.o & fi
+  # (headers are dependencies too: layout.h / the public header changing must rebuild every object)
+  if [ ! -f gpurun_tmp/obj/$f.o ] || [ nphm_amd/csrc/$f.hip -nt gpurun_tmp/obj/$f.o ] || [ -n "$(find nphm_amd/csrc include -name '*.h' -newer gpurun_tmp/obj/$f.o | head -1)" ]; then hipcc $FLAGS -c nphm_amd/csrc/$f.hip -o gpurun_tmp/obj/$f.o & fi
 done
 if [ ! -f gpurun_tmp/obj/marching_cubes.o ] || [ nphm_amd/csrc/marching_cubes.cpp -nt gpurun_tmp/obj/marching_cubes.o ]; then hipcc -O3 -std=c++17 -fPIC -pthread -I include -c nphm_amd/csrc/marching_cubes.cpp -o gpurun_tmp/obj/marching_cubes.o & fi
 SRC=${EVAL_SRC:-nphm_amd/csrc/$V.hip}
