@@ -768,7 +768,17 @@ __global__ __launch_bounds__(256) void tile_prepass_kernel(EvalArgs p) {
     p.tile_masks[3 * size_t(t) + 1] = hmask[half];
     p.tile_masks[3 * size_t(t) + 2] = fmask[half];
     // 40 mask bits + 24 bits that tell different heavy sets of one mask apart
+#ifndef NPHM_KEY_TIERS
+#define NPHM_KEY_TIERS 0
+#endif
+#if NPHM_KEY_TIERS
+    // ... ordered by how many members run three / more than one pass, so that tiles of one member set AND a similar pass
+    // structure share a workgroup (its wavefronts advance in lock step through the weight stream)
+    const uint64_t hh = (uint64_t(__popcll(fmask[half] & w)) << 18) | (uint64_t(__popcll(hmask[half] & w)) << 12) |
+                        ((h * 0x9E3779B97F4A7C15ull) >> 52);
+#else
     const uint64_t hh = (h * 0x9E3779B97F4A7C15ull) >> 40;
+#endif
     p.tile_keys[t] = (w << 24) | hh;
     p.tile_ids[t] = t;
   }
