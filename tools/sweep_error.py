@@ -17,7 +17,9 @@ import _util as U  # noqa: E402
 from nphm_amd import reconstruction as R  # noqa: E402
 
 dev = torch.device("cuda:0")
-axes = R.grid_axes(U.MINI, U.MAXI, 64)
+RES = int(os.environ.get("NPHM_SWEEP_RES", "64"))          # 256: the full extraction lattice (dense fp32 reference 0.3 s per latent)
+N_LAT = int(os.environ.get("NPHM_SWEEP_LATENTS", "12"))
+axes = R.grid_axes(U.MINI, U.MAXI, RES)
 modes = sys.argv[1:] or ["bf16x3a2", "f16x3a2"]
 prune = float(os.environ.get("NPHM_SWEEP_PRUNE", "1e-7"))
 
@@ -48,7 +50,7 @@ def sweep(n, lats, label):
             members[m].append((s[0] - s[15] - s[14], s[14], s[15]))
     line = f"{label}: max |sdf| {max(mags):.3f};"
     for m in modes:
-        h, t, l = np.mean(members[m], axis=0) / 64 ** 3
+        h, t, l = np.mean(members[m], axis=0) / RES ** 3
         line += f"  {m} {max(errs[m]):.2e} ({h:.2f}/{t:.2f}/{l:.2f})"
         if m == "auto":
             c = n.calibration
@@ -62,6 +64,6 @@ for wscale in (1.0, 1.5, 2.5):
         for i in range(5):
             getattr(n.ensembled_deep_sdf, f"lin{i}").weight.mul_(wscale)
     for lscale in (0.85, 1.5, 3.0):
-        sweep(n, [U.sample_latent(seed, scale=lscale).to(dev) for seed in range(12)], f"weights x{wscale} latent-sigma x{lscale}")
+        sweep(n, [U.sample_latent(seed, scale=lscale).to(dev) for seed in range(N_LAT)], f"weights x{wscale} latent-sigma x{lscale}")
 n, codes = U.build_trained_identity(device=dev)
 sweep(n.eval(), [codes[c] for c in range(0, 64, 8)], "trained-like checkpoint, 8 codes")
