@@ -890,10 +890,10 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         pred = sample_point_feature(xyz[..., :3], anchors, f.unsqueeze(-1), background=True, var=0.1 ** 2)
         return pred, anchors
 
-    def _train_tier_serves(self, xyz, lat_rep):
-        """The HIP training tier's conditions: train mode, trainable parameters, ROCm fp32 tensors, the NPHM
-        architecture, one latent per batch row."""
-        if not (self.training and self.backend != "composite" and self.train_backend == "hip" and xyz.is_cuda
+    def _train_tier_serves(self, xyz, lat_rep, eval_ok=False):
+        """The HIP training tier's conditions: train mode (or a caller that states the eval-mode overwrite itself),
+        trainable parameters, ROCm fp32 tensors, the NPHM architecture, one latent per batch row."""
+        if not ((self.training or eval_ok) and self.backend != "composite" and self.train_backend == "hip" and xyz.is_cuda
                 and xyz.dtype == torch.float32 and torch.is_grad_enabled() and self.hip_supported()):
             return False
         if self.assume_frozen_parameters or not any(p.requires_grad for p in self.parameters()):
@@ -901,17 +901,29 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         N = xyz.shape[1]
         return lat_rep.shape[1] == 1 or (lat_rep.shape[1] == N and bool((lat_rep == lat_rep[:, :1]).all()))
 
-    def value_and_gradient(self, xyz: torch.Tensor, lat_rep: torch.Tensor):
+    def value_and_gradient(self, xyz: torch.Tensor, lat_rep: torch.Tensor, last_points=None):
         """(sdf [B,N,1], d sdf / d xyz [B,N,3], anchors) in ONE differentiable evaluation - what ``compute_loss`` obtains
         from ``decoder(...)`` followed by ``gradient(pred, x)`` (loss_functions.py:36-49) - or None when the HIP
         training tier does not serve the call (the caller then does exactly that).  The spatial gradient is an output
         of the fused blend kernel, so no graph-recording backward pass is needed: ``loss.backward()`` on terms of both
-        outputs differentiates through the member kernels' second-order backward."""
+        outputs differentiates through the member kernels' second-order backward.
+
+        Eval mode (the validation step, training.py:250-268): the reference overwrites every member's value of the LAST
+        point of each decoder call with 1 (EnsembledDeepSDF.py:260-261).  A caller that evaluates several of the
+        reference's calls as one batch names those points in ``last_points`` (indices along N); without it an
+        eval-mode module is not served here (None)."""
         if xyz.dim() < 3:
             xyz = xyz.unsqueeze(0)
-        if not self._train_tier_serves(xyz, lat_rep):
+        if not self._train_tier_serves(xyz, lat_rep, eval_ok=last_points is not None):
             return None
         anchors, S, G = self._train_members(xyz, lat_rep[:, 0, :])
+        if not self.training:
+            # constants at the overwritten points: value 1 for all 40 members (the blend then returns
+            # sum(w) / (sum(w) + 1e-6)), no member gradient - written as a blend, autograd sees no in-place update
+            keep = torch.ones(xyz.shape[1], dtype=S.dtype, device=S.device)
+            keep[torch.as_tensor(last_points, device=S.device, dtype=torch.long)] = 0.0
+            S = S * keep[None, :, None] + (1.0 - keep)[None, :, None]
+            G = G * keep[None, :, None, None]
         pred, grad = _BlendFn.apply(xyz, anchors, S, G)
         return pred.unsqueeze(-1), grad, anchors
 

@@ -42,14 +42,23 @@ def actual_compute_loss(batch_cuda, decoder, glob_cond):
             grad = gradient(pred, x)
     else:
         # eval mode (validation, training.py:250-268): the NPHM decoder overwrites the member values of the LAST point of
-        # every call (EnsembledDeepSDF.py:260-261) - four calls, four overwritten points, as in the reference
-        preds, grads = [], []
-        for k in _POINT_SETS:
-            x = batch_cuda[k].clone().detach().requires_grad_()
-            p_k, anchors = decoder(x, glob_cond, anchors_gt)
-            preds.append(p_k)
-            grads.append(gradient(p_k, x))
-        pred, grad = torch.cat(preds, dim=1), torch.cat(grads, dim=1)
+        # every call (EnsembledDeepSDF.py:260-261) - four calls, four overwritten points, as in the reference.  The HIP
+        # training tier takes the four sets as one batch with those four points named; otherwise four calls
+        fused = None
+        if hasattr(decoder, "value_and_gradient") and min(sizes) > 0:
+            x = torch.cat([batch_cuda[k] for k in _POINT_SETS], dim=1).clone().detach().requires_grad_()
+            ends = [sum(sizes[:i + 1]) - 1 for i in range(len(sizes))]
+            fused = decoder.value_and_gradient(x, glob_cond, last_points=ends)
+        if fused is not None:
+            pred, grad, anchors = fused
+        else:
+            preds, grads = [], []
+            for k in _POINT_SETS:
+                x = batch_cuda[k].clone().detach().requires_grad_()
+                p_k, anchors = decoder(x, glob_cond, anchors_gt)
+                preds.append(p_k)
+                grads.append(gradient(p_k, x))
+            pred, grad = torch.cat(preds, dim=1), torch.cat(grads, dim=1)
     # the point sets are consecutive slices of the batch: [face | non-face | near | far].  The reference's means over
     # concatenated per-set terms are means over slices of ONE tensor (same values, a fraction of the autograd nodes):
     n_face, n_non, n_near, n_far = sizes

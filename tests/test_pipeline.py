@@ -146,7 +146,7 @@ def test_training_script_on_the_hip_tier_matches_composite():
         hip, _ = _train_script("cuda:0", "hip")
     finally:
         E.FastEnsembleDeepSDFMirrored._train_members = orig
-    assert used.get("n") == 3                       # the three training steps; the eval-mode validation step is composite
+    assert used.get("n") == 4                       # the three training steps and the eval-mode validation step
     ref, _ = _train_script("cuda:0", "composite")
     # same state at the first step: same losses.  Later steps: Adam divides every gradient entry by its own magnitude,
     # so codes whose gradient is round-off (local codes of members no sample is near: exactly 0 on the pruned HIP tier,

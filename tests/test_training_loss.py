@@ -91,6 +91,36 @@ def test_loss_and_gradients_match_reference_hip():
     _check(net, g, losses, total, lat, 1e-5, 2e-3)
 
 
+@pytest.mark.gpu
+def test_validation_step_matches_reference_hip():
+    """training.py:250-268 on the HIP training tier: eval mode, the four overwritten points named by the loss mirror
+    (one batched evaluation instead of four decoder calls), gradients of the codes."""
+    dev = torch.device("cuda:0")
+    g = U.golden("training")
+    net = U.build_identity(device=dev).eval()
+    used = {}
+    orig = net._train_members
+    net._train_members = lambda *a, **k: used.setdefault("hip", True) and orig(*a, **k)
+    batch = {k[6:]: torch.from_numpy(g[k]).to(dev) for k in g if k.startswith("batch_")}
+    for prune, tol in ((-1.0, 5e-4), (1e-7, 2e-3)):
+        net.prune_tol = prune
+        lat = torch.from_numpy(g["lat"]).to(dev).requires_grad_()
+        net.zero_grad(set_to_none=True)
+        losses = actual_compute_loss(batch, net, lat)
+        sum(LAMBDAS[k] * losses[k] for k in losses).backward()
+        assert used.pop("hip", False), "the HIP training tier did not run"
+        for k, v in losses.items():
+            assert abs(float(v.detach()) - float(g["val_loss_" + k])) <= 1e-5 * max(1.0, abs(float(g["val_loss_" + k]))), k
+        err = float(np.abs(lat.grad.cpu().numpy() - g["val_grad_lat"]).max()) / float(np.abs(g["val_grad_lat"]).max())
+        print(f"validation step on the HIP tier, prune_tol {prune}: code gradient within {err:.2e} of the reference")
+        assert err <= tol
+    # a plain eval-mode forward() that needs a graph keeps the composite formulation (its caller states no overwrite)
+    net._train_members = orig
+    x = batch["points_face"].clone().requires_grad_()
+    lat = torch.from_numpy(g["lat"]).to(dev).requires_grad_()
+    assert net.value_and_gradient(x, lat) is None
+
+
 # ---- deformation-stage losses (compute_loss_corresp_forward, loss_joint) ----------------------------------------------
 from NPHM.models.loss_functions import compute_loss_corresp_forward, loss_joint   # noqa: E402
 
