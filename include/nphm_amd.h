@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 5
+#define NPHM_AMD_ABI_VERSION 6
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -375,6 +375,17 @@ int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim
  * (src/NPHM/models/iterative_root_finding.py:118, src/NPHM/models/fitting.py:102) without the blocking
  * error-flag read of torch.linalg.inv. */
 int nphm_inverse3x3(const float* matrices, float* inverses, int64_t n, void* stream);
+/* The same for matrices addressed by strides (in floats): element (i, j) of matrix p at matrices[p * matrix_stride +
+ * i * row_stride + j * col_stride] - the Jacobian block of nphm_mlp_eval_points_jvp's [n, 4, out_dim] output, transposed
+ * (diff_operators.jac's layout), is inverted where it lies; inverses row-major [n, 3, 3] (ABI 6). */
+int nphm_inverse3x3_strided(const float* matrices, int64_t matrix_stride, int64_t row_stride, int64_t col_stride,
+                            float* inverses, int64_t n, void* stream);
+/* d L / d cond [n_rows, lat_dim] = grad_bias0 W0[:, off0 : off0 + lat_dim] + grad_bias_skip W_skip[:, off_skip : off_skip +
+ * lat_dim] / sqrt(2) from nphm_mlp_backward_cond's outputs [n_rows, hidden_dim] and the row-major fp32 weights of lin0 /
+ * the skip layer (leading dimensions ld0 / ld_skip = their in_features) in one launch (ABI 6). */
+int nphm_mlp_cond_grad(const float* grad_bias0, const float* grad_bias_skip, int n_rows, int hidden_dim,
+                       const float* lin0_weight, int ld0, int off0, const float* skip_weight, int ld_skip, int off_skip,
+                       int lat_dim, float* grad_cond, void* stream);
 
 /* The same on the x-slab [ix0, ix1) of an [rx,ry,rz] 'ij' lattice (utils/reconstruction.py:5-20):
  * out [(ix1-ix0)*ry*rz, out_dim] in flattened lattice order. */

@@ -94,6 +94,9 @@ SYMBOLS = {
     "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
                                                       c_void_p]),
     "nphm_inverse3x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nphm_inverse3x3_strided": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "nphm_mlp_cond_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                   c_void_p, c_void_p]),
     "nphm_mlp_eval_grid": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nphm_mc_extract": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_int, c_int,
@@ -128,7 +131,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 5:
+    if lib.nphm_abi_version() != 6:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -168,6 +168,53 @@ __global__ void root_bwd_kernel(const float* jinv, const float* g_xc, float* g_p
   for (int i = 0; i < 3; ++i) g_posed[3 * p + i] = -(J[i] * gx + J[3 + i] * gy + J[6 + i] * gz);
 }
 
+// batched 3x3 inverse (adjugate) of matrices addressed by strides - element (i, j) of matrix p at
+// in[p * sp + i * si + j * sj] - so that a transposed / sliced view (the Jacobian block of the value+Jacobian output
+// [.., 4, out_dim]) needs no contiguous copy first; out row-major [n][3][3]
+__global__ __launch_bounds__(256) void inverse3x3_strided_kernel(const float* __restrict__ in, int64_t sp, int64_t si, int64_t sj,
+                                                                  float* __restrict__ out, int64_t n) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float a[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[3 * i + j] = in[p * sp + i * si + j * sj];
+  const float c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+  const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+  const float r = 1.f / det;
+  float* o = out + p * 9;
+  o[0] = c00 * r; o[1] = (a[2] * a[7] - a[1] * a[8]) * r; o[2] = (a[1] * a[5] - a[2] * a[4]) * r;
+  o[3] = c01 * r; o[4] = (a[0] * a[8] - a[2] * a[6]) * r; o[5] = (a[2] * a[3] - a[0] * a[5]) * r;
+  o[6] = c02 * r; o[7] = (a[1] * a[6] - a[0] * a[7]) * r; o[8] = (a[0] * a[4] - a[1] * a[3]) * r;
+}
+
+// d L / d cond [R][lat] of the dense skip-MLP from the bias gradients of lin0 and of the skip layer [R][H]
+// (nphm_mlp_backward_cond): g0 W0[:, off0:] + gs Ws[:, offs:] / sqrt2 - two [R,H]x[H,lat] products on 5 rows, for which the
+// library launched two GEMMs, a divide and an add.  Block = 64 columns x 16 slices of H, slices combined through LDS.
+constexpr int CG_PARTS = 16;
+__global__ __launch_bounds__(64 * CG_PARTS) void cond_grad_kernel(const float* __restrict__ g0, const float* __restrict__ gs, int H,
+                                                                   const float* __restrict__ w0, int ld0, int off0,
+                                                                   const float* __restrict__ ws, int lds_, int offs, int lat,
+                                                                   float* __restrict__ out) {
+  __shared__ float part[CG_PARTS][64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6, r = blockIdx.y;
+  float acc0 = 0.f, acc1 = 0.f;
+  if (j < lat)
+    for (int h = s; h < H; h += CG_PARTS) {
+      acc0 = fmaf(g0[size_t(r) * H + h], w0[size_t(h) * ld0 + off0 + j], acc0);
+      acc1 = fmaf(gs[size_t(r) * H + h], ws[size_t(h) * lds_ + offs + j], acc1);
+    }
+  part[s][threadIdx.x & 63] = acc0 + acc1 * 0.70710678118654752440f;
+  __syncthreads();
+  if (s == 0 && j < lat) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < CG_PARTS; ++q) t += part[q][threadIdx.x];
+    out[size_t(r) * lat + j] = t;
+  }
+}
+
 // g_lat[b][:] from the bias gradients gb0 / gb2 [B][40][200] of lin0 and of the skip layer: the folded bias of member k is
 // W0[set(k)][:, 3:] cond_k + b (lin0) and W2[set(k)][:, 104:] cond_k / sqrt2 + b (skip layer), cond_k = [z_glob | z_k]
 // (EnsembledDeepSDF.py:247-255), so d/dcond_k = gb0_k W0_lat + gb2_k W2_lat / sqrt2.  One workgroup per (member, row):
@@ -389,6 +436,31 @@ int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight
                      g_bias0, g_bias2, g_lat, n_rows);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_identity_latent_grad launch", e);
+}
+
+int nphm_inverse3x3_strided(const float* matrices, int64_t matrix_stride, int64_t row_stride, int64_t col_stride,
+                            float* inverses, int64_t n, void* stream) {
+  if (!matrices || !inverses) return nphm_fail_msg("nphm_inverse3x3_strided: null pointer");
+  if (n <= 0) return n == 0 ? 0 : nphm_fail_msg("nphm_inverse3x3_strided: negative count");
+  hipLaunchKernelGGL(nphm::fit::inverse3x3_strided_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), matrices, matrix_stride, row_stride, col_stride, inverses, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_inverse3x3_strided launch", e);
+}
+
+int nphm_mlp_cond_grad(const float* grad_bias0, const float* grad_bias_skip, int n_rows, int hidden_dim,
+                       const float* lin0_weight, int ld0, int off0, const float* skip_weight, int ld_skip, int off_skip,
+                       int lat_dim, float* grad_cond, void* stream) {
+  if (!grad_bias0 || !grad_bias_skip || !lin0_weight || !skip_weight || !grad_cond)
+    return nphm_fail_msg("nphm_mlp_cond_grad: null pointer");
+  if (n_rows <= 0 || hidden_dim <= 0 || lat_dim <= 0 || off0 < 0 || off_skip < 0 || off0 + lat_dim > ld0 ||
+      off_skip + lat_dim > ld_skip)
+    return nphm_fail_msg("nphm_mlp_cond_grad: bad sizes");
+  hipLaunchKernelGGL(nphm::fit::cond_grad_kernel, dim3((lat_dim + 63) / 64, n_rows), dim3(64 * nphm::fit::CG_PARTS), 0,
+                     static_cast<hipStream_t>(stream), grad_bias0, grad_bias_skip, hidden_dim, lin0_weight, ld0, off0,
+                     skip_weight, ld_skip, off_skip, lat_dim, grad_cond);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_mlp_cond_grad launch", e);
 }
 
 }  // extern "C"

@@ -82,7 +82,15 @@ class _MlpCondFn(torch.autograd.Function):
         W0 = module.lin0.weight                                   # [H, d + lat]
         Ws = getattr(module, f"lin{skip}").weight                 # [H, k_act + d + lat]
         k_act = Ws.shape[1] - W0.shape[1]
-        grad_cond = gb0 @ W0[:, d:] + (gbs @ Ws[:, k_act + d:]) / _SQRT2
+        lat = W0.shape[1] - d
+        if W0.dtype == torch.float32 and W0.is_contiguous() and Ws.is_contiguous():
+            # gb0 W0[:, d:] + gbs Ws[:, k_act + d:] / sqrt2 in one launch (two library GEMMs on 5 rows, a divide, an add)
+            grad_cond = torch.empty(R, lat, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_mlp_cond_grad(gb0.data_ptr(), gbs.data_ptr(), R, H, W0.detach().data_ptr(), W0.shape[1], d,
+                                              Ws.detach().data_ptr(), Ws.shape[1], k_act + d, lat, grad_cond.data_ptr(), stream),
+                       "nphm_mlp_cond_grad")
+        else:
+            grad_cond = gb0 @ W0[:, d:] + (gbs @ Ws[:, k_act + d:]) / _SQRT2
         return None, None, grad_cond, None, None
 
 
@@ -293,7 +301,7 @@ class DeepSDF(nn.Module):
                                         x_init.data_ptr(), jinv_init.data_ptr(), B, N, int(max_steps),
                                         float(cvg_thresh), float(dvg_thresh), float(eps), x.data_ptr(),
                                         diff.data_ptr(), valid.data_ptr(), stream), "nphm_mlp_broyden")
-        return x, diff, valid.bool()
+        return x, diff, valid.view(torch.bool)           # the kernel writes 0 / 1 bytes
 
     def _hip_rows(self, xyz, cond, cond_grad_ok=False):
         """How the HIP tier can serve this call: returns (xyz_view [R,n,3], cond_rows [R,lat_dim]) or
@@ -414,17 +422,25 @@ class DeformationNetwork(nn.Module):
         """Conditioning vector [B,Lr,lat_dim] (Lr = 1 when it is constant along the points)."""
         scope = getattr(self, "_cond_scope", None)
         key = None
-        if (scope is not None and self.mode == "compress" and not self.training and anchors is not None
-                and not (torch.is_grad_enabled() and (lat_rep.requires_grad or anchors.requires_grad))):
+        wants_graph = torch.is_grad_enabled() and (lat_rep.requires_grad or (anchors is not None and anchors.requires_grad))
+        if scope is not None and self.mode == "compress" and not self.training and anchors is not None:
+            # (a detached alias has the address, version, shape and strides of its source: same key)
             key = (lat_rep.data_ptr(), lat_rep._version, tuple(lat_rep.shape), tuple(lat_rep.stride()),
                    anchors.data_ptr(), anchors._version, tuple(anchors.shape), tuple(anchors.stride()))
             hit = scope.get(key)
-            if hit is not None:
-                return hit[0]
+            if hit is not None and (hit[3] or not wants_graph):
+                return hit[0] if wants_graph else hit[0].detach()
         cond = self._condition_impl(xyz, lat_rep, anchors)
         if key is not None:
-            scope[key] = (cond, lat_rep, anchors)
+            scope[key] = (cond, lat_rep, anchors, cond.requires_grad)
         return cond
+
+    def prime_condition(self, lat_rep, anchors):
+        """Inside a ``condition_scope``: evaluate the conditioning of (lat_rep, anchors) ONCE, with its autograd graph, so that
+        the step's later calls - the no-grad ones of the correspondence search and the differentiable one at the roots -
+        share it (a fitting step otherwise runs the compressor twice).  No-op outside a scope / for other modes."""
+        if getattr(self, "_cond_scope", None) is not None and self.mode == "compress" and not self.training and anchors is not None:
+            self._condition(lat_rep[:, :1, :3], lat_rep, anchors)
 
     def _condition_impl(self, xyz, lat_rep, anchors):
         B, N, _ = xyz.shape

@@ -37,6 +37,23 @@ def gradient(outputs, inputs):
     return g[:, :, -3:]
 
 
+def _single_stride(J):
+    """stride between consecutive 3x3 matrices if the leading dimensions of J [..., 3, 3] collapse into one, else None"""
+    if J.dim() < 2 or tuple(J.shape[-2:]) != (3, 3):
+        return None
+    step = None
+    for size, stride in zip(reversed(J.shape[:-2]), reversed(J.stride()[:-2])):
+        if size == 1:
+            continue
+        if step is None:
+            step, span = stride, stride * size
+        elif stride == span:
+            span = stride * size
+        else:
+            return None
+    return 9 if step is None else step
+
+
 def inverse3x3(J):
     """Batched 3x3 inverse of a CONSTANT: the result never carries a graph (both callers - the root finder's initial
     inverse Jacobian and the implicit-differentiation correction of the fitting loop - detach it; the reference's
@@ -51,9 +68,15 @@ def inverse3x3(J):
     if J.is_cuda and J.dtype == torch.float32:
         from . import _lib
         lib = _lib.load()
-        Jc = J.detach().contiguous()
-        out = torch.empty_like(Jc)
-        _lib.check(lib.nphm_inverse3x3(Jc.data_ptr(), out.data_ptr(), Jc.numel() // 9,
-                                       torch.cuda.current_stream(J.device).cuda_stream), "nphm_inverse3x3")
+        Jd = J.detach()
+        out = torch.empty(Jd.shape, dtype=torch.float32, device=J.device)
+        stream = torch.cuda.current_stream(J.device).cuda_stream
+        lead = _single_stride(Jd)
+        if lead is None:
+            Jd, lead = Jd.contiguous(), 9
+        # one kernel for contiguous matrices and for transposed / sliced views (the Jacobian block of a value+Jacobian
+        # output is inverted where it lies): the same arithmetic, bit for bit
+        _lib.check(lib.nphm_inverse3x3_strided(Jd.data_ptr(), lead, Jd.stride(-2), Jd.stride(-1), out.data_ptr(),
+                                               Jd.numel() // 9, stream), "nphm_inverse3x3_strided")
         return out
     return torch.linalg.inv_ex(J)[0]

@@ -452,6 +452,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), lat_rep[obs_idx, :, :]], dim=-1)   # [B,1,L]
         anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
 
+        if hasattr(decoder_expr, "prime_condition"):
+            decoder_expr.prime_condition(glob_cond, anchors_b)       # one conditioning row per step, shared by the calls below
         # canonical correspondences by Broyden root finding (no gradient flows through it)
         p_corresp, search_result = search(obs, glob_cond, decoder_expr,
                                           None if anchors_b is None else anchors_b.detach(), multi_corresp=False)
@@ -459,15 +461,15 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         valid = search_result["valid_ids"]
 
         # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
-        fused = decoder_expr.posed_and_jacobian(p_corresp, glob_cond, anchors_b) if hasattr(decoder_expr, "posed_and_jacobian") else None
-        if fused is not None:              # posed points, Jacobian and the state of the backward in one launch
-            preds_posed, jac_posed = fused
+        pj = decoder_expr.posed_and_jacobian(p_corresp, glob_cond, anchors_b) if hasattr(decoder_expr, "posed_and_jacobian") else None
+        if pj is not None:                 # posed points, Jacobian and the state of the backward in one launch
+            preds_posed, jac_posed = pj
         else:
             preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
             preds_posed = preds_posed + p_corresp
             jac_posed = jac(decoder_expr, p_corresp, glob_cond, anchors_b)
         grad_inv = _inverse3x3(jac_posed.detach())
-        if fused:
+        if pj is not None:
             xc = _ImplicitRootFn.apply(p_corresp, preds_posed, grad_inv)
         else:
             correction = preds_posed - preds_posed.detach()
@@ -484,13 +486,15 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         if fused:                          # every loss term, the total and (backward) their gradients: two launches
             loss, row8 = _FitLossFn.apply(sdf, valid, lat_rep_shape, lat_rep, obs_idx, ctl.thr, ctl.lam6)
             loss.backward()
-            return ctl.fused_row(row8, extra=("n_valid",)), anchors.detach()
-        loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr, valid),
-                     "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
-        _shape_regularisers(decoder, lat_rep_shape, loss_dict)
-        loss = ctl.total(loss_dict)
-        loss.backward()
-        return hist.row(loss_dict, loss, n_valid=valid.sum()), anchors.detach()
+            row = ctl.fused_row(row8, extra=("n_valid",))
+        else:
+            loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr, valid),
+                         "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
+            _shape_regularisers(decoder, lat_rep_shape, loss_dict)
+            loss = ctl.total(loss_dict)
+            loss.backward()
+            row = hist.row(loss_dict, loss, n_valid=valid.sum())
+        return row, anchors.detach()
 
     step = _GraphedStep(body, use_graph, [lat_rep_shape, lat_rep])
     anchors = None

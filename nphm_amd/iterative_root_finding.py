@@ -80,7 +80,7 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
             a0 = anchors[:, 0, :, :] if anchors.dim() == 4 else anchors
             anchors = a0.unsqueeze(1).repeat(1, xc_init.shape[1], 1, 1)
     else:
-        xc_init = obs.detach().clone()
+        xc_init = obs.detach()                 # an alias: nothing below writes into it (the solvers copy / own their iterates)
 
     J_inv_init = inverse3x3(jac(decoder_expr, xc_init, cond, anchors).detach()).flatten(0, 1)    # the reference: `.inverse()`
     x0 = xc_init.reshape(-1, 3, 1)

@@ -268,6 +268,27 @@ def test_fused_step_pieces_match_the_pytorch_formulation():
     g_cond = torch.bmm(torch.cat([gb0, gb2], dim=2).transpose(0, 1), net._latent_blocks(dev)).transpose(0, 1)
     ref = torch.cat([g_cond[..., :64].sum(dim=1), g_cond[..., 64:].reshape(B, -1)], dim=-1)
     assert float((out - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+    # 3x3 inverse of a transposed / sliced view (the Jacobian block of the value+Jacobian output) where it lies
+    from nphm_amd.diff_operators import inverse3x3
+    full = 0.2 * torch.randn(5, 333, 4, 3, generator=g).to(dev)
+    full[:, :, 1:, :] += torch.eye(3, device=dev)                      # Jacobians of x + F(x): near the identity
+    view = full[:, :, 1:, :3].transpose(-1, -2)
+    assert not view.is_contiguous()
+    inv = inverse3x3(view)
+    assert inv.is_contiguous() and float((inv - torch.linalg.inv(view)).abs().max()) < 1e-5
+    assert float((inverse3x3(view.contiguous()) - inv).abs().max()) == 0.0
+    odd = (0.2 * torch.randn(4, 6, 3, 3, generator=g).to(dev) + torch.eye(3, device=dev))[::2, ::3]   # leading dims do not collapse
+    assert float((inverse3x3(odd) - torch.linalg.inv(odd)).abs().max()) < 1e-5
+    # conditioning gradient of the deformation backbone from the two bias gradients
+    H, lat, d, k_act = 512, 232, 3, 277
+    W0 = torch.randn(H, d + lat, generator=g).to(dev) * 0.1
+    Ws = torch.randn(H, k_act + d + lat, generator=g).to(dev) * 0.1
+    q0, qs = torch.randn(B, H, generator=g).to(dev), torch.randn(B, H, generator=g).to(dev)
+    got = torch.empty(B, lat, device=dev)
+    _lib.check(lib.nphm_mlp_cond_grad(q0.data_ptr(), qs.data_ptr(), B, H, W0.data_ptr(), W0.shape[1], d, Ws.data_ptr(), Ws.shape[1],
+                                      k_act + d, lat, got.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "cond_grad")
+    want = (q0.double() @ W0[:, d:].double() + (qs.double() @ Ws[:, k_act + d:].double()) / 2 ** 0.5).float()
+    assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
 
 
 @pytest.mark.gpu

@@ -3,8 +3,8 @@ src/NPHM/models/loss_functions.py:7-110) against tests/golden/training.npz = the
 actual_compute_loss + loss.backward() on a seeded batch (make_golden_training.py).
 
 CPU: the composite tier (same arithmetic as the reference) - loss terms to 1e-6, gradients to 1e-5 relative.
-GPU: the HIP training tier (ident_train_kernel.hip) - loss terms to 1e-5, gradients to 5e-4 relative of the tensor's
-largest entry (all 40 members; observed ~1e-5)."""
+GPU: the HIP training tier (ident_train_kernel.hip) - loss terms to 1e-5, gradients to 1e-4 relative of the tensor's
+largest entry with all 40 members (observed 1.7e-5), 2e-4 with default pruning (observed 3.9e-5)."""
 import numpy as np
 import pytest
 import torch
@@ -32,7 +32,7 @@ def _check(net, g, losses, total, lat, tol_loss, tol_grad):
         assert abs(float(v.detach()) - float(g["loss_" + k])) <= tol_loss * max(1.0, abs(float(g["loss_" + k]))), k
     assert abs(float(total.detach()) - float(g["total"])) <= tol_loss
     rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
-    assert rel(lat.grad.cpu().numpy(), g["grad_lat"]) < tol_grad
+    worst = {"latents": rel(lat.grad.cpu().numpy(), g["grad_lat"])}
     grads = dict(net.named_parameters())
     sets = g["sets"]
     for k in g:
@@ -41,10 +41,12 @@ def _check(net, g, losses, total, lat, tol_loss, tol_grad):
             ref = g[k]
             if mine.shape != ref.shape:
                 mine = mine[sets]
-            assert rel(mine, ref) < tol_grad, k
+            worst[k[5:]] = rel(mine, ref)
     names = list(g["grad_names"])
     norms = np.array([float(grads[n].grad.norm()) for n in names])
-    assert np.abs(norms - g["grad_norms"]).max() <= tol_grad * g["grad_norms"].max()
+    worst["norms"] = float(np.abs(norms - g["grad_norms"]).max() / g["grad_norms"].max())
+    print("gradient errors relative to each tensor's largest entry:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < tol_grad, worst
 
 
 def test_loss_and_gradients_match_reference_cpu():
@@ -84,11 +86,11 @@ def test_loss_and_gradients_match_reference_hip():
     net._train_members = lambda *a, **k: used.setdefault("hip", True) and orig(*a, **k)
     losses, total, lat = _step(net, g, dev)
     assert used.get("hip"), "the HIP training tier did not run"
-    _check(net, g, losses, total, lat, 1e-5, 5e-4)
+    _check(net, g, losses, total, lat, 1e-5, 1e-4)               # observed: worst tensor 1.7e-5
     # default pruning (members below 1e-7 normalised blend weight dropped)
     net.prune_tol = 1e-7
     losses, total, lat = _step(net, g, dev)
-    _check(net, g, losses, total, lat, 1e-5, 2e-3)
+    _check(net, g, losses, total, lat, 1e-5, 2e-4)               # observed: 3.9e-5
 
 
 @pytest.mark.gpu
@@ -102,7 +104,7 @@ def test_validation_step_matches_reference_hip():
     orig = net._train_members
     net._train_members = lambda *a, **k: used.setdefault("hip", True) and orig(*a, **k)
     batch = {k[6:]: torch.from_numpy(g[k]).to(dev) for k in g if k.startswith("batch_")}
-    for prune, tol in ((-1.0, 5e-4), (1e-7, 2e-3)):
+    for prune, tol in ((-1.0, 5e-5), (1e-7, 2e-4)):        # observed 2.8e-6 / 2.0e-5
         net.prune_tol = prune
         lat = torch.from_numpy(g["lat"]).to(dev).requires_grad_()
         net.zero_grad(set_to_none=True)
