@@ -39,8 +39,8 @@ class _MlpCondFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, xyz, cond_rows, add_input, with_jacobian=False):
-        """-> [R,n,out] or, ``with_jacobian``, [R,n,4,out] (value | d/dx | d/dy | d/dz as forward_hip_jvp; only the
-        value stream is differentiable)"""
+        """-> [R,n,out] or, ``with_jacobian``, (value [R,n,out], [R,n,3,out] = d/dx | d/dy | d/dz as forward_hip_jvp; only
+        the value is differentiable)"""
         lib = _lib.load()
         R, n, _ = xyz.shape
         dev = xyz.device
@@ -60,11 +60,18 @@ class _MlpCondFn(torch.autograd.Function):
                        "nphm_mlp_eval_points_saving")
         ctx.module, ctx.shape, ctx.with_jacobian = module, (R, n), bool(with_jacobian)
         ctx.save_for_backward(saved)
-        return out
+        if not with_jacobian:
+            return out
+        # value and Jacobian as TWO outputs (views of the kernel's interleaved buffer): the value's gradient then arrives
+        # as its own tensor - a single output would receive zeros [R,n,4,out] + a slice copy from autograd, and the
+        # backward below would copy the slice out again
+        jac = out[:, :, 1:]
+        ctx.mark_non_differentiable(jac)
+        return out[:, :, 0], jac
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _grad_jac=None):
         lib = _lib.load()
         module = ctx.module
         (saved,) = ctx.saved_tensors
@@ -72,7 +79,7 @@ class _MlpCondFn(torch.autograd.Function):
         dev = grad_out.device
         H = module.hidden_dim
         gb0, gbs = torch.zeros(2, R, H, dtype=torch.float32, device=dev).unbind(0)     # accumulated into: one zero-fill
-        g = (grad_out[:, :, 0] if ctx.with_jacobian else grad_out).detach().contiguous().float()
+        g = grad_out.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.nphm_mlp_backward_cond(*module._arch(), module._packed_bwd(dev).data_ptr(), saved.data_ptr(),
                                               g.data_ptr(), R, n, gb0.data_ptr(), gbs.data_ptr(), stream),
@@ -534,8 +541,12 @@ class DeformationNetwork(nn.Module):
         plan = self.defDeepSDF._hip_rows(xyz, cond, cond_grad_ok=True)
         if plan is None:
             return None
-        out = _MlpCondFn.apply(self.defDeepSDF, plan[0], plan[1], True, True).reshape(xyz.shape[0], xyz.shape[1], 4, -1)
-        return out[:, :, 0, :3], out[:, :, 1:, :3].transpose(-1, -2).detach()
+        val, jac = _MlpCondFn.apply(self.defDeepSDF, plan[0], plan[1], True, True)
+        B, N = xyz.shape[0], xyz.shape[1]
+        val, jac = val.reshape(B, N, -1), jac.reshape(B, N, 3, -1)
+        if val.shape[-1] != 3:             # (a full-range slice would still cost a zero-fill + copy in the backward pass)
+            val, jac = val[..., :3], jac[..., :3]
+        return val, jac.transpose(-1, -2).detach()
 
     def broyden(self, obs, x_init, jinv_init, lat_rep, anchors, max_steps=15, cvg_thresh=1e-6, dvg_thresh=0.2,
                 eps=1e-6):

@@ -294,6 +294,17 @@ def _fused_losses_ok(decoder, lambdas, device) -> bool:
             and all(k in _LOSS_SLOTS for k in lambdas))
 
 
+def _field_of_one_code(decoder, x, code, cond, local):
+    """decoder(x [B,N,3], the ONE identity code on every batch row)[0] (fitting.py:109 / :238).  The field is pointwise and the
+    rows share the code, so the NPHM decoder in train mode (no last-point overwrite to reproduce) takes them as one row of
+    B * N points: one latent prologue and one latent gradient instead of B, 40 member point lists instead of 40 B (fewer
+    partly filled tiles), and no expand / sum of the code's gradient over the rows.  Same values."""
+    if local and getattr(decoder, "training", False) and x.is_contiguous() and code.shape[0] == 1:
+        sdf, _ = decoder(x.reshape(1, -1, 3), code, None)
+        return sdf.reshape(x.shape[0], x.shape[1], 1)
+    return decoder(x, cond, None)[0]
+
+
 def _masked_surface_loss(sdf, thr, valid=None):
     """mean |sdf| over the (valid) points below the clamp ``thr`` (fitting.py:115-132; ``_StepControls`` holds the
     clamp as a device scalar).  The reference compacts the tensor with boolean masks (a device->host sync per mask);
@@ -479,7 +490,7 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             xc = p_corresp + correction
 
         shape_cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
-        sdf, _ = decoder(xc, shape_cond, None)
+        sdf = _field_of_one_code(decoder, xc, lat_rep_shape, shape_cond, local)
         if compute_unused_sdf_grad:
             _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
 
@@ -548,7 +559,7 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
         anchors = _anchors_of(decoder, lat_rep_shape, device)
         _, obs = sampler.gather(drawn_cur[0])
         cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
-        sdf, _ = decoder(obs, cond, None)
+        sdf = _field_of_one_code(decoder, obs, lat_rep_shape, cond, local)
         if fused:
             loss, row8 = _FitLossFn.apply(sdf, None, lat_rep_shape, None, None, ctl.thr, ctl.lam6)
             loss.backward()
