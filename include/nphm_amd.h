@@ -256,7 +256,8 @@ int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
  * nphm_fit_loss: the loss terms of one step in ONE launch - clamped surface loss, mean |sdf| over the valid points below the
  *   device scalar `thr` (fitting.py:115-132); reg_expr = mean over the n_rows drawn observations of |z_ex|^2 (:136);
  *   reg_global / reg_loc / reg_unobserved / symm_dist of the identity code (:139-166) - and their weighted total.
- *   row [8] = surface, reg_expr, reg_global, reg_unobserved, reg_loc, symm_dist, total (lam in that order), number of valid points.
+ *   row [9] = surface, reg_expr, reg_global, reg_unobserved, reg_loc, symm_dist, total (lam in that order), number of valid points,
+ *   the total once more (ABI 6: the caller's differentiable scalar next to the 8-entry report row).
  *   valid [n_points] bytes (torch.bool) or NULL; z_expr NULL for the identity-only loop (fitting.py:180-288).
  * nphm_fit_loss_backward: gradients of the total (times the device scalar *g_out, NULL = 1) w.r.t. sdf, the identity
  *   code [1344] and the expression codes [n_obs, expr_dim] (rows drawn several times collect every draw).
@@ -280,6 +281,10 @@ int nphm_fit_loss_backward(const float* sdf, const unsigned char* valid, int64_t
                            const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
                            const float* g_out, float* g_sdf, float* g_shape, float* g_expr, void* stream);
 int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g_posed, int64_t n, void* stream);
+/* sdf [n_points] = sum over the kept members of blend_weights * member_values (both [n_points, 40]; weights exactly 0 where
+ * the pruning rule dropped the member - nphm_identity_build_lists - and member_values is not read there: the output of
+ * nphm_identity_member_forward needs no zero-fill).  The blend of EnsembledDeepSDF.py:129-150 on the autograd tier (ABI 6). */
+int nphm_identity_blend_members(const float* blend_weights, const float* member_values, int64_t n_points, float* sdf, void* stream);
 int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight, const float* g_bias0, const float* g_bias2,
                               int n_rows, float* g_lat, void* stream);
 

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(1024) void fit_loss_kernel(LossArgs a) {
       }
       a.row[N_TERMS] = total;
       a.row[N_TERMS + 1] = nv;
+      a.row[N_TERMS + 2] = total;       // a second copy: the caller's differentiable scalar next to the report row
     }
     return;
   }
@@ -166,6 +167,26 @@ __global__ void root_bwd_kernel(const float* jinv, const float* g_xc, float* g_p
   const float gx = g_xc[3 * p], gy = g_xc[3 * p + 1], gz = g_xc[3 * p + 2];
 #pragma unroll
   for (int i = 0; i < 3; ++i) g_posed[3 * p + i] = -(J[i] * gx + J[3 + i] * gy + J[6 + i] * gz);
+}
+
+// sdf[p] = sum_k w[p][k] f[p][k] over the members the pruning rule kept (w is exactly 0 elsewhere and f holds nothing there:
+// the member kernel writes listed pairs only, so f needs no zero-fill); fixed order, one thread per point
+__global__ __launch_bounds__(256) void blend_members_kernel(const float* __restrict__ w, const float* __restrict__ f,
+                                                             float* __restrict__ out, int64_t n) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float4* w4 = reinterpret_cast<const float4*>(w + p * N_MEMBERS);
+  const float4* f4 = reinterpret_cast<const float4*>(f + p * N_MEMBERS);
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < N_MEMBERS / 4; ++q) {
+    const float4 a = w4[q], b = f4[q];
+    acc += a.x != 0.f ? a.x * b.x : 0.f;
+    acc += a.y != 0.f ? a.y * b.y : 0.f;
+    acc += a.z != 0.f ? a.z * b.z : 0.f;
+    acc += a.w != 0.f ? a.w * b.w : 0.f;
+  }
+  out[p] = acc;
 }
 
 // batched 3x3 inverse (adjugate) of matrices addressed by strides - element (i, j) of matrix p at
@@ -436,6 +457,15 @@ int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight
                      g_bias0, g_bias2, g_lat, n_rows);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_identity_latent_grad launch", e);
+}
+
+int nphm_identity_blend_members(const float* blend_weights, const float* member_values, int64_t n_points, float* sdf, void* stream) {
+  if (!blend_weights || !member_values || !sdf) return nphm_fail_msg("nphm_identity_blend_members: null pointer");
+  if (n_points <= 0) return n_points == 0 ? 0 : nphm_fail_msg("nphm_identity_blend_members: negative count");
+  hipLaunchKernelGGL(nphm::fit::blend_members_kernel, dim3(unsigned((n_points + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), blend_weights, member_values, sdf, n_points);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_identity_blend_members launch", e);
 }
 
 int nphm_inverse3x3_strided(const float* matrices, int64_t matrix_stride, int64_t row_stride, int64_t col_stride,

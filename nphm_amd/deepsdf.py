@@ -442,12 +442,27 @@ class DeformationNetwork(nn.Module):
             scope[key] = (cond, lat_rep, anchors, cond.requires_grad)
         return cond
 
-    def prime_condition(self, lat_rep, anchors):
+    def prime_condition(self, lat_rep, anchors, parts=None):
         """Inside a ``condition_scope``: evaluate the conditioning of (lat_rep, anchors) ONCE, with its autograd graph, so that
         the step's later calls - the no-grad ones of the correspondence search and the differentiable one at the roots -
-        share it (a fitting step otherwise runs the compressor twice).  No-op outside a scope / for other modes."""
-        if getattr(self, "_cond_scope", None) is not None and self.mode == "compress" and not self.training and anchors is not None:
+        share it (a fitting step otherwise runs the compressor twice).  No-op outside a scope / for other modes.
+
+        ``parts`` = (z_id [1,1,L_id], z_ex [B,1,e], anchors [1,K,3]) states that ``lat_rep`` is [z_id on every row | z_ex] and
+        ``anchors`` that one set on every row (the fitting loops: one identity, B sampled observations): the compressor then
+        runs on ONE row and the gradients reach z_id / the anchors without an expand-and-sum over the rows.  Same values."""
+        if getattr(self, "_cond_scope", None) is None or self.mode != "compress" or self.training or anchors is None:
+            return
+        if parts is None:
             self._condition(lat_rep[:, :1, :3], lat_rep, anchors)
+            return
+        z_id, z_ex, anchors1 = parts
+        from .ensembled_deepsdf import frozen_head
+        packed = torch.cat([z_id[:, 0, :], anchors1.reshape(1, -1)], dim=-1)
+        comp = frozen_head(self.compressor, packed, False)                       # [1,32]
+        cond = torch.cat([comp.unsqueeze(1).expand(z_ex.shape[0], 1, -1), z_ex], dim=-1)
+        key = (lat_rep.data_ptr(), lat_rep._version, tuple(lat_rep.shape), tuple(lat_rep.stride()),
+               anchors.data_ptr(), anchors._version, tuple(anchors.shape), tuple(anchors.stride()))
+        self._cond_scope[key] = (cond, lat_rep, anchors, cond.requires_grad)
 
     def _condition_impl(self, xyz, lat_rep, anchors):
         B, N, _ = xyz.shape

@@ -345,12 +345,14 @@ class _IdentityFieldFn(torch.autograd.Function):
         xyz_c = xyz.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         what, tiles, n_used, plist = _member_point_lists_device(state, xyz_c, module.prune_tol, A, stream)
-        fmem = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
+        fmem = torch.empty(B, N, A, dtype=torch.float32, device=dev)      # written for the listed (point, member) pairs only
         _lib.check(lib.nphm_identity_member_forward(
             packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N,
             tiles.data_ptr(), tiles.shape[0], n_used.data_ptr(), plist.data_ptr(), fmem.data_ptr(), stream),
             "nphm_identity_member_forward")
-        out = (what * fmem).sum(dim=2, keepdim=True)
+        out = torch.empty(B, N, 1, dtype=torch.float32, device=dev)
+        _lib.check(lib.nphm_identity_blend_members(what.data_ptr(), fmem.data_ptr(), B * N, out.data_ptr(), stream),
+                   "nphm_identity_blend_members")                        # reads fmem only where the blend weight is not 0
         ctx.module = module
         ctx.save_for_backward(xyz_c, out, packed, state, tiles, n_used, plist)
         return out

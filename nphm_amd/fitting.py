@@ -80,7 +80,8 @@ class _ObservationSampler:
         self.on_gpu = self.device.type == "cuda"
 
     def draw(self):
-        """host side: (obs_idx [n_batch], point indices [n_batch, n]) as one int64 tensor [n_batch, 1 + n]"""
+        """host side: (obs_idx [n_batch], point indices [n_batch, n]) as ONE flat int64 tensor [n_batch | n_batch * n]
+        (both parts contiguous on the device: no strided-column copies inside the step)"""
         obs_idx = torch.randint(0, len(self.sizes), [self.n_batch])
         rows = []
         for i in range(self.n_batch):
@@ -89,11 +90,11 @@ class _ObservationSampler:
         if len({r.shape[0] for r in rows}) != 1:
             raise RuntimeError("stack expects each tensor to be equal size (observations of different sizes below "
                                "n_points, as in the reference)")
-        return torch.cat([obs_idx[:, None], torch.stack(rows, 0)], dim=1)
+        return torch.cat([obs_idx, torch.stack(rows, 0).reshape(-1)])
 
     def draw_like(self):
         """an index tensor of the shape ``draw`` returns, WITHOUT touching the RNG (allocation of the static input)"""
-        return torch.zeros(self.n_batch, 1 + min(self.n_points, min(self.sizes)), dtype=torch.int64)
+        return torch.zeros(self.n_batch * (1 + min(self.n_points, min(self.sizes))), dtype=torch.int64)
 
     def upload(self, drawn, out=None):
         if self.on_gpu:
@@ -105,8 +106,8 @@ class _ObservationSampler:
 
     def gather(self, drawn_dev):
         """device side: (obs_idx [n_batch] long, points [n_batch, n, 3])"""
-        obs_idx = drawn_dev[:, 0]
-        return obs_idx, self.clouds[obs_idx[:, None], drawn_dev[:, 1:]]
+        obs_idx = drawn_dev[: self.n_batch]
+        return obs_idx, self.clouds[obs_idx[:, None], drawn_dev[self.n_batch:].view(self.n_batch, -1)]
 
 
 def _shape_regularisers(decoder, lat_rep_shape, loss_dict):
@@ -228,7 +229,8 @@ class _FitLossFn(torch.autograd.Function):
         zs = z_shape.detach().reshape(-1).contiguous()
         ze = None if z_expr is None else z_expr.detach().contiguous()
         obs_idx = None if obs_idx is None else obs_idx.to(torch.int64).contiguous()       # a strided column of the draw
-        row = torch.empty(8, dtype=torch.float32, device=dev)
+        buf = torch.empty(9, dtype=torch.float32, device=dev)           # the report row [8] | the total once more
+        row = buf[:8]
         stream = torch.cuda.current_stream(dev).cuda_stream
         n_obs, expr_dim = (ze.shape[0], ze.shape[-1]) if ze is not None else (0, 0)
         _lib.check(lib.nphm_fit_loss(sdf_c.data_ptr(), None if valid_c is None else valid_c.data_ptr(), sdf_c.numel(), thr.data_ptr(),
@@ -238,7 +240,7 @@ class _FitLossFn(torch.autograd.Function):
         ctx.save_for_backward(sdf_c, valid_c, zs, ze, obs_idx, thr, lam6)
         ctx.shapes = (sdf.shape, z_shape.shape, None if z_expr is None else z_expr.shape)
         ctx.mark_non_differentiable(row)
-        return row[6].clone(), row
+        return buf[8], row
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -460,11 +462,13 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
         anchors = _anchors_of(decoder, lat_rep_shape, device)
         obs_idx, obs = sampler.gather(drawn_cur[0])
-        glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), lat_rep[obs_idx, :, :]], dim=-1)   # [B,1,L]
+        z_ex = lat_rep[obs_idx, :, :]
+        glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), z_ex], dim=-1)                     # [B,1,L]
         anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
 
         if hasattr(decoder_expr, "prime_condition"):
-            decoder_expr.prime_condition(glob_cond, anchors_b)       # one conditioning row per step, shared by the calls below
+            # one conditioning per step, shared by the calls below; its identity half from ONE row
+            decoder_expr.prime_condition(glob_cond, anchors_b, parts=(lat_rep_shape, z_ex, anchors) if anchors_b is not None else None)
         # canonical correspondences by Broyden root finding (no gradient flows through it)
         p_corresp, search_result = search(obs, glob_cond, decoder_expr,
                                           None if anchors_b is None else anchors_b.detach(), multi_corresp=False)
