@@ -284,6 +284,12 @@ int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g
 /* sdf [n_points] = sum over the kept members of blend_weights * member_values (both [n_points, 40]; weights exactly 0 where
  * the pruning rule dropped the member - nphm_identity_build_lists - and member_values is not read there: the output of
  * nphm_identity_member_forward needs no zero-fill).  The blend of EnsembledDeepSDF.py:129-150 on the autograd tier (ABI 6). */
+/* One Adam step (torch.optim.Adam defaults: no weight decay / amsgrad) of a contiguous fp32 tensor in one launch:
+ * m += (1 - beta1)(g - m); v = beta2 v + (1 - beta2) g^2; p -= step_size * m / (sqrt(v) / bias_correction2_sqrt + eps), with
+ * step_size = lr / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the caller - the optimizers of the
+ * latent codes in fitting.py:47-48 / :196 (ABI 6). */
+int nphm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,
+                   float step_size, float bias_correction2_sqrt, float eps, void* stream);
 int nphm_identity_blend_members(const float* blend_weights, const float* member_values, int64_t n_points, float* sdf, void* stream);
 int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight, const float* g_bias0, const float* g_bias2,
                               int n_rows, float* g_lat, void* stream);

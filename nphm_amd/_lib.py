@@ -94,6 +94,8 @@ SYMBOLS = {
     "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
                                                       c_void_p]),
     "nphm_inverse3x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nphm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                               c_void_p]),
     "nphm_identity_blend_members": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "nphm_inverse3x3_strided": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "nphm_mlp_cond_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,

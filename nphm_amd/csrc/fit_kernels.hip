@@ -189,6 +189,25 @@ __global__ __launch_bounds__(256) void blend_members_kernel(const float* __restr
   out[p] = acc;
 }
 
+// One Adam update of a small code tensor (torch.optim.Adam's defaults as fitting.py:47-48 builds it: no weight decay, no
+// amsgrad) in ONE launch - exp_avg.lerp_(g, 1 - b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2);
+// p.addcdiv_(exp_avg, sqrt(exp_avg_sq) / sqrt(1 - b2^t) + eps, -lr / (1 - b1^t)) - where the multi-tensor implementation
+// runs eight launches per optimizer and step.  The bias corrections arrive as host scalars, like there.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float one_minus_b1, float b2,
+                                                    float one_minus_b2, float step_size, float bc2_sqrt, float eps) {
+#pragma clang fp contract(off)
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = m[i] + one_minus_b1 * (gi - m[i]);
+  const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] + (-step_size) * (mi / denom);
+}
+
 // batched 3x3 inverse (adjugate) of matrices addressed by strides - element (i, j) of matrix p at
 // in[p * sp + i * si + j * sj] - so that a transposed / sliced view (the Jacobian block of the value+Jacobian output
 // [.., 4, out_dim]) needs no contiguous copy first; out row-major [n][3][3]
@@ -466,6 +485,16 @@ int nphm_identity_blend_members(const float* blend_weights, const float* member_
                      static_cast<hipStream_t>(stream), blend_weights, member_values, sdf, n_points);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_identity_blend_members launch", e);
+}
+
+int nphm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,
+                   float step_size, float bias_correction2_sqrt, float eps, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq) return nphm_fail_msg("nphm_adam_step: null pointer");
+  if (n <= 0) return n == 0 ? 0 : nphm_fail_msg("nphm_adam_step: negative count");
+  hipLaunchKernelGGL(nphm::fit::adam_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     param, grad, exp_avg, exp_avg_sq, n, 1.f - beta1, beta2, 1.f - beta2, step_size, bias_correction2_sqrt, eps);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_adam_step launch", e);
 }
 
 int nphm_inverse3x3_strided(const float* matrices, int64_t matrix_stride, int64_t row_stride, int64_t col_stride,

@@ -63,6 +63,48 @@ def _apply_schedule(j, step_scale, schedule_cfg, lambdas, optimizers, with_expr)
         lambdas["reg_expr"] /= schedule_cfg["reg_expr"][key]
 
 
+class _CodeAdam(optim.Adam):
+    """optim.Adam(params=[code], lr=lr) as the reference builds it (fitting.py:47-48, :196) - same defaults, same
+    ``param_groups`` (the schedules write ``lr`` there) and ``state`` entries - whose ``step`` on a ROCm fp32 code tensor is
+    ONE launch (``nphm_adam_step``) instead of the multi-tensor implementation's eight: behind a replayed hipGraph the
+    step is bound by the GPU's launch rate, and the two optimizers' sixteen launches were 3 % of it.  Same update rule
+    (exp_avg.lerp_, exp_avg_sq.mul_.addcmul_, addcdiv_ with host-side bias corrections); other tensors: the parent's step."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        fast = closure is None and all(
+            p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and (p.grad is None or (p.grad.is_contiguous() and not p.grad.is_sparse))
+            for g in self.param_groups for p in g["params"]) and all(
+            not g["amsgrad"] and g["weight_decay"] == 0 and not g["maximize"] and not g.get("capturable") and not g.get("differentiable")
+            for g in self.param_groups)
+        if not fast:
+            return super().step(closure)
+        import math
+        from . import _lib
+        lib = _lib.load()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)          # a host tensor, as the parent keeps it
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                t = float(st["step"])
+                lr = float(group["lr"])
+                _lib.check(lib.nphm_adam_step(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                              p.numel(), b1, b2, lr / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t), group["eps"],
+                                              torch.cuda.current_stream(p.device).cuda_stream), "nphm_adam_step")
+        return None
+
+
+def _adam(code, lr):
+    return _CodeAdam(params=[code], lr=lr) if code.is_cuda else optim.Adam(params=[code], lr=lr)
+
+
 class _ObservationSampler:
     """n_batch observations with replacement, <= n_points points each with replacement (fitting.py:61-70):
     the same torch.randint calls in the same order as the reference (host RNG), but the picked indices travel
@@ -178,6 +220,7 @@ class _StepControls:
         self.keys = list(lambdas.keys())
         self.lam = torch.zeros(len(self.keys), dtype=torch.float32, device=device)
         self.thr = torch.zeros((), dtype=torch.float32, device=device)
+        self.one = torch.ones((), dtype=torch.float32, device=device)          # seed of loss.backward
         self.lam6 = torch.zeros(6, dtype=torch.float32, device=device)       # the weights in the fused kernel's term order
         self._lam_host, self._thr_host = None, None
 
@@ -271,7 +314,7 @@ class _ImplicitRootFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, root, posed, jac_inverse):
         ctx.save_for_backward(jac_inverse)
-        return root.detach().clone()
+        return root.detach()               # an alias of the root's storage (nothing writes into either)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -440,8 +483,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     lat_rep.requires_grad = True
     lat_rep_shape = torch.zeros([1, 1, decoder.lat_dim], device=device)
     lat_rep_shape.requires_grad = True
-    opt = optim.Adam(params=[lat_rep_shape], lr=0.01 * lr_scale)
-    opt_expr = optim.Adam(params=[lat_rep], lr=0.01 * lr_scale)
+    opt = _adam(lat_rep_shape, 0.01 * lr_scale)
+    opt_expr = _adam(lat_rep, 0.01 * lr_scale)
     local = hasattr(decoder, "lat_dim_loc")
     sampler = _ObservationSampler(all_obs, n_batch, n_points)
     n_iter = int(n_steps * step_scale)
@@ -500,14 +543,14 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
 
         if fused:                          # every loss term, the total and (backward) their gradients: two launches
             loss, row8 = _FitLossFn.apply(sdf, valid, lat_rep_shape, lat_rep, obs_idx, ctl.thr, ctl.lam6)
-            loss.backward()
+            loss.backward(gradient=ctl.one)       # (a preallocated seed: no ones_like launch per step)
             row = ctl.fused_row(row8, extra=("n_valid",))
         else:
             loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr, valid),
                          "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
             _shape_regularisers(decoder, lat_rep_shape, loss_dict)
             loss = ctl.total(loss_dict)
-            loss.backward()
+            loss.backward(gradient=ctl.one)
             row = hist.row(loss_dict, loss, n_valid=valid.sum())
         return row, anchors.detach()
 
@@ -547,7 +590,7 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
     n_batch, n_points = 5, 1000
     lat_rep_shape = torch.zeros([1, 1, decoder.lat_dim], device=device)
     lat_rep_shape.requires_grad = True
-    opt = optim.Adam(params=[lat_rep_shape], lr=0.01 * lr_scale)
+    opt = _adam(lat_rep_shape, 0.01 * lr_scale)
     local = hasattr(decoder, "lat_dim_loc")
     sampler = _ObservationSampler(all_obs, n_batch, n_points)
     n_iter = int(n_steps * step_scale)
@@ -566,12 +609,12 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
         sdf = _field_of_one_code(decoder, obs, lat_rep_shape, cond, local)
         if fused:
             loss, row8 = _FitLossFn.apply(sdf, None, lat_rep_shape, None, None, ctl.thr, ctl.lam6)
-            loss.backward()
+            loss.backward(gradient=ctl.one)
             return ctl.fused_row(row8), anchors.detach()
         loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr)}
         _shape_regularisers(decoder, lat_rep_shape, loss_dict)
         loss = ctl.total(loss_dict)
-        loss.backward()
+        loss.backward(gradient=ctl.one)
         return hist.row(loss_dict, loss), anchors.detach()
 
     step = _GraphedStep(body, use_graph, [lat_rep_shape])
