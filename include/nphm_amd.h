@@ -96,6 +96,13 @@ int nphm_identity_prepare_latent(const void* packed,
                                  const float* lat_rows, int n_rows,
                                  void* latent_state, float* anchors_out, void* stream);
 
+/* The same prologue when the caller already holds the anchors of the rows ([n_rows,39,3], mean anchors included): the
+ * autograd tier of the fitting loops evaluates mlp_pos as a differentiable head (nphm_head_forward) and needs the
+ * field state for exactly those anchors (ABI 6). */
+int nphm_identity_prepare_latent_anchors(const float* const lin_weight[5], const float* const lin_bias[5],
+                                         const float* lat_rows, const float* anchors, int n_rows, void* latent_state,
+                                         void* stream);
+
 /* Magnitude bounds of the ensemble members for the pruning rule and the precision tiers of the inference kernels
  * (nphm_identity_eval_*): bounds [40][4] = (b0, b1, b2, unused) per member with B_k(d) = b0 + b1 d + b2 d^2 >= |f_k| at
  * distance d from anchor k (member 39, the background member: d = 0).  With bounds installed, "weight" in the rules of
@@ -284,6 +291,10 @@ int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g
 /* sdf [n_points] = sum over the kept members of blend_weights * member_values (both [n_points, 40]; weights exactly 0 where
  * the pruning rule dropped the member - nphm_identity_build_lists - and member_values is not read there: the output of
  * nphm_identity_member_forward needs no zero-fill).  The blend of EnsembledDeepSDF.py:129-150 on the autograd tier (ABI 6). */
+/* Backward of out[b] = table[idx[b]] (fitting.py:83, the expression codes of the drawn observations): g_table [n_rows, width]
+ * = per row the sum of g_out [n_draws, width] over its draws, in draw order (deterministic; every row written) (ABI 6). */
+int nphm_gather_rows_backward(const float* g_out, const int64_t* idx, int n_draws, int n_rows, int width, float* g_table,
+                              void* stream);
 /* One Adam step (torch.optim.Adam defaults: no weight decay / amsgrad) of a contiguous fp32 tensor in one launch:
  * m += (1 - beta1)(g - m); v = beta2 v + (1 - beta2) g^2; p -= step_size * m / (sqrt(v) / bias_correction2_sqrt + eps), with
  * step_size = lr / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the caller - the optimizers of the

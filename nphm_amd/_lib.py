@@ -33,6 +33,7 @@ SYMBOLS = {
     "nphm_identity_pack": (c_int, [_PtrArr5, _PtrArr5, c_void_p, c_void_p]),
     "nphm_identity_prepare_latent": (c_int, [c_void_p, _PtrArr5, _PtrArr5, _PtrArr3, _PtrArr3, c_int,
                                              c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_prepare_latent_anchors": (c_int, [_PtrArr5, _PtrArr5, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nphm_head_forward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_head_backward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nphm_fit_loss": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -94,6 +95,7 @@ SYMBOLS = {
     "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
                                                       c_void_p]),
     "nphm_inverse3x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nphm_gather_rows_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nphm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                c_void_p]),
     "nphm_identity_blend_members": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -208,6 +208,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   p[i] = p[i] + (-step_size) * (mi / denom);
 }
 
+// backward of out[b] = table[idx[b]] (the expression codes of the drawn observations, fitting.py:83): g_table[r] = sum of
+// g_out[b] over the draws b of row r, in draw order - one launch where the index_put(accumulate) of autograd sorts the
+// indices first (eight launches for five rows)
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx, int n_draws,
+                                                               int n_rows, int width, float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_rows * width) return;
+  const int r = e / width, c = e % width;
+  float acc = 0.f;
+  for (int b = 0; b < n_draws; ++b)
+    if (idx[b] == r) acc += g[size_t(b) * width + c];
+  out[e] = acc;
+}
+
 // batched 3x3 inverse (adjugate) of matrices addressed by strides - element (i, j) of matrix p at
 // in[p * sp + i * si + j * sj] - so that a transposed / sliced view (the Jacobian block of the value+Jacobian output
 // [.., 4, out_dim]) needs no contiguous copy first; out row-major [n][3][3]
@@ -485,6 +499,17 @@ int nphm_identity_blend_members(const float* blend_weights, const float* member_
                      static_cast<hipStream_t>(stream), blend_weights, member_values, sdf, n_points);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_identity_blend_members launch", e);
+}
+
+int nphm_gather_rows_backward(const float* g_out, const int64_t* idx, int n_draws, int n_rows, int width, float* g_table,
+                              void* stream) {
+  if (!g_out || !idx || !g_table) return nphm_fail_msg("nphm_gather_rows_backward: null pointer");
+  if (n_draws <= 0 || n_rows <= 0 || width <= 0) return nphm_fail_msg("nphm_gather_rows_backward: bad sizes");
+  const int n = n_rows * width;
+  hipLaunchKernelGGL(nphm::fit::gather_rows_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     g_out, idx, n_draws, n_rows, width, g_table);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_gather_rows_backward launch", e);
 }
 
 int nphm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,

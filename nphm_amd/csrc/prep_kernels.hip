@@ -107,6 +107,7 @@ struct PrepArgs {
   const float* lat_rows;   // [n_rows, LAT_DIM]
   float* state;            // [n_rows, LS_ROW_STRIDE]
   float* anchors_out;      // [n_rows, 39, 3] (may be null)
+  const float* anchors_in; // [n_rows, 39, 3] or null: given instead of evaluated
 };
 
 __global__ __launch_bounds__(256) void prepare_latent_kernel(PrepArgs a) {
@@ -122,21 +123,32 @@ __global__ __launch_bounds__(256) void prepare_latent_kernel(PrepArgs a) {
     float* b0f = sh + 96;        // [224] folded lin0 bias by FEATURE index (0 beyond 200)
     if (t < LAT_COND) cond[t] = t < LAT_GLOB ? lat[t] : lat[LAT_GLOB + LAT_LOC * k + (t - LAT_GLOB)];
     __syncthreads();
-    // folded biases: b0'[f] = b0[f] + W0[f,3:] . cond ; b2'[f] = b2[f] + W2[f,104:] . cond / sqrt2
-    float v0 = 0.f, v2 = 0.f;
-    if (t < HID) {
-      const float* w0 = a.w[0] + (size_t(s) * HID + t) * D_IN + 3;
-      const float* w2 = a.w[2] + (size_t(s) * HID + t) * HID + L2_IN;
-      v0 = a.b[0][s * HID + t];
-      v2 = a.b[2][s * HID + t];
-      for (int j = 0; j < LAT_COND; ++j) {
-        const float c = cond[j];
-        v0 = fmaf(w0[j], c, v0);
-        v2 = fmaf(w2[j], c / INV_SQRT2_DIV, v2);
+    // folded biases: b0'[f] = b0[f] + W0[f,3:] . cond ; b2'[f] = b2[f] + W2[f,104:] . cond / sqrt2.  A wavefront per
+    // feature row: the lanes read the row's 96 latent columns coalesced (64 + 32) and meet in a butterfly sum - a thread per
+    // row walked its row with 96 dependent, uncoalesced loads (the prologue is on the critical chain of a fitting step)
+    float* b2f = sh + 96 + 224;  // [224]
+    static_assert(LAT_COND == 96, "two column groups per lane");
+    {
+      const int lane = t & 63, wv = t >> 6;
+      const float c0 = cond[lane], c1 = lane < 32 ? cond[64 + lane] : 0.f;
+      const float d0 = c0 / INV_SQRT2_DIV, d1 = c1 / INV_SQRT2_DIV;
+      for (int r = wv; r < 224; r += 4) {
+        float p0 = 0.f, p2 = 0.f;
+        if (r < HID) {
+          const float* w0 = a.w[0] + (size_t(s) * HID + r) * D_IN + 3;
+          const float* w2 = a.w[2] + (size_t(s) * HID + r) * HID + L2_IN;
+          p0 = w0[lane] * c0;
+          p2 = w2[lane] * d0;
+          if (lane < 32) { p0 = fmaf(w0[64 + lane], c1, p0); p2 = fmaf(w2[64 + lane], d1, p2); }
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { p0 += __shfl_xor(p0, m); p2 += __shfl_xor(p2, m); }
+        if (lane == 0) {
+          b0f[r] = r < HID ? a.b[0][s * HID + r] + p0 : 0.f;
+          b2f[r] = r < HID ? a.b[2][s * HID + r] + p2 : 0.f;
+        }
       }
     }
-    float* b2f = sh + 96 + 224;  // [224]
-    if (t < 224) { b0f[t] = v0; b2f[t] = v2; }
     __syncthreads();
 
     // chunk tails [18][64]: accumulator init (bias * k) per 32-row block, lin4 weights / k for L3
@@ -231,6 +243,14 @@ __global__ __launch_bounds__(256) void prepare_latent_kernel(PrepArgs a) {
       }
       l0h[e] = v;
     }
+  } else if (a.anchors_in) {
+    // the caller holds the anchors of these rows already (the autograd tier evaluates mlp_pos as a differentiable head)
+    for (int o = t; o < N_LOC * 3; o += blockDim.x) {
+      const float v = a.anchors_in[size_t(row) * N_LOC * 3 + o];
+      st[LS_OFF_ANCH + o] = v;
+      if (a.anchors_out) a.anchors_out[size_t(row) * N_LOC * 3 + o] = v;
+    }
+    for (int o = t; o < N_MEMBERS * 4; o += blockDim.x) st[LS_OFF_BND + o] = (o & 3) == 0 ? 1.f : 0.f;
   } else {
     // anchors = mlp_pos(z_glob) + mean anchors (EnsembledDeepSDF.py:228-229)
     float* h1 = sh;
@@ -331,10 +351,28 @@ int nphm_identity_prepare_latent(const void* packed,
   a.lat_rows = lat_rows;
   a.state = static_cast<float*>(latent_state);
   a.anchors_out = anchors_out;
+  a.anchors_in = nullptr;
   hipLaunchKernelGGL(nphm::prepare_latent_kernel, dim3(nphm::N_MEMBERS + 1, n_rows), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_prepare_latent launch", e);
+  return 0;
+}
+
+int nphm_identity_prepare_latent_anchors(const float* const lin_weight[5], const float* const lin_bias[5],
+                                         const float* lat_rows, const float* anchors, int n_rows, void* latent_state,
+                                         void* stream) {
+  if (n_rows <= 0) return nphm_fail_msg("nphm_identity_prepare_latent_anchors: n_rows must be > 0");
+  if (!lat_rows || !latent_state || !anchors) return nphm_fail_msg("nphm_identity_prepare_latent_anchors: null pointer");
+  nphm::PrepArgs a{};
+  for (int i = 0; i < 5; ++i) { a.w[i] = lin_weight[i]; a.b[i] = lin_bias[i]; }
+  a.lat_rows = lat_rows;
+  a.state = static_cast<float*>(latent_state);
+  a.anchors_in = anchors;
+  hipLaunchKernelGGL(nphm::prepare_latent_kernel, dim3(nphm::N_MEMBERS + 1, n_rows), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_prepare_latent_anchors launch", e);
   return 0;
 }
 

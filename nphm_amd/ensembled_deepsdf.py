@@ -341,7 +341,7 @@ class _IdentityFieldFn(torch.autograd.Function):
         B, N, _ = xyz.shape
         dev = xyz.device
         A = module.num_kps + 1
-        packed, state, _ = module.prepare_latent(lat_rows.detach())
+        packed, state, _ = module.prepare_latent(lat_rows.detach(), anchors=anchors)     # the field of exactly these anchors
         xyz_c = xyz.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         what, tiles, n_used, plist = _member_point_lists_device(state, xyz_c, module.prune_tol, A, stream)
@@ -733,12 +733,13 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         self._pack_bwd_cache = (key, packed)
         return packed
 
-    def prepare_latent(self, lat_rows: torch.Tensor, inference: bool = False, bounds="auto"):
+    def prepare_latent(self, lat_rows: torch.Tensor, inference: bool = False, bounds="auto", anchors=None):
         """lat_rows [B, lat_dim] -> (packed weights, latent_state, anchors [B,n_loc,3]) via the HIP prologue kernel.
         ``inference``: the state feeds the inference kernels (eval_kernel.hip) - with numerics = "auto" the knobs are
         calibrated for the current weights first (once per weight version) and the fitted member magnitude bounds are
         installed into the state.  ``bounds``: "auto" (the calibrated bounds when they belong to the current weights,
-        else the plain-weight rule), None, or a [40,4] device tensor."""
+        else the plain-weight rule), None, or a [40,4] device tensor.  ``anchors`` [B,n_loc,3]: the anchors of these rows when
+        the caller has evaluated ``mlp_pos`` already (the autograd tier's differentiable head) - the prologue then skips it."""
         lib = _lib.load()
         device = lat_rows.device
         if getattr(self, "_needs_validation", False):
@@ -757,9 +758,16 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         B = lat_rows.shape[0]
         lat_rows = lat_rows.contiguous().float()
         state = torch.empty(lib.nphm_identity_latent_state_bytes(B), dtype=torch.uint8, device=device)
+        ws, bs = self._lin_params()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        if anchors is not None and bounds is None and tuple(anchors.shape) == (B, self.num_kps, 3):
+            given = anchors.detach().contiguous().float()
+            _lib.check(lib.nphm_identity_prepare_latent_anchors(_lib.ptr_array5(ws), _lib.ptr_array5(bs), lat_rows.data_ptr(),
+                                                                given.data_ptr(), B, state.data_ptr(), stream),
+                       "nphm_identity_prepare_latent_anchors")
+            return packed, state, given
         anchors = torch.empty(B, self.num_kps, 3, dtype=torch.float32, device=device)
         mean = self.anchors.reshape(self.num_kps, 3).to(device=device, dtype=torch.float32).contiguous()
-        ws, bs = self._lin_params()
         pw = [self.mlp_pos[i].weight for i in (0, 2, 4)]
         pb = [self.mlp_pos[i].bias for i in (0, 2, 4)]
         for t in pw + pb:

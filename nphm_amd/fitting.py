@@ -307,6 +307,38 @@ class _FitLossFn(torch.autograd.Function):
         return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None)
 
 
+class _GatherRowsFn(torch.autograd.Function):
+    """table[idx] along dim 0 (the expression codes of the drawn observations, fitting.py:83) whose backward is ONE launch
+    (``nphm_gather_rows_backward``: per row the sum over its draws, in draw order) - autograd's index_put(accumulate)
+    sorts the indices first: eight launches for five rows."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = table.shape
+        return table.detach().index_select(0, idx)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        width = out.numel() // out.shape[0]
+        _lib.check(lib.nphm_gather_rows_backward(g.data_ptr(), idx.data_ptr(), idx.numel(), out.shape[0], width, out.data_ptr(),
+                                                 torch.cuda.current_stream(g.device).cuda_stream), "nphm_gather_rows_backward")
+        return out, None
+
+
+def _rows_of(table, idx):
+    """table[idx, ...] (rows along dim 0)"""
+    if table.is_cuda and table.dtype == torch.float32 and table.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous():
+        return _GatherRowsFn.apply(table, idx)
+    return table[idx]
+
+
 class _ImplicitRootFn(torch.autograd.Function):
     """x_c = root - J^-1 (F(root) - F(root).detach()) (fitting.py:99-106): the value is the root itself, the gradient
     g_posed = -J^-T g_xc flows to the posed points F(root) - one small launch each way instead of the einsum chain."""
@@ -505,7 +537,7 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
         anchors = _anchors_of(decoder, lat_rep_shape, device)
         obs_idx, obs = sampler.gather(drawn_cur[0])
-        z_ex = lat_rep[obs_idx, :, :]
+        z_ex = _rows_of(lat_rep, obs_idx)
         glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), z_ex], dim=-1)                     # [B,1,L]
         anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
 

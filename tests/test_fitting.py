@@ -279,6 +279,15 @@ def test_fused_step_pieces_match_the_pytorch_formulation():
     assert float((inverse3x3(view.contiguous()) - inv).abs().max()) == 0.0
     odd = (0.2 * torch.randn(4, 6, 3, 3, generator=g).to(dev) + torch.eye(3, device=dev))[::2, ::3]   # leading dims do not collapse
     assert float((inverse3x3(odd) - torch.linalg.inv(odd)).abs().max()) < 1e-5
+    # rows of the expression-code table and their gradient (rows drawn several times collect every draw)
+    table = torch.randn(n_obs, 1, 200, generator=g).to(dev)
+    ta, tb = table.clone().requires_grad_(), table.clone().requires_grad_()
+    seed3 = torch.randn(B, 1, 200, generator=g).to(dev)
+    ra, rb = F._rows_of(ta, obs_idx), tb[obs_idx]
+    assert torch.equal(ra, rb)
+    ra.backward(seed3)
+    rb.backward(seed3)
+    assert float((ta.grad - tb.grad).abs().max()) < 1e-6 and float(ta.grad[1].abs().max()) > 0
     # conditioning gradient of the deformation backbone from the two bias gradients
     H, lat, d, k_act = 512, 232, 3, 277
     W0 = torch.randn(H, d + lat, generator=g).to(dev) * 0.1
