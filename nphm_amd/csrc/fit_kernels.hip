@@ -309,10 +309,16 @@ struct HeadArgs {
 };
 constexpr int HEAD_MAX = 1536;   // widest layer input / output held in LDS
 
-// forward: a wavefront takes 8 output features at a time (lanes split the input: coalesced weight rows, 8 x din / 64 loads
-// in flight per lane - the kernel is one workgroup per row and therefore latency-bound), ReLU between the layers
+// Both kernels are ONE workgroup per row on a handful of rows: latency-bound, and the latency is the round trips to the
+// weights (447 KB for mlp_pos, rarely in L2 between two replays of a fitting step).  So every layer is ONE round trip: a
+// wavefront's task holds all of its loads in flight at once (64 per lane), the partial sums of the tasks meet in LDS in a
+// fixed order (deterministic).  Round 3 before this: 8-16 loads in flight, 14 round trips forward (23 us), more backward (34 us).
+constexpr int HEAD_U = 16;        // forward task: 16 output features x 256 input features (lanes x 4)
+constexpr int HEAD_BO = 32;       // backward task: 64 input features (the lanes) x 32 output features
+constexpr int HEAD_PART = 8192;   // floats of partial sums: ceil(din / 256) * dout (forward), ceil(dout / 32) * din (backward)
+
 __global__ __launch_bounds__(1024) void head_fwd_kernel(HeadArgs a) {
-  __shared__ float cur[HEAD_MAX], nxt[HEAD_MAX];
+  __shared__ float cur[HEAD_MAX], part[HEAD_PART];
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
   for (int i = t; i < a.dims[0]; i += blockDim.x) cur[i] = a.x[size_t(row) * a.dims[0] + i];
   __syncthreads();
@@ -321,33 +327,40 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(HeadArgs a) {
   for (int l = 0; l < a.n_layers; ++l) {
     const int din = a.dims[l], dout = a.dims[l + 1];
     const bool last = l == a.n_layers - 1;
-    constexpr int U = 8;
-    for (int o0 = wave * U; o0 < dout; o0 += nw * U) {
-      float acc[U];
+    const float* __restrict__ W = a.w[l];
+    const int n_og = (dout + HEAD_U - 1) / HEAD_U, n_ic = (din + 255) / 256;
+    for (int task = wave; task < n_og * n_ic; task += nw) {
+      const int og = task % n_og, ic = task / n_og;
+      float x[4], acc[HEAD_U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc[u] = 0.f;
-      for (int i = lane; i < din; i += 64) {
-        const float x = cur[i];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int o = min(o0 + u, dout - 1);
-          acc[u] = fmaf(a.w[l][size_t(o) * din + i], x, acc[u]);
-        }
+      for (int c = 0; c < 4; ++c) {
+        const int i = ic * 256 + c * 64 + lane;
+        x[c] = i < din ? cur[i] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < HEAD_U; ++u) {
+        const int o = min(og * HEAD_U + u, dout - 1);
+        float w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = ic * 256 + c * 64 + lane;
+          w[c] = i < din ? W[size_t(o) * din + i] : 0.f;
+        }
+        acc[u] = fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], w[0] * x[0])));
+      }
+#pragma unroll
+      for (int u = 0; u < HEAD_U; ++u) {
         float v = acc[u];
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-        if (lane == 0 && o0 + u < dout) {
-          v += a.b[l][o0 + u];
-          nxt[o0 + u] = last ? v : fmaxf(v, 0.f);
-        }
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0 && og * HEAD_U + u < dout) part[ic * dout + og * HEAD_U + u] = v;
       }
     }
     __syncthreads();
     for (int i = t; i < dout; i += blockDim.x) {
-      const float v = nxt[i];
+      float v = a.b[l][i];
+      for (int ic = 0; ic < n_ic; ++ic) v += part[ic * dout + i];
+      if (!last) v = fmaxf(v, 0.f);
       cur[i] = v;
       if (last) a.y[size_t(row) * dout + i] = v;
       else if (a.hidden) a.hidden[size_t(row) * hstride + hoff + i] = v;
@@ -357,11 +370,12 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(HeadArgs a) {
   }
 }
 
-// backward w.r.t. the input only (the weights are constants here): g_in = W^T (g_out * relu').  Thread (i, s) sums segment s
-// of the output features for input feature i (coalesced over i, 16 loads in flight per thread), the segments meet in LDS.
+// backward w.r.t. the input only (the weights are constants here): g_in = W^T (g_out * relu').  Task = 64 input features
+// (the lanes: coalesced weight rows) x 32 output features (32 loads in flight per lane - 64 spill at 128 VGPRs -, no
+// cross-lane step).
 __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadArgs a) {
-  __shared__ float cur[HEAD_MAX], part[4096];
-  const int row = blockIdx.x, t = threadIdx.x;
+  __shared__ float cur[HEAD_MAX], part[HEAD_PART];
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
   const int dout_last = a.dims[a.n_layers];
   for (int i = t; i < dout_last; i += blockDim.x) cur[i] = a.g_y[size_t(row) * dout_last + i];
   __syncthreads();
@@ -370,30 +384,40 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadArgs a) {
     const int din = a.dims[l], dout = a.dims[l + 1];
     int hoff = 0;
     for (int q = 1; q < l; ++q) hoff += a.dims[q];          // offset of this layer's INPUT activation (layer l - 1's output)
-    // segments: as many as fit 1024 threads and the 4096-float scratch (input features beyond one pass loop)
-    int S = 1;
-    while (S * 2 * min(din, 1024) <= 1024 && S * 2 <= dout) S *= 2;
-    const int per = (dout + S - 1) / S;
-    for (int i0 = 0; i0 < din; i0 += 1024 / S) {
-      const int i = i0 + t % (1024 / S), sgm = t / (1024 / S);
+    const float* __restrict__ W = a.w[l];
+    const int n_ib = (din + 63) / 64, n_oc = (dout + HEAD_BO - 1) / HEAD_BO;
+    for (int task = wave; task < n_ib * n_oc; task += nw) {
+      const int ib = task % n_ib, oc = task / n_ib;
+      const int i = ib * 64 + lane;
+      const int ii = min(i, din - 1);
+      float w[HEAD_BO];
+#pragma unroll
+      for (int k = 0; k < HEAD_BO; ++k) {
+        const int o = min(oc * HEAD_BO + k, dout - 1);
+        w[k] = W[size_t(o) * din + ii];
+      }
       float acc = 0.f;
-      if (i < din && sgm < S) {
-        const int o1 = min(dout, (sgm + 1) * per);
-#pragma unroll 16
-        for (int o = sgm * per; o < o1; ++o) acc = fmaf(a.w[l][size_t(o) * din + i], cur[o], acc);
-      }
-      part[t] = acc;
-      __syncthreads();
-      if (t < 1024 / S && i0 + t < din) {
-        float v = 0.f;
-        for (int q = 0; q < S; ++q) v += part[q * (1024 / S) + t];
-        if (l > 0) v = a.hidden[size_t(row) * hstride + hoff + i0 + t] > 0.f ? v : 0.f;       // ReLU of the previous layer
-        if (l == 0) a.g_x[size_t(row) * din + i0 + t] = v;
-        part[2048 + ((i0 + t) & 2047)] = v;          // next layer's cotangent, staged (din <= HEAD_MAX <= 2048)
-      }
-      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < HEAD_BO; ++k) acc = fmaf(w[k], oc * HEAD_BO + k < dout ? cur[oc * HEAD_BO + k] : 0.f, acc);
+      if (i < din) part[oc * din + i] = acc;
     }
-    for (int i = t; i < din; i += blockDim.x) cur[i] = part[2048 + i];
+    __syncthreads();
+    float keep[2];                                    // din <= HEAD_MAX = 1536 < 2 * 1024
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = t + q * 1024;
+      float v = 0.f;
+      if (i < din) {
+        for (int oc = 0; oc < n_oc; ++oc) v += part[oc * din + i];
+        if (l > 0) v = a.hidden[size_t(row) * hstride + hoff + i] > 0.f ? v : 0.f;       // ReLU of the previous layer
+        if (l == 0) a.g_x[size_t(row) * din + i] = v;
+      }
+      keep[q] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (t + q * 1024 < din) cur[t + q * 1024] = keep[q];
     __syncthreads();
   }
 }
@@ -447,6 +471,9 @@ static int head_args(nphm::fit::HeadArgs& a, const float* const w[3], const floa
   if (n_layers < 1 || n_layers > 3) return nphm_fail_msg(who);
   for (int l = 0; l <= n_layers; ++l)
     if (dims[l] <= 0 || dims[l] > nphm::fit::HEAD_MAX) return nphm_fail_msg(who);
+  for (int l = 0; l < n_layers; ++l)        // the partial sums of a layer's tasks live in LDS
+    if (((dims[l] + 255) / 256) * dims[l + 1] > nphm::fit::HEAD_PART || ((dims[l + 1] + nphm::fit::HEAD_BO - 1) / nphm::fit::HEAD_BO) * dims[l] > nphm::fit::HEAD_PART)
+      return nphm_fail_msg(who);
   for (int l = 0; l < 3; ++l) { a.w[l] = l < n_layers ? w[l] : nullptr; a.b[l] = l < n_layers ? b[l] : nullptr; }
   for (int l = 0; l < 4; ++l) a.dims[l] = l <= n_layers ? dims[l] : 0;
   a.n_layers = n_layers;

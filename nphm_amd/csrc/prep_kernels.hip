@@ -110,7 +110,7 @@ struct PrepArgs {
   const float* anchors_in; // [n_rows, 39, 3] or null: given instead of evaluated
 };
 
-__global__ __launch_bounds__(256) void prepare_latent_kernel(PrepArgs a) {
+__global__ __launch_bounds__(1024) void prepare_latent_kernel(PrepArgs a) {
   __shared__ float sh[2 * 256 + 96];
   const int row = blockIdx.y;
   const int t = threadIdx.x;
@@ -129,23 +129,32 @@ __global__ __launch_bounds__(256) void prepare_latent_kernel(PrepArgs a) {
     float* b2f = sh + 96 + 224;  // [224]
     static_assert(LAT_COND == 96, "two column groups per lane");
     {
-      const int lane = t & 63, wv = t >> 6;
+      const int lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
       const float c0 = cond[lane], c1 = lane < 32 ? cond[64 + lane] : 0.f;
       const float d0 = c0 / INV_SQRT2_DIV, d1 = c1 / INV_SQRT2_DIV;
-      for (int r = wv; r < 224; r += 4) {
-        float p0 = 0.f, p2 = 0.f;
-        if (r < HID) {
+      constexpr int RB = 7;                       // rows per round trip: 4 x 7 loads in flight per lane
+      for (int r0 = wv * RB; r0 < 224; r0 += nw * RB) {
+        float p0[RB], p2[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          const int r = min(r0 + q, HID - 1);
           const float* w0 = a.w[0] + (size_t(s) * HID + r) * D_IN + 3;
           const float* w2 = a.w[2] + (size_t(s) * HID + r) * HID + L2_IN;
-          p0 = w0[lane] * c0;
-          p2 = w2[lane] * d0;
-          if (lane < 32) { p0 = fmaf(w0[64 + lane], c1, p0); p2 = fmaf(w2[64 + lane], d1, p2); }
+          const int l1 = 64 + (lane & 31);
+          const float a0 = w0[lane], a1 = w0[l1], e0 = w2[lane], e1 = w2[l1];
+          p0[q] = fmaf(a1, c1, a0 * c0);          // c1 = d1 = 0 on lanes 32..63
+          p2[q] = fmaf(e1, d1, e0 * d0);
         }
 #pragma unroll
-        for (int m = 32; m > 0; m >>= 1) { p0 += __shfl_xor(p0, m); p2 += __shfl_xor(p2, m); }
-        if (lane == 0) {
-          b0f[r] = r < HID ? a.b[0][s * HID + r] + p0 : 0.f;
-          b2f[r] = r < HID ? a.b[2][s * HID + r] + p2 : 0.f;
+        for (int q = 0; q < RB; ++q) {
+          float v0 = p0[q], v2 = p2[q];
+#pragma unroll
+          for (int m = 32; m > 0; m >>= 1) { v0 += __shfl_xor(v0, m); v2 += __shfl_xor(v2, m); }
+          const int r = r0 + q;
+          if (lane == 0 && r < 224) {
+            b0f[r] = r < HID ? a.b[0][s * HID + r] + v0 : 0.f;
+            b2f[r] = r < HID ? a.b[2][s * HID + r] + v2 : 0.f;
+          }
         }
       }
     }
@@ -352,7 +361,7 @@ int nphm_identity_prepare_latent(const void* packed,
   a.state = static_cast<float*>(latent_state);
   a.anchors_out = anchors_out;
   a.anchors_in = nullptr;
-  hipLaunchKernelGGL(nphm::prepare_latent_kernel, dim3(nphm::N_MEMBERS + 1, n_rows), dim3(256), 0,
+  hipLaunchKernelGGL(nphm::prepare_latent_kernel, dim3(nphm::N_MEMBERS + 1, n_rows), dim3(1024), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_prepare_latent launch", e);
@@ -369,7 +378,7 @@ int nphm_identity_prepare_latent_anchors(const float* const lin_weight[5], const
   a.lat_rows = lat_rows;
   a.state = static_cast<float*>(latent_state);
   a.anchors_in = anchors;
-  hipLaunchKernelGGL(nphm::prepare_latent_kernel, dim3(nphm::N_MEMBERS + 1, n_rows), dim3(256), 0,
+  hipLaunchKernelGGL(nphm::prepare_latent_kernel, dim3(nphm::N_MEMBERS + 1, n_rows), dim3(1024), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_prepare_latent_anchors launch", e);
