@@ -457,7 +457,7 @@ class DeformationNetwork(nn.Module):
             return
         z_id, z_ex, anchors1 = parts
         from .ensembled_deepsdf import frozen_head
-        packed = torch.cat([z_id[:, 0, :], anchors1.reshape(1, -1)], dim=-1)
+        packed = torch.cat([z_id.reshape(1, -1), anchors1.reshape(1, -1)], dim=-1)
         comp = frozen_head(self.compressor, packed, False)                       # [1,32]
         cond = torch.cat([comp.unsqueeze(1).expand(z_ex.shape[0], 1, -1), z_ex], dim=-1)
         key = (lat_rep.data_ptr(), lat_rep._version, tuple(lat_rep.shape), tuple(lat_rep.stride()),

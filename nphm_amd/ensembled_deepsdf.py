@@ -310,6 +310,12 @@ class _FrozenHeadFn(torch.autograd.Function):
         return (g_x, None) + (None,) * len(wb)
 
 
+def _row0(lat_rep):
+    """lat_rep[:, 0, :]; for a [B,1,L] code as a reshape - the backward of a select is a zero-fill plus a copy (two launches on
+    the fitting step's serial chain), the backward of a view is nothing"""
+    return lat_rep.reshape(lat_rep.shape[0], lat_rep.shape[2]) if lat_rep.shape[1] == 1 else lat_rep[:, 0, :]
+
+
 def frozen_head(seq, x, frozen: bool):
     """``seq(x)`` for an nn.Sequential of Linear (+ ReLU between) layers; on a ROCm device, with parameters that do not
     require grad (or ``frozen``), fp32 rows and <= 3 linear layers of width <= 1536 through the fused kernels."""
@@ -942,7 +948,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         second return value of ``forward`` (EnsembledDeepSDF.py:228-229) without evaluating any SDF -
         differentiable w.r.t. the global code.  The fitting loops call it instead of the reference's
         one-point ``decoder(zeros, lat, None)`` whose SDF value they discard (fitting.py:58, :208)."""
-        return self._anchors_of_rows(lat_rep[:, 0, :])
+        return self._anchors_of_rows(_row0(lat_rep))
 
     def _anchors_of_rows(self, lat_rows):
         """anchors [B,39,3] of latent rows [B, lat_dim] (differentiable w.r.t. the global code).  Inside ``anchor_scope()``
@@ -1031,7 +1037,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             # first-order HIP autograd tier: latent fitting (no parameter requires grad, train mode, no
             # chunk overwrite to differentiate around); everything else builds the composite graph
             if self.training and not params_train:
-                return self._forward_hip_autograd(xyz, lat_rep[:, 0, :])
+                return self._forward_hip_autograd(xyz, _row0(lat_rep))
             if self.training and self.train_backend == "hip":
                 return self._forward_hip_train(xyz, lat_rep[:, 0, :])
             return self._forward_composite(xyz, lat_rep)
