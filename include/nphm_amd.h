@@ -305,6 +305,25 @@ int nphm_identity_blend_members(const float* blend_weights, const float* member_
 int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight, const float* g_bias0, const float* g_bias2,
                               int n_rows, float* g_lat, void* stream);
 
+/* ---- loss terms of the identity decoder's training step (ABI 6) ------------------------- */
+/* src/NPHM/models/loss_functions.py:51-110 after the decoder evaluations, on the batched layout of the mirrored
+ * compute_loss: sdf [n_rows, N], grad = d sdf / d x [n_rows, N, 3] with N = sizes[0..3] = face | non-face | near-surface |
+ * far points as consecutive slices, normals [n_rows, sizes[0] + sizes[1], 3], z [n_rows, lat_dim] the latent codes,
+ * anchors / anchors_gt [n_rows, n_anchors, 3] (both NULL for a decoder without anchors), layout = (glob, loc, n_symm,
+ * n_middle_pairs) of the code [glob | 2 n_symm local codes | middle codes | ...] ((g, 0, 0, 0): no local codes).
+ *   nphm_train_loss          : row [8] = surf_sdf, normals, space_sdf, grad, lat_reg, anchors, symm_dist, middle_dist - one
+ *     launch (per-block partial sums in `partial` [nphm_train_loss_blocks() * 8], combined in block order by the last block:
+ *     deterministic; `counter` is a zero-initialised device word the kernel resets).
+ *   nphm_train_loss_backward : g_terms [8] = d L / d term (device) -> gradients w.r.t. sdf, grad, z and anchors - one launch. */
+int nphm_train_loss_blocks(void);
+int nphm_train_loss(const float* sdf, const float* grad, const float* normals, const float* z, const float* anchors,
+                    const float* anchors_gt, int n_rows, const int sizes[4], int lat_dim, int n_anchors, const int layout[4],
+                    float* partial, unsigned* counter, float* row, void* stream);
+int nphm_train_loss_backward(const float* sdf, const float* grad, const float* normals, const float* z, const float* anchors,
+                             const float* anchors_gt, int n_rows, const int sizes[4], int lat_dim, int n_anchors,
+                             const int layout[4], const float* g_terms, float* g_sdf, float* g_grad, float* g_z,
+                             float* g_anchors, void* stream);
+
 /* ---- dense skip-MLP: DeepSDF (NPM global SDF, backbone of DeformationNetwork) ----------- */
 /* Architecture (src/NPHM/models/deepSDF.py:7-62): dims = [3 + lat_dim] + [hidden_dim]*nlayers + [out_dim],
  * input re-injected (concat, / sqrt 2) before layer nlayers/2, Softplus(beta) activations.

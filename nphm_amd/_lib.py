@@ -95,6 +95,11 @@ SYMBOLS = {
     "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
                                                       c_void_p]),
     "nphm_inverse3x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nphm_train_loss_blocks": (c_int, []),
+    "nphm_train_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_train_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_gather_rows_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nphm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                c_void_p]),

@@ -9,7 +9,7 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip", "mlp_bwd_kernel.hip", "ident_bwd_kernel.hip", "ident_train_kernel.hip", "fit_kernels.hip", "mc_device.hip", "probe.hip", "marching_cubes.cpp"]
+SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip", "mlp_bwd_kernel.hip", "ident_bwd_kernel.hip", "ident_train_kernel.hip", "fit_kernels.hip", "train_loss_kernels.hip", "mc_device.hip", "probe.hip", "marching_cubes.cpp"]
 OUT = os.path.join(HERE, "libnphm_amd.so")
 
 

@@ -15,6 +15,93 @@ import torch
 from .diff_operators import gradient
 
 _POINT_SETS = ("points_face", "points_non_face", "sup_grad_near", "sup_grad_far")
+_TERMS = ("surf_sdf", "normals", "space_sdf", "grad", "lat_reg", "anchors", "symm_dist", "middle_dist")
+
+
+class _TrainLossFn(torch.autograd.Function):
+    """The eight loss terms below from ONE launch and their gradients w.r.t. the SDF values, the spatial gradients, the codes
+    and the predicted anchors from a second one (``nphm_train_loss[_backward]``, csrc/train_loss_kernels.hip) - the PyTorch
+    formulation of the same terms is ~40 launches forward and ~50 in the backward pass, 4 % of a training step that three
+    large kernels bound.  Outputs: eight 0-dim tensors in ``_TERMS`` order (the last three are zeros without anchors / local
+    codes and are dropped by the caller)."""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, normals, z, anchors, anchors_gt, sizes, layout):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        dev = sdf.device
+        B = sdf.shape[0]
+        sdf_c, grad_c = sdf.detach().reshape(B, -1).contiguous(), grad.detach().contiguous()
+        nrm_c, z_c = normals.detach().contiguous(), z.detach().reshape(B, -1).contiguous()
+        a_c = None if anchors is None else anchors.detach().contiguous()
+        gt_c = None if anchors is None else anchors_gt.detach().contiguous().float()
+        key = str(dev)
+        ws = _TrainLossFn._scratch.get(key)
+        if ws is None:
+            ws = (torch.zeros(lib.nphm_train_loss_blocks() * 8, dtype=torch.float32, device=dev),
+                  torch.zeros(1, dtype=torch.int32, device=dev))
+            _TrainLossFn._scratch[key] = ws
+        row = torch.empty(8, dtype=torch.float32, device=dev)
+        csizes, clayout = (ctypes.c_int * 4)(*sizes), (ctypes.c_int * 4)(*layout)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        K = 0 if a_c is None else a_c.shape[1]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.nphm_train_loss(sdf_c.data_ptr(), grad_c.data_ptr(), nrm_c.data_ptr(), z_c.data_ptr(), ptr(a_c), ptr(gt_c), B,
+                                       csizes, z_c.shape[1], K, clayout, ws[0].data_ptr(), ws[1].data_ptr(), row.data_ptr(), stream),
+                   "nphm_train_loss")
+        ctx.save_for_backward(sdf_c, grad_c, nrm_c, z_c, a_c, gt_c)
+        ctx.meta = (tuple(sizes), tuple(layout), sdf.shape, z.shape)
+        return tuple(row.unbind(0))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *g_terms):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        sdf_c, grad_c, nrm_c, z_c, a_c, gt_c = ctx.saved_tensors
+        sizes, layout, sdf_shape, z_shape = ctx.meta
+        dev = sdf_c.device
+        zero = None
+        parts = []
+        for g in g_terms:
+            if g is None:
+                zero = torch.zeros((), dtype=torch.float32, device=dev) if zero is None else zero
+                g = zero
+            parts.append(g.reshape(()).float())
+        c = torch.stack(parts)
+        g_sdf, g_grad, g_z = torch.empty_like(sdf_c), torch.empty_like(grad_c), torch.empty_like(z_c)
+        g_a = None if a_c is None else torch.empty_like(a_c)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        B = sdf_c.shape[0]
+        _lib.check(lib.nphm_train_loss_backward(sdf_c.data_ptr(), grad_c.data_ptr(), nrm_c.data_ptr(), z_c.data_ptr(), ptr(a_c), ptr(gt_c),
+                                                B, (ctypes.c_int * 4)(*sizes), z_c.shape[1], 0 if a_c is None else a_c.shape[1],
+                                                (ctypes.c_int * 4)(*layout), c.data_ptr(), g_sdf.data_ptr(), g_grad.data_ptr(),
+                                                g_z.data_ptr(), ptr(g_a), torch.cuda.current_stream(dev).cuda_stream),
+                   "nphm_train_loss_backward")
+        return g_sdf.view(sdf_shape), g_grad, None, g_z.view(z_shape), g_a, None, None, None
+
+
+_TrainLossFn._scratch = {}
+
+
+def _fused_terms(decoder, pred, grad, normals, glob_cond, anchors, anchors_gt, sizes):
+    """the loss dictionary through ``_TrainLossFn`` or None (CPU tensors, other dtypes, NPHM_AMD_TRAIN_LOSS_FUSED=0)"""
+    import os
+    if not (pred.is_cuda and pred.dtype == torch.float32 and grad.dtype == torch.float32 and glob_cond.dim() == 3
+            and glob_cond.shape[1] == 1 and os.environ.get("NPHM_AMD_TRAIN_LOSS_FUSED", "1") not in ("0", "")):
+        return None
+    layout = (glob_cond.shape[-1], 0, 0, 0)
+    if hasattr(decoder, "lat_dim_glob"):
+        n_mid = decoder.num_kps - 2 * decoder.num_symm_pairs
+        layout = (decoder.lat_dim_glob, decoder.lat_dim_loc, decoder.num_symm_pairs, n_mid // 2)
+    terms = _TrainLossFn.apply(pred.squeeze(-1), grad, normals, glob_cond, anchors, anchors_gt, sizes, layout)
+    n = 5 if anchors is None else (6 if not hasattr(decoder, "lat_dim_glob") else 8)
+    out = dict(zip(_TERMS[:n], terms[:n]))
+    if n == 6:
+        out["symm_dist"], out["middle_dist"] = None, None          # as _lat_regularisers answers without local codes
+    return out
 
 
 def compute_loss(batch, decoder, latent_codes, device):
@@ -65,6 +152,10 @@ def actual_compute_loss(batch_cuda, decoder, glob_cond):
     n_surf = n_face + n_non
     sdf = pred.squeeze(-1)
     normals = torch.cat([batch_cuda["normals_face"], batch_cuda["normals_non_face"]], dim=1)
+    fused_out = _fused_terms(decoder, pred, grad, normals, glob_cond, anchors,
+                             None if anchors is None else batch_cuda["gt_anchors"], sizes)
+    if fused_out is not None:
+        return fused_out
     normal_err = (grad[:, :n_surf] - normals).norm(2, dim=-1)
     # non-face points: error clamped at 0.75 and halved (loss_functions.py:56-57)
     cap = torch.cat([normal_err.new_full((n_face,), float("inf")), normal_err.new_full((n_non,), 0.75)])

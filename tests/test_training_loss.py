@@ -94,6 +94,29 @@ def test_loss_and_gradients_match_reference_hip():
 
 
 @pytest.mark.gpu
+def test_fused_loss_terms_match_the_pytorch_formulation(monkeypatch):
+    """nphm_train_loss / _backward (one launch each) against the elementwise formulation of the same eight terms:
+    values, code gradients and every parameter gradient at identical state."""
+    dev = torch.device("cuda:0")
+    g = U.golden("training")
+    got = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NPHM_AMD_TRAIN_LOSS_FUSED", fused)
+        net = U.build_identity(device=dev).train()
+        net.prune_tol = -1.0
+        losses, total, lat = _step(net, g, dev)
+        got[fused] = ({k: float(v) for k, v in losses.items()}, lat.grad.clone(),
+                      {n: p.grad.clone() for n, p in net.named_parameters()})
+    assert list(got["1"][0]) == list(got["0"][0])
+    for k, v in got["0"][0].items():
+        assert abs(got["1"][0][k] - v) <= 2e-6 * max(1.0, abs(v)), (k, got["1"][0][k], v)
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    worst = max([rel(got["1"][1], got["0"][1])] + [rel(got["1"][2][n], got["0"][2][n]) for n in got["0"][2]])
+    print(f"fused loss terms vs PyTorch formulation: gradients within {worst:.1e} of each tensor's largest entry")
+    assert worst < 5e-5          # (the training kernels behind both accumulate with atomics: run-to-run 1e-6)
+
+
+@pytest.mark.gpu
 def test_validation_step_matches_reference_hip():
     """training.py:250-268 on the HIP training tier: eval mode, the four overwritten points named by the loss mirror
     (one batched evaluation instead of four decoder calls), gradients of the codes."""
