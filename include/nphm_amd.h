@@ -381,6 +381,16 @@ int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                      const float* obs, const float* x_init, const float* jinv_init, int n_rows, int64_t n_points,
                      int max_steps, float cvg_thresh, float dvg_thresh, float eps,
                      float* x_out, float* diff_out, unsigned char* valid_out, void* stream);
+/* The same solve when the caller already holds x_init + F(x_init) - the value stream of the nphm_mlp_eval_points_jvp launch
+ * that produced jinv_init (search evaluates the Jacobian at the start points, iterative_root_finding.py:118): posed_init
+ * [n_rows, n_points] 3-vectors, posed_stride floats apart (4 * out_dim inside the value+Jacobian output).  The residual of
+ * iteration 0 is read instead of evaluated: one pass of the network less per solve, same iterates (ABI 6). */
+int nphm_mlp_broyden_from(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                          const void* packed, const void* latent_state,
+                          const float* obs, const float* x_init, const float* jinv_init, const float* posed_init,
+                          int64_t posed_stride, int n_rows, int64_t n_points,
+                          int max_steps, float cvg_thresh, float dvg_thresh, float eps,
+                          float* x_out, float* diff_out, unsigned char* valid_out, void* stream);
 
 /* First-order backward of the skip-MLP with respect to its conditioning rows, for the fitting loop's
  * loss.backward() through decoder_expr(p_corresp, cond) (src/NPHM/models/fitting.py:99-106 with the decoders

@@ -163,6 +163,8 @@ struct EvalArgs {
   // KIND 2 (Broyden): xyz = initial iterates, out = final iterates [n_rows, n_points, 3]
   const float* obs;       // [n_rows, n_points, 3] observed (posed) points
   const float* jinv;      // [n_rows, n_points, 3, 3] initial inverse Jacobians
+  const float* posed0;    // or null: x_init + F(x_init) of every point (stride posed0_stride floats), spares the first evaluation
+  int64_t posed0_stride;
   float* diff_out;        // [n_rows, n_points] smallest residual norm seen
   unsigned char* valid_out;   // [n_rows, n_points] converged
   int max_steps;
@@ -320,6 +322,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 
 #pragma unroll 1
   for (int it = 0;; ++it) {                 // one pass unless KIND 2
+  // KIND 2 with the posed start points given (the caller's value+Jacobian launch at x_init produced them with the inverse
+  // Jacobians): the residual of iteration 0 is read, not evaluated - one network pass less per solve
+  const bool given0 = BROY && it == 0 && p.posed0 != nullptr;
+  if (!given0) {
   bf16x8 bv[MT];
   if (BROY) __syncthreads();                // the iterate written by the owners is visible
 #pragma unroll
@@ -590,6 +596,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       }
     }
   }
+  }  // evaluation (skipped when the start residual is given)
   if (!BROY) break;
 
   // ---- KIND 2: one Broyden step per evaluation (iterative_root_finding.py:24-69) ------------------
@@ -597,12 +604,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   if (threadIdx.x < M) {
     const int m = threadIdx.x;
     float gnew[3];
+    if (given0) {
+      const int64_t i = base + m;
+      const int64_t ic = int64_t(row) * n_pts + (i < n_pts ? i : n_pts - 1);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float v = 0.f;
+      for (int c = 0; c < 3; ++c) gnew[c] = p.posed0[ic * p.posed0_stride + c] - bobs[c];
+    } else {
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
-      gnew[c] = (v + bx[c]) - bobs[c];                    // residual (x + F(x)) - obs
+      for (int c = 0; c < 3; ++c) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
+        gnew[c] = (v + bx[c]) - bobs[c];                    // residual (x + F(x)) - obs
+      }
     }
     if (it == 0) {
 #pragma unroll
@@ -920,6 +934,37 @@ int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   a.n_points = n_points;
   a.obs = obs;
   a.jinv = jinv_init;
+  a.diff_out = diff_out;
+  a.valid_out = valid_out;
+  a.max_steps = max_steps;
+  a.cvg = cvg_thresh; a.dvg = dvg_thresh; a.eps = eps;
+  return launch_eval<0, 2>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+}
+
+int nphm_mlp_broyden_from(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                          const void* packed, const void* latent_state,
+                          const float* obs, const float* x_init, const float* jinv_init, const float* posed_init,
+                          int64_t posed_stride, int n_rows, int64_t n_points,
+                          int max_steps, float cvg_thresh, float dvg_thresh, float eps,
+                          float* x_out, float* diff_out, unsigned char* valid_out, void* stream) {
+  Plan plan;
+  if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) || out_dim < 3)
+    return nphm_fail_msg("nphm_mlp_broyden_from: unsupported architecture (needs a 3-vector field)");
+  if (!packed || !latent_state || !obs || !x_init || !jinv_init || !posed_init || !x_out || !diff_out || !valid_out)
+    return nphm_fail_msg("nphm_mlp_broyden_from: null pointer");
+  if (n_rows <= 0 || n_points <= 0 || max_steps < 0 || posed_stride < 3) return nphm_fail_msg("nphm_mlp_broyden_from: bad sizes");
+  nphm::mlp::EvalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const char*>(packed);
+  a.state = static_cast<const char*>(latent_state);
+  a.out = x_out;
+  a.out_dim = out_dim;
+  a.xyz = x_init;
+  a.n_points = n_points;
+  a.obs = obs;
+  a.jinv = jinv_init;
+  a.posed0 = posed_init;
+  a.posed0_stride = posed_stride;
   a.diff_out = diff_out;
   a.valid_out = valid_out;
   a.max_steps = max_steps;

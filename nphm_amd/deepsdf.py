@@ -291,10 +291,11 @@ class DeepSDF(nn.Module):
                    "nphm_mlp_eval_points_jvp")
         return out
 
-    def broyden_hip(self, obs, x_init, jinv_init, cond_rows, max_steps, cvg_thresh, dvg_thresh, eps=1e-6):
+    def broyden_hip(self, obs, x_init, jinv_init, cond_rows, max_steps, cvg_thresh, dvg_thresh, eps=1e-6, posed_init=None):
         """Roots of x + f(x) = obs by Broyden's method, fused around the network in one launch
         (nphm_mlp_broyden).  obs / x_init [B,N,3], jinv_init [B,N,3,3], cond_rows [B,lat_dim] ->
-        (x [B,N,3], smallest residual norm [B,N], converged [B,N] bool)."""
+        (x [B,N,3], smallest residual norm [B,N], converged [B,N] bool).  ``posed_init`` [B,N,3] (any point stride):
+        x_init + f(x_init) when the caller holds it already - the first evaluation is then skipped."""
         lib = _lib.load()
         B, N, _ = x_init.shape
         packed, state = self.prepare_latent(cond_rows)
@@ -304,10 +305,21 @@ class DeepSDF(nn.Module):
         diff = torch.empty(B, N, dtype=torch.float32, device=dev)
         valid = torch.empty(B, N, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.nphm_mlp_broyden(*self._arch(), packed.data_ptr(), state.data_ptr(), obs.data_ptr(),
-                                        x_init.data_ptr(), jinv_init.data_ptr(), B, N, int(max_steps),
-                                        float(cvg_thresh), float(dvg_thresh), float(eps), x.data_ptr(),
-                                        diff.data_ptr(), valid.data_ptr(), stream), "nphm_mlp_broyden")
+        stride = None
+        if posed_init is not None and posed_init.dtype == torch.float32 and posed_init.shape == x_init.shape and posed_init.stride(-1) == 1:
+            ps = posed_init.stride(1)
+            if posed_init.stride(0) == ps * N:                # the rows collapse into one point stride
+                stride = ps
+        if stride is not None:
+            _lib.check(lib.nphm_mlp_broyden_from(*self._arch(), packed.data_ptr(), state.data_ptr(), obs.data_ptr(),
+                                                 x_init.data_ptr(), jinv_init.data_ptr(), posed_init.data_ptr(), stride, B, N,
+                                                 int(max_steps), float(cvg_thresh), float(dvg_thresh), float(eps), x.data_ptr(),
+                                                 diff.data_ptr(), valid.data_ptr(), stream), "nphm_mlp_broyden_from")
+        else:
+            _lib.check(lib.nphm_mlp_broyden(*self._arch(), packed.data_ptr(), state.data_ptr(), obs.data_ptr(),
+                                            x_init.data_ptr(), jinv_init.data_ptr(), B, N, int(max_steps),
+                                            float(cvg_thresh), float(dvg_thresh), float(eps), x.data_ptr(),
+                                            diff.data_ptr(), valid.data_ptr(), stream), "nphm_mlp_broyden")
         return x, diff, valid.view(torch.bool)           # the kernel writes 0 / 1 bytes
 
     def _hip_rows(self, xyz, cond, cond_grad_ok=False):
@@ -564,7 +576,7 @@ class DeformationNetwork(nn.Module):
         return val, jac.transpose(-1, -2).detach()
 
     def broyden(self, obs, x_init, jinv_init, lat_rep, anchors, max_steps=15, cvg_thresh=1e-6, dvg_thresh=0.2,
-                eps=1e-6):
+                eps=1e-6, posed_init=None):
         """Canonical correspondences x_c with x_c + F_ex(x_c) = obs for all points in ONE fused launch
         (the reference iterates <= max_steps + 1 forwards with a host sync each,
         iterative_root_finding.py:5-71).  obs / x_init [B,N,3], jinv_init [B,N,3,3], lat_rep / anchors as
@@ -580,9 +592,11 @@ class DeformationNetwork(nn.Module):
                 return None
             xv, rows = plan
             R, n = xv.shape[0], xv.shape[1]
+            if posed_init is not None and tuple(posed_init.shape) != (R, n, 3):
+                posed_init = None                              # (a re-viewed batch: let the kernel evaluate the start itself)
             x, diff, valid = self.defDeepSDF.broyden_hip(obs.detach().reshape(R, n, 3), xv,
                                                          jinv_init.detach().reshape(R, n, 3, 3), rows, max_steps,
-                                                         cvg_thresh, dvg_thresh, eps)
+                                                         cvg_thresh, dvg_thresh, eps, posed_init=posed_init)
         return {"result": x.reshape(-1, 3, 1), "diff": diff.reshape(-1), "valid_ids": valid.reshape(-1)}
 
     def canonical_points(self, xyz, lat_rep, anchors):

@@ -82,7 +82,15 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
     else:
         xc_init = obs.detach()                 # an alias: nothing below writes into it (the solvers copy / own their iterates)
 
-    J_inv_init = inverse3x3(jac(decoder_expr, xc_init, cond, anchors).detach()).flatten(0, 1)    # the reference: `.inverse()`
+    # the reference: jac(...) then `.inverse()` (:118).  The fused value+Jacobian launch also yields x_init + F(x_init),
+    # i.e. the residual of the solver's iteration 0: handed to the fused solver, which then skips that evaluation
+    posed_init = None
+    fused = decoder_expr.jacobian(xc_init, cond, anchors) if hasattr(decoder_expr, "jacobian") else None
+    if fused is not None:
+        posed_init, J0 = fused
+    else:
+        J0 = jac(decoder_expr, xc_init, cond, anchors).detach()
+    J_inv_init = inverse3x3(J0.detach()).flatten(0, 1)
     x0 = xc_init.reshape(-1, 3, 1)
     # conditioning may come as one row per batch entry (cond [B,1,L], anchors [B,K,3]: what the mirrored fitting
     # loop passes); the python solver below wants the reference's per-point tensors
@@ -112,7 +120,7 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
         if multi_corresp or cond.shape[0] == 1 or cond.shape[1] == 1:
             # batch rows stay batch rows (one conditioning row each): no flattening, nothing to re-discover
             result = decoder_expr.broyden(obs, xc_init, J_inv_init, cond, anchors, max_steps=15, cvg_thresh=1e-6,
-                                          dvg_thresh=0.2)
+                                          dvg_thresh=0.2, **({} if posed_init is None else {"posed_init": posed_init}))
         else:      # the reference flattens the batch into one row of points (:137-139)
             result = decoder_expr.broyden(obs.reshape(1, -1, 3), xc_init.reshape(1, -1, 3), J_inv_init,
                                           cond_full.reshape(1, -1, cond.shape[2]),
