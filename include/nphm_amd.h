@@ -276,11 +276,14 @@ int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
 /* Small dense heads with FROZEN weights on a handful of rows - mlp_pos (EnsembledDeepSDF.py:194-200: 64 -> 256 -> 256 -> 117,
  * ReLU between the layers) and the compressor of the deformation field (deepSDF.py:212-223: 1461 -> 32): y = W_n(relu(...)) + b_n
  * in one launch, and the gradient w.r.t. the input in one launch (nn.Linear layout: weight [out, in]).  dims = {in, ..., out},
- * 1..3 layers, widths <= 1536; hidden [n_rows, dims[1] + dims[2]] receives the post-ReLU activations the backward needs. */
+ * 1..3 layers, widths <= 1536; hidden [n_rows, dims[1] + dims[2]] receives the post-ReLU activations the backward needs.
+ * ABI 6: the input is the first dims[0] columns of rows x_stride floats apart (the global part of a latent row, no slice copy), g_x
+ * has the same row stride and is written in full (zeros beyond dims[0]); y_add [out] or NULL is added to every output row (the mean
+ * anchors). */
 int nphm_head_forward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* x,
-                      int n_rows, float* y, float* hidden, void* stream);
+                      int x_stride, const float* y_add, int n_rows, float* y, float* hidden, void* stream);
 int nphm_head_backward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* hidden,
-                       const float* g_y, int n_rows, float* g_x, void* stream);
+                       const float* g_y, int n_rows, float* g_x, int x_stride, void* stream);
 int nphm_fit_loss(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
                   const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
                   float* row, void* stream);

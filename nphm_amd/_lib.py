@@ -34,8 +34,8 @@ SYMBOLS = {
     "nphm_identity_prepare_latent": (c_int, [c_void_p, _PtrArr5, _PtrArr5, _PtrArr3, _PtrArr3, c_int,
                                              c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_prepare_latent_anchors": (c_int, [_PtrArr5, _PtrArr5, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "nphm_head_forward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "nphm_head_backward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nphm_head_forward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nphm_head_backward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "nphm_fit_loss": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_void_p, c_void_p]),
     "nphm_fit_loss_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -301,11 +301,13 @@ struct HeadArgs {
   const float* b[3];
   int dims[4];                 // in, (hidden ...), out
   int n_layers;
-  const float* x;              // [rows, dims[0]]
+  const float* x;              // [rows, x_stride >= dims[0]]: the first dims[0] columns of every row are the input
+  int x_stride;
+  const float* y_add;          // or null: [dims[n_layers]] added to every output row (e.g. the mean anchors)
   float* y;                    // [rows, dims[n_layers]]
   float* hidden;               // [rows, dims[1] + dims[2]] post-ReLU activations (saved for the backward pass)
   const float* g_y;            // backward: [rows, out]
-  float* g_x;                  // backward: [rows, in]
+  float* g_x;                  // backward: [rows, x_stride] - columns beyond dims[0] are written as zeros
 };
 constexpr int HEAD_MAX = 1536;   // widest layer input / output held in LDS
 
@@ -320,7 +322,7 @@ constexpr int HEAD_PART = 8192;   // floats of partial sums: ceil(din / 256) * d
 __global__ __launch_bounds__(1024) void head_fwd_kernel(HeadArgs a) {
   __shared__ float cur[HEAD_MAX], part[HEAD_PART];
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
-  for (int i = t; i < a.dims[0]; i += blockDim.x) cur[i] = a.x[size_t(row) * a.dims[0] + i];
+  for (int i = t; i < a.dims[0]; i += blockDim.x) cur[i] = a.x[size_t(row) * a.x_stride + i];
   __syncthreads();
   int hoff = 0;
   const int hstride = a.dims[1] + (a.n_layers > 2 ? a.dims[2] : 0);
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(HeadArgs a) {
       float v = a.b[l][i];
       for (int ic = 0; ic < n_ic; ++ic) v += part[ic * dout + i];
       if (!last) v = fmaxf(v, 0.f);
+      else if (a.y_add) v += a.y_add[i];
       cur[i] = v;
       if (last) a.y[size_t(row) * dout + i] = v;
       else if (a.hidden) a.hidden[size_t(row) * hstride + hoff + i] = v;
@@ -410,10 +413,12 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadArgs a) {
       if (i < din) {
         for (int oc = 0; oc < n_oc; ++oc) v += part[oc * din + i];
         if (l > 0) v = a.hidden[size_t(row) * hstride + hoff + i] > 0.f ? v : 0.f;       // ReLU of the previous layer
-        if (l == 0) a.g_x[size_t(row) * din + i] = v;
+        if (l == 0) a.g_x[size_t(row) * a.x_stride + i] = v;
       }
       keep[q] = v;
     }
+    if (l == 0)
+      for (int i = din + t; i < a.x_stride; i += blockDim.x) a.g_x[size_t(row) * a.x_stride + i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -482,22 +487,24 @@ static int head_args(nphm::fit::HeadArgs& a, const float* const w[3], const floa
 }
 
 int nphm_head_forward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* x,
-                      int n_rows, float* y, float* hidden, void* stream) {
+                      int x_stride, const float* y_add, int n_rows, float* y, float* hidden, void* stream) {
   nphm::fit::HeadArgs a{};
   if (!x || !y || n_rows <= 0 || (n_layers > 1 && !hidden)) return nphm_fail_msg("nphm_head_forward: bad arguments");
   if (head_args(a, weight, bias, dims, n_layers, "nphm_head_forward: unsupported head (1..3 layers, widths <= 1536)")) return -2;
-  a.x = x; a.y = y; a.hidden = hidden;
+  if (x_stride < dims[0]) return nphm_fail_msg("nphm_head_forward: x_stride < input width");
+  a.x = x; a.x_stride = x_stride; a.y_add = y_add; a.y = y; a.hidden = hidden;
   hipLaunchKernelGGL(nphm::fit::head_fwd_kernel, dim3(n_rows), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_head_forward launch", e);
 }
 
 int nphm_head_backward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* hidden,
-                       const float* g_y, int n_rows, float* g_x, void* stream) {
+                       const float* g_y, int n_rows, float* g_x, int x_stride, void* stream) {
   nphm::fit::HeadArgs a{};
   if (!g_y || !g_x || n_rows <= 0 || (n_layers > 1 && !hidden)) return nphm_fail_msg("nphm_head_backward: bad arguments");
   if (head_args(a, weight, bias, dims, n_layers, "nphm_head_backward: unsupported head (1..3 layers, widths <= 1536)")) return -2;
-  a.hidden = const_cast<float*>(hidden); a.g_y = g_y; a.g_x = g_x;
+  if (x_stride < dims[0]) return nphm_fail_msg("nphm_head_backward: x_stride < input width");
+  a.hidden = const_cast<float*>(hidden); a.g_y = g_y; a.g_x = g_x; a.x_stride = x_stride;
   hipLaunchKernelGGL(nphm::fit::head_bwd_kernel, dim3(n_rows), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_head_backward launch", e);

@@ -349,7 +349,7 @@ class DeepSDF(nn.Module):
             return None
         B, N = xyz.shape[0], xyz.shape[1]
         if cond.shape[1] == 1:
-            return xyz, cond[:, 0, :]
+            return xyz, cond.reshape(cond.shape[0], cond.shape[2])         # (a view: the backward of a select costs two launches)
         if cond.shape[1] != N:
             return None
         change = (cond[:, 1:] != cond[:, :-1]).any(dim=-1)                 # [B, N-1]

@@ -273,7 +273,9 @@ class _FrozenHeadFn(torch.autograd.Function):
     (``nphm_head_forward / _backward``) - the PyTorch formulation is a GEMM + bias + ReLU launch per layer and direction."""
 
     @staticmethod
-    def forward(ctx, x, n_layers, *wb):
+    def forward(ctx, x, n_layers, y_add, *wb):
+        """x [rows, >= in_features]: the head reads the first in_features columns of every row (a latent row goes in whole -
+        no slice, whose backward would be a zero-fill plus a copy); y_add [out] or None is added to every output row"""
         lib = _lib.load()
         ws, bs = list(wb[0::2]), list(wb[1::2])
         rows = x.shape[0]
@@ -285,10 +287,11 @@ class _FrozenHeadFn(torch.autograd.Function):
         cdims = (ctypes.c_int * 4)(*(dims + [0] * (4 - len(dims))))
         pad = lambda ts: _lib.ptr_array3([t.detach() for t in ts] + [ts[0].detach()] * (3 - len(ts)))
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(lib.nphm_head_forward(pad(ws), pad(bs), cdims, n_layers, xc.data_ptr(), rows, y.data_ptr(), hidden.data_ptr(), stream),
+        _lib.check(lib.nphm_head_forward(pad(ws), pad(bs), cdims, n_layers, xc.data_ptr(), xc.shape[1],
+                                         None if y_add is None else y_add.data_ptr(), rows, y.data_ptr(), hidden.data_ptr(), stream),
                    "nphm_head_forward")
         ctx.save_for_backward(hidden, *[t.detach() for t in wb])
-        ctx.meta = (n_layers, dims)
+        ctx.meta = (n_layers, dims, xc.shape[1])
         return y
 
     @staticmethod
@@ -296,18 +299,18 @@ class _FrozenHeadFn(torch.autograd.Function):
     def backward(ctx, g_y):
         lib = _lib.load()
         hidden, *wb = ctx.saved_tensors
-        n_layers, dims = ctx.meta
+        n_layers, dims, width = ctx.meta
         ws, bs = list(wb[0::2]), list(wb[1::2])
         g = g_y.contiguous().float()
         rows = g.shape[0]
-        g_x = torch.empty(rows, dims[0], dtype=torch.float32, device=g.device)
+        g_x = torch.empty(rows, width, dtype=torch.float32, device=g.device)        # written in full: zeros beyond the input columns
         import ctypes
         cdims = (ctypes.c_int * 4)(*(dims + [0] * (4 - len(dims))))
         pad = lambda ts: _lib.ptr_array3(list(ts) + [ts[0]] * (3 - len(ts)))
         stream = torch.cuda.current_stream(g.device).cuda_stream
-        _lib.check(lib.nphm_head_backward(pad(ws), pad(bs), cdims, n_layers, hidden.data_ptr(), g.data_ptr(), rows, g_x.data_ptr(), stream),
-                   "nphm_head_backward")
-        return (g_x, None) + (None,) * len(wb)
+        _lib.check(lib.nphm_head_backward(pad(ws), pad(bs), cdims, n_layers, hidden.data_ptr(), g.data_ptr(), rows, g_x.data_ptr(), width,
+                                          stream), "nphm_head_backward")
+        return (g_x, None, None) + (None,) * len(wb)
 
 
 def _row0(lat_rep):
@@ -316,20 +319,25 @@ def _row0(lat_rep):
     return lat_rep.reshape(lat_rep.shape[0], lat_rep.shape[2]) if lat_rep.shape[1] == 1 else lat_rep[:, 0, :]
 
 
-def frozen_head(seq, x, frozen: bool):
-    """``seq(x)`` for an nn.Sequential of Linear (+ ReLU between) layers; on a ROCm device, with parameters that do not
-    require grad (or ``frozen``), fp32 rows and <= 3 linear layers of width <= 1536 through the fused kernels."""
+def frozen_head(seq, x, frozen: bool, add=None):
+    """``seq(x[:, :in_features]) (+ add)`` for an nn.Sequential of Linear (+ ReLU between) layers; on a ROCm device, with
+    parameters that do not require grad (or ``frozen``), fp32 rows and <= 3 linear layers of width <= 1536 through the fused
+    kernels.  ``x`` may be wider than the head's input (a whole latent row); ``add`` [out_features] is a constant."""
     lins = [m for m in seq if isinstance(m, nn.Linear)]
     others = [m for m in seq if not isinstance(m, nn.Linear)]
     ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= len(lins) <= 3 and len(others) == len(lins) - 1
+          and x.shape[1] >= lins[0].in_features
           and all(isinstance(m, nn.ReLU) for m in others)
           and all(max(l.in_features, l.out_features) <= 1536 and l.bias is not None for l in lins)
           and (frozen or not any(p.requires_grad for l in lins for p in l.parameters()))
           and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", ""))
     if not ok:
-        return seq(x)
+        y = seq(x[:, :lins[0].in_features] if x.shape[1] != lins[0].in_features else x)
+        return y if add is None else y + add.reshape(1, -1).to(y)
     wb = [t for l in lins for t in (l.weight, l.bias)]
-    return _FrozenHeadFn.apply(x, len(lins), *wb)
+    if add is not None:
+        add = add.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+    return _FrozenHeadFn.apply(x, len(lins), add, *wb)
 
 
 class _IdentityFieldFn(torch.autograd.Function):
@@ -965,8 +973,8 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             if B > 1 and lat_rows.stride(0) == 0:
                 lat_rows = lat_rows[:1]                      # identical rows (an expanded code): evaluate one
         frozen = self.assume_frozen_parameters
-        a = frozen_head(self.mlp_pos, lat_rows[:, :self.lat_dim_glob], frozen).view(lat_rows.shape[0], self.num_kps, 3)
-        a = a + self.anchors.reshape(1, self.num_kps, 3).to(a)
+        # the head reads the global part of the whole row and adds the mean anchors itself (no slice / add launches)
+        a = frozen_head(self.mlp_pos, lat_rows, frozen, add=self.anchors).view(lat_rows.shape[0], self.num_kps, 3)
         if key is not None:
             scope[key] = (a, lat_rows)
         return a if a.shape[0] == B else a.expand(B, -1, -1)

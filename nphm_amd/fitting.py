@@ -195,14 +195,24 @@ class _History:
         vals += [torch.as_tensor(extra[k], device=dev).detach().reshape(()).float() for k in self.extra]
         return torch.stack(vals)
 
+    perm = None          # fused steps hand over the loss kernel's raw row [8]; this is its order in the history's columns
+
     def record(self, j, row):
         if self.buf is not None:
+            if self.perm is not None and self.buf.shape[1] != row.shape[0]:
+                self.buf = torch.zeros(self.buf.shape[0], row.shape[0], dtype=torch.float32, device=self.buf.device)
             self.buf[j].copy_(row)
+
+    def ordered(self, row_host):
+        """a step's row on the host in (lambdas order, total, extras)"""
+        return row_host if self.perm is None else row_host[self.perm]
 
     def flush(self, n_done):
         if self.buf is None:
             return
         rows = self.buf[:n_done].cpu().numpy()
+        if self.perm is not None:
+            rows = rows[:, self.perm]
         for r in rows:
             d = {k: float(v) for k, v in zip(self.keys + ["loss"], r)}
             for k, v in zip(self.extra, r[len(self.keys) + 1:]):
@@ -239,12 +249,10 @@ class _StepControls:
             self.thr.fill_(thr)
             self._thr_host = thr
 
-    def fused_row(self, row8, extra=()):
-        """history row (lambdas order, total, extras) out of the fused kernel's row"""
-        if getattr(self, "_perm", None) is None or self._perm_n != len(extra):
-            idx = [_LOSS_SLOTS[k] for k in self.keys] + [6] + [7] * len(extra)
-            self._perm, self._perm_n = torch.tensor(idx, dtype=torch.long, device=row8.device), len(extra)
-        return row8.index_select(0, self._perm)
+    def fused_perm(self, extra=()):
+        """columns of the fused kernel's row [8] in the history's order (lambdas order, total, extras): applied on the host when
+        the trace is read - the step itself hands the raw row over (no index_select launch per step)"""
+        return [_LOSS_SLOTS[k] for k in self.keys] + [6] + [7] * len(extra)
 
     def total(self, loss_dict):
         loss = 0
@@ -525,6 +533,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     drawn_static = sampler.upload(sampler.draw_like())       # static input of the step: the sampled indices
     drawn_cur = [drawn_static]                               # what the step reads (another tensor for odd-shaped draws)
     fused = _fused_losses_ok(decoder, lambdas, device) and "reg_expr" in lambdas
+    if fused:
+        hist.perm = ctl.fused_perm(extra=("n_valid",))
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder, decoder_expr) and not compute_unused_sdf_grad
 
@@ -576,7 +586,7 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         if fused:                          # every loss term, the total and (backward) their gradients: two launches
             loss, row8 = _FitLossFn.apply(sdf, valid, lat_rep_shape, lat_rep, obs_idx, ctl.thr, ctl.lam6)
             loss.backward(gradient=ctl.one)       # (a preallocated seed: no ones_like launch per step)
-            row = ctl.fused_row(row8, extra=("n_valid",))
+            row = row8                     # raw: hist.perm orders it on the host
         else:
             loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr, valid),
                          "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
@@ -603,7 +613,7 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             hist.record(j, row)
             done = j + 1
             if verbose:
-                r = row.cpu().numpy()
+                r = hist.ordered(row.cpu().numpy())
                 _report(j, lambdas, dict(zip(ctl.keys, r)), int(round(float(r[-1]))))
     hist.flush(done)
     _flush_timing(timing)
@@ -631,6 +641,8 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
     drawn_static = sampler.upload(sampler.draw_like())
     drawn_cur = [drawn_static]
     fused = _fused_losses_ok(decoder, lambdas, device) and "reg_expr" not in lambdas
+    if fused:
+        hist.perm = ctl.fused_perm()
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder)
 
@@ -642,7 +654,7 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
         if fused:
             loss, row8 = _FitLossFn.apply(sdf, None, lat_rep_shape, None, None, ctl.thr, ctl.lam6)
             loss.backward(gradient=ctl.one)
-            return ctl.fused_row(row8), anchors.detach()
+            return row8, anchors.detach()
         loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr)}
         _shape_regularisers(decoder, lat_rep_shape, loss_dict)
         loss = ctl.total(loss_dict)
@@ -662,7 +674,7 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
             hist.record(j, row)
             done = j + 1
             if verbose:
-                _report(j, lambdas, dict(zip(ctl.keys, row.cpu().numpy())))
+                _report(j, lambdas, dict(zip(ctl.keys, hist.ordered(row.cpu().numpy()))))
     hist.flush(done)
     if anchors is not None:
         anchors = anchors.clone()
