@@ -680,18 +680,18 @@ def mfma_sustained(dev):
         n = 8192
         a = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
         b = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
-        for _ in range(3):
+        for _ in range(100):              # (a 10-launch burst reads 1.16 PFLOP/s where 6 000 launches sustain 1.41: let it settle)
             torch.matmul(a, b)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        reps = 10
+        reps = 300
         for _ in range(reps):
             torch.matmul(a, b)
         e1.record()
         torch.cuda.synchronize()
         out["library_gemm_bf16_tflops"] = 2.0 * n ** 3 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
-        out["library_gemm_shape"] = f"torch.matmul bf16 {n}^3 randn"
+        out["library_gemm_shape"] = f"torch.matmul bf16 {n}^3 randn, {reps} launches after 100 warm-up launches"
     except Exception as e:            # noqa: BLE001 - a reference figure only
         out["library_gemm_bf16_tflops"] = None
         out["library_gemm_shape"] = repr(e)
