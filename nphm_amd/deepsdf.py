@@ -464,6 +464,8 @@ class DeformationNetwork(nn.Module):
         runs on ONE row and the gradients reach z_id / the anchors without an expand-and-sum over the rows.  Same values."""
         if getattr(self, "_cond_scope", None) is None or self.mode != "compress" or self.training or anchors is None:
             return
+        if parts is not None and not (parts[0].shape[0] == 1 and parts[2].shape[0] == 1 and parts[1].shape[0] == lat_rep.shape[0]):
+            parts = None                          # not "one identity on every row": the generic evaluation
         if parts is None:
             self._condition(lat_rep[:, :1, :3], lat_rep, anchors)
             return

@@ -36,7 +36,8 @@ class _TrainLossFn(torch.autograd.Function):
         nrm_c, z_c = normals.detach().contiguous(), z.detach().reshape(B, -1).contiguous()
         a_c = None if anchors is None else anchors.detach().contiguous()
         gt_c = None if anchors is None else anchors_gt.detach().contiguous().float()
-        key = str(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        key = (str(dev), stream)                # the partial sums and the arrival counter belong to one stream's launches
         ws = _TrainLossFn._scratch.get(key)
         if ws is None:
             ws = (torch.zeros(lib.nphm_train_loss_blocks() * 8, dtype=torch.float32, device=dev),
@@ -46,7 +47,6 @@ class _TrainLossFn(torch.autograd.Function):
         csizes, clayout = (ctypes.c_int * 4)(*sizes), (ctypes.c_int * 4)(*layout)
         ptr = lambda t: None if t is None else t.data_ptr()
         K = 0 if a_c is None else a_c.shape[1]
-        stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.nphm_train_loss(sdf_c.data_ptr(), grad_c.data_ptr(), nrm_c.data_ptr(), z_c.data_ptr(), ptr(a_c), ptr(gt_c), B,
                                        csizes, z_c.shape[1], K, clayout, ws[0].data_ptr(), ws[1].data_ptr(), row.data_ptr(), stream),
                    "nphm_train_loss")
