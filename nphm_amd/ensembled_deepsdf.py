@@ -441,7 +441,7 @@ class _MemberFieldFn(torch.autograd.Function):
         xyz_c = xyz.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         # members the pruning rule keeps per point: the list kernel's normalised blend weights (0 where pruned)
-        tol = module.prune_tol if module.train_prune_tol is None else module.train_prune_tol
+        tol = module._train_tol()
         what = _member_point_lists_device(state, xyz_c, tol, A, stream)[0]
         tiles_fwd, tiles, plist, chunks, pieces = _train_member_lists(what > 0, module.ensembled_deep_sdf.lin0._sets)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
@@ -449,6 +449,9 @@ class _MemberFieldFn(torch.autograd.Function):
         _lib.check(lib.nphm_identity_train_forward(
             packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N, tiles_fwd.data_ptr(),
             tiles_fwd.shape[0], plist.data_ptr(), S.data_ptr(), G.data_ptr(), stream), "nphm_identity_train_forward")
+        if module.train_prune_tol is None:
+            # size of the kept member values (their RMS; 0 marks a pruned pair): next step's pruning budget (_train_tol)
+            module._train_mag = (torch.linalg.vector_norm(S.detach()), torch.count_nonzero(S.detach()))
         ctx.module = module
         ctx.pieces = pieces
         ctx.shapes = [t.shape for t in (W0, W1, W2, W3, W4, b1, b3, b4)]
@@ -887,6 +890,28 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             anchors = anchors + self.anchors.reshape(1, self.num_kps, 3).to(anchors)
         sdf = _IdentityFieldFn.apply(self, xyz, lat_rows, anchors)
         return sdf, anchors
+
+    _TRAIN_MAG_REF = 0.04     # RMS of the kept member values at the seeded initialisation (0.044)
+
+    def _train_tol(self):
+        """Pruning budget of the training tier.  ``train_prune_tol`` if the caller pinned one; otherwise ``prune_tol`` scaled
+        to the size of the member values: the rule drops members by their BLEND WEIGHT, the error it leaves is weight x
+        member value, and training takes the member values from RMS 0.04 (initialisation: 1e-7 leaves 5e-6 of a gradient)
+        to ~0.3 with far-field values of several units (a trained-like checkpoint: 1e-7 leaves 6e-3 of some bias gradients,
+        1e-8 leaves 3e-5).  The size is the RMS of the kept member values of the previous step (read here - the step
+        synchronises once anyway to size its tile lists); the first step, which has none, takes a tenth of the budget.
+        Consequence: the kept set follows the weights from step to step - pin ``train_prune_tol`` for bitwise-repeatable
+        calls."""
+        if self.train_prune_tol is not None:
+            return float(self.train_prune_tol)
+        tol = float(self.prune_tol)
+        if tol <= 0:
+            return tol
+        mag = getattr(self, "_train_mag", None)
+        if mag is None:
+            return tol / 10.0
+        rms = float(mag[0]) / max(float(mag[1]), 1.0) ** 0.5
+        return tol / min(max(1.0, rms / self._TRAIN_MAG_REF), 100.0)
 
     def _train_members(self, xyz, lat_rows):
         """(anchors, member values S [B,N,40], member gradients G = dS/dxyz [B,N,40,3]) on the training kernels."""
