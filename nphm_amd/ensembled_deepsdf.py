@@ -358,7 +358,8 @@ class _IdentityFieldFn(torch.autograd.Function):
         packed, state, _ = module.prepare_latent(lat_rows.detach(), anchors=anchors)     # the field of exactly these anchors
         xyz_c = xyz.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        what, tiles, n_used, plist = _member_point_lists_device(state, xyz_c, module.prune_tol, A, stream)
+        what, tiles, n_used, plist = _member_point_lists_device(state, xyz_c, module._autograd_tol(packed, state, xyz_c, stream),
+                                                                A, stream)
         fmem = torch.empty(B, N, A, dtype=torch.float32, device=dev)      # written for the listed (point, member) pairs only
         _lib.check(lib.nphm_identity_member_forward(
             packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N,
@@ -892,6 +893,36 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         return sdf, anchors
 
     _TRAIN_MAG_REF = 0.04     # RMS of the kept member values at the seeded initialisation (0.044)
+
+    def _autograd_tol(self, packed, state, xyz, stream):
+        """Pruning budget of the first-order autograd tier (latent fitting).  A pinned ``prune_tol`` (numerics = "fixed") is
+        taken as it is; with numerics = "auto" it is scaled like the training tier's (``_train_tol``) to the size of the
+        member values, measured ONCE per weight version on the first call's own points (the members the plain rule keeps, one
+        extra forward launch and one read-back; fitting loops freeze the weights): on a trained-like checkpoint the plain 1e-7
+        leaves 1.7e-5 of the values and 3.7e-4 of the spatial gradients, the scaled budget (1.5e-8) 1e-6 / 3e-5.  Inside a
+        graph capture without a measurement: a tenth of the budget."""
+        tol = float(self._prune_tol)
+        if self.numerics != "auto" or tol <= 0:
+            return tol
+        key = self._weights_key(xyz.device)
+        c = getattr(self, "_fit_mag", None)
+        if c is None or c[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return tol / 10.0
+            lib = _lib.load()
+            A = self.num_kps + 1
+            x = xyz[:1, : min(xyz.shape[1], 4096)].contiguous()
+            what, tiles, n_used, plist = _member_point_lists_device(state, x, tol, A, stream)
+            fmem = torch.empty(1, x.shape[1], A, dtype=torch.float32, device=x.device)
+            _lib.check(lib.nphm_identity_member_forward(
+                packed.data_ptr(), self._packed_bwd(x.device).data_ptr(), state.data_ptr(), x.data_ptr(), x.shape[1],
+                tiles.data_ptr(), tiles.shape[0], n_used.data_ptr(), plist.data_ptr(), fmem.data_ptr(), stream),
+                "nphm_identity_member_forward")
+            kept = what > 0
+            rms = float(torch.sqrt(torch.where(kept, fmem, torch.zeros_like(fmem)).square().sum() / kept.sum().clamp(min=1)))
+            c = (key, rms)
+            object.__setattr__(self, "_fit_mag", c)
+        return tol / min(max(1.0, c[1] / self._TRAIN_MAG_REF), 100.0)
 
     def _train_tol(self):
         """Pruning budget of the training tier.  ``train_prune_tol`` if the caller pinned one; otherwise ``prune_tol`` scaled

@@ -6,6 +6,8 @@ extraction box, a real zero level set).  tests/golden/trained.npz holds the REFE
 CPU tests pin the numpy oracle and the composite tier to those outputs; GPU tests pin every precision mode of the HIP
 kernels - the default (adaptive split-bf16, prune_tol 1e-7) at a tenth of the 1e-4 bar - and report the guard's
 verdict (nphm_amd.validate_numerics) and the member statistics of the checkpoint."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -136,3 +138,43 @@ def test_validate_numerics_and_member_statistics_on_trained_weights(dev):
     n = 128 ** 3
     print(f"trained checkpoint 128^3: members per wavefront {s[0] / n:.2f} (single-pass {s[15] / n:.2f}, two-pass {s[14] / n:.2f})")
     assert 2.0 < s[0] / n < 20.0
+
+
+@pytest.mark.gpu
+def test_fitting_tier_on_trained_weights(dev):
+    """The first-order autograd tier (what the latent fitting loops differentiate) on the trained-like checkpoint: values
+    and the gradients w.r.t. points and code against the composite PyTorch tier at 5 000 near-surface points.  With
+    numerics = "auto" the pruning budget follows the size of the member values (measured once per weight version): the
+    plain 1e-7, calibrated on the seeded initialisation, leaves 1.7e-5 / 3.7e-4 here and is shown next to it."""
+    net, codes = U.build_trained_identity(device=dev)
+    net.train()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    surf = torch.from_numpy(np.load(os.path.join(U.GOLDEN, "trained_state.npz"))["subject_anchors"]).float()
+    c = 2
+    i, j = torch.randint(0, 39, (5000,), generator=g), torch.randint(0, 39, (5000,), generator=g)
+    t = torch.rand(5000, 1, generator=g) * 0.3
+    x0 = (surf[c][i] * (1 - t) + surf[c][j] * t + 0.01 * torch.randn(5000, 3, generator=g)).to(dev)[None]
+    seed = torch.randn(1, 5000, 1, generator=g).to(dev)
+
+    def run(backend):
+        net.backend = backend
+        lat = codes[c][None, None].clone().requires_grad_()
+        x = x0.clone().requires_grad_()
+        sdf, _ = net(x, lat, None)
+        (sdf * seed).sum().backward()
+        return sdf.detach(), x.grad.clone(), lat.grad.clone()
+
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    ref = run("composite")
+    assert net.numerics == "auto"
+    out = run("hip")
+    e_auto = (float((out[0] - ref[0]).abs().max()), rel(out[1], ref[1]), rel(out[2], ref[2]))
+    net.prune_tol = 1e-7                                   # pinned: the plain rule
+    out = run("hip")
+    e_plain = (float((out[0] - ref[0]).abs().max()), rel(out[1], ref[1]), rel(out[2], ref[2]))
+    print(f"fitting tier on the trained-like checkpoint: auto budget |sdf| {e_auto[0]:.1e}, d/dx {e_auto[1]:.1e}, d/dcode {e_auto[2]:.1e}; "
+          f"plain 1e-7: {e_plain[0]:.1e}, {e_plain[1]:.1e}, {e_plain[2]:.1e}")
+    assert e_auto[0] < 1e-5 and e_auto[1] < 3e-4 and e_auto[2] < 1e-5
+    assert e_plain[0] < TOL_BAR and e_plain[0] > e_auto[0]
