@@ -178,3 +178,24 @@ def test_fitting_tier_on_trained_weights(dev):
           f"plain 1e-7: {e_plain[0]:.1e}, {e_plain[1]:.1e}, {e_plain[2]:.1e}")
     assert e_auto[0] < 1e-5 and e_auto[1] < 3e-4 and e_auto[2] < 1e-5
     assert e_plain[0] < TOL_BAR and e_plain[0] > e_auto[0]
+
+
+@pytest.mark.gpu
+def test_mesh_of_a_trained_code_matches_the_composite_tier(dev):
+    """the north star's mesh criterion on trained-like weights: get_logits -> mesh_from_logits at 96^3 on the calibrated HIP
+    path and on the composite PyTorch tier (the reference's arithmetic), Chamfer distance of the two meshes < 1e-5"""
+    from scipy.spatial import cKDTree
+    from NPHM.utils.reconstruction import create_grid_points_from_bounds, mesh_from_logits
+    net, codes = U.build_trained_identity(device=dev)
+    net.eval()
+    res = 96
+    grid = torch.from_numpy(create_grid_points_from_bounds(U.MINI, U.MAXI, res)).float()[None].to(dev)
+    vol_h = R.get_logits(net, codes[1], grid, nbatch_points=25000)
+    net.backend = "composite"
+    vol_c = R.get_logits(net, codes[1], grid, nbatch_points=25000)
+    mh, mc = mesh_from_logits(vol_h, U.MINI, U.MAXI, res), mesh_from_logits(vol_c, U.MINI, U.MAXI, res)
+    vh, vc = np.asarray(mh.vertices), np.asarray(mc.vertices)
+    chamfer = max(cKDTree(vc).query(vh)[0].mean(), cKDTree(vh).query(vc)[0].mean())
+    print(f"trained code 1, 96^3: {len(vh)} / {len(vc)} vertices, Chamfer {chamfer:.2e}, max |volume difference| {np.abs(vol_h - vol_c).max():.2e}")
+    assert len(vc) > 5000 and abs(len(vh) - len(vc)) <= 0.002 * len(vc)
+    assert chamfer < 1e-5
