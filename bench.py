@@ -142,7 +142,8 @@ class IdentityBench:
         net = self.net
         if precision == "auto":
             net.numerics = "auto"
-            net.kernel_knobs(self.dev, self.lat[None])         # calibrate outside the timed region, with the latent at hand
+            # calibrate (and verify on this latent) outside the timed region
+            net.kernel_knobs(self.dev, self.lat[None], self.rx * self.ry * self.rz)
             c = net.calibration
             return c["precision"]
         net.precision = precision                              # pins the numerics
@@ -152,7 +153,7 @@ class IdentityBench:
 
     def step(self, precision, binned, stats=None, ev=None):
         net, R = self.net, self.R
-        packed, state, _ = net.prepare_latent(self.lat[None], inference=True)
+        packed, state, _ = net.prepare_latent(self.lat[None], inference=True, n_points=self.rx * self.ry * self.rz)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         ws = R.grid_workspace(self.dev, self.n_planes, self.ry, self.rz) if binned and self.n_planes else None
         i = self.k & 1
@@ -167,7 +168,7 @@ class IdentityBench:
             self._lib.check(self.lib.nphm_identity_eval_grid_planes(
                 packed.data_ptr(), state.data_ptr(), self.axes_dev[0].data_ptr(), self.axes_dev[1].data_ptr(),
                 self.axes_dev[2].data_ptr(), self.rx, self.ry, self.rz, self.planes_dev.data_ptr(), self.n_planes,
-                self.args.chunk, *net.kernel_knobs(self.dev, self.lat[None]), self.shard.data_ptr(),
+                self.args.chunk, *state.nphm_knobs, self.shard.data_ptr(),
                 None if stats is None else stats.data_ptr(), None if ws is None else ws.data_ptr(),
                 0 if ws is None else ws.numel(), stream), "eval_grid_planes")
         if ev is not None:
@@ -325,6 +326,30 @@ class IdentityBench:
 # ------------------------------------------------------------------------------------------------------
 # configs[2], configs[0], configs[4]
 # ------------------------------------------------------------------------------------------------------
+def _mlp_exec_flops(mlp, mask):
+    """executed MFMA FLOPs per point of the dense skip-MLP kernel: hidden GEMM layer l runs 2 terms of the split product if
+    bit l of ``mask`` is set (DeepSDF.two_pass tier, calibrated per checkpoint) else 3; lin0's coordinate step and the
+    (folded) last layer always 3.  Also returns the per-layer pass list."""
+    d_in = mlp.lat_dim + mlp.input_dim
+    total, passes = 0.0, []
+    for l in range(mlp.num_layers - 1):
+        W = getattr(mlp, f"lin{l}").weight
+        out_f, in_f = W.shape
+        k = 3 if l == 0 else (in_f - d_in if l in mlp.skip_in else in_f) + (3 if l in mlp.skip_in else 0)
+        p = 2 if (0 < l < mlp.num_layers - 2 and (mask >> l) & 1) else 3
+        passes.append(p)
+        total += p * 2.0 * out_f * k
+    return total, passes
+
+
+def _mlp_numerics_report(mlp):
+    r = dict(mlp.last_numerics or {})
+    mask = int(r.get("mask", 0))
+    flops, passes = _mlp_exec_flops(mlp, mask)
+    return {"precision": mlp.precision, "numerics": mlp.numerics, "two_pass_mask": mask, "passes_per_layer": passes,
+            "target": r.get("target"), "sample_err": r.get("err"), "verified_err": r.get("verified_err")}, flops
+
+
 def two_stage_record(args, dev, steps, warmup):
     """configs[2]: deformation -> identity on the 256^3 lattice (get_logits_backward semantics with anchors)"""
     import _util as U
@@ -340,12 +365,14 @@ def two_stage_record(args, dev, steps, warmup):
     mlp, cond = R._expr_condition(dnet, lat_ex, anchors, dev)
     dt, _ = _timed(lambda: R.evaluate_grid_two_stage(inet, dnet, lat_id, lat_ex, axes, hack_chunk=args.chunk), steps, warmup)
     _, k_ms = _timed(lambda: R.evaluate_grid_mlp(mlp, cond, axes, add_input=True), steps, 1)
-    flops = 3 * FLOP_DEFORMATION_FOLDED
+    num, flops = _mlp_numerics_report(mlp)
     ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
     kname = "nphm::mlp::mlp_eval_kernel<2,2,1,0>"
     return {"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice",
             "value": n * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "dtype": "bf16x3(split-bf16 MFMA) deformation + " + (inet.calibration or {}).get("precision", inet.precision) + " identity",
+            "dtype": f"{mlp.precision} (split-f16 MFMA, fp32 accumulate; {num['passes_per_layer']} product terms per layer, calibrated) deformation + "
+                     + (inet.calibration or {}).get("precision", inet.precision) + " identity",
+            "numerics": num,
             "config": {"workload": f"NPHM identity + forward-deformation field, {args.res}^3 (BASELINE.json configs[2])",
                        "res": args.res},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
@@ -366,12 +393,13 @@ def npm_record(args, dev, steps, warmup, cpu):
     lat = torch.from_numpy(gn["lat"][None]).to(dev)
     n = res ** 3
     dt, k_ms = _timed(lambda: R.evaluate_grid_mlp(npm, lat, axes_dev), steps, warmup)
-    flops = 3 * FLOP_NPM_FOLDED
+    num, flops = _mlp_numerics_report(npm)
     ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
     kname = "nphm::mlp::mlp_eval_kernel<1,4,1,0>"
     out = {"metric": "SDF query throughput, NPM global DeepSDF, dense lattice", "value": n * steps / dt / 1e6,
            "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-           "dtype": "bf16x3(split-bf16 MFMA, fp32 accumulate)",
+           "dtype": f"{npm.precision} (split-f16 MFMA, fp32 accumulate; {num['passes_per_layer']} product terms per layer, calibrated)",
+           "numerics": num,
            "config": {"workload": "NPM global DeepSDF (lat 512, hidden 1024, 8 layers), 64^3 lattice "
                                   "(BASELINE.json configs[0])", "res": res},
            "roofline": {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
@@ -799,7 +827,9 @@ def two_stage_sharded(args, world):
         print(json.dumps({"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice", "value": n * args.steps / dt / 1e6,
                           "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                          "dtype": "bf16x3(split-bf16 MFMA) deformation + " + (inet.calibration or {}).get("precision", inet.precision) + " identity", "data": "synthetic (seeded random-init weights)",
+                          "dtype": f"{mlp.precision} (split-f16 MFMA, fp32 accumulate; {num['passes_per_layer']} product terms per layer, calibrated) deformation + "
+                     + (inet.calibration or {}).get("precision", inet.precision) + " identity",
+            "numerics": num, "data": "synthetic (seeded random-init weights)",
                           "config": {"workload": f"NPHM identity + forward-deformation field, {args.res}^3 (BASELINE.json configs[2]), sharded",
                                      "res": args.res, "parallelism": f"cyclic 8-plane x-slabs x{world} + all_gather"},
                           "ranks": {"step_ms": [round(x / args.steps * 1e3, 3) for x in allt]}, "roofline": None, "cpu_baseline": None}))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 6
+#define NPHM_AMD_ABI_VERSION 7
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -340,7 +340,8 @@ size_t nphm_mlp_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_d
 size_t nphm_mlp_latent_state_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows);
 
 /* Re-lay the state_dict tensors lin{0..nlayers}.{weight,bias} (arrays of nlayers+1 device pointers)
- * into split-bf16 MFMA fragment order (replaces the per-call nn.Linear GEMMs of deepSDF.py:76-88). */
+ * into MFMA fragment order, once as split-bf16 and once as split-f16 halves (ABI 7: both live in `packed`, and both
+ * forms of the folded fragments in every latent-state row; replaces the per-call nn.Linear GEMMs of deepSDF.py:76-88). */
 int nphm_mlp_pack(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                   const float* const* lin_weight, const float* const* lin_bias, void* packed, void* stream);
 
@@ -352,12 +353,23 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
                             const float* const* lin_weight, const float* const* lin_bias,
                             const float* cond_rows, int n_rows, void* latent_state, void* stream);
 
+/* `numerics` of the plain evaluation entry points (ABI 7): operand format | NPHM_MLP_TWO_PASS(mask).
+ *   NPHM_MLP_BF16X3  x w = xh wh + xl wh + xh wl on bf16 halves (16 product bits; what every other MLP entry point runs)
+ *   NPHM_MLP_F16X3   the same on IEEE binary16 halves (22 product bits, v_mfma_f32_32x32x16_f16, same rate)
+ *   NPHM_MLP_TWO_PASS(mask): bit l of mask = linear layer l (1 <= l <= nlayers - 1: the hidden GEMM layers) drops the
+ *   xh wl term, i.e. runs on weights rounded to the half format - two MFMAs instead of three and half the weight bytes;
+ *   a systematic 2^-12 (f16) / 2^-9 (bf16) perturbation of that layer's weights.  Which layers may is a property of the
+ *   checkpoint: the host module measures it against the three-term product (nphm_amd/deepsdf.py, calibrate). */
+#define NPHM_MLP_BF16X3 0
+#define NPHM_MLP_F16X3 1
+#define NPHM_MLP_TWO_PASS(mask) ((int)((unsigned)(mask) << 8))
+
 /* DeepSDF.forward (deepSDF.py:64-89) for row-constant latents: out[b,n,:out_dim] for xyz[b,n,:3].
  * add_input != 0 adds xyz to the first 3 outputs: canonical points x + F_ex(x) of get_logits_backward
  * (src/NPHM/models/reconstruction.py:44-46) / posed vertices of deform_mesh (:83-84). */
 int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                          const void* packed, const void* latent_state,
-                         const float* xyz, int n_rows, int64_t n_points, int add_input,
+                         const float* xyz, int n_rows, int64_t n_points, int add_input, int numerics,
                          float* out, void* stream);
 
 /* Value AND spatial Jacobian in one launch (forward-mode, tangents carried through the same GEMMs):
@@ -446,7 +458,7 @@ int nphm_mlp_cond_grad(const float* grad_bias0, const float* grad_bias_skip, int
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                        const void* packed, const void* latent_state,
                        const float* axis_x, const float* axis_y, const float* axis_z,
-                       int rx, int ry, int rz, int ix0, int ix1, int add_input,
+                       int rx, int ry, int rz, int ix0, int ix1, int add_input, int numerics,
                        float* out, void* stream);
 
 /* ---- host side: iso-surface extraction for mesh_from_logits ------------------------------- */

@@ -79,7 +79,7 @@ SYMBOLS = {
     "nphm_mlp_latent_state_bytes": (c_size_t, [c_int] * 5),
     "nphm_mlp_pack": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_mlp_prepare_latent": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "nphm_mlp_eval_points": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+    "nphm_mlp_eval_points": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
                                                     c_void_p, c_void_p]),
     "nphm_mlp_eval_points_jvp": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                                         c_void_p, c_void_p]),
@@ -110,7 +110,7 @@ SYMBOLS = {
     "nphm_mlp_cond_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                    c_void_p, c_void_p]),
     "nphm_mlp_eval_grid": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                  c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nphm_mc_extract": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_int, c_int,
                                 ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "nphm_mc_fetch": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -143,7 +143,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 6:
+    if lib.nphm_abi_version() != 7:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

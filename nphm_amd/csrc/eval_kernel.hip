@@ -88,6 +88,22 @@ struct EvalArgs {
 #ifndef NPHM_SOFTPLUS4
 #define NPHM_SOFTPLUS4 1   // 1: softplus as log2(1 + 2^d) + v_med3 (4 VALU), 0: max + log2(1 + 2^-|d|) (5 VALU)
 #endif
+#ifndef NPHM_LAUNDER_WAVE
+#define NPHM_LAUNDER_WAVE 1   // 1: per-wavefront DMA offsets / conditions recomputed per site (SALU) instead of hoisted and spilled
+#endif
+#ifndef NPHM_SETPRIO
+#define NPHM_SETPRIO 0        // 1: the second-dispatched half of the workgroup (waves 4..7) runs at s_setprio 1
+#endif
+// K-steps per back-to-back MFMA run of a GEMM chunk, per precision tier (0 = one epilogue slice behind every MFMA)
+#ifndef NPHM_RUNK_HEAVY
+#define NPHM_RUNK_HEAVY 0
+#endif
+#ifndef NPHM_RUNK_MID
+#define NPHM_RUNK_MID 0
+#endif
+#ifndef NPHM_RUNK_LIGHT
+#define NPHM_RUNK_LIGHT 0
+#endif
 #ifndef NPHM_PROF
 #define NPHM_PROF 0  // 1: per-phase s_memtime accounting into stats[2..8] (timing builds only)
 #endif
@@ -396,6 +412,13 @@ struct Streamer {
     if (NPHM_ABLATE & 32) k = 0;
     int l = lane;
     asm volatile("" : "+v"(l));           // the lane offset is recomputed per site, not kept live
+#if NPHM_LAUNDER_WAVE
+    // ... and so is everything derived from the wavefront index: hipcc otherwise hoists `wave * 1024 + <site constant>`
+    // and the `wave == c` / `wave < rem` conditions of all ~150 DMA sites out of the member loop (loop invariants), runs
+    // out of SGPRs, spills 181 of them to VGPR lanes and reads them back with v_readlane inside the MFMA stream
+    int wave = this->wave;
+    asm volatile("" : "+s"(wave));
+#endif
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(ring + (ci % RING) * SLOT_BYTES));
     const int ng = Stream<PREC>::groups(ci);
     const int q = ng / NW, rem = ng - q * NW;
@@ -530,18 +553,60 @@ __host__ __device__ constexpr bool epilogue_exposed(int P) {
 // in the shadow of that MFMA (32 cycles of matrix pipe, 4 of issue) - measured in
 // tools/micro/overlap.hip: MFMA + softplus interleaved in one wavefront cost max(...) + ~15 %, not the sum.
 // sched_barrier(0) after every slot keeps hipcc from regrouping the stream.
-template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, bool F16, class Epi, class Pre, class Slot>
+template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, bool F16, int RUNK, class Epi, class Pre, class Slot>
 __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc, const ActB (&in)[NIN],
                                                   int lane, Epi&& epi, Pre&& pre, Slot&& slot_hook) {
   const u32x4* A = reinterpret_cast<const u32x4*>(afrag) + lane;
   u32x4 wh[NKS16], wl[NKS16];
+  constexpr int NM = NPASS;                // MFMAs per K-step: hh | hh, hl | hh, hl, lh
+  constexpr int NS = NKS16 * NM;           // issue slots
+  if constexpr (RUNK > 0) {
+    // RUNS: the MFMAs of RUNK consecutive K-steps issue back to back with nothing between them; the LDS reads of the
+    // NEXT run's A fragments, the epilogue units and slot hooks of this run's slots follow it, the DMA pieces precede
+    // it.  A dependent MFMA (same accumulator) that directly follows its predecessor issues at the 32-cycle cadence of
+    // the matrix pipe; with ANY instruction of the same wavefront in between it waits for the accumulator's write-back
+    // first (MI355X_MICROARCH.md: +43 cycles for the first extra issue slot, a cliff) - threading one epilogue slice
+    // behind EVERY MFMA of the chain (RUNK = 0, rounds 1-3) pays that on every MFMA.
+    constexpr int NRUN = (NKS16 + RUNK - 1) / RUNK;
+    auto load_run = [&](auto rr) __attribute__((always_inline)) {
+      constexpr int k0 = decltype(rr)::value * RUNK, k1 = (k0 + RUNK < NKS16) ? k0 + RUNK : NKS16;
+      static_range<k0, k1>([&](auto kk) __attribute__((always_inline)) {
+        constexpr int ks = decltype(kk)::value;
+        wh[ks] = A[(2 * ks) * 64];
+        if (NPASS == 3) wl[ks] = A[(2 * ks + 1) * 64];
+      });
+    };
+    load_run(std::integral_constant<int, 0>{});
+    static_for<NRUN>([&](auto rr) __attribute__((always_inline)) {
+      constexpr int r = decltype(rr)::value;
+      constexpr int k0 = r * RUNK, k1 = (k0 + RUNK < NKS16) ? k0 + RUNK : NKS16;
+      static_range<k0, k1>([&](auto kk) __attribute__((always_inline)) { pre(kk); });
+      __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0) HERE: the run's A fragments have landed, no counted wait inside the run
+      __builtin_amdgcn_sched_barrier(0);
+      static_range<k0, k1>([&](auto kk) __attribute__((always_inline)) {
+        constexpr int ks = decltype(kk)::value;
+        constexpr int b = ks < 2 * FULL ? (ks >> 1) : FULL;
+        constexpr int sb = ks < 2 * FULL ? (ks & 1) : 0;
+        acc = mfma16<F16>(wh[ks], in[b].hi[sb], acc);
+        if constexpr (NM >= 2) acc = mfma16<F16>(wh[ks], in[b].lo[sb], acc);
+        if constexpr (NM >= 3) acc = mfma16<F16>(wl[ks], in[b].hi[sb], acc);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (r + 1 < NRUN) load_run(std::integral_constant<int, r + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_range<unit_begin(k0 * NM, NS, NU), unit_begin(k1 * NM, NS, NU)>(epi);
+      static_range<k0, k1>([&](auto kk) __attribute__((always_inline)) {
+        static_for<NM>([&](auto mm) __attribute__((always_inline)) { slot_hook(kk, mm); });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    return acc;
+  }
 #pragma unroll
   for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
     wh[ks] = A[(2 * ks) * 64];
     if (NPASS == 3) wl[ks] = A[(2 * ks + 1) * 64];
   }
-  constexpr int NM = NPASS;                // MFMAs per K-step: hh | hh, hl | hh, hl, lh
-  constexpr int NS = NKS16 * NM;           // issue slots
   static_for<NKS16>([&](auto kk) __attribute__((always_inline)) {
     constexpr int ks = decltype(kk)::value;
     if constexpr (ks + PF < NKS16) {
@@ -897,6 +962,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       wg_list[__popcll(gmask & ((1ull << threadIdx.x) - 1))] = (unsigned char)threadIdx.x;
   }
   __syncthreads();
+#if NPHM_SETPRIO
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);    // the younger wavefront of each SIMD loses every issue arbitration otherwise
+#endif
   WS ws{p, st, ring, wg_list, n_active, 0, wave, lane, WS::make_rsrc(Stream<PREC>::set_base(p, 0)), WS::make_rsrc(st)};
   ws.load_ids();
   ws.issue(false, 0);
@@ -1135,9 +1203,13 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         } else {
           constexpr int PF = LIGHT ? NPHM_PF_LIGHT : NPHM_PF_HEAVY;
           constexpr bool F16 = PREC == 2;
-          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NPASS, PF, NU, F16>(buf, d, H, lane, epi, pre, slot_hook);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NPASS, PF, NU, F16>(buf, d, G, lane, epi, pre, slot_hook);
-          else d = gemm_fused_bf16<L3_KS16, 6, 7, NPASS, PF, NU, F16>(buf, d, H, lane, epi, pre, slot_hook);
+          // (lin1's first chunk drains the L0 block b + 1 in the slots of K-steps 2b, 2b + 1 and reads it in K-step 2b + 2: runs
+          // of at most one aligned K-step pair there)
+          constexpr int RUNK_T = TIER == 1 ? NPHM_RUNK_LIGHT : TIER == 2 ? NPHM_RUNK_MID : NPHM_RUNK_HEAVY;
+          constexpr int RUNK = (L0_FUSED && c == 1 && RUNK_T > 2) ? 2 : RUNK_T;
+          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NPASS, PF, NU, F16, RUNK>(buf, d, H, lane, epi, pre, slot_hook);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NPASS, PF, NU, F16, RUNK>(buf, d, G, lane, epi, pre, slot_hook);
+          else d = gemm_fused_bf16<L3_KS16, 6, 7, NPASS, PF, NU, F16, RUNK>(buf, d, H, lane, epi, pre, slot_hook);
         }
         accs[c & 1] = d;
         if constexpr (epilogue_exposed(c)) {
@@ -1353,9 +1425,13 @@ static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t
     const int64_t round = nphm::XCD_RUN > 1 ? 8 * int64_t(nphm::XCD_RUN) : 1;
     const int64_t groups = ((l.n_tiles + nphm::NW - 1) / nphm::NW + round - 1) / round * round;
     const dim3 grid((unsigned)groups), block(64 * nphm::NW);
+#ifdef NPHM_DEV_ONLY22   // ISA-inspection builds: one instantiation (20 s instead of 3 min); never for a library that runs
+    hipLaunchKernelGGL((nphm::eval_kernel<2, 2>), grid, block, 0, st, a);
+#else
     if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<2, 0>), grid, block, 0, st, a);
     else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<2, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((nphm::eval_kernel<2, 1>), grid, block, 0, st, a);
+#endif
     e = hipGetLastError();
     if (e != hipSuccess) return nphm_fail(who, e);
     return 0;
@@ -1368,9 +1444,11 @@ static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t
   const int64_t bricks = supers * (nphm::SBX * nphm::SBY * nphm::SBZ);
   if (bricks > 0x7fffffffLL) return nphm_fail_msg("slab too large for one launch");
   const dim3 grid((unsigned)bricks), block(64 * nphm::NW);
+#ifndef NPHM_DEV_ONLY22
   if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), grid, block, 0, st, a);
   else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<1, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((nphm::eval_kernel<1, 1>), grid, block, 0, st, a);
+#endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail(who, e);
   return 0;
@@ -1395,9 +1473,11 @@ int nphm_identity_eval_points(const void* packed, const void* latent_state,
 #if NPHM_PROF
   if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
 #endif
+#ifndef NPHM_DEV_ONLY22
   if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), grid, block, 0, st, a);
   else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<0, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((nphm::eval_kernel<0, 1>), grid, block, 0, st, a);
+#endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_eval_points launch", e);
   return 0;

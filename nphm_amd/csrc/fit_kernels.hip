@@ -110,7 +110,9 @@ __global__ __launch_bounds__(1024) void fit_loss_kernel(LossArgs a) {
       float total = 0.f;
       for (int i = 0; i < N_TERMS; ++i) {
         a.row[i] = terms[i];
-        if (i != 1 || a.z_expr) total += a.lam[i] * terms[i];
+        // (a term that carries no weight stays out of the total, as in the PyTorch formulation, which never touches an
+        // absent term: 0 x NaN / 0 x inf must not poison the loss)
+        if ((i != 1 || a.z_expr) && a.lam[i] != 0.f) total += a.lam[i] * terms[i];
       }
       a.row[N_TERMS] = total;
       a.row[N_TERMS + 1] = nv;
@@ -271,26 +273,60 @@ __global__ __launch_bounds__(64 * CG_PARTS) void cond_grad_kernel(const float* _
 
 // g_lat[b][:] from the bias gradients gb0 / gb2 [B][40][200] of lin0 and of the skip layer: the folded bias of member k is
 // W0[set(k)][:, 3:] cond_k + b (lin0) and W2[set(k)][:, 104:] cond_k / sqrt2 + b (skip layer), cond_k = [z_glob | z_k]
-// (EnsembledDeepSDF.py:247-255), so d/dcond_k = gb0_k W0_lat + gb2_k W2_lat / sqrt2.  One workgroup per (member, row):
-// the global part is accumulated over the members with atomics (g_lat zeroed by the caller), the local part written.
-__global__ __launch_bounds__(128) void latent_blocks_kernel(const float* w0, const float* w2, const float* gb0, const float* gb2,
-                                                             float* g_lat, int B) {
-  const int k = blockIdx.x, b = blockIdx.y, j = threadIdx.x;           // j: conditioning column 0..95
-  if (j >= LAT_COND) return;
-  const int s = member_set(k);
-  const float* g0 = gb0 + (size_t(b) * N_MEMBERS + k) * HID;
-  const float* g2 = gb2 + (size_t(b) * N_MEMBERS + k) * HID;
-  const float* W0 = w0 + size_t(s) * HID * D_IN + 3 + j;               // [200][99]: column 3 + j
-  const float* W2 = w2 + size_t(s) * HID * HID + L2_IN + j;            // [200][200]: column 104 + j
-  float acc0 = 0.f, acc2 = 0.f;
-  for (int f = 0; f < HID; ++f) {
-    acc0 = fmaf(g0[f], W0[size_t(f) * D_IN], acc0);
-    acc2 = fmaf(g2[f], W2[size_t(f) * HID], acc2);
-  }
-  const float v = acc0 + acc2 / INV_SQRT2_DIV;
+// (EnsembledDeepSDF.py:247-255), so d/dcond_k = gb0_k W0_lat + gb2_k W2_lat / sqrt2.  Grid (41, B): block 0 owns the 64 GLOBAL
+// columns (the sum over the 40 members and their 200 features, 16 slices of the feature axis per column), block 1 + k the 32
+// local columns of member k (32 slices); the slices meet in LDS in a fixed order and every element of g_lat is written
+// exactly once - bitwise reproducible, nothing to zero beforehand (round 3 had a block per member add its share of the
+// global columns with float atomics, in arbitrary order, behind a zero-fill launch; 16.8 us, now a launch less).
+__global__ __launch_bounds__(1024) void latent_blocks_kernel(const float* __restrict__ w0, const float* __restrict__ w2,
+                                                              const float* __restrict__ gb0, const float* __restrict__ gb2,
+                                                              float* __restrict__ g_lat, int B) {
+  __shared__ float part[1024];
+  const int b = blockIdx.y, t = threadIdx.x;
   float* out = g_lat + size_t(b) * LAT_DIM;
-  if (j < LAT_GLOB) atomicAdd(out + j, v);
-  else out[LAT_GLOB + k * LAT_LOC + (j - LAT_GLOB)] = v;
+  float acc0 = 0.f, acc2 = 0.f;
+  if (blockIdx.x == 0) {
+    const int j = t & 63, sl = t >> 6;                                  // column 0..63, slice 0..15 of the feature axis
+    for (int k = 0; k < N_MEMBERS; ++k) {
+      const int s = member_set(k);
+      const float* g0 = gb0 + (size_t(b) * N_MEMBERS + k) * HID;
+      const float* g2 = gb2 + (size_t(b) * N_MEMBERS + k) * HID;
+      const float* W0 = w0 + size_t(s) * HID * D_IN + 3 + j;             // [200][99]: column 3 + j
+      const float* W2 = w2 + size_t(s) * HID * HID + L2_IN + j;          // [200][200]: column 104 + j
+#pragma unroll 4
+      for (int f = sl; f < HID; f += 16) {
+        acc0 = fmaf(g0[f], W0[size_t(f) * D_IN], acc0);
+        acc2 = fmaf(g2[f], W2[size_t(f) * HID], acc2);
+      }
+    }
+    part[t] = acc0 + acc2 / INV_SQRT2_DIV;
+    __syncthreads();
+    if (sl == 0) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += part[q * 64 + j];
+      out[j] = v;
+    }
+  } else {
+    const int k = blockIdx.x - 1, j = t & 31, sl = t >> 5;               // local column 0..31, slice 0..31
+    const int s = member_set(k);
+    const float* g0 = gb0 + (size_t(b) * N_MEMBERS + k) * HID;
+    const float* g2 = gb2 + (size_t(b) * N_MEMBERS + k) * HID;
+    const float* W0 = w0 + size_t(s) * HID * D_IN + 3 + LAT_GLOB + j;
+    const float* W2 = w2 + size_t(s) * HID * HID + L2_IN + LAT_GLOB + j;
+    for (int f = sl; f < HID; f += 32) {
+      acc0 = fmaf(g0[f], W0[size_t(f) * D_IN], acc0);
+      acc2 = fmaf(g2[f], W2[size_t(f) * HID], acc2);
+    }
+    part[t] = acc0 + acc2 / INV_SQRT2_DIV;
+    __syncthreads();
+    if (sl == 0) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v += part[q * 32 + j];
+      out[LAT_GLOB + k * LAT_LOC + j] = v;
+    }
+  }
 }
 
 // ---- small dense heads with frozen weights: mlp_pos (64 -> 256 -> 256 -> 117, ReLU; EnsembledDeepSDF.py:194-200) and the
@@ -427,10 +463,6 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadArgs a) {
   }
 }
 
-__global__ void zero_kernel(float* p, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0.f;
-}
 
 }  // namespace fit
 }  // namespace nphm
@@ -515,12 +547,9 @@ int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight
   if (!lin0_weight || !lin2_weight || !g_bias0 || !g_bias2 || !g_lat || n_rows <= 0)
     return nphm_fail_msg("nphm_identity_latent_grad: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // (a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node was not replayed reliably - the atomics below then
-  // accumulated onto the previous replay's values)
-  const int n = n_rows * nphm::LAT_DIM;
-  hipLaunchKernelGGL(nphm::fit::zero_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g_lat, n);
   hipError_t e;
-  hipLaunchKernelGGL(nphm::fit::latent_blocks_kernel, dim3(nphm::N_MEMBERS, n_rows), dim3(128), 0, st, lin0_weight, lin2_weight,
+  static_assert(nphm::LAT_GLOB == 64 && nphm::LAT_LOC == 32 && nphm::LAT_COND == 96, "column split of latent_blocks_kernel");
+  hipLaunchKernelGGL(nphm::fit::latent_blocks_kernel, dim3(nphm::N_MEMBERS + 1, n_rows), dim3(1024), 0, st, lin0_weight, lin2_weight,
                      g_bias0, g_bias2, g_lat, n_rows);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_identity_latent_grad launch", e);

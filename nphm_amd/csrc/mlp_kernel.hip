@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 
 #include "capi_common.h"
 #include "mlp_layout.h"
@@ -29,6 +30,14 @@ namespace mlp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// one 16-byte MFMA operand fragment: 8 bf16 or 8 binary16 values (the kernels are templates on the format, F16)
+typedef unsigned frag_t __attribute__((ext_vector_type(4)));
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const frag_t& a, const frag_t& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 __device__ inline uint16_t f32_to_bf16_rn(float x) {
   uint32_t u = __float_as_uint(x);
@@ -36,6 +45,12 @@ __device__ inline uint16_t f32_to_bf16_rn(float x) {
   return uint16_t(r >> 16);
 }
 __device__ inline float bf16_to_f32(uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+// IEEE binary16, round to nearest even (subnormals kept: v_mfma_f32_32x32x16_f16 does not flush them, tools/micro/f16split.hip)
+__device__ inline uint16_t f32_to_f16_rn(float x) { return __builtin_bit_cast(uint16_t, (_Float16)x); }
+__device__ inline float f16_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// the two formats of a split operand behind one name: hi = round(x), lo = round(x - hi)
+template <bool F16> __device__ inline uint16_t half_rn(float x) { return F16 ? f32_to_f16_rn(x) : f32_to_bf16_rn(x); }
+template <bool F16> __device__ inline float half_f32(uint16_t v) { return F16 ? f16_to_f32(v) : bf16_to_f32(v); }
 
 // ---------------------------------------------------------------------------------------------
 // pack: nn.Linear weights -> split-bf16 MFMA A fragments (once per weight update)
@@ -63,10 +78,18 @@ __global__ void mlp_pack_kernel(PackArgs a) {
     const int row = 32 * n + (lane & 31);
     const int f = 32 * (ks >> 1) + feat_local(8 * (ks & 1) + i, lane >> 5);
     float w = 0.f;
-    if (row < L.out_dim && f < L.k_act) w = a.t.w[l][size_t(row) * L.in_dim + f] * L.act_scale;
+    // The LAST layer's 1 / k (mlp_layout.h: its act_scale) is applied to the fp32 result by the evaluation kernel, not folded
+    // into the fragments: w / k ~ 1e-4 has an f16 lo half below 1e-7, where binary16 subnormals are 6e-8 apart - the folded
+    // form left the split-f16 path with 12-bit last-layer weights (2.4e-6 on the deformation fixture against 2e-7)
+    const float wscale = l == a.plan.n_linear - 1 ? 1.f : L.act_scale;
+    if (row < L.out_dim && f < L.k_act) w = a.t.w[l][size_t(row) * L.in_dim + f] * wscale;
     const uint16_t hi = f32_to_bf16_rn(w);
     const uint16_t lo = f32_to_bf16_rn(w - bf16_to_f32(hi));
     a.out[L.w_off / 2 + e] = part ? lo : hi;
+    // the split-f16 fragments: same position in the second half of the packed buffer
+    const uint16_t hh = f32_to_f16_rn(w);
+    const uint16_t hl = f32_to_f16_rn(w - f16_to_f32(hh));
+    a.out[(a.plan.packed_bytes + L.w_off) / 2 + e] = part ? hl : hh;
   }
 }
 
@@ -94,7 +117,7 @@ __global__ __launch_bounds__(PREP_THREADS) void mlp_prepare_kernel(PrepArgs a) {
   const float* W = a.t.w[l];
   const float* cond = a.cond + size_t(row) * a.lat_dim;
   for (int j = t; j < a.lat_dim; j += blockDim.x) lat[j] = cond[j];
-  uint16_t* out = reinterpret_cast<uint16_t*>(a.state + size_t(row) * a.plan.state_row_bytes + L.c_off);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.state + size_t(row) * 2 * a.plan.state_row_bytes + L.c_off);   // rows: [bf16 | f16]
   for (int n = blockIdx.z; n < L.n_tiles; n += gridDim.z) {
     __syncthreads();                       // lat is loaded / the previous tile's bias values have been consumed
     // folded biases of the tile's 32 outputs: a WAVEFRONT per output (lanes stride over the latent columns: coalesced
@@ -115,28 +138,33 @@ __global__ __launch_bounds__(PREP_THREADS) void mlp_prepare_kernel(PrepArgs a) {
       const int o = 32 * n + wave * PER_WAVE + q;
 #pragma unroll
       for (int sft = 32; sft > 0; sft >>= 1) v[q] += __shfl_xor(v[q], sft);
-      if (lane == 0) bias[wave * PER_WAVE + q] = o < L.out_dim ? (v[q] * L.in_scale + a.t.b[l][o]) * L.add_scale : 0.f;
+      // (the last layer's accumulators live in the scaled domain too: its bias carries k, the kernel divides the sum by k)
+      const float add_scale = l == a.plan.n_linear - 1 ? SP_SCALE : L.add_scale;
+      if (lane == 0) bias[wave * PER_WAVE + q] = o < L.out_dim ? (v[q] * L.in_scale + a.t.b[l][o]) * add_scale : 0.f;
     }
     __syncthreads();
     const int e = t;                        // 64 lanes x 8 entries of the tile's coordinate-step fragment
     const int i = e & 7, flane = (e >> 3) & 63;
     const int o = 32 * n + (flane & 31), hh = flane >> 5;
-    uint16_t r = 0;
-    if (o < L.out_dim) {
+    auto entry = [&](auto F) -> uint16_t {
+      constexpr bool F16 = decltype(F)::value;
+      if (o >= L.out_dim) return uint16_t(0);
       const float b = bias[flane & 31];
-      const uint16_t bh = f32_to_bf16_rn(b);
-      const float r1 = b - bf16_to_f32(bh);
-      const uint16_t bm = f32_to_bf16_rn(r1);
-      const uint16_t bl = f32_to_bf16_rn(r1 - bf16_to_f32(bm));
+      const uint16_t bh = half_rn<F16>(b);
+      const float r1 = b - half_f32<F16>(bh);
+      const uint16_t bm = half_rn<F16>(r1);
+      const uint16_t bl = half_rn<F16>(r1 - half_f32<F16>(bm));
       auto wc = [&](int c) -> float {
         return L.coord_col < 0 ? 0.f : W[size_t(o) * L.in_dim + L.coord_col + c] * L.in_scale * L.add_scale;
       };
-      auto whi = [&](int c) { return f32_to_bf16_rn(wc(c)); };
-      auto wlo = [&](int c) { const float w = wc(c); return f32_to_bf16_rn(w - bf16_to_f32(f32_to_bf16_rn(w))); };
-      if (hh == 0) r = i < 3 ? whi(i) : i < 6 ? whi(i - 3) : i == 6 ? bh : bm;
-      else r = i < 3 ? wlo(i) : i == 3 ? bl : i < 7 ? whi(i - 4) : uint16_t(0);
-    }
-    out[size_t(n) * 512 + e] = r;
+      auto whi = [&](int c) { return half_rn<F16>(wc(c)); };
+      auto wlo = [&](int c) { const float w = wc(c); return half_rn<F16>(w - half_f32<F16>(half_rn<F16>(w))); };
+      if (hh == 0) return i < 3 ? whi(i) : i < 6 ? whi(i - 3) : i == 6 ? bh : bm;
+      return i < 3 ? wlo(i) : i == 3 ? bl : i < 7 ? whi(i - 4) : uint16_t(0);
+    };
+    out[size_t(n) * 512 + e] = entry(std::false_type{});
+    // split-f16 fragments of the same K-step: second half of the state row
+    out[a.plan.state_row_bytes / 2 + size_t(n) * 512 + e] = entry(std::true_type{});
   }
 }
 
@@ -156,6 +184,7 @@ struct EvalArgs {
   int out_dim;
   int add_input;          // out[..., c] += xyz[..., c] (c < 3): canonical / posed points
   int n_linear;
+  unsigned two_pass_mask;  // bit l: hidden layer l runs the two-term product xh wh + xl wh (weights rounded to the half format)
   LayerDev layer[MAX_LINEAR];
   // MODE 0
   const float* xyz;       // [n_rows, n_points, 3]
@@ -194,52 +223,63 @@ __device__ __forceinline__ float softplus2(float d) {
 #endif
 }
 
-struct Split8 { bf16x8 hi, lo; };
+struct Split8 { frag_t hi, lo; };
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   const f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-// 8 values -> bf16 hi | lo operands: per pair one packed convert, a shift / a mask back to fp32, the residuals through a
-// second packed convert (the generic __bf16 casts made hipcc convert every value twice)
+// 8 values -> hi | lo operands.  bf16: per pair one packed convert, a shift / a mask back to fp32, the residuals through a
+// second packed convert (the generic __bf16 casts made hipcc convert every value twice).  binary16 (eval_kernel.hip,
+// pack_pair): hi by v_cvt_pkrtz_f16_f32 (round toward zero: beyond the f16 range it saturates at 65504 and the lo half carries
+// the rest instead of becoming inf), lo = x - hi straight into its packed half by v_fma_mixlo / mixhi_f16.
+template <bool F16>
 __device__ __forceinline__ Split8 split8(const float* x) {
-  u32x4 h, l;
+  Split8 o;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const unsigned ph = cvt_pk_bf16(x[2 * q], x[2 * q + 1]);
-    const float h0 = __builtin_bit_cast(float, ph << 16), h1 = __builtin_bit_cast(float, ph & 0xffff0000u);
-    h[q] = ph;
-    l[q] = cvt_pk_bf16(x[2 * q] - h0, x[2 * q + 1] - h1);
+    if constexpr (F16) {
+      const unsigned ph = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]));
+      unsigned pl;
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(pl) : "v"(ph), "v"(x[2 * q]));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(pl) : "v"(ph), "v"(x[2 * q + 1]));
+      o.hi[q] = ph;
+      o.lo[q] = pl;
+    } else {
+      const unsigned ph = cvt_pk_bf16(x[2 * q], x[2 * q + 1]);
+      const float h0 = __builtin_bit_cast(float, ph << 16), h1 = __builtin_bit_cast(float, ph & 0xffff0000u);
+      o.hi[q] = ph;
+      o.lo[q] = cvt_pk_bf16(x[2 * q] - h0, x[2 * q + 1] - h1);
+    }
   }
-  Split8 o;
-  o.hi = __builtin_bit_cast(bf16x8, h);
-  o.lo = __builtin_bit_cast(bf16x8, l);
   return o;
 }
 
 // B operand of the coordinate K-step for one point (see mlp_layout.h)
-__device__ __forceinline__ bf16x8 coord_operand(float x, float y, float z, int h) {
+template <bool F16>
+__device__ __forceinline__ frag_t coord_operand(float x, float y, float z, int h) {
+  using half_t = typename std::conditional<F16, _Float16, __bf16>::type;
+  typedef half_t half8 __attribute__((ext_vector_type(8)));
   const float cs[3] = {x, y, z};
-  __bf16 xh[3], xl[3], xll[3];
+  half_t xh[3], xl[3], xll[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    xh[i] = (__bf16)cs[i];
+    xh[i] = (half_t)cs[i];
     const float r1 = cs[i] - (float)xh[i];
-    xl[i] = (__bf16)r1;
-    xll[i] = (__bf16)(r1 - (float)xl[i]);
+    xl[i] = (half_t)r1;
+    xll[i] = (half_t)(r1 - (float)xl[i]);
   }
-  const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-  bf16x8 bv;
+  const half_t one = (half_t)1.f, zero = (half_t)0.f;
+  half8 bv;
   bv[0] = xh[0]; bv[1] = xh[1]; bv[2] = xh[2];
   bv[3] = h ? one : xl[0];
   bv[4] = h ? xll[0] : xl[1];
   bv[5] = h ? xll[1] : xl[2];
   bv[6] = h ? xll[2] : one;
   bv[7] = h ? zero : one;
-  return bv;
+  return __builtin_bit_cast(frag_t, bv);
 }
 
 // d softplus / d d in the scaled domain: 1 / (1 + 2^-d)
@@ -249,16 +289,19 @@ __device__ __forceinline__ float sigmoid2(float d) {
 }
 
 // B operand of the coordinate K-step for the tangent stream d/dx_c: the unit vector e_c in the xh
-// slots (exact in bf16), zeros in the xl / xll / bias slots
-__device__ __forceinline__ bf16x8 unit_operand(int c) {
-  const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-  bf16x8 bv;
+// slots (exact in either half format), zeros in the xl / xll / bias slots
+template <bool F16>
+__device__ __forceinline__ frag_t unit_operand(int c) {
+  using half_t = typename std::conditional<F16, _Float16, __bf16>::type;
+  typedef half_t half8 __attribute__((ext_vector_type(8)));
+  const half_t one = (half_t)1.f, zero = (half_t)0.f;
+  half8 bv;
 #pragma unroll
   for (int i = 0; i < 8; ++i) bv[i] = zero;
   bv[0] = c == 0 ? one : zero;
   bv[1] = c == 1 ? one : zero;
   bv[2] = c == 2 ? one : zero;
-  return bv;
+  return __builtin_bit_cast(frag_t, bv);
 }
 
 // JVP = forward-mode derivative w.r.t. xyz carried along: the M columns of a workgroup are 4 streams
@@ -271,7 +314,10 @@ __device__ __forceinline__ bf16x8 unit_operand(int c) {
 // keeps its M points for up to max_steps + 1 evaluations, thread m < M owns point m's solver state
 // (x, g, dx, dg, 3x3 inverse Jacobian, best residual) in registers, the iterate travels to the
 // wavefronts through LDS; a workgroup leaves as soon as none of its points is active.
-template <int MT, int NTW, int MODE, int KIND>
+// F16: binary16 halves on v_mfma_f32_32x32x16_f16 (11-bit significands: the three-term product carries 22 bits against 16,
+// the two-term product of the layers in two_pass_mask is 8x closer to fp32 than its bf16 form) - the plain evaluation
+// entry points (KIND 0); the tangent / Broyden / saving variants stay on bf16 halves (wider exponent range for tangents)
+template <int MT, int NTW, int MODE, int KIND, bool F16 = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   constexpr bool JVP = KIND == 1 || KIND == 4, BROY = KIND == 2, SAVE = KIND == 3 || KIND == 4;   // 4: value+Jacobian, sigma' saved
   constexpr int M = 32 * MT;               // columns per workgroup
@@ -326,7 +372,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   // Jacobians): the residual of iteration 0 is read, not evaluated - one network pass less per solve
   const bool given0 = BROY && it == 0 && p.posed0 != nullptr;
   if (!given0) {
-  bf16x8 bv[MT];
+  frag_t bv[MT];
   if (BROY) __syncthreads();                // the iterate written by the owners is visible
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -337,8 +383,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     } else {
       point_coords(base + col % PTS, x, y, z);
     }
-    bv[t] = coord_operand(x, y, z, h);
-    if (JVP && col >= PTS) bv[t] = unit_operand(col / PTS - 1);
+    bv[t] = coord_operand<F16>(x, y, z, h);
+    if (JVP && col >= PTS) bv[t] = unit_operand<F16>(col / PTS - 1);
   }
   // lane that holds the value stream of this lane's point in m-tile 0 (JVP epilogue)
   int value_lane[MT];
@@ -392,8 +438,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
               v[r] = softplus2(acc[i][t][r]);
             }
           }
-          packed_out[i][t][0] = split8(v);
-          packed_out[i][t][1] = split8(v + 8);
+          packed_out[i][t][0] = split8<F16>(v);
+          packed_out[i][t][1] = split8<F16>(v + 8);
         }
       }
     }
@@ -409,8 +455,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int off = ((4 * n + 2 * half + h) * M + 32 * t + j) * 16;
-            *reinterpret_cast<bf16x8*>(act_hi + off) = packed_out[i][t][half].hi;
-            *reinterpret_cast<bf16x8*>(act_lo + off) = packed_out[i][t][half].lo;
+            *reinterpret_cast<frag_t*>(act_hi + off) = packed_out[i][t][half].hi;
+            *reinterpret_cast<frag_t*>(act_lo + off) = packed_out[i][t][half].lo;
           }
         }
       }
@@ -418,9 +464,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   };
   auto tiles_of = [&](int n_tiles) { return n_tiles > wave ? (n_tiles - wave + WAVES - 1) / WAVES : 0; };
   // accumulator init: coordinate K-step (bias, folded latent, xyz columns)
-  bf16x8 cfrag[NTW];
+  frag_t cfrag[NTW];
   auto coord_load = [&](const LayerDev& L, int ni) __attribute__((always_inline)) {
-    const bf16x8* C = reinterpret_cast<const bf16x8*>(st + L.c_off) + lane;
+    const frag_t* C = reinterpret_cast<const frag_t*>(st + L.c_off) + lane;
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
       if (i < ni) cfrag[i] = C[(wave + WAVES * i) * 64];
@@ -431,7 +477,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       if (i < ni) {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag[i], bv[t], zero16, 0, 0, 0);
+          acc[i][t] = mfma16<F16>(cfrag[i], bv[t], zero16);
       }
     }
   };
@@ -460,34 +506,42 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #define NPHM_MLP_XPREFETCH 1
 #endif
   const unsigned w_lane = lane * 16;
-  bf16x8 ah[2][NTW], al[2][NTW];
-  auto load_a = [&](const LayerDev& L, int ni, int slot, int s) __attribute__((always_inline)) {
+  frag_t ah[2][NTW], al[2][NTW];
+  // Terms of the split product of a layer: three = xh wh + xl wh + xh wl, two = without the wl term (EvalArgs::two_pass_mask).
+  // One loop body serves both (two specialised loops under a branch made hipcc spill 60-250 VGPRs): the wl fragments of a
+  // two-term layer are requested out of the buffer's range (lo_lane: the range check covers the VGPR offset; such a load
+  // returns zeros without a memory request - half the L2 bytes of the layer) and their MFMAs sit under one wave-uniform branch.
+  auto load_a = [&](const LayerDev& L, int ni, int slot, int s, unsigned lo_lane) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
         const unsigned o = __builtin_amdgcn_readfirstlane(L.w_off + (unsigned(wave + WAVES * i) * unsigned(L.k_steps) + unsigned(s)) * 2048u);
-        ah[slot][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o, 0));
-        al[slot][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o + 1024u, 0));
+        ah[slot][i] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o, 0));
+        al[slot][i] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lo_lane, o + 1024u, 0));
       }
     }
   };
+  auto lo_lane_of = [&](int l) { return ((p.two_pass_mask >> l) & 1u) ? (w_lane | 0x80000000u) : w_lane; };
   if (NPHM_MLP_XPREFETCH && p.n_linear > 2) {
     const LayerDev& L1 = p.layer[1];
     const int n1 = tiles_of(L1.n_tiles);
-    load_a(L1, n1, 0, 0);
-    load_a(L1, n1, 1, 1);
+    const unsigned lo1 = lo_lane_of(1);
+    load_a(L1, n1, 0, 0, lo1);
+    load_a(L1, n1, 1, 1, lo1);
   }
 #pragma unroll 1
   for (int l = 1; l < p.n_linear - 1; ++l) {
     const LayerDev& L = p.layer[l];
     const int ni = tiles_of(L.n_tiles);
     const int ks = L.k_steps;
+    const bool three = !((p.two_pass_mask >> l) & 1u);
+    const unsigned lo_lane = lo_lane_of(l);
     coord_step(L, ni);       // (requesting these fragments a layer ahead as well: +-0, and the Broyden variants spill)
     __syncthreads();                                  // the previous layer's tile is complete
     if (ni > 0) {
-      const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
-      const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
-      bf16x8 bh[2][MT], bl[2][MT];
+      const frag_t* Bh = reinterpret_cast<const frag_t*>(act_hi) + h * M + j;
+      const frag_t* Bl = reinterpret_cast<const frag_t*>(act_lo) + h * M + j;
+      frag_t bh[2][MT], bl[2][MT];
       auto load_b = [&](int slot, int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -501,16 +555,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           if (i < ni) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot][i], bh[slot][t], acc[i][t], 0, 0, 0);
-              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot][i], bl[slot][t], acc[i][t], 0, 0, 0);
-              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot][i], bh[slot][t], acc[i][t], 0, 0, 0);
+              acc[i][t] = mfma16<F16>(ah[slot][i], bh[slot][t], acc[i][t]);
+              acc[i][t] = mfma16<F16>(ah[slot][i], bl[slot][t], acc[i][t]);
+            }
+          }
+        }
+        if (three) {
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (i < ni) {
+#pragma unroll
+              for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(al[slot][i], bh[slot][t], acc[i][t]);
             }
           }
         }
       };
       if (!NPHM_MLP_XPREFETCH) {
-        load_a(L, ni, 0, 0);
-        load_a(L, ni, 1, 1);
+        load_a(L, ni, 0, 0, lo_lane);
+        load_a(L, ni, 1, 1, lo_lane);
       }
       load_b(0, 0);
 #pragma unroll 1
@@ -519,18 +581,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         mma(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < ks) { load_a(L, ni, 0, s + 2); load_b(0, s + 2); }
+        if (s + 2 < ks) { load_a(L, ni, 0, s + 2, lo_lane); load_b(0, s + 2); }
         __builtin_amdgcn_sched_barrier(0);
         mma(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 3 < ks) load_a(L, ni, 1, s + 3);
+        if (s + 3 < ks) load_a(L, ni, 1, s + 3, lo_lane);
       }
     }
     if (NPHM_MLP_XPREFETCH && l + 1 < p.n_linear - 1) {
       const LayerDev& Ln = p.layer[l + 1];
       const int nn = tiles_of(Ln.n_tiles);
-      load_a(Ln, nn, 0, 0);
-      load_a(Ln, nn, 1, 1);
+      const unsigned lon = lo_lane_of(l + 1);
+      load_a(Ln, nn, 0, 0, lon);
+      load_a(Ln, nn, 1, 1, lon);
       __builtin_amdgcn_sched_barrier(0);
     }
     activate(ni, l);
@@ -549,18 +612,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       for (int t = 0; t < MT; ++t) acc[0][t] = zero16;
     }
     __syncthreads();
-    const bf16x8* W = reinterpret_cast<const bf16x8*>(p.packed + L.w_off) + lane;
-    const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
-    const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
+    const frag_t* W = reinterpret_cast<const frag_t*>(p.packed + L.w_off) + lane;
+    const frag_t* Bh = reinterpret_cast<const frag_t*>(act_hi) + h * M + j;
+    const frag_t* Bl = reinterpret_cast<const frag_t*>(act_lo) + h * M + j;
 #pragma unroll 1
     for (int s = wave; s < ks; s += WAVES) {
-      const bf16x8 wh = W[size_t(s) * 128], wl = W[size_t(s) * 128 + 64];
+      const frag_t wh = W[size_t(s) * 128], wl = W[size_t(s) * 128 + 64];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const bf16x8 xh = Bh[2 * s * M + 32 * t], xl = Bl[2 * s * M + 32 * t];
-        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[0][t], 0, 0, 0);
-        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[0][t], 0, 0, 0);
-        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[0][t], 0, 0, 0);
+        const frag_t xh = Bh[2 * s * M + 32 * t], xl = Bl[2 * s * M + 32 * t];
+        acc[0][t] = mfma16<F16>(wh, xh, acc[0][t]);
+        acc[0][t] = mfma16<F16>(wh, xl, acc[0][t]);
+        acc[0][t] = mfma16<F16>(wl, xh, acc[0][t]);
       }
     }
     // rows 0..3 of the tile are registers 0..3 of the lanes with h == 0
@@ -581,6 +644,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           float v = 0.f;
 #pragma unroll
           for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
+          v *= 1.f / SP_SCALE;                                // the last layer's 1 / k (see mlp_pack_kernel)
           if (p.add_input && c < 3) {
             if (stream == 0) {
               float x, y, z;
@@ -615,7 +679,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
-        gnew[c] = (v + bx[c]) - bobs[c];                    // residual (x + F(x)) - obs
+        gnew[c] = (v * (1.f / SP_SCALE) + bx[c]) - bobs[c];     // residual (x + F(x)) - obs
       }
     }
     if (it == 0) {
@@ -701,9 +765,15 @@ constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) *
 using nphm::mlp::Config;
 using nphm::mlp::Plan;
 
+// `numerics` of the plain evaluation entry points (include/nphm_amd.h): low byte = operand format (0 split-bf16, 1 split-f16),
+// bits 8.. = mask of the hidden layers that run the two-term product (bit l = linear layer l; layer 0 and the last never)
+static bool mlp_numerics_ok(int numerics) { return (numerics & 0xff) <= 1 && numerics >= 0; }
+
 template <int MODE, int KIND = 0>
-static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st) {
+static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st, int numerics = 0) {
   using namespace nphm::mlp;
+  const bool f16 = (numerics & 0xff) == 1;
+  if (f16 && KIND != 0) return nphm_fail_msg("nphm_mlp_eval: the split-f16 format serves the plain evaluation only");
   for (int l = 0; l < plan.n_linear; ++l) {
     a.layer[l].n_tiles = plan.layer[l].n_tiles;
     a.layer[l].k_steps = plan.layer[l].k_steps;
@@ -711,7 +781,10 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
     a.layer[l].c_off = plan.layer[l].c_off;
   }
   a.n_linear = plan.n_linear;
-  a.state_row_bytes = plan.state_row_bytes;
+  // both buffers hold the two formats back to back: [bf16 fragments | f16 fragments], per state row [bf16 | f16]
+  a.state_row_bytes = 2 * plan.state_row_bytes;
+  if (f16) { a.packed += plan.packed_bytes; a.state += plan.state_row_bytes; }
+  a.two_pass_mask = (unsigned(numerics) >> 8) & ((1u << (plan.n_linear - 1)) - 2u);     // hidden GEMM layers 1 .. n_linear - 2
   a.sig_tiles = 0;
   for (int l = 0; l < plan.n_linear - 1; ++l) { a.sig_base[l] = a.sig_tiles; a.sig_tiles += plan.layer[l].n_tiles; }
   // Small Broyden batches of the hidden <= 512 nets (the fitting loop: 5 x 1000 points) run 32 points per workgroup:
@@ -726,29 +799,27 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   const int64_t tiles = (n_pts + M - 1) / M;
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * WAVES);
-  hipError_t e;
-  if (small) {
-    if constexpr (SMALL_OK) {
-      auto k = mlp_eval_kernel<1, 2, MODE, KIND>;
-      constexpr size_t lds = lds_bytes<1, 2>();
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
-      hipLaunchKernelGGL(k, grid, block, lds, st, a);
-    }
-  } else if (plan.variant == 0) {
-    auto k = mlp_eval_kernel<2, 2, MODE, KIND>;
-    constexpr size_t lds = lds_bytes<2, 2>();
+  hipError_t e = hipSuccess;
+  auto go = [&](auto k, size_t lds) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
+    return 0;
+  };
+  if (small) {
+    if constexpr (SMALL_OK) { if (go(mlp_eval_kernel<1, 2, MODE, KIND>, lds_bytes<1, 2>())) return -2; }
+  } else if (plan.variant == 0) {
+    if constexpr (KIND == 0) {
+      if (f16 ? go(mlp_eval_kernel<2, 2, MODE, 0, true>, lds_bytes<2, 2>()) : go(mlp_eval_kernel<2, 2, MODE, 0, false>, lds_bytes<2, 2>())) return -2;
+    } else {
+      if (go(mlp_eval_kernel<2, 2, MODE, KIND>, lds_bytes<2, 2>())) return -2;
+    }
   } else if constexpr (KIND == 3 || KIND == 4) {
     return nphm_fail_msg("nphm_mlp_eval_points_saving: only the hidden <= 512 variant has a backward kernel");
+  } else if constexpr (KIND == 0) {
+    if (f16 ? go(mlp_eval_kernel<1, 4, MODE, 0, true>, lds_bytes<1, 4>()) : go(mlp_eval_kernel<1, 4, MODE, 0, false>, lds_bytes<1, 4>())) return -2;
   } else {
-    auto k = mlp_eval_kernel<1, 4, MODE, KIND>;
-    constexpr size_t lds = lds_bytes<1, 4>();
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: LDS opt-in", e);
-    hipLaunchKernelGGL(k, grid, block, lds, st, a);
+    if (go(mlp_eval_kernel<1, 4, MODE, KIND>, lds_bytes<1, 4>())) return -2;
   }
   e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_mlp_eval launch", e);
@@ -770,12 +841,12 @@ int nphm_mlp_supported(int lat_dim, int hidden_dim, int nlayers, int out_dim, in
 
 size_t nphm_mlp_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim) {
   Plan plan;
-  return plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) ? plan.packed_bytes : 0;
+  return plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) ? 2 * plan.packed_bytes : 0;      // [split-bf16 | split-f16] fragments
 }
 
 size_t nphm_mlp_latent_state_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows) {
   Plan plan;
-  return plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) ? plan.state_row_bytes * size_t(n_rows > 0 ? n_rows : 0) : 0;
+  return plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) ? 2 * plan.state_row_bytes * size_t(n_rows > 0 ? n_rows : 0) : 0;
 }
 
 static int fill_table(nphm::mlp::PtrTable& t, const Plan& plan, const float* const* w, const float* const* b,
@@ -824,12 +895,13 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
 
 int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                          const void* packed, const void* latent_state,
-                         const float* xyz, int n_rows, int64_t n_points, int add_input,
+                         const float* xyz, int n_rows, int64_t n_points, int add_input, int numerics,
                          float* out, void* stream) {
   Plan plan;
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points: unsupported architecture");
   if (!packed || !latent_state || !xyz || !out) return nphm_fail_msg("nphm_mlp_eval_points: null pointer");
   if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_mlp_eval_points: empty input");
+  if (!mlp_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_points: unknown numerics format");
   nphm::mlp::EvalArgs a;
   memset(&a, 0, sizeof(a));
   a.packed = static_cast<const char*>(packed);
@@ -839,7 +911,7 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   a.add_input = add_input;
   a.xyz = xyz;
   a.n_points = n_points;
-  return launch_eval<0>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream));
+  return launch_eval<0>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream), numerics);
 }
 
 size_t nphm_mlp_saved_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows, int64_t n_points) {
@@ -985,13 +1057,14 @@ int nphm_inverse3x3(const float* matrices, float* inverses, int64_t n, void* str
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                        const void* packed, const void* latent_state,
                        const float* axis_x, const float* axis_y, const float* axis_z,
-                       int rx, int ry, int rz, int ix0, int ix1, int add_input,
+                       int rx, int ry, int rz, int ix0, int ix1, int add_input, int numerics,
                        float* out, void* stream) {
   Plan plan;
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_grid: unsupported architecture");
   if (!packed || !latent_state || !axis_x || !axis_y || !axis_z || !out) return nphm_fail_msg("nphm_mlp_eval_grid: null pointer");
   if (rx <= 0 || ry <= 0 || rz <= 0 || ix0 < 0 || ix1 > rx || ix0 >= ix1)
     return nphm_fail_msg("nphm_mlp_eval_grid: bad grid / slab bounds");
+  if (!mlp_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_grid: unknown numerics format");
   nphm::mlp::EvalArgs a;
   memset(&a, 0, sizeof(a));
   a.packed = static_cast<const char*>(packed);
@@ -1001,7 +1074,7 @@ int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   a.add_input = add_input;
   a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
   a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
-  return launch_eval<1>(plan, a, int64_t(ix1 - ix0) * ry * rz, 1, static_cast<hipStream_t>(stream));
+  return launch_eval<1>(plan, a, int64_t(ix1 - ix0) * ry * rz, 1, static_cast<hipStream_t>(stream), numerics);
 }
 
 }  // extern "C"

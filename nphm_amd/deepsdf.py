@@ -20,6 +20,8 @@ import math
 from contextlib import contextmanager
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -121,6 +123,18 @@ class DeepSDF(nn.Module):
         self.backend = "hip"            # "hip" | "composite"
         self._pack_cache = None         # (key, packed tensor)
         self._pack_bwd_cache = None     # (key, transposed pack of the backward kernel)
+        # Numerics of the plain HIP evaluation (forward_hip / lattice launches; include/nphm_amd.h NPHM_MLP_*):
+        #   precision "f16x3" (default) | "bf16x3": operand format of the split products;
+        #   numerics "auto": on evaluations of >= two_pass_min_points points the hidden layers named by a per-checkpoint
+        #   calibrated mask run the two-term product (calibrate_two_pass / _numerics_code below), verified on a sample of
+        #   every such call; "fixed": exactly `two_pass_mask` (0 = the three-term product everywhere).
+        self.precision = os.environ.get("NPHM_AMD_MLP_PRECISION", "f16x3")
+        self.numerics = os.environ.get("NPHM_AMD_MLP_NUMERICS", "auto")
+        self.two_pass_mask = 0
+        self.two_pass_target = 2e-6     # max |two-term - three-term| allowed on the calibration / verification sample (output units)
+        self.two_pass_min_points = 1 << 18
+        self._two_pass_cache = None     # (weight key, calibrated mask, report)
+        self.last_numerics = None       # what the most recent large evaluation ran (for bench.py / diagnostics)
         self._state_scope = None        # inside DeformationNetwork.condition_scope(): {cond tensor key: (tensor, state)}
         print(d_in)
         print(hidden_dim)
@@ -176,6 +190,7 @@ class DeepSDF(nn.Module):
         needed after writes that bypass the parameters' version counters)."""
         self._pack_cache = None
         self._pack_bwd_cache = None
+        self._two_pass_cache = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -262,19 +277,99 @@ class DeepSDF(nn.Module):
             self._state_scope[key] = (cond_in, state)
         return packed, state
 
-    def forward_hip(self, xyz, cond_rows, add_input=False):
-        """xyz [B,N,3] fp32 on a ROCm device, cond_rows [B, lat_dim] -> [B,N,out_dim]
-        (+ xyz on the first three outputs if ``add_input``)."""
+    # ---- numerics of the plain evaluation --------------------------------------------------------------------------
+    def _format_code(self) -> int:
+        if self.precision not in ("f16x3", "bf16x3"):
+            raise ValueError(f"DeepSDF.precision must be 'f16x3' or 'bf16x3', got {self.precision!r}")
+        return 1 if self.precision == "f16x3" else 0
+
+    def _hidden_mask(self) -> int:
+        """Bits of the linear layers that are hidden GEMM layers (1 .. nlayers - 1): the ones a two-term product may serve."""
+        return ((1 << self.nlayers) - 1) & ~1
+
+    def _eval_points_raw(self, packed, state, xyz, add_input, code):
         lib = _lib.load()
         B, N, _ = xyz.shape
-        packed, state = self.prepare_latent(cond_rows)
-        xyz = xyz.contiguous().float()
         out = torch.empty(B, N, self.n_out, dtype=torch.float32, device=xyz.device)
         stream = torch.cuda.current_stream(xyz.device).cuda_stream
         _lib.check(lib.nphm_mlp_eval_points(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(),
-                                            B, N, int(bool(add_input)), out.data_ptr(), stream),
+                                            B, N, int(bool(add_input)), int(code), out.data_ptr(), stream),
                    "nphm_mlp_eval_points")
         return out
+
+    def calibrate_two_pass(self, packed, state, sample_xyz):
+        """Which hidden layers may run the two-term product xh wh + xl wh (weights rounded to the half format) on THIS
+        checkpoint: the largest set whose output stays within ``two_pass_target`` of the three-term product on
+        ``sample_xyz`` [1,n,3] with the conditioning in ``state`` (row 0).  All layers at once if that holds; otherwise
+        the layers are added in the order of their individual errors while the measured error of the set stays inside.
+        Synchronises (one scalar per candidate); ~2 (best case) .. 2 nlayers small launches.  Returns (mask, report)."""
+        fmt = self._format_code()
+        ref = self._eval_points_raw(packed, state, sample_xyz, False, fmt)
+        err_of = lambda m: float((self._eval_points_raw(packed, state, sample_xyz, False, fmt | (m << 8)) - ref).abs().max())
+        full = self._hidden_mask()
+        e_all = err_of(full)
+        report = {"target": self.two_pass_target, "all_layers_err": e_all, "sample_points": int(sample_xyz.shape[1])}
+        if e_all <= self.two_pass_target:
+            report.update(mask=full, err=e_all)
+            return full, report
+        layers = [l for l in range(1, self.nlayers) if (full >> l) & 1]
+        single = sorted((err_of(1 << l), l) for l in layers)
+        report["per_layer_err"] = {l: e for e, l in single}
+        mask, err = 0, 0.0
+        for e, l in single:
+            if e > self.two_pass_target:
+                break
+            trial = mask | (1 << l)
+            et = err_of(trial)
+            if et > self.two_pass_target:
+                break
+            mask, err = trial, et
+        report.update(mask=mask, err=err)
+        return mask, report
+
+    def _numerics_code(self, packed, state, n_points, sample_fn):
+        """`numerics` argument of this evaluation.  ``sample_fn()`` -> [1,n,3] points of THIS call (a strided subsample)."""
+        fmt = self._format_code()
+        if self.numerics == "fixed":
+            return fmt | ((int(self.two_pass_mask) & self._hidden_mask()) << 8)
+        if self.numerics != "auto":
+            raise ValueError(f"DeepSDF.numerics must be 'auto' or 'fixed', got {self.numerics!r}")
+        if n_points < self.two_pass_min_points or torch.cuda.is_current_stream_capturing():
+            return fmt                       # small or captured evaluations: the three-term product everywhere
+        ws, bs = self._lin_params()
+        key = tuple((t.data_ptr(), t._version) for t in ws + bs) + (self.precision, float(self.two_pass_target))
+        sample = sample_fn()
+        if self._two_pass_cache is None or self._two_pass_cache[0] != key:
+            mask, report = self.calibrate_two_pass(packed, state, sample)
+            self._two_pass_cache = (key, mask, report)
+            self.last_numerics = dict(report, precision=self.precision, verified_err=report.get("err", 0.0), calibrated_here=True)
+            return fmt | (mask << 8)
+        mask = self._two_pass_cache[1]
+        if mask == 0:
+            return fmt
+        # a later conditioning / point set inherits the calibrated mask only after it is VERIFIED on a sample of this call
+        ref = self._eval_points_raw(packed, state, sample, False, fmt)
+        err = float((self._eval_points_raw(packed, state, sample, False, fmt | (mask << 8)) - ref).abs().max())
+        self.last_numerics = dict(self._two_pass_cache[2], precision=self.precision, verified_err=err, calibrated_here=False)
+        if err > self.two_pass_target:
+            mask, report = self.calibrate_two_pass(packed, state, sample)     # this conditioning needs a smaller set
+            self.last_numerics = dict(report, precision=self.precision, verified_err=report.get("err", 0.0), calibrated_here=True,
+                                      recalibrated_for_conditioning=True)
+        return fmt | (mask << 8)
+
+    def forward_hip(self, xyz, cond_rows, add_input=False):
+        """xyz [B,N,3] fp32 on a ROCm device, cond_rows [B, lat_dim] -> [B,N,out_dim]
+        (+ xyz on the first three outputs if ``add_input``)."""
+        B, N, _ = xyz.shape
+        packed, state = self.prepare_latent(cond_rows)
+        xyz = xyz.contiguous().float()
+
+        def sample():
+            step = max(1, N // 4096)
+            return xyz[:1, ::step][:, :4096].contiguous()
+
+        code = self._numerics_code(packed, state, B * N, sample) if B == 1 else self._format_code()
+        return self._eval_points_raw(packed, state, xyz, add_input, code)
 
     def forward_hip_jvp(self, xyz, cond_rows, add_input=False):
         """Value and spatial Jacobian in one fused launch (forward-mode tangents carried through the

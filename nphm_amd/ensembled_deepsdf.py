@@ -472,8 +472,12 @@ class _MemberFieldFn(torch.autograd.Function):
             # Where the engine can tell that such a gradient is wanted this raises; where it cannot (leaf inputs under
             # torch.autograd.grad) the gradient is returned NaN-filled: discarded by the engine when nobody asked for it,
             # unmistakable otherwise.
+            # next_functions holds one edge per TENSOR input (13: the non-tensor `module` argument has none), whereas
+            # needs_input_grad, `shapes` and the returned tuple are indexed by ARGUMENT position (14): edge e <-> argument e + 1.
             wanted, unknown = [], []
-            for i, (node, _) in enumerate(ctx.next_functions):
+            assert len(ctx.next_functions) == n_in - 1, "one autograd edge per tensor argument of _MemberFieldFn.forward"
+            for e, (node, _) in enumerate(ctx.next_functions):
+                i = e + 1                                                          # argument index of this edge
                 if i in (1, 2) or node is None or not ctx.needs_input_grad[i]:     # xyz, anchors: _AttachGradientFn
                     continue
                 try:
@@ -650,6 +654,11 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         pinned = "NPHM_AMD_PRECISION" in os.environ or "NPHM_AMD_PRUNE_TOL" in os.environ
         self.numerics = os.environ.get("NPHM_AMD_NUMERICS", "fixed" if pinned else "auto")
         self._calibration = None        # (weights key, preset dict) of numerics = "auto"
+        self._verified_latents = {}     # digest of a latent -> sample error of the calibrated knobs on it (per-latent verification)
+        # guard of pinned approximate modes: max |pinned - fp32-equivalent| allowed on a sample of the first call's latent
+        # before the setting is tightened (numerics.clamp_pinned); None / 0 switches the check off
+        self.pinned_guard = float(os.environ.get("NPHM_AMD_PINNED_GUARD", "2e-5")) or None
+        self._pinned_check = None       # ((weights key, pinned knobs), clamp report)
         self._pack_cache = None         # (key, packed tensor)
         self._pack_bwd_cache = None     # (key, transposed pack for the backward kernel)
         # latent fitting with the REFERENCE's unchanged fitting.py: it leaves the decoder's parameters trainable and
@@ -751,7 +760,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         self._pack_bwd_cache = (key, packed)
         return packed
 
-    def prepare_latent(self, lat_rows: torch.Tensor, inference: bool = False, bounds="auto", anchors=None):
+    def prepare_latent(self, lat_rows: torch.Tensor, inference: bool = False, bounds="auto", anchors=None, n_points=None):
         """lat_rows [B, lat_dim] -> (packed weights, latent_state, anchors [B,n_loc,3]) via the HIP prologue kernel.
         ``inference``: the state feeds the inference kernels (eval_kernel.hip) - with numerics = "auto" the knobs are
         calibrated for the current weights first (once per weight version) and the fitted member magnitude bounds are
@@ -764,8 +773,11 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             from .numerics import validate_numerics
             self._needs_validation = False
             validate_numerics(self, lat_rows[:1].detach(), n=1 << 14)
+        knobs = None
         if inference:
-            self.kernel_knobs(device, lat_rows)          # numerics = "auto": calibrate for these weights if needed
+            # numerics = "auto": calibrate for these weights if needed, verify the knobs on this latent (n_points given);
+            # "fixed": the guard of a pinned approximate mode.  The decision travels with the state: state.nphm_knobs
+            knobs = self.kernel_knobs(device, lat_rows, n_points)
         if isinstance(bounds, str):
             # the bounds only matter to the inference kernels; the autograd / training tiers build their member lists with
             # the plain rule
@@ -799,6 +811,8 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         if bounds is not None:
             _lib.check(lib.nphm_identity_set_member_bounds(state.data_ptr(), B, bounds.data_ptr(), stream),
                        "nphm_identity_set_member_bounds")
+        if knobs is not None:
+            state.nphm_knobs = knobs          # (prune_tol, precision code) the inference kernels run this state with
         return packed, state, anchors
 
     def _weights_key(self, device):
@@ -846,20 +860,111 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     def _precision_code(self):
         return self.precision_code(self._precision, self._light_tol, self._mid_tol, self._refine_band)
 
-    def kernel_knobs(self, device=None, lat_rows=None):
-        """(prune_tol, precision code with its tier thresholds) of the inference kernels: the pinned values, or with
-        numerics = "auto" on a ROCm device the setting calibrated for the current weights (cached per weight
-        version - the first call after a weight change calibrates, with ``lat_rows`` [B, lat_dim] when given;
-        ``calibration`` holds the report)."""
-        if self.numerics != "auto" or device is None or torch.device(device).type != "cuda":
+    # evaluations below this many points never use the fast tiers of numerics = "auto" (they run every member on the
+    # three-pass split-f16 product: fp32-equivalent, and cheap at that size); larger ones use the calibrated knobs after they
+    # have been VERIFIED on a sample of that call's latent
+    AUTO_MIN_POINTS = 1 << 16
+    _EXACT_KNOBS = (-1.0, "f16x3")
+
+    def _pinned_is_approximate(self):
+        return self._prune_tol >= 0 or self._precision in ("bf16x3a", "bf16x3a2", "f16x3a2")
+
+    def kernel_knobs(self, device=None, lat_rows=None, n_points=None):
+        """(prune_tol, precision code with its tier thresholds) of the inference kernels for this call.
+
+        numerics = "fixed": the pinned values - for an approximate setting (pruning budget and / or precision tiers) after a
+        one-off guard per weight version (``numerics.clamp_pinned``, ``pinned_guard``: measured on the first call's latent,
+        tightened with a warning when it deviates by more than the guard; no shipped mode may run outside the 1e-4 bar).
+
+        numerics = "auto" on a ROCm device: the setting calibrated for the current weights (``numerics.calibrate_numerics``,
+        cached per weight version, ``calibration`` holds the report).  ``n_points`` (points of this evaluation) and
+        ``lat_rows`` [B, lat_dim] make it per-call: below ``AUTO_MIN_POINTS`` points every member runs the three-pass
+        product (no knob to trust); a larger evaluation of a latent that has not been seen yet first measures the
+        calibrated knobs on a sample of THAT latent (``numerics.sample_error``: 512 lattice tiles against the three-pass
+        kernel with all members, ~0.3 ms, one synchronisation) and re-calibrates on the union of the latents when the
+        sample exceeds 1.5 x the target - later latents do not inherit the first one's knobs unverified.  Under stream
+        capture nothing can be measured: cached knobs of a verified latent are used, anything else runs the exact setting."""
+        if device is None or torch.device(device).type != "cuda":
             return float(self._prune_tol), self._precision_code()
+        capturing = torch.cuda.is_current_stream_capturing()
         key = self._weights_key(device)
-        if self._calibration is None or self._calibration[0] != key:
+        if self.numerics != "auto":
+            guard = self.pinned_guard
+            if not guard or not self._pinned_is_approximate() or lat_rows is None:
+                return float(self._prune_tol), self._precision_code()
+            pin = (self._precision, self._light_tol, self._mid_tol, self._prune_tol, self._refine_band, float(guard))
+            c = self._pinned_check
+            if c is None or c[0] != (key, pin):
+                if capturing:
+                    return float(self._prune_tol), self._precision_code()
+                from .numerics import clamp_pinned
+                lat = lat_rows.detach().reshape(-1, self.lat_dim)[:1].float()
+                rep = clamp_pinned(self, lat, precision=self._precision, light_tol=self._light_tol, mid_tol=self._mid_tol,
+                                   prune_tol=self._prune_tol, refine_band=self._refine_band, guard=float(guard))
+                c = ((key, pin), rep)
+                object.__setattr__(self, "_pinned_check", c)
+            r = c[1]
+            if not r["clamped"]:
+                return float(self._prune_tol), self._precision_code()
+            return float(r["prune_tol"]), self.precision_code(r["precision"], r["light_tol"], r["mid_tol"], self._refine_band)
+        exact = (self._EXACT_KNOBS[0], self.precision_code(self._EXACT_KNOBS[1]))
+        if n_points is not None and n_points < self.AUTO_MIN_POINTS:
+            return exact
+        have = self._calibration is not None and self._calibration[0] == key
+        if not have:
+            if capturing:
+                return exact
             from .numerics import calibrate_numerics
             lat = None if lat_rows is None else lat_rows.detach().reshape(-1, self.lat_dim)[:2]
             object.__setattr__(self, "_calibration", (key, calibrate_numerics(self, lat, device=device)))
+            object.__setattr__(self, "_verified_latents", {})
+            if lat is not None:
+                self._verified_latents[self._latent_digest(lat)] = self._calibration[1]["error"]
+        elif lat_rows is not None and n_points is not None:
+            lat = lat_rows.detach().reshape(-1, self.lat_dim)[:2]
+            if capturing:
+                return exact                  # (a digest needs a device -> host copy; captured evaluations stay exact)
+            dig = self._latent_digest(lat)
+            lat = lat.float()
+            if dig not in self._verified_latents:
+                self._verify_latent(lat, dig, device)
         c = self._calibration[1]
         return float(c["prune_tol"]), self.precision_code(c["precision"], c["light_tol"], c["mid_tol"], c.get("refine_band"))
+
+    def _latent_digest(self, lat):
+        """Content digest of the latent rows (a device -> host copy of a few KiB = one synchronisation), memoised per
+        (address, version counter, size) WHILE the tensor is held alive by the memo itself: a tensor we keep a reference to
+        cannot have its memory recycled for another latent, and an unchanged version counter means unchanged content -
+        the repeated evaluations of one latent (a benchmark loop, the chunks of one extraction) synchronise once."""
+        import hashlib
+        memo = self.__dict__.setdefault("_digest_memo", {})
+        k = (lat.data_ptr(), lat._version, lat.numel())
+        hit = memo.get(k)
+        if hit is not None:
+            return hit[1]
+        dig = hashlib.sha1(lat.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+        if len(memo) >= 8:
+            memo.pop(next(iter(memo)))
+        memo[k] = (lat, dig)
+        return dig
+
+    def _verify_latent(self, lat, dig, device):
+        """The calibrated knobs measured on a sample of ``lat`` [R <= 2, lat_dim]; above 1.5 x target: re-calibrate on the
+        union of the calibration latents (at most 4 are kept) and this one."""
+        from .numerics import calibrate_numerics, sample_error
+        c = self._calibration[1]
+        err = max(sample_error(self, lat[r:r + 1], precision=c["precision"], light_tol=c["light_tol"], mid_tol=c["mid_tol"],
+                               prune_tol=c["prune_tol"], refine_band=c.get("refine_band"), bounds=c.get("bounds"))
+                  for r in range(lat.shape[0]))
+        if err > 1.5 * c["target"]:
+            union = torch.cat([c["latents"].to(lat), lat])[-4:]
+            new = calibrate_numerics(self, union, device=device)
+            new["recalibrated_for"] = {"digest": dig, "error_before": err}
+            object.__setattr__(self, "_calibration", (self._calibration[0], new))
+            err = new["error"]
+        if len(self._verified_latents) >= 256:
+            self._verified_latents.pop(next(iter(self._verified_latents)))
+        self._verified_latents[dig] = err
 
     @property
     def calibration(self):
@@ -869,13 +974,13 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     def _forward_hip(self, xyz, lat_rows):
         lib = _lib.load()
         B, N, _ = xyz.shape
-        packed, state, anchors = self.prepare_latent(lat_rows, inference=True)
+        packed, state, anchors = self.prepare_latent(lat_rows, inference=True, n_points=B * N)
         xyz = xyz.contiguous().float()
         out = torch.empty(B, N, 1, dtype=torch.float32, device=xyz.device)
         stream = torch.cuda.current_stream(xyz.device).cuda_stream
         _lib.check(lib.nphm_identity_eval_points(
             packed.data_ptr(), state.data_ptr(), xyz.data_ptr(), B, N, 0 if self.training else N,
-            *self.kernel_knobs(xyz.device, lat_rows), out.data_ptr(), None, stream),
+            *state.nphm_knobs, out.data_ptr(), None, stream),
             "nphm_identity_eval_points")
         return out, anchors
 

@@ -98,6 +98,9 @@ class _CodeAdam(optim.Adam):
                 _lib.check(lib.nphm_adam_step(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                               p.numel(), b1, b2, lr / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t), group["eps"],
                                               torch.cuda.current_stream(p.device).cuda_stream), "nphm_adam_step")
+                # the kernel wrote through the raw pointer: tell autograd (and every cache keyed on the code's version
+                # counter - anchor_scope, DeformationNetwork.prime_condition, prepare_latent's state scope) that it changed
+                torch.autograd.graph.increment_version(p)
         return None
 
 
@@ -374,8 +377,13 @@ def _fused_losses_ok(decoder, lambdas, device) -> bool:
     import os
     if os.environ.get("NPHM_AMD_FIT_FUSED", "1") in ("0", ""):
         return False
+    # (fit_loss_kernel hard-codes the split of the code - 64 global + 40 x 32 local columns, the unobserved blocks and the 16
+    # symmetric pairs: a decoder with the same total width but another split must not reach it)
     return (device.type == "cuda" and hasattr(decoder, "lat_dim_glob") and getattr(decoder, "backend", "hip") == "hip"
             and getattr(decoder, "lat_dim", 0) == 1344 and getattr(decoder, "num_symm_pairs", 0) == 16
+            and getattr(decoder, "lat_dim_glob", 0) == 64 and getattr(decoder, "lat_dim_loc", 0) == 32
+            and getattr(decoder, "num_kps", 0) == 39
+            and callable(getattr(decoder, "hip_supported", None)) and decoder.hip_supported()
             and all(k in _LOSS_SLOTS for k in lambdas))
 
 

@@ -345,8 +345,69 @@ def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int =
                 choice, e_choice = ("f16x3a2", light, mid), e
                 break
     return {"precision": choice[0], "light_tol": choice[1], "mid_tol": choice[2], "prune_tol": prune, "bounds": bounds,
-            "refine_band": band,
+            "refine_band": band, "latents": latents.detach().clone(),
             "error": e_choice, "target": target, "n_points": int(n), "n_latents": int(latents.shape[0]), "searched": searched}
+
+
+def sample_error(decoder, lat: torch.Tensor, *, precision, light_tol, mid_tol, prune_tol, refine_band=None, bounds=None,
+                 n_tiles: int = 512, seed: int = 0, exact: bool = False) -> float:
+    """max |fast setting - reference| on ``n_tiles`` compact 4x4x2 lattice tiles (``_sample_tiles``) of the latent ``lat``
+    [1, lat_dim] for the decoder's CURRENT weights.  Reference: all 40 members on the three-pass split-f16 product (within
+    1e-6 of fp32 on every checkpoint measured, 16x the fp32 MFMA rate: 0.3 ms for 512 tiles), or with ``exact`` the
+    fp32-MFMA kernel.  One synchronisation.  The cheap check behind the per-latent verification of numerics = "auto" and the
+    guard of pinned fast modes (FastEnsembleDeepSDFMirrored.kernel_knobs)."""
+    lib = _lib.load()
+    dev = lat.device
+    with torch.no_grad():
+        packed, state, anchors = decoder.prepare_latent(lat.reshape(1, -1), bounds=bounds)
+        xyz, dims = _sample_tiles(anchors[0], n_tiles, seed)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        code = decoder.precision_code(precision, light_tol, mid_tol, refine_band)
+        fast = _eval_tiles(lib, decoder, packed, state, xyz, dims, code, prune_tol, stream)
+        ref = _eval_tiles(lib, decoder, packed, state, xyz, dims, _lib.NPHM_PREC_F32 if exact else _lib.NPHM_PREC_F16X3, -1.0, stream)
+        return float((fast - ref).abs().max())
+
+
+_BASE_MODE = {"bf16x3a": "bf16x3", "bf16x3a2": "bf16x3", "f16x3a2": "f16x3"}
+
+
+def clamp_pinned(decoder, lat: torch.Tensor, *, precision, light_tol, mid_tol, prune_tol, refine_band=None,
+                 guard: float = 2e-5, n_tiles: int = 512) -> dict:
+    """Guard of a PINNED fast mode (numerics = "fixed" with a tiered precision and / or a pruning budget): its error on the
+    checkpoint at hand, measured once per weight version with the first call's latent; above ``guard`` the setting is
+    tightened - tier thresholds / 4 per step down to the mode without tiers, then the pruning budget / 10 per step down to
+    no pruning - until it is inside, and a warning names what was asked and what runs instead.  (Seeded-weight thresholds
+    on a trained checkpoint: f16x3a2 at 8e-3 / 8e-2 measured 2.1e-4, twice the 1e-4 bar, in round 3.)"""
+    light0, mid0 = TIERS[precision][:2] if precision in TIERS else (None, None)
+    light = light_tol if light_tol is not None else light0
+    mid = mid_tol if mid_tol is not None else mid0
+    asked = {"precision": precision, "light_tol": light, "mid_tol": mid, "prune_tol": prune_tol}
+    cur = dict(asked)
+    steps = []
+    for _ in range(24):
+        e = sample_error(decoder, lat, precision=cur["precision"], light_tol=cur["light_tol"], mid_tol=cur["mid_tol"],
+                         prune_tol=cur["prune_tol"], refine_band=refine_band, n_tiles=n_tiles)
+        steps.append((dict(cur), e))
+        if e <= guard:
+            break
+        if cur["precision"] in _BASE_MODE:
+            if cur["light_tol"] is not None and cur["light_tol"] > 2e-5:
+                cur["light_tol"] = cur["light_tol"] / 4.0
+                cur["mid_tol"] = None if cur["mid_tol"] is None else cur["mid_tol"] / 4.0
+            else:
+                cur.update(precision=_BASE_MODE[cur["precision"]], light_tol=None, mid_tol=None)
+        elif cur["prune_tol"] >= 0:
+            cur["prune_tol"] = cur["prune_tol"] / 10.0 if cur["prune_tol"] > 2e-10 else -1.0
+        else:
+            break                                            # all members, full products: nothing left to tighten
+    clamped = cur != asked
+    out = dict(cur, error=steps[-1][1], asked=asked, asked_error=steps[0][1], clamped=clamped, guard=guard, steps=steps)
+    if clamped:
+        warnings.warn("nphm_amd: the pinned fast mode %s deviates from the fp32-equivalent kernel by %.2e on this checkpoint "
+                      "(guard %.0e); running %s instead (%.2e).  numerics = 'auto' calibrates the knobs per checkpoint; "
+                      "decoder.pinned_guard = None disables this check."
+                      % (asked, steps[0][1], guard, {k: cur[k] for k in asked}, steps[-1][1]))
+    return out
 
 
 def validate_training_numerics(decoder, latents: torch.Tensor, n: int = 2048, *, tol: float = 1e-3, strict: bool = False,

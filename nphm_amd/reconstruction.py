@@ -229,7 +229,6 @@ def evaluate_grid(decoder: FastEnsembleDeepSDFMirrored, encoding: torch.Tensor, 
     if hack_chunk is None:
         hack_chunk = 0 if decoder.training else rx * ry * rz
     lat = _as_lat_row(encoding.to(device=device, dtype=torch.float32), decoder.lat_dim)
-    packed, state, anchors = decoder.prepare_latent(lat, inference=True)
     planes_dev = None
     if x_planes is not None:
         planes_dev = torch.as_tensor(np.ascontiguousarray(x_planes, dtype=np.int32)).to(device) \
@@ -238,6 +237,9 @@ def evaluate_grid(decoder: FastEnsembleDeepSDFMirrored, encoding: torch.Tensor, 
     else:
         n_planes = ix1 - ix0
     n = n_planes * ry * rz
+    # the knobs are decided for the WHOLE lattice (rx * ry * rz points), not for this rank's share of it: every rank of a
+    # sharded extraction must run the same setting (the shards of a volume are slices of one evaluation)
+    packed, state, anchors = decoder.prepare_latent(lat, inference=True, n_points=rx * ry * rz)
     if n == 0:                                  # a rank without planes (more ranks than brick slabs)
         empty = torch.empty(0, dtype=torch.float32, device=device)
         return (empty, anchors) if return_anchors else empty
@@ -252,12 +254,12 @@ def evaluate_grid(decoder: FastEnsembleDeepSDFMirrored, encoding: torch.Tensor, 
     if planes_dev is not None:
         _lib.check(lib.nphm_identity_eval_grid_planes(
             packed.data_ptr(), state.data_ptr(), ax.data_ptr(), ay.data_ptr(), az.data_ptr(), rx, ry, rz,
-            planes_dev.data_ptr(), n_planes, int(hack_chunk), *decoder.kernel_knobs(device, lat),
+            planes_dev.data_ptr(), n_planes, int(hack_chunk), *state.nphm_knobs,
             out.data_ptr(), stats_ptr, ws_ptr, ws_bytes, stream), "nphm_identity_eval_grid_planes")
     else:
         _lib.check(lib.nphm_identity_eval_grid(
             packed.data_ptr(), state.data_ptr(), ax.data_ptr(), ay.data_ptr(), az.data_ptr(), rx, ry, rz,
-            ix0, ix1, int(hack_chunk), *decoder.kernel_knobs(device, lat),
+            ix0, ix1, int(hack_chunk), *state.nphm_knobs,
             out.data_ptr(), stats_ptr, ws_ptr, ws_bytes, stream), "nphm_identity_eval_grid")
     return (out, anchors) if return_anchors else out
 
@@ -287,8 +289,16 @@ def evaluate_grid_mlp(mlp: DeepSDF, cond_row: torch.Tensor, axes: Sequence, *, x
     elif out.numel() != n * mlp.n_out or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError("out must be a contiguous fp32 tensor with (ix1-ix0)*ry*rz*out_dim elements")
     stream = torch.cuda.current_stream(device).cuda_stream
+
+    def sample():
+        # 16 x 16 x 16 lattice points spread over the slab: what the two-term layers are verified on (DeepSDF._numerics_code)
+        pick = lambda a, lo, hi: a[torch.linspace(lo, hi - 1, min(16, hi - lo), device=device).round().long()]
+        sx, sy, sz = pick(ax, ix0, ix1), pick(ay, 0, ry), pick(az, 0, rz)
+        return torch.stack(torch.meshgrid(sx, sy, sz, indexing="ij"), dim=-1).reshape(1, -1, 3).contiguous()
+
+    code = mlp._numerics_code(packed, state, n, sample)
     _lib.check(lib.nphm_mlp_eval_grid(*mlp._arch(), packed.data_ptr(), state.data_ptr(), ax.data_ptr(),
-                                      ay.data_ptr(), az.data_ptr(), rx, ry, rz, ix0, ix1, int(bool(add_input)),
+                                      ay.data_ptr(), az.data_ptr(), rx, ry, rz, ix0, ix1, int(bool(add_input)), int(code),
                                       out.data_ptr(), stream), "nphm_mlp_eval_grid")
     return out
 
@@ -328,7 +338,7 @@ def evaluate_grid_two_stage(decoder_shape: FastEnsembleDeepSDFMirrored, decoder_
     if hack_chunk is None:
         hack_chunk = 0 if decoder_shape.training else rx * ry * rz
     lat = _as_lat_row(encoding_shape.to(device=device, dtype=torch.float32), decoder_shape.lat_dim)
-    packed, state, anchors_pred = decoder_shape.prepare_latent(lat, inference=True)
+    packed, state, anchors_pred = decoder_shape.prepare_latent(lat, inference=True, n_points=rx * ry * rz)
     if anchors is None:
         anchors = anchors_pred
     mlp, cond = _expr_condition(decoder_expr, encoding_expr, anchors, device)
@@ -344,7 +354,7 @@ def evaluate_grid_two_stage(decoder_shape: FastEnsembleDeepSDFMirrored, decoder_
     ws = grid_workspace(device, ix1 - ix0, ry, rz)
     _lib.check(lib.nphm_identity_eval_grid_points(
         packed.data_ptr(), state.data_ptr(), canonical.data_ptr(), rx, ry, rz, ix0, ix1, int(hack_chunk),
-        *decoder_shape.kernel_knobs(device, lat), out.data_ptr(), None,
+        *state.nphm_knobs, out.data_ptr(), None,
         ws.data_ptr(), ws.numel(), stream), "nphm_identity_eval_grid_points")
     return (out, canonical) if return_canonical else out
 
@@ -495,13 +505,13 @@ def get_logits(decoder, encoding, grid_points, nbatch_points=100000, return_anch
             vol, anchors = evaluate_grid(decoder, lat, lattice, hack_chunk=hack, return_anchors=True)
         else:
             lib = _lib.load()
-            packed, state, anchors = decoder.prepare_latent(lat.to(device), inference=True)
+            packed, state, anchors = decoder.prepare_latent(lat.to(device), inference=True, n_points=grid_points.shape[1])
             pts = grid_points.contiguous()
             vol = torch.empty(pts.shape[1], dtype=torch.float32, device=device)
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nphm_identity_eval_points(
                 packed.data_ptr(), state.data_ptr(), pts.data_ptr(), 1, pts.shape[1], hack,
-                *decoder.kernel_knobs(device, lat.to(device)), vol.data_ptr(), None, stream),
+                *state.nphm_knobs, vol.data_ptr(), None, stream),
                 "nphm_identity_eval_points")
         logits = to_host(vol)
         return (logits, anchors) if return_anchors else logits
@@ -556,12 +566,12 @@ def get_logits_backward(decoder_shape, decoder_expr, encoding_shape, encoding_ex
         else:
             mlp, cond = _expr_condition(decoder_expr, encoding_expr, anchors, device)
             canonical = mlp.forward_hip(grid_points, cond, add_input=True)[..., :3].contiguous()
-            packed, state, anchors_pred = decoder_shape.prepare_latent(lat, inference=True)
+            packed, state, anchors_pred = decoder_shape.prepare_latent(lat, inference=True, n_points=canonical.shape[1])
             vol = torch.empty(canonical.shape[1], dtype=torch.float32, device=device)
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nphm_identity_eval_points(
                 packed.data_ptr(), state.data_ptr(), canonical.data_ptr(), 1, canonical.shape[1], hack,
-                *decoder_shape.kernel_knobs(device, lat), vol.data_ptr(), None, stream),
+                *state.nphm_knobs, vol.data_ptr(), None, stream),
                 "nphm_identity_eval_points")
         logits = to_host(vol)
         return (logits, anchors_pred) if return_anchors else logits

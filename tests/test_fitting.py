@@ -326,3 +326,40 @@ def test_frozen_heads_match_the_linear_layers():
         a1 = net.predict_anchors(lat)
         a5 = net._anchors_of_rows(lat.expand(5, -1, -1)[:, 0, :])
         assert a5.shape == (5, 39, 3) and a5.data_ptr() == a1.data_ptr()
+
+
+def test_draws_of_another_length_run_eagerly_on_their_own_indices_cpu():
+    """Observations of different sizes below n_points (the reference needs the rows of ONE draw equal, fitting.py:64-70, not
+    those of all draws): the static index tensor of the graphed step has the length of `draw_like` (the smallest cloud); a
+    draw of another length must not be copied into it - `_run_step` runs that step eagerly on its own tensor - and a draw
+    whose rows differ raises like the reference's torch.stack."""
+    from nphm_amd import fitting as F
+    torch.manual_seed(0)
+    obs = [torch.randn(800, 3), torch.randn(2000, 3), torch.randn(2000, 3)]
+    sampler = F._ObservationSampler(obs, n_batch=2, n_points=1000)
+    static = sampler.upload(sampler.draw_like())
+    assert static.shape == (2 * (1 + 800),)
+    seen = {"graph": 0, "eager": 0, "raised": 0}
+    cur = [static]
+
+    class Step:
+        def __call__(self):
+            seen["graph"] += 1
+            assert cur[0] is static
+            return cur[0].shape[0]
+
+        def eager(self):
+            seen["eager"] += 1
+            assert cur[0] is not static and cur[0].shape == (2 * (1 + 1000),)
+            _, pts = sampler.gather(cur[0])
+            assert pts.shape == (2, 1000, 3)
+            return cur[0].shape[0]
+
+    for _ in range(40):
+        try:
+            F._run_step(Step(), sampler, static, cur)
+        except RuntimeError as e:
+            assert "equal size" in str(e)
+            seen["raised"] += 1
+        assert cur[0] is static                     # whatever the step ran on, the graph's input is current again
+    assert seen["graph"] > 0 and seen["eager"] > 0 and seen["raised"] > 0, seen

@@ -514,3 +514,105 @@ def test_posed_and_jacobian_in_one_launch(dev, n):
     net.backend = "hip"
     scale = float(lat_c.grad.abs().max())
     assert float((lat.grad - lat_c.grad).abs().max()) < 2e-5 * scale + 1e-9
+
+
+# ---- round 4: operand format and two-term layers of the plain evaluation (include/nphm_amd.h NPHM_MLP_*) ------------------
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3"])
+def test_deformation_golden_both_formats(dnet, dev, precision):
+    """Either operand format reproduces the reference fixture; the split-f16 one (22 product bits) is the default."""
+    g = U.golden("deformation")
+    xyz, lat, anc = _t(g["xyz"], dev), _t(g["lat"], dev), _t(g["anchors"], dev)
+    mlp = dnet.defDeepSDF
+    keep = (mlp.precision, mlp.numerics)
+    try:
+        mlp.precision, mlp.numerics = precision, "fixed"
+        with torch.no_grad():
+            off, _ = dnet(xyz, lat, anc)
+    finally:
+        mlp.precision, mlp.numerics = keep
+    err = U.maxdiff(off.cpu().numpy(), g["offsets"])
+    print(f"deformation golden, {precision}: max|hip - reference| = {err:.3e}")
+    assert err < (5e-7 if precision == "f16x3" else 2e-6)
+
+
+def _big_points(dev, n=1 << 18, seed=3):
+    gen = torch.Generator().manual_seed(seed)
+    lo, hi = torch.tensor(U.MINI), torch.tensor(U.MAXI)
+    return (torch.rand(1, n, 3, generator=gen) * (hi - lo) + lo).to(dev)
+
+
+def test_two_term_layers_fixed_mask_and_auto(dev):
+    """Two-term products (weights rounded to f16) on every hidden layer: a small, measurable perturbation; `auto` picks a
+    mask whose measured error stays inside two_pass_target and reports it; small evaluations never use the tier."""
+    dnet = U.build_deformation(device=dev).eval()
+    mlp = dnet.defDeepSDF
+    cond = torch.randn(1, mlp.lat_dim, device=dev) * 0.05
+    xyz = _big_points(dev)
+    with torch.no_grad():
+        mlp.numerics, mlp.two_pass_mask = "fixed", 0
+        ref = mlp.forward_hip(xyz, cond)
+        mlp.two_pass_mask = mlp._hidden_mask()
+        two = mlp.forward_hip(xyz, cond)
+        e_two = float((two - ref).abs().max())
+        scale = float(ref.abs().max())
+        print(f"all hidden layers two-term: max|d| = {e_two:.3e} on outputs up to {scale:.3e}")
+        assert 0.0 < e_two < 1e-4
+        mlp.numerics, mlp.two_pass_mask = "auto", 0
+        auto = mlp.forward_hip(xyz, cond)
+        rep = mlp.last_numerics
+        e_auto = float((auto - ref).abs().max())
+        print("auto:", rep, f"full-set error {e_auto:.3e}")
+        assert rep is not None and rep["calibrated_here"] and rep["err"] <= mlp.two_pass_target
+        assert e_auto <= 2.0 * mlp.two_pass_target
+        # a second conditioning: the calibrated mask is verified on a sample of that call before it is used
+        cond2 = torch.randn(1, mlp.lat_dim, device=dev) * 0.3
+        mlp.numerics = "fixed"; mlp.two_pass_mask = 0
+        ref2 = mlp.forward_hip(xyz, cond2)
+        mlp.numerics = "auto"
+        auto2 = mlp.forward_hip(xyz, cond2)
+        rep2 = mlp.last_numerics
+        assert rep2["calibrated_here"] is False or rep2.get("recalibrated_for_conditioning")
+        assert float((auto2 - ref2).abs().max()) <= 2.0 * mlp.two_pass_target
+        # small calls: three-term everywhere, bitwise the fixed mode
+        small = xyz[:, :5000].contiguous()
+        mlp.numerics = "fixed"; mlp.two_pass_mask = 0
+        a = mlp.forward_hip(small, cond)
+        mlp.numerics = "auto"
+        b = mlp.forward_hip(small, cond)
+        assert torch.equal(a, b)
+
+
+def test_two_term_tier_on_sharp_weights_stays_inside_target(dev):
+    """Weights x 2.5 (the stress model of trained sharpness): whatever mask `auto` settles on, the evaluation stays within
+    twice the target of the three-term product - the tier shrinks instead of the error growing."""
+    dnet = U.build_deformation(device=dev).eval()
+    mlp = dnet.defDeepSDF
+    with torch.no_grad():
+        for i in range(mlp.num_layers - 2):
+            getattr(mlp, f"lin{i}").weight.mul_(2.5 if i else 1.5)
+        mlp.invalidate_pack()
+        cond = torch.randn(1, mlp.lat_dim, device=dev) * 0.2
+        xyz = _big_points(dev, seed=5)
+        mlp.numerics, mlp.two_pass_mask = "fixed", 0
+        ref = mlp.forward_hip(xyz, cond)
+        mlp.numerics = "auto"
+        auto = mlp.forward_hip(xyz, cond)
+        rep = mlp.last_numerics
+        err = float((auto - ref).abs().max())
+        print(f"weights x2.5: outputs up to {float(ref.abs().max()):.3e}, auto mask {rep['mask']:#x}, error {err:.3e}", rep)
+        assert err <= 2.0 * mlp.two_pass_target
+
+
+def test_npm_formats_agree_with_fixture(npm, dev):
+    g = U.golden("npm")
+    keep = (npm.precision, npm.numerics)
+    try:
+        for precision, tol in (("f16x3", 1e-6), ("bf16x3", 2e-6)):
+            npm.precision, npm.numerics = precision, "fixed"
+            with torch.no_grad():
+                out, _ = npm(_t(g["xyz"], dev), _t(g["lat"][None, None], dev))
+            err = U.maxdiff(out.cpu().numpy(), g["sdf"])
+            print(f"npm golden, {precision}: {err:.3e}")
+            assert err < tol
+    finally:
+        npm.precision, npm.numerics = keep

@@ -282,3 +282,11 @@ def test_graph_recording_pass_refuses_latent_and_parameter_gradients(dev):
         assert gw is None or bool(torch.isnan(gw).all())
     except RuntimeError as e:
         assert "graph-recording" in str(e)
+    # the advisor's round-3 case: the spatial gradient AND one weight in one graph-recording call - the weight's slot (argument
+    # 7 of _MemberFieldFn.forward, autograd edge 6) must carry the refusal, not a neighbour's
+    w1 = net.ensembled_deep_sdf.lin1.weight
+    try:
+        gx, gw1 = torch.autograd.grad(pred.sum(), [x, w1], create_graph=True, allow_unused=True)
+        assert gw1 is not None and gw1.shape == w1.shape and bool(torch.isnan(gw1).all())
+    except RuntimeError as e:
+        assert "graph-recording" in str(e)

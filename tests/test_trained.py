@@ -66,11 +66,13 @@ def dev():
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision,prune,tol", [
     ("auto", None, 1e-5),                                   # the default: knobs calibrated for THIS checkpoint, a decade inside the bar
-    ("f32", -1.0, 2e-5), ("bf16x3", -1.0, 1e-5), ("f16x3", -1.0, 1e-5),      # exact / split products, all 40 members
-    ("f16x3", 1e-8, 1e-5), ("bf16x3", 1e-7, TOL_BAR), ("f16x3", 1e-7, TOL_BAR),
-    # the pinned round-2 default and the f16 tiers at their seeded-weight thresholds: inside the 1e-4 bar, NOT a decade
-    # inside on trained weights (their tiers were calibrated on seeded random-init weights) - what "auto" is for
-    ("bf16x3a", 1e-7, TOL_BAR), ("bf16x3a2", 1e-7, TOL_BAR), ("f16x3a2", 1e-7, 5e-4)])
+    # exact / split products, all 40 members: measured 4.0e-7 / 1.1e-6 / 3.7e-7 (round 3), asserted at ~2x
+    ("f32", -1.0, 1e-6), ("bf16x3", -1.0, 2.5e-6), ("f16x3", -1.0, 1e-6),
+    # plain pruning budgets: measured 1.4e-5 at 1e-7 (a trained member predicts tens of SDF units where its weight is 1e-7)
+    ("f16x3", 1e-8, 1e-5), ("bf16x3", 1e-7, 3e-5), ("f16x3", 1e-7, 3e-5),
+    # PINNED tiered modes at their seeded-weight thresholds: 2.9e-5 (bf16x3a2) .. 2.1e-4 (f16x3a2, outside the bar) when run as
+    # pinned in round 3 - the guard of pinned approximate modes (numerics.clamp_pinned, 2e-5 on a sample) now re-tiers them
+    ("bf16x3a", 1e-7, 4e-5), ("bf16x3a2", 1e-7, 4e-5), ("f16x3a2", 1e-7, 4e-5)])
 def test_hip_modes_on_trained_weights(fx, dev, precision, prune, tol):
     """every precision mode against the reference fixture: 4 codes x (4 608 stratified voxels of a 256^3 extraction + 2 048
     near-surface points)"""
@@ -97,6 +99,12 @@ def test_hip_modes_on_trained_weights(fx, dev, precision, prune, tol):
         print(f"trained checkpoint, calibrated: {c['precision']} light {c['light_tol']} mid {c['mid_tol']} prune {c['prune_tol']:g} "
               f"(sample error {c['error']:.2e})")
         prune = c["prune_tol"]
+    elif net._pinned_check is not None:
+        r = net._pinned_check[1]
+        print(f"pinned guard: asked {r['asked']} -> error {r['asked_error']:.2e}; runs {({k: r[k] for k in r['asked']})} -> {r['error']:.2e}"
+              f" (clamped: {r['clamped']})")
+        if precision == "f16x3a2":
+            assert r["clamped"] and r["asked_error"] > 1e-4 > r["error"]          # the mode round 3 shipped outside the bar
     print(f"trained checkpoint, {precision}, prune_tol {prune:g}: max |hip - reference| " +
           ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
     assert max(worst.values()) < tol
@@ -199,3 +207,73 @@ def test_mesh_of_a_trained_code_matches_the_composite_tier(dev):
     print(f"trained code 1, 96^3: {len(vh)} / {len(vc)} vertices, Chamfer {chamfer:.2e}, max |volume difference| {np.abs(vol_h - vol_c).max():.2e}")
     assert len(vc) > 5000 and abs(len(vh) - len(vc)) <= 0.002 * len(vc)
     assert chamfer < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weights", ["seeded", "trained"])
+def test_auto_numerics_holds_for_latents_it_was_not_calibrated_with(dev, weights):
+    """numerics = "auto" calibrates with the FIRST large evaluation's latent; every later latent's knobs are verified on a sample
+    of that latent (and re-calibrated on the union when the sample disagrees).  Eight other latents - up to 3 sigma / up to
+    twice as far from the mean code as any training code - as full 128^3 volumes against the dense exact-fp32 kernel."""
+    if weights == "seeded":
+        net = U.build_identity(device=dev).eval()
+        first = U.sample_latent(0).to(dev)
+        others = [U.sample_latent(10 + i, scale=sc).to(dev) for i, sc in enumerate((0.85, 0.85, 1.5, 1.5, 1.5, 3.0, 3.0, 3.0))]
+    else:
+        net, codes = U.build_trained_identity(device=dev)
+        net.eval()
+        first = codes[0]
+        mean = codes.mean(0)
+        others = [codes[i] for i in (1, 2, 3, 5, 8, 13)] + [mean + 2.0 * (codes[21] - mean), mean + 2.0 * (codes[34] - mean)]
+    axes = R.grid_axes(U.MINI, U.MAXI, 128)
+    with torch.no_grad():
+        R.evaluate_grid(net, first, axes, hack_chunk=0)                        # calibrates (and verifies) with `first`
+        cal0 = dict(net.calibration)
+        worst, recal = 0.0, 0
+        for lat in others:
+            fast = R.evaluate_grid(net, lat, axes, hack_chunk=0)
+            assert net.numerics == "auto"
+            knobs = (net.calibration["precision"], net.calibration["light_tol"], net.calibration["mid_tol"], net.calibration["prune_tol"])
+            recal += int("recalibrated_for" in net.calibration)
+            net.precision, net.prune_tol = "f32", -1.0                         # dense exact-fp32 reference (pins the numerics)
+            ref = R.evaluate_grid(net, lat, axes, hack_chunk=0)
+            net.numerics = "auto"
+            e = float((fast - ref).abs().max())
+            worst = max(worst, e)
+            print(f"{weights}: latent |z - first| {float((lat - first).norm()):.2f}, knobs {knobs}: max |auto - dense f32| = {e:.2e}")
+    print(f"{weights}: calibrated with the first latent as {cal0['precision']} / {cal0['light_tol']} / {cal0['mid_tol']} / "
+          f"{cal0['prune_tol']:g}; worst later latent {worst:.2e}; re-calibrations {recal}; verified latents {len(net._verified_latents)}")
+    assert worst <= 1e-5
+    assert len(net._verified_latents) >= 1 + len(others) - recal
+
+
+@pytest.mark.gpu
+def test_small_evaluations_and_captured_streams_stay_exact(dev):
+    """Below AUTO_MIN_POINTS points numerics = "auto" runs every member on the three-pass product (nothing to calibrate, nothing
+    to trust); a captured stream cannot synchronise, so it never calibrates or verifies there."""
+    net, codes = U.build_trained_identity(device=dev)
+    net.eval()
+    pts = (torch.rand(1, 4096, 3, device=dev) - 0.5)
+    with torch.no_grad():
+        a, _ = net(pts, codes[3][None, None], None)
+        assert net.calibration is None                                          # no calibration was needed
+        net.precision, net.prune_tol = "f16x3", -1.0
+        b, _ = net(pts, codes[3][None, None], None)
+        assert torch.equal(a, b)
+        net.numerics = "auto"
+        g = torch.cuda.CUDAGraph()
+        big = (torch.rand(1, 1 << 17, 3, device=dev) - 0.5)
+        out = torch.empty(1, 1 << 17, 1, device=dev)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            net(big[:, :64], codes[4][None, None], None)                        # warm-up outside the capture (packs the weights)
+            torch.cuda.current_stream().synchronize()
+            with torch.cuda.graph(g, stream=s):
+                out.copy_(net(big, codes[4][None, None], None)[0])
+        g.replay()
+        torch.cuda.synchronize()
+        assert net.calibration is None                                          # captured: exact setting, no calibration
+        net.precision, net.prune_tol = "f16x3", -1.0
+        ref, _ = net(big, codes[4][None, None], None)
+        assert torch.equal(out, ref)
