@@ -305,8 +305,11 @@ int nphm_gather_rows_backward(const float* g_out, const int64_t* idx, int n_draw
 int nphm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,
                    float step_size, float bias_correction2_sqrt, float eps, void* stream);
 int nphm_identity_blend_members(const float* blend_weights, const float* member_values, int64_t n_points, float* sdf, void* stream);
+/* (ABI 7: `scratch` of nphm_identity_latent_grad_scratch_bytes(n_rows) bytes holds the members' shares of the 64 global columns;
+ * they are summed in member order - every element of g_lat is written once, bitwise reproducible, nothing to zero beforehand) */
+size_t nphm_identity_latent_grad_scratch_bytes(int n_rows);
 int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight, const float* g_bias0, const float* g_bias2,
-                              int n_rows, float* g_lat, void* stream);
+                              int n_rows, float* g_lat, void* scratch, void* stream);
 
 /* ---- loss terms of the identity decoder's training step (ABI 6) ------------------------- */
 /* src/NPHM/models/loss_functions.py:51-110 after the decoder evaluations, on the batched layout of the mirrored

@@ -41,7 +41,8 @@ SYMBOLS = {
     "nphm_fit_loss_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_fit_root_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
-    "nphm_identity_latent_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nphm_identity_latent_grad_scratch_bytes": (c_size_t, [c_int]),
+    "nphm_identity_latent_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_set_member_bounds": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "nphm_identity_eval_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_float,
                                           c_int, c_void_p, c_void_p, c_void_p]),

@@ -273,60 +273,52 @@ __global__ __launch_bounds__(64 * CG_PARTS) void cond_grad_kernel(const float* _
 
 // g_lat[b][:] from the bias gradients gb0 / gb2 [B][40][200] of lin0 and of the skip layer: the folded bias of member k is
 // W0[set(k)][:, 3:] cond_k + b (lin0) and W2[set(k)][:, 104:] cond_k / sqrt2 + b (skip layer), cond_k = [z_glob | z_k]
-// (EnsembledDeepSDF.py:247-255), so d/dcond_k = gb0_k W0_lat + gb2_k W2_lat / sqrt2.  Grid (41, B): block 0 owns the 64 GLOBAL
-// columns (the sum over the 40 members and their 200 features, 16 slices of the feature axis per column), block 1 + k the 32
-// local columns of member k (32 slices); the slices meet in LDS in a fixed order and every element of g_lat is written
-// exactly once - bitwise reproducible, nothing to zero beforehand (round 3 had a block per member add its share of the
-// global columns with float atomics, in arbitrary order, behind a zero-fill launch; 16.8 us, now a launch less).
-__global__ __launch_bounds__(1024) void latent_blocks_kernel(const float* __restrict__ w0, const float* __restrict__ w2,
-                                                              const float* __restrict__ gb0, const float* __restrict__ gb2,
-                                                              float* __restrict__ g_lat, int B) {
-  __shared__ float part[1024];
-  const int b = blockIdx.y, t = threadIdx.x;
-  float* out = g_lat + size_t(b) * LAT_DIM;
+// (EnsembledDeepSDF.py:247-255), so d/dcond_k = gb0_k W0_lat + gb2_k W2_lat / sqrt2.  Two launches, bitwise reproducible:
+//   latent_blocks_kernel  grid (40, B), 96 columns x 8 slices of the 200 features per workgroup, the slices combined through
+//                         LDS in a fixed order; member k's 32 local columns go straight to g_lat, its share of the 64 GLOBAL
+//                         columns to scratch[b][k][:];
+//   latent_global_kernel  g_lat[b][j] = sum over the members of scratch[b][k][j], k ascending.
+// (Round 3: a thread per column walked the 200 features alone and the members added their global share with float atomics
+// behind a zero-fill launch - arbitrary order, 16.8 us.  One workgroup owning all global columns reads 4 MB through ONE CU:
+// 100 us - the reduction over the members has to stay spread over the chip.)
+constexpr int LB_SLICES = 8;
+__global__ __launch_bounds__(LAT_COND * LB_SLICES) void latent_blocks_kernel(const float* __restrict__ w0, const float* __restrict__ w2,
+                                                                             const float* __restrict__ gb0, const float* __restrict__ gb2,
+                                                                             float* __restrict__ g_lat, float* __restrict__ scratch) {
+  __shared__ float part[LB_SLICES][LAT_COND];
+  const int k = blockIdx.x, b = blockIdx.y, j = threadIdx.x % LAT_COND, sl = threadIdx.x / LAT_COND;   // j: conditioning column 0..95
+  const int s = member_set(k);
+  const float* g0 = gb0 + (size_t(b) * N_MEMBERS + k) * HID;
+  const float* g2 = gb2 + (size_t(b) * N_MEMBERS + k) * HID;
+  const float* W0 = w0 + size_t(s) * HID * D_IN + 3 + j;               // [200][99]: column 3 + j
+  const float* W2 = w2 + size_t(s) * HID * HID + L2_IN + j;            // [200][200]: column 104 + j
   float acc0 = 0.f, acc2 = 0.f;
-  if (blockIdx.x == 0) {
-    const int j = t & 63, sl = t >> 6;                                  // column 0..63, slice 0..15 of the feature axis
-    for (int k = 0; k < N_MEMBERS; ++k) {
-      const int s = member_set(k);
-      const float* g0 = gb0 + (size_t(b) * N_MEMBERS + k) * HID;
-      const float* g2 = gb2 + (size_t(b) * N_MEMBERS + k) * HID;
-      const float* W0 = w0 + size_t(s) * HID * D_IN + 3 + j;             // [200][99]: column 3 + j
-      const float* W2 = w2 + size_t(s) * HID * HID + L2_IN + j;          // [200][200]: column 104 + j
-#pragma unroll 4
-      for (int f = sl; f < HID; f += 16) {
-        acc0 = fmaf(g0[f], W0[size_t(f) * D_IN], acc0);
-        acc2 = fmaf(g2[f], W2[size_t(f) * HID], acc2);
-      }
-    }
-    part[t] = acc0 + acc2 / INV_SQRT2_DIV;
-    __syncthreads();
-    if (sl == 0) {
-      float v = 0.f;
+  constexpr int PER = HID / LB_SLICES;                                  // 25 features per slice, all loads independent
+  static_assert(HID % LB_SLICES == 0, "whole slices");
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v += part[q * 64 + j];
-      out[j] = v;
-    }
-  } else {
-    const int k = blockIdx.x - 1, j = t & 31, sl = t >> 5;               // local column 0..31, slice 0..31
-    const int s = member_set(k);
-    const float* g0 = gb0 + (size_t(b) * N_MEMBERS + k) * HID;
-    const float* g2 = gb2 + (size_t(b) * N_MEMBERS + k) * HID;
-    const float* W0 = w0 + size_t(s) * HID * D_IN + 3 + LAT_GLOB + j;
-    const float* W2 = w2 + size_t(s) * HID * HID + L2_IN + LAT_GLOB + j;
-    for (int f = sl; f < HID; f += 32) {
-      acc0 = fmaf(g0[f], W0[size_t(f) * D_IN], acc0);
-      acc2 = fmaf(g2[f], W2[size_t(f) * HID], acc2);
-    }
-    part[t] = acc0 + acc2 / INV_SQRT2_DIV;
-    __syncthreads();
-    if (sl == 0) {
-      float v = 0.f;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) v += part[q * 32 + j];
-      out[LAT_GLOB + k * LAT_LOC + j] = v;
-    }
+  for (int i = 0; i < PER; ++i) {
+    const int f = sl * PER + i;
+    acc0 = fmaf(g0[f], W0[size_t(f) * D_IN], acc0);
+    acc2 = fmaf(g2[f], W2[size_t(f) * HID], acc2);
   }
+  part[sl][j] = acc0 + acc2 / INV_SQRT2_DIV;
+  __syncthreads();
+  if (sl == 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < LB_SLICES; ++q) v += part[q][j];
+    if (j < LAT_GLOB) scratch[(size_t(b) * N_MEMBERS + k) * LAT_GLOB + j] = v;
+    else g_lat[size_t(b) * LAT_DIM + LAT_GLOB + k * LAT_LOC + (j - LAT_GLOB)] = v;
+  }
+}
+
+__global__ __launch_bounds__(LAT_GLOB) void latent_global_kernel(const float* __restrict__ scratch, float* __restrict__ g_lat) {
+  const int b = blockIdx.x, j = threadIdx.x;
+  const float* p = scratch + size_t(b) * N_MEMBERS * LAT_GLOB + j;
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < N_MEMBERS; ++k) v += p[k * LAT_GLOB];
+  g_lat[size_t(b) * LAT_DIM + j] = v;
 }
 
 // ---- small dense heads with frozen weights: mlp_pos (64 -> 256 -> 256 -> 117, ReLU; EnsembledDeepSDF.py:194-200) and the
@@ -542,16 +534,21 @@ int nphm_head_backward(const float* const weight[3], const float* const bias[3],
   return e == hipSuccess ? 0 : nphm_fail("nphm_head_backward launch", e);
 }
 
+size_t nphm_identity_latent_grad_scratch_bytes(int n_rows) {
+  return n_rows > 0 ? size_t(n_rows) * nphm::N_MEMBERS * nphm::LAT_GLOB * sizeof(float) : 0;
+}
+
 int nphm_identity_latent_grad(const float* lin0_weight, const float* lin2_weight, const float* g_bias0, const float* g_bias2,
-                              int n_rows, float* g_lat, void* stream) {
-  if (!lin0_weight || !lin2_weight || !g_bias0 || !g_bias2 || !g_lat || n_rows <= 0)
+                              int n_rows, float* g_lat, void* scratch, void* stream) {
+  if (!lin0_weight || !lin2_weight || !g_bias0 || !g_bias2 || !g_lat || !scratch || n_rows <= 0)
     return nphm_fail_msg("nphm_identity_latent_grad: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e;
   static_assert(nphm::LAT_GLOB == 64 && nphm::LAT_LOC == 32 && nphm::LAT_COND == 96, "column split of latent_blocks_kernel");
-  hipLaunchKernelGGL(nphm::fit::latent_blocks_kernel, dim3(nphm::N_MEMBERS + 1, n_rows), dim3(1024), 0, st, lin0_weight, lin2_weight,
-                     g_bias0, g_bias2, g_lat, n_rows);
-  e = hipGetLastError();
+  hipLaunchKernelGGL(nphm::fit::latent_blocks_kernel, dim3(nphm::N_MEMBERS, n_rows), dim3(nphm::LAT_COND * nphm::fit::LB_SLICES), 0, st,
+                     lin0_weight, lin2_weight, g_bias0, g_bias2, g_lat, static_cast<float*>(scratch));
+  hipLaunchKernelGGL(nphm::fit::latent_global_kernel, dim3(n_rows), dim3(nphm::LAT_GLOB), 0, st,
+                     static_cast<const float*>(scratch), g_lat);
+  hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_identity_latent_grad launch", e);
 }
 

@@ -403,8 +403,10 @@ class _IdentityFieldFn(torch.autograd.Function):
         e = module.ensembled_deep_sdf
         w0, w2 = e.lin0.weight.detach(), e.lin2.weight.detach()
         g_lat = torch.empty(B, module.lat_dim, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.nphm_identity_latent_grad_scratch_bytes(B), dtype=torch.uint8, device=dev)
         _lib.check(lib.nphm_identity_latent_grad(w0.data_ptr(), w2.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), B, g_lat.data_ptr(),
-                                                 torch.cuda.current_stream(dev).cuda_stream), "nphm_identity_latent_grad")
+                                                 scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                   "nphm_identity_latent_grad")
         return None, gx, g_lat, ga
 
 

@@ -154,7 +154,9 @@ def validate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int = 
         with torch.no_grad():
             for r in range(latents.shape[0]):
                 lat = latents[r:r + 1]
-                packed, state, anchors = decoder.prepare_latent(lat, inference=True)
+                # (the knobs under examination are (prune_eff, code_eff) above: no second decision - calibration, per-latent
+                # verification, guard of a pinned mode - inside the prologue)
+                packed, state, anchors = decoder.prepare_latent(lat, bounds=bounds_eff)
                 pts = (points.to(dev).float() if points is not None else _sample_points(anchors[0], n, seed + r))[None]
                 N = pts.shape[1]
                 stream = torch.cuda.current_stream(dev).cuda_stream

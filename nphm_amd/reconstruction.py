@@ -291,12 +291,14 @@ def evaluate_grid_mlp(mlp: DeepSDF, cond_row: torch.Tensor, axes: Sequence, *, x
     stream = torch.cuda.current_stream(device).cuda_stream
 
     def sample():
-        # 16 x 16 x 16 lattice points spread over the slab: what the two-term layers are verified on (DeepSDF._numerics_code)
-        pick = lambda a, lo, hi: a[torch.linspace(lo, hi - 1, min(16, hi - lo), device=device).round().long()]
-        sx, sy, sz = pick(ax, ix0, ix1), pick(ay, 0, ry), pick(az, 0, rz)
+        # 16 x 16 x 16 lattice points spread over the WHOLE lattice: what the two-term layers are verified on
+        # (DeepSDF._numerics_code).  The decision is taken for the lattice, not for this slab of it: every rank of a sharded
+        # evaluation, and a slab evaluated on its own, runs the setting of the full volume (slabs are exact slices of it)
+        pick = lambda a, hi: a[torch.linspace(0, hi - 1, min(16, hi), device=device).round().long()]
+        sx, sy, sz = pick(ax, rx), pick(ay, ry), pick(az, rz)
         return torch.stack(torch.meshgrid(sx, sy, sz, indexing="ij"), dim=-1).reshape(1, -1, 3).contiguous()
 
-    code = mlp._numerics_code(packed, state, n, sample)
+    code = mlp._numerics_code(packed, state, rx * ry * rz, sample)
     _lib.check(lib.nphm_mlp_eval_grid(*mlp._arch(), packed.data_ptr(), state.data_ptr(), ax.data_ptr(),
                                       ay.data_ptr(), az.data_ptr(), rx, ry, rz, ix0, ix1, int(bool(add_input)), int(code),
                                       out.data_ptr(), stream), "nphm_mlp_eval_grid")

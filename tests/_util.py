@@ -116,3 +116,12 @@ def build_trained_identity(device="cpu"):
     sd, codes = trained_checkpoint()
     net.load_state_dict(sd, strict=True)
     return net, codes.to(device)
+
+
+def build_trained_deformation(device="cpu"):
+    """(deformation net with the trained-like checkpoint tests/golden/trained_def_state.npz - the reference's module trained on
+    analytic expression warps, tools/train_synthetic_expressions.py - , expression codes [P,200], (subject, expression) pairs)"""
+    ck = np.load(os.path.join(GOLDEN, "trained_def_state.npz"))
+    net = build_deformation(device=device)
+    net.load_state_dict({k[3:]: torch.from_numpy(ck[k]) for k in ck.files if k.startswith("sd.")}, strict=True)
+    return net.eval(), torch.from_numpy(ck["z_ex"]).float().to(device), [tuple(int(v) for v in p) for p in ck["pairs"]]

@@ -262,9 +262,14 @@ def test_fused_step_pieces_match_the_pytorch_formulation():
     gb0 = torch.randn(B, 40, 200, generator=g).to(dev)
     gb2 = torch.randn(B, 40, 200, generator=g).to(dev)
     e = net.ensembled_deep_sdf
-    out = torch.empty(B, 1344, device=dev)
-    _lib.check(lib.nphm_identity_latent_grad(e.lin0.weight.data_ptr(), e.lin2.weight.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), B,
-                                             out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "latent_grad")
+    out = torch.full((B, 1344), float("nan"), device=dev)              # every element is written (nothing to zero beforehand)
+    scratch = torch.empty(lib.nphm_identity_latent_grad_scratch_bytes(B), dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        _lib.check(lib.nphm_identity_latent_grad(e.lin0.weight.data_ptr(), e.lin2.weight.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), B,
+                                                 out.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "latent_grad")
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])                                # fixed summation order: bitwise reproducible
     g_cond = torch.bmm(torch.cat([gb0, gb2], dim=2).transpose(0, 1), net._latent_blocks(dev)).transpose(0, 1)
     ref = torch.cat([g_cond[..., :64].sum(dim=1), g_cond[..., 64:].reshape(B, -1)], dim=-1)
     assert float((out - ref).abs().max()) < 2e-4 * float(ref.abs().max())

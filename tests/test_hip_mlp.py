@@ -390,7 +390,12 @@ def test_two_stage_full_size_256_cubed_properties(dnet, dev):
     with torch.no_grad():
         off, _ = dnet(_t(pts[None], dev), lat_ex[None, None], anchors)
     k = torch.from_numpy(keep).to(dev)
-    assert U.maxdiff(can[k].cpu().numpy(), pts + off[0].cpu().numpy()) < 1e-6
+    # (the lattice launch runs the calibrated two-term layers - DeepSDF.two_pass_target = 2e-6 on its sample - the 4 608-point
+    # call below the three-term product everywhere)
+    assert U.maxdiff(can[k].cpu().numpy(), pts + off[0].cpu().numpy()) < 3e-6
+    rep = dnet.defDeepSDF.last_numerics
+    print("two-stage 256^3: deformation layers", rep)
+    assert rep is not None and rep["verified_err"] <= dnet.defDeepSDF.two_pass_target
     off_o, _ = O.deformation_forward(U.np_state(dnet), pts[None], g["lat"], anchors.cpu().numpy())
     ref, _ = O.nphm_identity_forward(U.np_state(inet), U.anchors_mean(), (pts[None] + off_o).astype(np.float32),
                                      g["lat"][:, :, :1344], training=True)

@@ -104,7 +104,8 @@ def test_hip_modes_on_trained_weights(fx, dev, precision, prune, tol):
         print(f"pinned guard: asked {r['asked']} -> error {r['asked_error']:.2e}; runs {({k: r[k] for k in r['asked']})} -> {r['error']:.2e}"
               f" (clamped: {r['clamped']})")
         if precision == "f16x3a2":
-            assert r["clamped"] and r["asked_error"] > 1e-4 > r["error"]          # the mode round 3 shipped outside the bar
+            # the mode round 3 shipped at 2.1e-4 on these voxels (8.5e-5 on the guard's 512-tile sample): re-tiered
+            assert r["clamped"] and r["asked_error"] > r["guard"] >= r["error"]
     print(f"trained checkpoint, {precision}, prune_tol {prune:g}: max |hip - reference| " +
           ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
     assert max(worst.values()) < tol
@@ -277,3 +278,79 @@ def test_small_evaluations_and_captured_streams_stay_exact(dev):
         net.precision, net.prune_tol = "f16x3", -1.0
         ref, _ = net(big, codes[4][None, None], None)
         assert torch.equal(out, ref)
+
+
+# ---- round 4: the trained-like DEFORMATION checkpoint (reference module trained on analytic expression warps) -------------------
+def _def_fixture():
+    return U.golden("trained_def")
+
+
+def test_oracle_and_composite_tier_reproduce_the_trained_deformation_fixture():
+    """CPU: the numpy oracle and this repo's composite tier against the reference's outputs on the trained deformation network"""
+    fx = _def_fixture()
+    dnet, z_ex, pairs = U.build_trained_deformation()
+    assert U.state_hash(dnet) == str(fx["state_sha256"])
+    _, codes = U.trained_checkpoint()
+    dnet.defDeepSDF.backend = "composite"
+    params = U.np_state(dnet)
+    for i, (s, e) in enumerate(pairs):
+        lat = torch.cat([codes[s], z_ex[i]])[None, None]
+        x, anc = torch.from_numpy(fx[f"p{i}_xyz"]), torch.from_numpy(fx[f"p{i}_anchors"])
+        with torch.no_grad():
+            off, _ = dnet(x, lat, anc)
+        assert U.maxdiff(off.numpy(), fx[f"p{i}_offsets"]) < 2e-6
+        off_o, _ = O.deformation_forward(params, fx[f"p{i}_xyz"], lat.numpy(), fx[f"p{i}_anchors"])
+        assert U.maxdiff(off_o, fx[f"p{i}_offsets"]) < 2e-6
+    assert float(np.abs(fx["p0_offsets"]).max()) > 5e-3 and float(fx["max_weight"]) > 0.2      # it IS a trained network
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("f16x3", 1e-6), ("bf16x3", 5e-6)])
+def test_hip_deformation_on_trained_weights(dev, precision, tol):
+    fx = _def_fixture()
+    dnet, z_ex, pairs = U.build_trained_deformation(device=dev)
+    _, codes = U.trained_checkpoint()
+    codes = codes.to(dev)
+    dnet.defDeepSDF.precision, dnet.defDeepSDF.numerics = precision, "fixed"
+    worst = 0.0
+    for i, (s, e) in enumerate(pairs):
+        lat = torch.cat([codes[s], z_ex[i]])[None, None]
+        with torch.no_grad():
+            off, _ = dnet(torch.from_numpy(fx[f"p{i}_xyz"]).to(dev), lat, torch.from_numpy(fx[f"p{i}_anchors"]).to(dev))
+        worst = max(worst, U.maxdiff(off.cpu().numpy(), fx[f"p{i}_offsets"]))
+    print(f"trained deformation checkpoint, {precision}: max |hip - reference| = {worst:.2e} (offsets up to {float(np.abs(fx['p0_offsets']).max()):.2e})")
+    assert worst < tol
+
+
+@pytest.mark.gpu
+def test_two_stage_on_trained_identity_and_deformation_weights(dev):
+    """the reference's get_logits_backward (eval mode, chunk 1 500: overwrite voxels included) on a 20^3 lattice, both networks
+    trained-like; and the two-term tier of the deformation stage on THIS checkpoint (what `auto` decides, and what it costs)"""
+    fx = _def_fixture()
+    dnet, z_ex, pairs = U.build_trained_deformation(device=dev)
+    inet, codes = U.build_trained_identity(device=dev)
+    inet.eval()
+    s, e = pairs[0]
+    res, chunk = int(fx["lattice_res"]), int(fx["lattice_chunk"])
+    grid = torch.from_numpy(R.create_grid_points_from_bounds(U.MINI, U.MAXI, res)).float()[None].to(dev)
+    lat_all = torch.cat([codes[s], z_ex[0]])
+    vol = R.get_logits_backward(inet, dnet, codes[s], lat_all, grid, nbatch_points=chunk,
+                                anchors=torch.from_numpy(fx["p0_anchors"]).to(dev))
+    err = np.abs(vol - fx["two_stage_logits"])
+    print(f"two-stage, trained identity + trained deformation, {res}^3: max |err| {err.max():.2e}")
+    assert float(err.max()) < 1e-5
+    # a lattice-sized evaluation of the deformation stage: the calibrated two-term layers against the three-term product
+    mlp = dnet.defDeepSDF
+    gen = torch.Generator().manual_seed(2)
+    xyz = ((torch.rand(1, 1 << 18, 3, generator=gen) - 0.5) * 0.9).to(dev)
+    _, cond = R._expr_condition(dnet, lat_all, torch.from_numpy(fx["p0_anchors"]).to(dev), dev)
+    with torch.no_grad():
+        mlp.numerics, mlp.two_pass_mask = "fixed", 0
+        ref = mlp.forward_hip(xyz, cond.reshape(1, -1))
+        mlp.numerics = "auto"
+        auto = mlp.forward_hip(xyz, cond.reshape(1, -1))
+    rep = mlp.last_numerics
+    e_auto = float((auto - ref).abs().max())
+    print(f"trained deformation checkpoint: auto mask {rep['mask']:#x} (all-layers error {rep['all_layers_err']:.2e}, "
+          f"per layer {rep.get('per_layer_err')}), full-set error {e_auto:.2e}, outputs up to {float(ref.abs().max()):.2e}")
+    assert e_auto <= 2.0 * mlp.two_pass_target
