@@ -424,7 +424,7 @@ def npm_record(args, dev, steps, warmup, cpu):
     return out
 
 
-FIT_LAUNCHES_PER_STEP = 51      # kernel launches of one replayed step (profiles/r03_e_fitting_kernel_stats.csv; refreshed per round)
+FIT_LAUNCHES_PER_STEP = 45      # kernel launches of one replayed step (profiles/r04_fitting_kernel_stats.csv; refreshed per round)
 FIT_LAMBDAS = {"surface": 2.0, "reg_expr": 0.01, "reg_global": 0.25, "reg_unobserved": 10, "reg_loc": 0.05,
                "symm_dist": 5.0}                                                   # fitting_pointclouds.py:253-259
 FIT_SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 500: 9999},
@@ -508,7 +508,10 @@ def fitting_record(args, dev, with_reference_loop=True):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         tail = hist[-20:]
-        return {"steps_per_s": len(hist) / dt, "ms_per_step": dt / len(hist) * 1e3, "steps": len(hist), "step_scale": step_scale,
+        fc = getattr(expr_net.defDeepSDF, "_fit_cache", None)
+        fit_num = {"fit_numerics": expr_net.defDeepSDF.fit_numerics, "two_pass_mask": None if fc is None else int(fc[1]),
+                   "sample_err": None if fc is None else fc[2].get("err"), "target": expr_net.defDeepSDF.two_pass_target}
+        return {"expr_decoder_numerics": fit_num, "steps_per_s": len(hist) / dt, "ms_per_step": dt / len(hist) * 1e3, "steps": len(hist), "step_scale": step_scale,
                 "first_surface_loss": hist[0]["surface"], "final_surface_loss": float(np.mean([h["surface"] for h in tail])),
                 "final_total_loss": float(np.mean([h["loss"] for h in tail])),
                 "final_valid_correspondences": float(np.mean([h["n_valid"] for h in tail])),
@@ -518,7 +521,8 @@ def fitting_record(args, dev, with_reference_loop=True):
     busy = None if not ours["graph_ms"] else ours["graph_ms"] / ours["ms_per_step"]
     out = {"metric": "latent-code fitting steps/s (inference_iterative_root_finding_joint)", "value": ours["steps_per_s"],
            "unit": "steps/s", "ms_per_step": ours["ms_per_step"], "steps": ours["steps"],
-           "dtype": "bf16x3 kernels + fp32 PyTorch ops",
+           "dtype": "split-f16 (expression decoder: calibrated two-term layers, expr_decoder_numerics) / split-bf16 (identity tier, backward) kernels + fp32 PyTorch ops",
+           "expr_decoder_numerics": ours["expr_decoder_numerics"],
            "config": {"workload": "latent fitting, 3 synthetic observations x 2500 points, 5 x 1000 points per step, Adam on "
                                   f"identity + expression codes, n_steps {args.fit_steps} at step_scale 1 = {ours['steps']} steps, "
                                   "the published schedule (BASELINE.json configs[4])"},

@@ -362,7 +362,9 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
  *   NPHM_MLP_TWO_PASS(mask): bit l of mask = linear layer l (1 <= l <= nlayers - 1: the hidden GEMM layers) drops the
  *   xh wl term, i.e. runs on weights rounded to the half format - two MFMAs instead of three and half the weight bytes;
  *   a systematic 2^-12 (f16) / 2^-9 (bf16) perturbation of that layer's weights.  Which layers may is a property of the
- *   checkpoint: the host module measures it against the three-term product (nphm_amd/deepsdf.py, calibrate). */
+ *   checkpoint: the host module measures it against the three-term product (nphm_amd/deepsdf.py, calibrate).
+ * The value+Jacobian, Broyden and saving entry points below take the same argument (hidden_dim <= 512: both formats;
+ * the 1024-wide variant runs them on bf16 halves only). */
 #define NPHM_MLP_BF16X3 0
 #define NPHM_MLP_F16X3 1
 #define NPHM_MLP_TWO_PASS(mask) ((int)((unsigned)(mask) << 8))
@@ -384,7 +386,7 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
 int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                              const void* packed, const void* latent_state,
                              const float* xyz, int n_rows, int64_t n_points, int add_input,
-                             float* out, void* stream);
+                             float* out, int numerics, void* stream);
 
 /* Correspondence search of the fitting loop in ONE launch: Broyden root finding of
  * x + F(x) = obs per point (src/NPHM/models/iterative_root_finding.py:5-71 broyden as called by
@@ -398,7 +400,7 @@ int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                      const void* packed, const void* latent_state,
                      const float* obs, const float* x_init, const float* jinv_init, int n_rows, int64_t n_points,
                      int max_steps, float cvg_thresh, float dvg_thresh, float eps,
-                     float* x_out, float* diff_out, unsigned char* valid_out, void* stream);
+                     float* x_out, float* diff_out, unsigned char* valid_out, int numerics, void* stream);
 /* The same solve when the caller already holds x_init + F(x_init) - the value stream of the nphm_mlp_eval_points_jvp launch
  * that produced jinv_init (search evaluates the Jacobian at the start points, iterative_root_finding.py:118): posed_init
  * [n_rows, n_points] 3-vectors, posed_stride floats apart (4 * out_dim inside the value+Jacobian output).  The residual of
@@ -408,7 +410,7 @@ int nphm_mlp_broyden_from(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                           const float* obs, const float* x_init, const float* jinv_init, const float* posed_init,
                           int64_t posed_stride, int n_rows, int64_t n_points,
                           int max_steps, float cvg_thresh, float dvg_thresh, float eps,
-                          float* x_out, float* diff_out, unsigned char* valid_out, void* stream);
+                          float* x_out, float* diff_out, unsigned char* valid_out, int numerics, void* stream);
 
 /* First-order backward of the skip-MLP with respect to its conditioning rows, for the fitting loop's
  * loss.backward() through decoder_expr(p_corresp, cond) (src/NPHM/models/fitting.py:99-106 with the decoders
@@ -424,14 +426,14 @@ size_t nphm_mlp_saved_bytes(int lat_dim, int hidden_dim, int nlayers, int out_di
 int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                                 const void* packed, const void* latent_state,
                                 const float* xyz, int n_rows, int64_t n_points, int add_input,
-                                float* out, void* saved, void* stream);
+                                float* out, void* saved, int numerics, void* stream);
 /* nphm_mlp_eval_points_jvp that also leaves sigma' of the VALUE stream in `saved` (same layout and size as
  * nphm_mlp_eval_points_saving): posed points, their Jacobian and the state of the backward in one launch - what the
  * fitting step needs at the canonical correspondences (fitting.py:99-103). */
 int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                                     const void* packed, const void* latent_state,
                                     const float* xyz, int n_rows, int64_t n_points, int add_input,
-                                    float* out, void* saved, void* stream);
+                                    float* out, void* saved, int numerics, void* stream);
 size_t nphm_mlp_bwd_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim);
 int nphm_mlp_pack_bwd(int lat_dim, int hidden_dim, int nlayers, int out_dim, const float* const* lin_weight,
                       void* packed_bwd, void* stream);

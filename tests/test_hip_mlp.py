@@ -26,14 +26,21 @@ def dev():
     return torch.device("cuda:0")
 
 
+def _exact(net):
+    """the value+Jacobian / Broyden / saving launches on the three-term product (the exactness tests below compare them with
+    autograd to 1e-6 .. 2e-5; the default, fit_numerics = "auto", runs calibrated two-term layers there: its own test)"""
+    (net.defDeepSDF if hasattr(net, "defDeepSDF") else net).fit_numerics = "f16x3"
+    return net
+
+
 @pytest.fixture(scope="module")
 def dnet(dev):
-    return U.build_deformation(device=dev).eval()
+    return _exact(U.build_deformation(device=dev).eval())
 
 
 @pytest.fixture(scope="module")
 def npm(dev):
-    return U.build_npm(device=dev).eval()
+    return _exact(U.build_npm(device=dev).eval())
 
 
 def _t(a, dev):
@@ -435,7 +442,7 @@ def test_npm_full_size_64_cubed_vs_reference_sequence(npm, dev):
 def test_backward_wrt_conditioning_matches_autograd(dev, n):
     """d/d(lat_rep, anchors) of sum(offsets * cotangent) through DeformationNetwork with frozen parameters and
     detached points: HIP forward + mlp_bwd_kernel vs autograd through the composite formulation."""
-    net = U.build_deformation(device=dev).eval()
+    net = _exact(U.build_deformation(device=dev).eval())
     for p in net.parameters():
         p.requires_grad_(False)
     g = torch.Generator().manual_seed(11)
@@ -495,7 +502,7 @@ def test_posed_and_jacobian_in_one_launch(dev, n):
     """DeformationNetwork.posed_and_jacobian = forward (+ x) and jacobian at the same points from ONE launch that also
     leaves the backward's state: same values as the two separate calls, same conditioning gradient as autograd through
     the composite formulation."""
-    net = U.build_deformation(device=dev).eval()
+    net = _exact(U.build_deformation(device=dev).eval())
     for p in net.parameters():
         p.requires_grad_(False)
     g = torch.Generator().manual_seed(21)
@@ -621,3 +628,37 @@ def test_npm_formats_agree_with_fixture(npm, dev):
             assert err < tol
     finally:
         npm.precision, npm.numerics = keep
+
+
+def test_fit_tier_two_term_layers_against_the_three_term_launches(dev):
+    """fit_numerics = "auto" (the default of the correspondence-search / implicit-differentiation launches): split-f16
+    operands, two-term layers calibrated once per weight version on the first call's points - value, Jacobian, Broyden
+    roots and the conditioning gradient against the three-term launches of the same kernels."""
+    net = U.build_deformation(device=dev).eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    mlp = net.defDeepSDF
+    assert mlp.fit_numerics == "auto"
+    g = torch.Generator().manual_seed(5)
+    xyz = ((torch.rand(5, 1000, 3, generator=g) - 0.5) * 0.6).to(dev)
+    cot = torch.randn(5, 1000, 3, generator=g).to(dev)
+    lat0 = (torch.randn(5, 1, 1544, generator=g) * 0.05).to(dev)
+    anc = (torch.from_numpy(U.anchors_mean()).float()[None] + 0.01 * torch.randn(5, 39, 3, generator=g)).to(dev)
+
+    def run():
+        lat = lat0.clone().requires_grad_(True)
+        posed, J = net.posed_and_jacobian(xyz, lat, anc)
+        (posed * cot).sum().backward()
+        return posed.detach(), J, lat.grad
+
+    p_a, J_a, g_a = run()
+    rep = mlp._fit_cache
+    assert rep is not None and rep[2]["err"] <= mlp.two_pass_target
+    mlp.fit_numerics = "f16x3"
+    p_x, J_x, g_x = run()
+    e = (float((p_a - p_x).abs().max()), float((J_a - J_x).abs().max()), float((g_a - g_x).abs().max()) / float(g_x.abs().max()))
+    print(f"fit tier, mask {rep[1]:#x} (sample {rep[2]['err']:.2e}): posed {e[0]:.2e}, Jacobian {e[1]:.2e}, conditioning gradient (rel) {e[2]:.2e}")
+    assert e[0] < 5e-6 and e[1] < 2e-4 and e[2] < 5e-4
+    mlp.fit_numerics = "bf16x3"                        # rounds 1-3: still available, three-term on bf16 halves
+    p_b, J_b, g_b = run()
+    assert float((p_b - p_x).abs().max()) < 3e-6 and float((J_b - J_x).abs().max()) < 5e-5
