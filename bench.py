@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_DENSE = 9_616_000            # reference formulation, 40 x 2 x 120 200
 FLOP_MEMBER_FOLDED = 2 * 81_800   # one member, one point, latent folded
-FLOP_DEFORMATION_FOLDED = 2 * 1_074_688   # deformation backbone, latent folded (DESIGN.md §4.2)
+FLOP_DEFORMATION_FOLDED = 2 * 1_074_688   # deformation backbone, latent folded (DESIGN.md 4.2)
 FLOP_NPM_FOLDED = 2 * 6_292_480
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16x3a": 2500.0, "bf16x3a2": 2500.0, "f16x3": 2500.0, "f16x3a2": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (bf16 = f16 rate)
 DTYPE = {"f32": "f32", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)",
@@ -118,7 +118,7 @@ class IdentityBench:
         self.axes_dev = [torch.from_numpy(a).to(dev) for a in self.axes]
         self.rx = self.ry = self.rz = args.res
         self.plane = self.ry * self.rz
-        # N > 1: every rank takes the x-planes of every N-th 8-plane brick slab (work-balanced, DESIGN.md §7)
+        # N > 1: every rank takes the x-planes of every N-th 8-plane brick slab (work-balanced, DESIGN.md 7)
         self.planes = R.cyclic_planes(self.rx, world, rank)
         self.planes_dev = torch.from_numpy(self.planes).to(dev)
         self.n_planes = len(self.planes)
@@ -590,7 +590,7 @@ def training_record(args, dev, with_composite=True, steps=8):
            "roofline": ours["roofline"]}
     o16 = run("hip", "bf16")
     out["operands_bf16"] = {"ms_per_step": o16["ms_per_step"], "roofline": o16["roofline"], "steps_per_s": o16["steps_per_s"], "last_loss": o16["last_loss"],
-                            "peak_mem_gb": o16["peak_mem_gb"]}      # opt-in: decoder.train_operands = 'bf16' 
+                            "peak_mem_gb": o16["peak_mem_gb"]}      # opt-in: decoder.train_operands = 'bf16' (profiles/NOTES.md section 12)
     if with_composite:
         ref = run("composite")
         ref.pop("roofline", None)
@@ -886,7 +886,7 @@ def main():
                        "parallelism": (f"cyclic 8-plane x-slabs x{world} + all_gather (of step k, on a side stream, under the "
                                        "kernel of step k+1)" if distributed else "single GPU")},
             # achieved counts EXECUTED matrix FLOPs (tile padding excluded); peak is the datasheet figure - an MFMA-only loop
-            # sustains `mfma_sustained.tflops` on this box (power-limited clock), DESIGN.md section 4.1
+            # sustains `mfma_sustained.tflops` on this box (power-limited clock), DESIGN.md 4.1
             "roofline": rec["roofline"],
             "mesh_extract": mesh,
         }

@@ -2,7 +2,7 @@
 
 The shipped default drops, per point, the smallest blend weights while they sum to <= 40 * prune_tol and runs
 members below ``NPHM_LIGHT_TOL`` (1e-3) normalised weight single-pass; both are validated on seeded
-random-init weights, where every member's |f_k| is small.  A trained checkpoint can
+random-init weights (profiles/NOTES.md section 3), where every member's |f_k| is small.  A trained checkpoint can
 carry large far-field member values (the reference's blend, EnsembledDeepSDF.py:129-150, multiplies them by
 weights that are tiny but not zero), so ``validate_numerics`` measures, for the weights and latents at hand,
 
@@ -284,7 +284,7 @@ def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int =
     anchors (``_sample_tiles``: the tile geometry of an extraction at its finest BASELINE resolution, where a
     wavefront's points share the fewest members - the worst case of the per-wavefront rules) - for the weights the
     decoder holds NOW.  ``target`` defaults to 5e-6: full 256^3 extractions then stay below 1e-5, a decade inside the 1e-4
-    bar (their maximum over 16.7 M voxels is up to twice the sample's).  ``target_surface`` bounds the
+    bar (their maximum over 16.7 M voxels is up to twice the sample's, profiles/NOTES.md section 3a).  ``target_surface`` bounds the
     MEAN displacement of the zero level set, |error| / |grad f| over the sample points next to it (the mesh criterion of
     the north star: Chamfer within 1e-5; only binding for fields with small gradients, e.g. seeded weights).
     ``refine_band`` (default: target): the sign-safe refinement band every candidate runs with - values that close to

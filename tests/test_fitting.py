@@ -374,3 +374,43 @@ def test_draws_of_another_length_run_eagerly_on_their_own_indices_cpu():
             seen["raised"] += 1
         assert cur[0] is static                     # whatever the step ran on, the graph's input is current again
     assert seen["graph"] > 0 and seen["eager"] > 0 and seen["raised"] > 0, seen
+
+
+@pytest.mark.gpu
+def test_joint_fit_on_trained_identity_and_deformation_weights_gpu():
+    """60 steps of the reference's joint loop on the TRAINED-LIKE pair of checkpoints (tests/golden/fitting_trained.npz:
+    observations posed by the trained deformation network, every transition of the published schedule crossed) against the
+    product's tier mix: same converged correspondences every step, surface trace inside a 5 % band, the end of the fit
+    within 3 %, fitted codes close."""
+    g = U.golden("fitting_trained")
+    dev = torch.device("cuda:0")
+    shape_net, _ = U.build_trained_identity(device=dev)
+    shape_net.train()
+    expr_net, _, _ = U.build_trained_deformation(device=dev)
+    assert U.state_hash(shape_net) == str(g["shape_sha256"]) and U.state_hash(expr_net) == str(g["expr_sha256"])
+    obs = [torch.from_numpy(g[f"obs{i}"]).to(dev) for i in range(3)]
+    hist = []
+    torch.manual_seed(0)
+    lat_e, lat_s, anc = F.inference_iterative_root_finding_joint(
+        shape_net, expr_net, obs, dict(LAMBDAS), int(g["n_steps"]), {k: dict(v) for k, v in LONG_SCHEDULE.items()},
+        step_scale=float(g["step_scale"]), verbose=False, history=hist)
+    keys = [str(k) for k in g["keys"]]
+    table = np.array([[h[k] for k in keys] + [h["n_valid"]] for h in hist])
+    ref = g["history"]
+    assert table.shape == ref.shape
+    print("n_valid (ours / reference), first steps:", table[:6, -1], ref[:6, -1])
+    assert np.array_equal(table[:, -1], ref[:, -1])
+    surf, rsurf = table[:, keys.index("surface")], ref[:, keys.index("surface")]
+    d = np.abs(surf - rsurf)
+    fc = expr_net.defDeepSDF._fit_cache
+    print(f"trained pair, 60 steps: surface trace max abs {d.max():.2e}, max rel {(d / rsurf).max():.2e}, first 10 steps rel "
+          f"{(d / rsurf)[:10].max():.2e}; end of fit {surf[-10:].mean():.4e} vs {rsurf[-10:].mean():.4e}; fit-tier mask "
+          f"{None if fc is None else hex(fc[1])}")
+    assert d.max() < 1e-4 and (d / rsurf).max() < 0.05 and (d / rsurf)[:10].max() < 2.5e-3
+    assert abs(surf[-10:].mean() / rsurf[-10:].mean() - 1) < 3e-2
+    for k in ("reg_expr", "reg_global", "reg_loc"):
+        a, b = table[-10:, keys.index(k)].mean(), ref[-10:, keys.index(k)].mean()
+        assert abs(a / b - 1) < 0.03, (k, a, b)
+    assert U.maxdiff(lat_e.detach().cpu().numpy(), g["lat_expr"]) < 2e-3 and U.maxdiff(anc.detach().cpu().numpy(), g["anchors"]) < 5e-4
+    ds = np.abs(lat_s.detach().cpu().numpy() - g["lat_shape"]).reshape(-1)
+    assert np.median(ds) < 2e-4 and ds.max() < 1e-2

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment (development tool): what would sorting the 4x4x2 voxel tiles by their member mask buy?
 Feeds the 256^3 lattice to the POINT-LIST entry (workgroup = 8 consecutive 32-point tiles) in brick order
-and in mask-sorted order.  Needs /tmp/tile_w.npy (tile masks) - computed here
+and in mask-sorted order.  Needs /tmp/tile_w.npy (tile masks, see profiles/NOTES.md section 4.1) - computed here
 on the GPU with torch if absent."""
 import os, sys, time
 import numpy as np
