@@ -368,12 +368,12 @@ class DeepSDF(nn.Module):
 
     def _fit_code(self, packed, state, xyz):
         """`numerics` argument of the tangent / Broyden / saving launches (``fit_numerics``).  xyz [B,N,3]: this call's points."""
-        if self.fit_numerics in ("bf16x3", "f16x3"):
-            return 0 if self.fit_numerics == "bf16x3" else 1
-        if self.fit_numerics != "auto":
+        if self.fit_numerics not in ("auto", "bf16x3", "f16x3"):
             raise ValueError(f"DeepSDF.fit_numerics must be 'auto', 'f16x3' or 'bf16x3', got {self.fit_numerics!r}")
-        if self.hidden_dim > 512:
-            return 0                          # the 1024-wide variant has bf16 tangent kernels only
+        if self.hidden_dim > 512 or self.fit_numerics == "bf16x3":
+            return 0                          # (the 1024-wide variant has bf16 tangent kernels only)
+        if self.fit_numerics == "f16x3":
+            return 1
         ws, bs = self._lin_params()
         key = tuple((t.data_ptr(), t._version) for t in ws + bs) + (float(self.two_pass_target),)
         c = self._fit_cache
