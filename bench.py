@@ -136,14 +136,20 @@ class IdentityBench:
         self.full = None
         self.collective_events = []      # (start, all-gather done, reorder done) on the side stream, timed steps only
         self.rank_report = None
+        self.calibration_ms = 0.0
 
     def set_precision(self, precision):
         """'auto' = calibrated knobs (the module's default); anything else pins the mode at prune_tol 1e-7 / --prune-tol"""
         net = self.net
         if precision == "auto":
             net.numerics = "auto"
-            # calibrate (and verify on this latent) outside the timed region
+            # calibrate (and verify on this latent) outside the timed region; every rank does this on its own and must arrive
+            # at the same knobs (the shards are slices of one volume): its wall time and a hash of the result go into `ranks`
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             net.kernel_knobs(self.dev, self.lat[None], self.rx * self.ry * self.rz)
+            torch.cuda.synchronize()
+            self.calibration_ms = (time.perf_counter() - t0) * 1e3
             c = net.calibration
             return c["precision"]
         net.precision = precision                              # pins the numerics
@@ -220,8 +226,15 @@ class IdentityBench:
             self.collective_events = []
             # per-rank figures of the timed region: what makes an N > 1 line diagnosable (load balance, how much of the
             # all-gather + reorder stays exposed behind the next step's kernel)
+            c = self.net.calibration if self.net.numerics == "auto" else None
+            knob_hash = 0.0
+            if c is not None:                                 # a float64 carries 52 bits of the digest: enough to see a disagreement
+                import hashlib
+                blob = repr((c["precision"], c["light_tol"], c["mid_tol"], c["prune_tol"], c.get("refine_band"))).encode() + \
+                    (b"" if c.get("bounds") is None else c["bounds"].cpu().numpy().tobytes())
+                knob_hash = float(int(hashlib.sha1(blob).hexdigest()[:13], 16))
             mine = torch.tensor([dt, k_ms, float(np.mean(ag)) if ag else 0.0, float(np.mean(ro)) if ro else 0.0,
-                                 float(self.n_planes)], dtype=torch.float64, device=self.dev)
+                                 float(self.n_planes), self.calibration_ms, knob_hash], dtype=torch.float64, device=self.dev)
             allr = [torch.zeros_like(mine) for _ in range(self.world)]
             dist.all_gather(allr, mine)
             allr = torch.stack(allr).cpu().numpy()
@@ -229,6 +242,10 @@ class IdentityBench:
             self.rank_report = {"step_ms": [round(v / steps * 1e3, 3) for v in allr[:, 0]], "kernel_ms": [round(v, 3) for v in allr[:, 1]],
                                 "allgather_ms": [round(v, 3) for v in allr[:, 2]], "reorder_ms": [round(v, 3) for v in allr[:, 3]],
                                 "planes": [int(v) for v in allr[:, 4]],
+                                # one-off per rank and weight version, outside the timed region; kernel_ms includes the tile
+                                # pre-pass and the radix sort of the rank's planes (they run inside the C call)
+                                "calibration_ms": [round(v, 1) for v in allr[:, 5]],
+                                "knobs_agree": bool(len(set(allr[:, 6].tolist())) == 1),
                                 "kernel_max_over_mean": float(allr[:, 1].max() / max(allr[:, 1].mean(), 1e-12)),
                                 "exposed_ms_per_step": float(dt / steps * 1e3 - allr[:, 1].max())}
         return dt, k_ms, stats.cpu().numpy()
@@ -367,7 +384,7 @@ def two_stage_record(args, dev, steps, warmup):
     _, k_ms = _timed(lambda: R.evaluate_grid_mlp(mlp, cond, axes, add_input=True), steps, 1)
     num, flops = _mlp_numerics_report(mlp)
     ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
-    kname = "nphm::mlp::mlp_eval_kernel<2,2,1,0>"
+    kname = "nphm::mlp::mlp_eval_kernel<2,2,1,0,true>" if mlp.precision == 'f16x3' else "nphm::mlp::mlp_eval_kernel<2,2,1,0,false>"
     return {"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice",
             "value": n * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "dtype": f"{mlp.precision} (split-f16 MFMA, fp32 accumulate; {num['passes_per_layer']} product terms per layer, calibrated) deformation + "
@@ -395,7 +412,7 @@ def npm_record(args, dev, steps, warmup, cpu):
     dt, k_ms = _timed(lambda: R.evaluate_grid_mlp(npm, lat, axes_dev), steps, warmup)
     num, flops = _mlp_numerics_report(npm)
     ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
-    kname = "nphm::mlp::mlp_eval_kernel<1,4,1,0>"
+    kname = "nphm::mlp::mlp_eval_kernel<1,4,1,0,true>" if npm.precision == 'f16x3' else "nphm::mlp::mlp_eval_kernel<1,4,1,0,false>"
     out = {"metric": "SDF query throughput, NPM global DeepSDF, dense lattice", "value": n * steps / dt / 1e6,
            "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "dtype": f"{npm.precision} (split-f16 MFMA, fp32 accumulate; {num['passes_per_layer']} product terms per layer, calibrated)",

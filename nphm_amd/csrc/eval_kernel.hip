@@ -104,6 +104,9 @@ struct EvalArgs {
 #ifndef NPHM_RUNK_LIGHT
 #define NPHM_RUNK_LIGHT 0
 #endif
+#ifndef NPHM_STACK_TAILS
+#define NPHM_STACK_TAILS 1    // split-f16 path: the last 32-row block of a layer holds 8 real rows - its A fragment carries wh in rows
+#endif                        // 0..7 and wl in rows 8..15 (prep_kernels.hip), two MFMAs per K-step instead of three, half the DMA bytes
 #ifndef NPHM_PROF
 #define NPHM_PROF 0  // 1: per-phase s_memtime accounting into stats[2..8] (timing builds only)
 #endif
@@ -334,11 +337,18 @@ template <> struct Stream<1> {
   }
 };
 
+// chunk index (inside the member) of the LAST 32-row block of lin1 / lin2 / lin3: 8 real rows (5 + the coordinate slots for lin1)
+__host__ __device__ constexpr bool is_tail_chunk(int ci) { return ci == L1_OB || ci == L1_OB + L2_OB || ci == CHUNKS_PER_MEMBER - 1; }
+
 template <> struct Stream<2> : Stream<1> {
   __device__ static __forceinline__ const char* set_base(const EvalArgs& p, int s) {
     return reinterpret_cast<const char*>(p.packed_f16 + size_t(s) * BF_SET_STRIDE);
   }
   static constexpr int LS_OFF_L0 = LS_OFF_L0H;
+  // stacked tail blocks: ONE fragment per K-step ([ks][lane][8]: wh in rows 0..7, wl in rows 8..15), at the front of the chunk
+  __host__ __device__ static constexpr int groups(int ci) {
+    return (NPHM_STACK_TAILS && is_tail_chunk(ci)) ? Stream<1>::groups(ci) / 2 : Stream<1>::groups(ci);
+  }
 };
 
 template <int PREC>
@@ -426,6 +436,7 @@ struct Streamer {
                                   : unsigned(member_set(k)) * Stream<PREC>::SET_BYTES + unsigned(Stream<PREC>::offset(ci - 1));
     const v4i& rs = ci == 0 ? rs_s : rs_w;
     if (i == 0) {
+      if (q == 0) return;                   // (a stacked lin2 tail: 7 groups, all of them "left-over" pieces)
       const unsigned g = unsigned(q * wave) * 1024u;
       const unsigned soff = __builtin_amdgcn_readfirstlane(base + g), d = __builtin_amdgcn_readfirstlane(dst + g);
       if (q == 1) dma16<1>(rs, l * 16, soff, d);
@@ -553,9 +564,10 @@ __host__ __device__ constexpr bool epilogue_exposed(int P) {
 // in the shadow of that MFMA (32 cycles of matrix pipe, 4 of issue) - measured in
 // tools/micro/overlap.hip: MFMA + softplus interleaved in one wavefront cost max(...) + ~15 %, not the sum.
 // sched_barrier(0) after every slot keeps hipcc from regrouping the stream.
-template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, bool F16, int RUNK, class Epi, class Pre, class Slot>
+template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, bool F16, int RUNK, int AS, class Epi, class Pre, class Slot>
 __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc, const ActB (&in)[NIN],
                                                   int lane, Epi&& epi, Pre&& pre, Slot&& slot_hook) {
+  static_assert(AS == 2 || (AS == 1 && NPASS <= 2), "AS = 1: stacked tail fragments (one fragment per K-step, no separate lo fragment)");
   const u32x4* A = reinterpret_cast<const u32x4*>(afrag) + lane;
   u32x4 wh[NKS16], wl[NKS16];
   constexpr int NM = NPASS;                // MFMAs per K-step: hh | hh, hl | hh, hl, lh
@@ -572,8 +584,8 @@ __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc,
       constexpr int k0 = decltype(rr)::value * RUNK, k1 = (k0 + RUNK < NKS16) ? k0 + RUNK : NKS16;
       static_range<k0, k1>([&](auto kk) __attribute__((always_inline)) {
         constexpr int ks = decltype(kk)::value;
-        wh[ks] = A[(2 * ks) * 64];
-        if (NPASS == 3) wl[ks] = A[(2 * ks + 1) * 64];
+        wh[ks] = A[(AS * ks) * 64];
+        if (NPASS == 3) wl[ks] = A[(AS * ks + 1) * 64];
       });
     };
     load_run(std::integral_constant<int, 0>{});
@@ -604,14 +616,14 @@ __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc,
   }
 #pragma unroll
   for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
-    wh[ks] = A[(2 * ks) * 64];
-    if (NPASS == 3) wl[ks] = A[(2 * ks + 1) * 64];
+    wh[ks] = A[(AS * ks) * 64];
+    if (NPASS == 3) wl[ks] = A[(AS * ks + 1) * 64];
   }
   static_for<NKS16>([&](auto kk) __attribute__((always_inline)) {
     constexpr int ks = decltype(kk)::value;
     if constexpr (ks + PF < NKS16) {
-      wh[ks + PF] = A[(2 * (ks + PF)) * 64];
-      if (NPASS == 3) wl[ks + PF] = A[(2 * (ks + PF) + 1) * 64];
+      wh[ks + PF] = A[(AS * (ks + PF)) * 64];
+      if (NPASS == 3) wl[ks + PF] = A[(AS * (ks + PF) + 1) * 64];
     }
     pre(kk);                               // one piece of the weight prefetch (LDS-DMA issue) per K-step
     __builtin_amdgcn_sched_barrier(0);     // the reads above are issued HERE, ahead of the MFMAs
@@ -1041,6 +1053,8 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       constexpr int g = P - 1;
       constexpr bool last_block = P == 0 || g == L1_OB - 1 || g == L1_OB + L2_OB - 1 || P == CHUNKS_PER_MEMBER - 1;
       (void)last_block;
+      // stacked tail block of a three-term member: register r + 4 of the same lane holds the wl rows of register r's features
+      if constexpr (PREC == 2 && NPHM_STACK_TAILS && is_tail_chunk(P) && decltype(LL)::value == 0 && r < LAST_BLOCK_REGS) a[r] += a[r + 4];
       float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
       if constexpr (P >= 1 + L1_OB + L2_OB) {
         // lin3 block: lin4 (200 -> 1) fused; its 16 weights sit in the chunk's ring-slot tail
@@ -1207,9 +1221,13 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           // of at most one aligned K-step pair there)
           constexpr int RUNK_T = TIER == 1 ? NPHM_RUNK_LIGHT : TIER == 2 ? NPHM_RUNK_MID : NPHM_RUNK_HEAVY;
           constexpr int RUNK = (L0_FUSED && c == 1 && RUNK_T > 2) ? 2 : RUNK_T;
-          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NPASS, PF, NU, F16, RUNK>(buf, d, H, lane, epi, pre, slot_hook);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NPASS, PF, NU, F16, RUNK>(buf, d, G, lane, epi, pre, slot_hook);
-          else d = gemm_fused_bf16<L3_KS16, 6, 7, NPASS, PF, NU, F16, RUNK>(buf, d, H, lane, epi, pre, slot_hook);
+          // stacked tail block (split-f16): its one fragment per K-step multiplies xh and xl - rows 0..7 collect xh wh + xl wh,
+          // rows 8..15 xh wl + xl wl (added to rows 0..7 by a three-term member's epilogue, ignored by the other tiers)
+          constexpr bool STACK = F16 && NPHM_STACK_TAILS && is_tail_chunk(c);
+          constexpr int NP = (STACK && NPASS == 3) ? 2 : NPASS, AS = STACK ? 1 : 2;
+          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NP, PF, NU, F16, RUNK, AS>(buf, d, H, lane, epi, pre, slot_hook);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NP, PF, NU, F16, RUNK, AS>(buf, d, G, lane, epi, pre, slot_hook);
+          else d = gemm_fused_bf16<L3_KS16, 6, 7, NP, PF, NU, F16, RUNK, AS>(buf, d, H, lane, epi, pre, slot_hook);
         }
         accs[c & 1] = d;
         if constexpr (epilogue_exposed(c)) {

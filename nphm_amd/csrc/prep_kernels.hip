@@ -13,6 +13,10 @@
 #include "capi_common.h"
 #include "layout.h"
 
+#ifndef NPHM_STACK_TAILS
+#define NPHM_STACK_TAILS 1   // must match eval_kernel.hip: stacked [wh; wl] fragments of the split-f16 tail blocks
+#endif
+
 namespace nphm {
 
 struct PackArgs {
@@ -88,10 +92,32 @@ __global__ void pack_bf16_kernel(PackArgs a) {
   const uint16_t hi = f32_to_bf16_rn(w);
   const uint16_t lo = f32_to_bf16_rn(w - bf16_to_f32(hi));
   a.out_bf16[size_t(s) * BF_SET_STRIDE + e] = part ? lo : hi;
-  // the split-f16 fragments: same position, binary16 halves
+  // the split-f16 fragments: same position, binary16 halves ...
   const uint16_t hh = f32_to_f16_rn(w);
   const uint16_t hl = f32_to_f16_rn(w - f16_to_f32(hh));
-  a.out_f16[size_t(s) * BF_SET_STRIDE + e] = part ? hl : hh;
+  uint16_t* out16 = a.out_f16 + size_t(s) * BF_SET_STRIDE;
+#if NPHM_STACK_TAILS
+  // ... except the LAST 32-row block of every layer (8 real rows, 5 for lin1): ONE stacked fragment per K-step at the front
+  // of the chunk, [ks][lane][8], with wh in rows 0..7 and wl of the same weights in rows 8..15 (eval_kernel.hip: two MFMAs
+  // per K-step instead of three, half the bytes to stream); the second half of the chunk stays zero
+  if (ob == (L == 1 ? L1_OB : L == 2 ? L2_OB : L3_OB) - 1) {
+    const int chunk0 = x - ((x >> 10) % nks) * 1024 - part * 512 - (lane * 8 + i);     // first element of this chunk
+    const int r = lane & 31;
+    if (part == 0) {
+      uint16_t v = 0;
+      if (r < 8) v = hh;                                   // (this thread's w belongs to row 32 ob + r: the hi half)
+      else if (r < 16) {
+        const float w8 = layer_weight(a, L, s, 32 * ob + r - 8, feat_of(b, 8 * sub + i, h));
+        v = f32_to_f16_rn(w8 - f16_to_f32(f32_to_f16_rn(w8)));
+      }
+      out16[(L == 1 ? BF_OFF_L1A : L == 2 ? BF_OFF_L2A : BF_OFF_L3A) + chunk0 + ks * 512 + lane * 8 + i] = v;
+    } else {
+      out16[(L == 1 ? BF_OFF_L1A : L == 2 ? BF_OFF_L2A : BF_OFF_L3A) + chunk0 + nks * 512 + ks * 512 + lane * 8 + i] = 0;
+    }
+    return;
+  }
+#endif
+  out16[e] = part ? hl : hh;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ params, amean = U.np_state(net), U.anchors_mean()
 fwd = lambda p, l: O.nphm_identity_forward(params, amean, p, l, training=False)
 ref = O.get_logits(fwd, lat.cpu().numpy(), grid.cpu().numpy(), nbatch_points=1000)
 errs = []
-for prec in ("auto", "f16x3", "bf16x3", "bf16x3a2", "f32"):
+for prec in ("auto", "f16x3", "f16x3a2", "bf16x3", "bf16x3a2", "f32"):
     if prec != "auto": net.precision = prec
     vol = R.get_logits(net, lat, grid, nbatch_points=1000)
     errs.append(f"{prec} {float(np.max(np.abs(vol - ref))):.2e}")
