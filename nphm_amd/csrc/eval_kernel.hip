@@ -107,6 +107,9 @@ struct EvalArgs {
 #ifndef NPHM_STACK_TAILS
 #define NPHM_STACK_TAILS 1    // split-f16 path: the last 32-row block of a layer holds 8 real rows - its A fragment carries wh in rows
 #endif                        // 0..7 and wl in rows 8..15 (prep_kernels.hip), two MFMAs per K-step instead of three, half the DMA bytes
+#ifndef NPHM_LDS_STASH
+#define NPHM_LDS_STASH 1      // per-lane (qx, qy, qz, denom) parked in LDS across the member loop instead of in VGPRs
+#endif
 #ifndef NPHM_PROF
 #define NPHM_PROF 0  // 1: per-phase s_memtime accounting into stats[2..8] (timing builds only)
 #endif
@@ -867,6 +870,12 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   __shared__ __attribute__((aligned(16))) char ring[RING * WS::SLOT_BYTES];
   __shared__ unsigned int wg_mask[2];
   __shared__ unsigned char wg_list[N_MEMBERS];
+  // per-lane query point and blend normaliser, parked in LDS across the member loop: the loop body holds 7 + 4 activation
+  // blocks, 2-3 accumulators and the A fragments in 256 VGPRs - every VGPR that merely LIVES across it ends up as a scratch
+  // spill at kernel entry (round 3: 0.32 GB of private-segment writes per 256^3 launch, with the stacked tail blocks 1.3 GB).
+  // A member reads its four floats back with one ds_read_b128.
+  __shared__ f32x4 lane_q[64 * NW];
+  __shared__ float lane_S[64 * NW];
 
   const int lane_inv = threadIdx.x & 63;
   const int lane = lane_inv;
@@ -874,6 +883,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   const int h_inv = lane >> 5;
   const int h = h_inv;
   const int j = lane & 31;
+  auto my_slot = [&]() __attribute__((always_inline)) -> int {      // this lane's LDS slot, from the execution mask: no live VGPR
+    return wave * 64 + int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+  };
 
   // ---- locate this lane's query point ------------------------------------------------------
   bool valid;
@@ -934,15 +946,27 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     const float2 sd = p.tile_sd[size_t(tile) * 32 + j];
     S = sd.x; denom = sd.y;
     const bool in_tile = binned_group(blockIdx.x) * NW + wave < unsigned(p.n_tiles);
-    wmask = in_tile ? p.tile_masks[3 * size_t(tile)] : 0ull;
-    hmask = in_tile ? p.tile_masks[3 * size_t(tile) + 1] : 0ull;
-    fmask = in_tile ? p.tile_masks[3 * size_t(tile) + 2] : 0ull;
+    // (wave-uniform values: into SGPRs - as VGPR pairs they live across the member loop and get spilled to scratch)
+    auto uni64 = [](uint64_t v) __attribute__((always_inline)) {
+      return (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))))) << 32) |
+             uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
+    };
+    wmask = uni64(in_tile ? p.tile_masks[3 * size_t(tile)] : 0ull);
+    hmask = uni64(in_tile ? p.tile_masks[3 * size_t(tile) + 1] : 0ull);
+    fmask = uni64(in_tile ? p.tile_masks[3 * size_t(tile) + 2] : 0ull);
   } else {
     uint64_t wm[2], hm[2], fm[2];
     blend_masks<false>(anch, qx, qy, qz, valid, hack, p.prune_tol, p.light_tol, p.mid_tol, S, denom, wm, hm, fm);
     wmask = wm[0]; hmask = hm[0]; fmask = fm[0];
   }
 
+#if NPHM_LDS_STASH
+  {
+    f32x4 q4 = {qx, qy, qz, denom};
+    lane_q[threadIdx.x] = q4;
+    lane_S[threadIdx.x] = S;
+  }
+#endif
   const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
   if (p.stats && lane == 0) {
     atomicAdd(p.stats, nv * __popcll(wmask));
@@ -1001,8 +1025,18 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     }
     // lane-derived values are re-materialised per member (opaque to LICM): hoisting the dozens of
     // per-site lane offsets out of this loop costs more registers than recomputing them
+#if NPHM_LDS_STASH
+    // lane index from the execution mask (2 VALU) instead of a register kept alive across the loop
+    int lane = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    asm volatile("" : "+v"(lane));
+    int h = lane >> 5;
+    const f32x4 q4 = lane_q[wave * 64 + lane];
+    asm volatile("" : "+v"(lane));          // (re-materialised per site below, not kept: see the DMA code)
+    const float qx = q4[0], qy = q4[1], qz = q4[2], denom = q4[3];
+#else
     int h = h_inv, lane = lane_inv;
     asm volatile("" : "+v"(h), "+v"(lane));
+#endif
     PROF_T(t_m0);
     // adaptive precision (bf16 path): single-pass products for a member that weighs < light_tol at
     // every point of this wavefront (its error enters the blend scaled by that weight)
@@ -1281,7 +1315,18 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
 #endif
     if (pass == 1 || !(p.refine_band > 0.f)) break;
     // ---- does any wavefront of the workgroup sit on the zero level set? -------------------------------------------
-    const bool wave_near = __ballot(valid && !hack && fabsf(acc) < p.refine_band) != 0ull;
+    // (MODE 2: validity recomputed from the tile id and the lane, laundered like the final store's - `valid` as a 0/1 VGPR
+    // that lives across the member loop is a scratch spill)
+    bool valid_r = valid;
+    if (MODE == 2) {
+      unsigned t3 = tile;
+      int l3 = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+      asm volatile("" : "+s"(t3), "+v"(l3));
+      int lx3, iy3, iz3;
+      tile_lane(p, t3, l3 & 31, lx3, iy3, iz3);
+      valid_r = binned_group(blockIdx.x) * NW + wave < unsigned(p.n_tiles) && lx3 < p.ix1 - p.ix0 && iy3 < p.ry && iz3 < p.rz;
+    }
+    const bool wave_near = __ballot(valid_r && !hack && fabsf(acc) < p.refine_band) != 0ull;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) wg_mask[0] = 0u;
@@ -1294,7 +1339,16 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     if (wave_near) {
       float S2, denom2;
       uint64_t wm[2], hm[2], fm[2];
+#if NPHM_LDS_STASH
+      const f32x4 qr = lane_q[my_slot()];
+      // (the anchor table's address is laundered: hipcc otherwise hoists the ~60 `state + constant` address pairs of this
+      // rarely taken path above the member loop and parks them in VGPR lanes - three VGPRs of spill storage for the loop)
+      const float* anch_r = anch;
+      asm volatile("" : "+s"(anch_r));
+      blend_masks<false>(anch_r, qr[0], qr[1], qr[2], valid_r, hack, p.refine_prune_tol, -1.f, -1.f, S2, denom2, wm, hm, fm);
+#else
       blend_masks<false>(anch, qx, qy, qz, valid, hack, p.refine_prune_tol, -1.f, -1.f, S2, denom2, wm, hm, fm);
+#endif
       wmask = wm[0];
       acc = 0.f;
       if (p.stats && lane == 0) atomicAdd(p.stats + 13, (unsigned long long)(nv * __popcll(wmask)));   // refined pairs
@@ -1305,7 +1359,26 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   }
 
   // eval-mode overwrite (EnsembledDeepSDF.py:260-261): every member predicts 1 for this point
+#if NPHM_LDS_STASH
+  if (hack) { const int sl = my_slot(); acc = lane_S[sl] / lane_q[sl][3]; }
+#else
   if (hack) acc = S / denom;
+#endif
+  if (MODE == 2) {
+    // binned traversal: the output index is not carried through the member loop (a 64-bit VGPR pair that only lives
+    // across it becomes a scratch spill); it follows from the tile id (an SGPR) and the lane
+    // ... and so does `valid` (everything laundered: the same expressions exist in the prologue, and a CSE'd copy would
+    // live across the loop again)
+    unsigned t2 = tile;
+    int l2 = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    asm volatile("" : "+s"(t2), "+v"(l2));
+    int lx, iy, iz;
+    tile_lane(p, t2, l2 & 31, lx, iy, iz);
+    const bool in_tile2 = binned_group(blockIdx.x) * NW + wave < unsigned(p.n_tiles);
+    if (in_tile2 && l2 < 32 && lx < p.ix1 - p.ix0 && iy < p.ry && iz < p.rz)
+      p.out[(int64_t(lx) * p.ry + iy) * p.rz + iz] = acc;
+    return;
+  }
   if (valid && h == 0) p.out[out_idx] = acc;
 }
 
