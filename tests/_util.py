@@ -125,3 +125,12 @@ def build_trained_deformation(device="cpu"):
     net = build_deformation(device=device)
     net.load_state_dict({k[3:]: torch.from_numpy(ck[k]) for k in ck.files if k.startswith("sd.")}, strict=True)
     return net.eval(), torch.from_numpy(ck["z_ex"]).float().to(device), [tuple(int(v) for v in p) for p in ck["pairs"]]
+
+
+def build_trained_npm(device="cpu"):
+    """(NPM DeepSDF with the trained-like checkpoint tests/golden/trained_npm_state.npz - the reference's module trained on
+    analytic head surfaces, tools/train_synthetic_npm.py - , the codes [4,512] of the fixture)"""
+    ck = np.load(os.path.join(GOLDEN, "trained_npm_state.npz"))
+    net = build_npm(device=device)
+    net.load_state_dict({k[3:]: torch.from_numpy(ck[k]) for k in ck.files if k.startswith("sd.")}, strict=True)
+    return net.eval(), torch.from_numpy(ck["codes"]).float().to(device)

@@ -354,3 +354,55 @@ def test_two_stage_on_trained_identity_and_deformation_weights(dev):
     print(f"trained deformation checkpoint: auto mask {rep['mask']:#x} (all-layers error {rep['all_layers_err']:.2e}, "
           f"per layer {rep.get('per_layer_err')}), full-set error {e_auto:.2e}, outputs up to {float(ref.abs().max()):.2e}")
     assert e_auto <= 2.0 * mlp.two_pass_target
+
+
+# ---- round 4: the trained-like NPM checkpoint (reference DeepSDF trained on analytic head surfaces) -------------------------
+def test_oracle_and_composite_tier_reproduce_the_trained_npm_fixture():
+    fx = U.golden("trained_npm")
+    net, codes = U.build_trained_npm()
+    assert U.state_hash(net) == str(fx["state_sha256"])
+    net.backend = "composite"
+    params = U.np_state(net)
+    for i in range(codes.shape[0]):
+        x = torch.from_numpy(fx[f"c{i}_xyz"])
+        with torch.no_grad():
+            sdf, _ = net(x, codes[i][None, None])
+        assert U.maxdiff(sdf.numpy(), fx[f"c{i}_sdf"]) < 5e-6
+        lat_rep = np.repeat(codes[i].numpy()[None, None], x.shape[1], axis=1)
+        sdf_o = O.deepsdf_forward(params, "", fx[f"c{i}_xyz"], lat_rep, nlayers=8)
+        assert U.maxdiff(np.asarray(sdf_o).reshape(fx[f"c{i}_sdf"].shape), fx[f"c{i}_sdf"]) < 5e-6
+    assert float(fx["max_weight"]) > 0.15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("f16x3", 3e-6), ("bf16x3", 1e-5)])
+def test_hip_npm_on_trained_weights(dev, precision, tol):
+    fx = U.golden("trained_npm")
+    net, codes = U.build_trained_npm(device=dev)
+    net.precision, net.numerics = precision, "fixed"
+    worst = 0.0
+    for i in range(codes.shape[0]):
+        with torch.no_grad():
+            sdf, _ = net(torch.from_numpy(fx[f"c{i}_xyz"]).to(dev), codes[i][None, None])
+        worst = max(worst, U.maxdiff(sdf.cpu().numpy(), fx[f"c{i}_sdf"]))
+    res, chunk = int(fx["lattice_res"]), int(fx["lattice_chunk"])
+    grid = torch.from_numpy(R.create_grid_points_from_bounds(U.MINI, U.MAXI, res)).float()[None].to(dev)
+    vol = R.get_logits(net, codes[0], grid, nbatch_points=chunk)
+    e_lat = U.maxdiff(vol, fx["lattice_logits"])
+    print(f"trained NPM checkpoint, {precision}: points {worst:.2e}, {res}^3 get_logits {e_lat:.2e}")
+    assert worst < tol and e_lat < tol
+
+
+@pytest.mark.gpu
+def test_two_term_tier_on_trained_npm_weights(dev):
+    net, codes = U.build_trained_npm(device=dev)
+    axes = R.grid_axes(U.MINI, U.MAXI, 64)
+    with torch.no_grad():
+        net.numerics, net.two_pass_mask = "fixed", 0
+        ref = R.evaluate_grid_mlp(net, codes[1][None], axes)
+        net.numerics = "auto"
+        auto = R.evaluate_grid_mlp(net, codes[1][None], axes)
+    rep = net.last_numerics
+    e = float((auto - ref).abs().max())
+    print(f"trained NPM checkpoint, 64^3: auto mask {rep['mask']:#x} (all-layers error {rep['all_layers_err']:.2e}), full-volume error {e:.2e}")
+    assert e <= 2.0 * net.two_pass_target
