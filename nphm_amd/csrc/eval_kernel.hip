@@ -13,6 +13,10 @@
 //     whose blend weight stays below 1e-3 in the wavefront) with the VALU epilogue of the PREVIOUS chunk
 //     (base-2 softplus, re-split to bf16 hi/lo; bias is the accumulator init) threaded through its
 //     dependent MFMA chain - one wavefront keeps both pipes busy;
+//   * the last 32-row block of a layer holds 8 real rows: on the split-f16 path its fragment carries wh in rows 0..7 and wl in
+//     rows 8..15 (two MFMAs per K-step for every tier, half the bytes to stream);
+//   * 256 VGPRs inside the member loop: nothing lane-private LIVES across it in registers - the query point and the blend
+//     normaliser are parked in LDS, wave-uniform masks sit in SGPRs, the output index is recomputed (no scratch);
 //   * MODE 0 reads xyz[n,3]; MODE 1 generates the 'ij' lattice from three axis arrays (or reads
 //     lattice-ordered displaced points: two-stage evaluation), bricks enumerated so that each XCD works
 //     on a compact region; MODE 2 is the same lattice traversed tile by tile (4x4x2 voxels = one
