@@ -364,7 +364,12 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
  *   a systematic 2^-12 (f16) / 2^-9 (bf16) perturbation of that layer's weights.  Which layers may is a property of the
  *   checkpoint: the host module measures it against the three-term product (nphm_amd/deepsdf.py, calibrate).
  * The value+Jacobian, Broyden and saving entry points below take the same argument (hidden_dim <= 512: both formats;
- * the 1024-wide variant runs them on bf16 halves only). */
+ * the 1024-wide variant runs them on bf16 halves only).
+ * The two value+Jacobian entry points also take a point RANGE and a workgroup width (ABI 7): the launch covers points
+ * [point_base, point_base + point_count) of every row (0, 0 = all; point_base a multiple of 16, of 64 for the saving form)
+ * with `columns` = 64 (16 points per workgroup; 0 = default) or 32 (8 points per workgroup, hidden_dim <= 512) - a batch whose
+ * 16-point workgroups fill 1.2 rounds of the chip runs as one full round of them plus a round of 8-point workgroups over the
+ * rest (nphm_amd/deepsdf.py: _jvp_split). */
 #define NPHM_MLP_BF16X3 0
 #define NPHM_MLP_F16X3 1
 #define NPHM_MLP_TWO_PASS(mask) ((int)((unsigned)(mask) << 8))
@@ -386,7 +391,7 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
 int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                              const void* packed, const void* latent_state,
                              const float* xyz, int n_rows, int64_t n_points, int add_input,
-                             float* out, int numerics, void* stream);
+                             float* out, int numerics, int64_t point_base, int64_t point_count, int columns, void* stream);
 
 /* Correspondence search of the fitting loop in ONE launch: Broyden root finding of
  * x + F(x) = obs per point (src/NPHM/models/iterative_root_finding.py:5-71 broyden as called by
@@ -433,7 +438,7 @@ int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int ou
 int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                                     const void* packed, const void* latent_state,
                                     const float* xyz, int n_rows, int64_t n_points, int add_input,
-                                    float* out, void* saved, int numerics, void* stream);
+                                    float* out, void* saved, int numerics, int64_t point_base, int64_t point_count, int columns, void* stream);
 size_t nphm_mlp_bwd_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim);
 int nphm_mlp_pack_bwd(int lat_dim, int hidden_dim, int nlayers, int out_dim, const float* const* lin_weight,
                       void* packed_bwd, void* stream);

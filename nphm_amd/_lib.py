@@ -83,7 +83,7 @@ SYMBOLS = {
     "nphm_mlp_eval_points": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
                                                     c_void_p, c_void_p]),
     "nphm_mlp_eval_points_jvp": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
-                                                        c_void_p, c_int, c_void_p]),
+                                                        c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "nphm_mlp_broyden": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                                 c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nphm_mlp_broyden_from": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -92,7 +92,7 @@ SYMBOLS = {
     "nphm_mlp_eval_points_saving": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                                            c_void_p, c_void_p, c_int, c_void_p]),
     "nphm_mlp_eval_points_jvp_saving": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
-                                                               c_void_p, c_void_p, c_int, c_void_p]),
+                                                               c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "nphm_mlp_bwd_packed_bytes": (c_size_t, [c_int] * 4),
     "nphm_mlp_pack_bwd": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,

@@ -2,15 +2,16 @@
 the GPU box with the repo snapshot."""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
-import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip", "mlp_bwd_kernel.hip", "ident_bwd_kernel.hip", "ident_train_kernel.hip", "fit_kernels.hip", "train_loss_kernels.hip", "mc_device.hip", "probe.hip", "marching_cubes.cpp"]
 OUT = os.path.join(HERE, "libnphm_amd.so")
+OBJ_CACHE = os.path.join(HERE, "..", ".build_cache")      # objects by content hash (git- and gpurun-ignored)
 
 
 def _stale() -> bool:
@@ -26,30 +27,44 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-fn
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every source for gfx950 (the translation units in parallel: eval_kernel.hip alone holds six
-    instantiations of the fused kernel) and link them into one shared library."""
+    instantiations of the fused kernel) and link them into one shared library.  Objects are kept by content hash of
+    (flags, headers, source) under .build_cache/: an edit recompiles its translation unit only; ``force`` recompiles all."""
     if not force and not _stale():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     inc = ["-I", os.path.join(HERE, "..", "include")]
-    objdir = tempfile.mkdtemp(prefix="nphm_amd_build_")
-    try:
-        jobs = []
-        for src in SOURCES:
-            obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-            cmd = [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, src), "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            jobs.append((cmd, obj, subprocess.Popen(cmd)))
-        for cmd, _, proc in jobs:
-            if proc.wait() != 0:
-                raise subprocess.CalledProcessError(proc.returncode, cmd)
-        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + [obj for _, obj, _ in jobs] + ["-o", OUT + ".tmp"]
+    os.makedirs(OBJ_CACHE, exist_ok=True)
+    # every translation unit sees every header: one digest of them + the flags, then one of the source per object
+    common = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".h"):
+            common.update(open(os.path.join(CSRC, f), "rb").read())
+    common.update(open(os.path.join(HERE, "..", "include", "nphm_amd.h"), "rb").read())
+    jobs, objs = [], []
+    for src in SOURCES:
+        h = common.copy()
+        h.update(open(os.path.join(CSRC, src), "rb").read())
+        obj = os.path.join(OBJ_CACHE, f"{os.path.splitext(src)[0]}-{h.hexdigest()[:20]}.o")
+        objs.append(obj)
+        if os.path.exists(obj) and not force:
+            continue
+        cmd = [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
         if verbose:
-            print(" ".join(link))
-        subprocess.run(link, check=True)
-        os.replace(OUT + ".tmp", OUT)
-    finally:
-        shutil.rmtree(objdir, ignore_errors=True)
+            print(" ".join(cmd))
+        jobs.append((cmd, obj, subprocess.Popen(cmd)))
+    for cmd, obj, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        os.replace(obj + ".tmp", obj)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", OUT + ".tmp"]
+    if verbose:
+        print(" ".join(link))
+    subprocess.run(link, check=True)
+    os.replace(OUT + ".tmp", OUT)
+    keep = set(objs)
+    for f in os.listdir(OBJ_CACHE):                         # objects of older source versions
+        if os.path.join(OBJ_CACHE, f) not in keep:
+            os.remove(os.path.join(OBJ_CACHE, f))
     return OUT
 
 

@@ -19,6 +19,7 @@
 // all in the scaled domain of mlp_layout.h (d' = k d), so gb_l = k * sum_n G_l[n].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "capi_common.h"
@@ -31,10 +32,13 @@ namespace bwd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int MT = 2, NTW = 2, M = 32 * MT;       // the hidden <= 512 variant of the forward kernel
+constexpr int NTW = 2;                            // the hidden <= 512 variant of the forward kernel
 constexpr int HMAX = 32 * WAVES * NTW;
 constexpr int NCH = HMAX / 8;
-constexpr int PART_BYTES = NCH * M * 16;
+// MT point tiles of 32 per workgroup: 2 (64 points, the forward's workgroup) or 1 - a workgroup's time is the stream of the
+// transposed pack out of L2 (7.3 MB at the CU's 64 B/clk) whatever its columns, so a launch that leaves CUs idle with
+// 64-point workgroups (the fitting loop: 5 x 16 = 80 of them) runs twice as many 32-point ones, each faster
+constexpr int part_bytes(int mt) { return NCH * 32 * mt * 16; }
 
 __device__ inline uint16_t f32_to_bf16_rn(float x) {
   uint32_t u = __float_as_uint(x);
@@ -172,7 +176,9 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
+template <int MT>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
+  constexpr int M = 32 * MT, PART_BYTES = part_bytes(MT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act_hi = smem;
   char* act_lo = smem + PART_BYTES;
@@ -181,7 +187,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
   const int h = lane >> 5, j = lane & 31;
   const int row = blockIdx.y;
   const int64_t base = int64_t(blockIdx.x) * M;
-  const float* sig_wg = p.saved + (size_t(row) * gridDim.x + blockIdx.x) * p.sig_tiles * (MT * 64 * 16);
+  // saved layout: [row][64-point group][sig_tiles][2 point tiles][64 lanes][16]; a 32-point workgroup reads one tile of a group
+  const size_t groups = size_t((p.n_points + 63) >> 6), group = size_t(base >> 6);
+  const int tile0 = MT == 2 ? 0 : int(base >> 5) & 1;
+  const float* sig_wg = p.saved + (size_t(row) * groups + group) * p.sig_tiles * (2 * 64 * 16);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed_bwd), 0, 0x7fffffff, 0x00020000);
   const f32x16 zero16 = {};
   auto tiles_of = [&](int n_tiles) { return n_tiles > wave ? (n_tiles - wave + WAVES - 1) / WAVES : 0; };
@@ -199,10 +208,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
         float v[MT][16];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-          const float4* sg = reinterpret_cast<const float4*>(sig_wg + ((size_t(p.sig_base[s] + n) * MT + t) * 64 + lane) * 16);
+          const float4* sg = reinterpret_cast<const float4*>(sig_wg + ((size_t(p.sig_base[s] + n) * 2 + tile0 + t) * 64 + lane) * 16);
+          // points past the row's end: the value+Jacobian forward leaves their slots unwritten (whatever the allocator
+          // handed out, NaN bit patterns included) and their accumulators are exact zeros - keep 0 x NaN out of the sums
+          const bool in_row = base + 32 * t + j < p.n_points;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 s4 = sg[q];
+            const float4 s4 = in_row ? sg[q] : make_float4(0.f, 0.f, 0.f, 0.f);
             v[t][4 * q] = acc[i][t][4 * q] * s4.x; v[t][4 * q + 1] = acc[i][t][4 * q + 1] * s4.y;
             v[t][4 * q + 2] = acc[i][t][4 * q + 2] * s4.z; v[t][4 * q + 3] = acc[i][t][4 * q + 3] * s4.w;
           }
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
   }
 }
 
-constexpr size_t lds_bytes() { return size_t(2) * PART_BYTES; }
+constexpr size_t lds_bytes(int mt) { return size_t(2) * part_bytes(mt); }
 
 }  // namespace bwd
 }  // namespace mlp
@@ -410,10 +422,16 @@ int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim
   a.hidden = hidden_dim;
   a.gb0 = grad_bias0;
   a.gb_skip = grad_bias_skip;
-  const int64_t wgs = (n_points + nphm::mlp::bwd::M - 1) / nphm::mlp::bwd::M;
+  // 64-point workgroups unless their 32-point halves still fit one round of the chip (see part_bytes)
+  int cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  const int64_t wgs32 = (n_points + 31) / 32;
+  const char* force = getenv("NPHM_AMD_MLP_BWD_POINTS");      // dev knob: 64 / 32 pins the workgroup shape (A/B runs)
+  const bool small = force && atoi(force) == 64 ? false : force && atoi(force) == 32 ? true : wgs32 * n_rows <= cus;
+  const int64_t wgs = small ? wgs32 : (n_points + 63) / 64;
   if (wgs > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_backward_cond: too many points for one launch");
-  auto k = nphm::mlp::bwd::mlp_bwd_kernel;
-  constexpr size_t lds = nphm::mlp::bwd::lds_bytes();
+  auto k = small ? nphm::mlp::bwd::mlp_bwd_kernel<1> : nphm::mlp::bwd::mlp_bwd_kernel<2>;
+  const size_t lds = nphm::mlp::bwd::lds_bytes(small ? 1 : 2);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return nphm_fail("nphm_mlp_backward_cond: LDS opt-in", e);
   hipLaunchKernelGGL(k, dim3((unsigned)wgs, n_rows), dim3(64 * nphm::mlp::WAVES), lds, static_cast<hipStream_t>(stream), a);

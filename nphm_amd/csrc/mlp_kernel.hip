@@ -189,6 +189,7 @@ struct EvalArgs {
   // MODE 0
   const float* xyz;       // [n_rows, n_points, 3]
   int64_t n_points;
+  int64_t point_base, point_end;   // MODE 0: the launch covers points [point_base, point_end) of every row (0, n_points: all)
   // KIND 2 (Broyden): xyz = initial iterates, out = final iterates [n_rows, n_points, 3]
   const float* obs;       // [n_rows, n_points, 3] observed (posed) points
   const float* jinv;      // [n_rows, n_points, 3, 3] initial inverse Jacobians
@@ -336,8 +337,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, j = lane & 31;
   const int row = blockIdx.y;
-  const int64_t base = int64_t(blockIdx.x) * PTS;
   const int64_t n_pts = MODE == 0 ? p.n_points : int64_t(p.ix1 - p.ix0) * p.ry * p.rz;
+  const int64_t base = (MODE == 0 ? p.point_base : 0) + int64_t(blockIdx.x) * PTS;
+  const int64_t n_end = MODE == 0 ? p.point_end : n_pts;          // first point of the row this launch does not own
 
   auto point_coords = [&](int64_t i, float& x, float& y, float& z) {
     const int64_t ic = i < n_pts ? i : n_pts - 1;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   bool bactive = false, bowner = false;
   if (BROY && threadIdx.x < M) {
     const int64_t i = base + threadIdx.x;
-    bowner = i < n_pts;
+    bowner = i < n_end;
     const int64_t ic = (int64_t(row) * n_pts + (bowner ? i : n_pts - 1));
 #pragma unroll
     for (int c = 0; c < 3; ++c) { bx[c] = p.xyz[ic * 3 + c]; bobs[c] = p.obs[ic * 3 + c]; }
@@ -406,7 +408,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           if constexpr (SAVE && !JVP) {
-            float* so = p.sig_out + ((((size_t(row) * gridDim.x + blockIdx.x) * p.sig_tiles + p.sig_base[layer] + wave + WAVES * i) * MT + t) * 64 + lane) * 16;
+            static_assert(!(SAVE && !JVP) || M == 64, "the saving forward runs 64-point workgroups (mlp_bwd_kernel's layout)");
+            float* so = p.sig_out + ((((size_t(row) * size_t((n_pts + 63) >> 6) + size_t(base >> 6)) * p.sig_tiles + p.sig_base[layer] + wave + WAVES * i) * MT + t) * 64 + lane) * 16;
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
               float4 sg = make_float4(sigmoid2(acc[i][t][r]), sigmoid2(acc[i][t][r + 1]), sigmoid2(acc[i][t][r + 2]), sigmoid2(acc[i][t][r + 3]));
@@ -415,12 +418,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           }
           if constexpr (SAVE && JVP) {
             // the value stream (columns 0 .. PTS-1 of point tile 0) into the 64-point-workgroup layout mlp_bwd_kernel reads:
-            // this workgroup's PTS = 16 points are lanes 16 (b & 1) .. + 15 of point tile (b >> 1) & 1 of workgroup b >> 2
-            static_assert(!JVP || PTS == 16, "value + Jacobian workgroups hold 16 points");
+            // this workgroup's PTS (16, or 8 in the 32-column form) points start at `base` (a multiple of PTS): 64-point group
+            // base / 64, point tile (base / 32) & 1, lanes base % 32 .. + PTS - 1 of it.  (The saved layout has TWO point tiles
+            // per 64-point group whatever MT is here.)
+            static_assert(!JVP || PTS == 16 || PTS == 8, "value + Jacobian workgroups hold 16 or 8 points");
             if (t == 0 && j < PTS) {
-              const unsigned b = blockIdx.x;
-              const size_t wg64 = size_t(row) * ((gridDim.x + 3) >> 2) + (b >> 2);
-              float* so = p.sig_out + (((wg64 * p.sig_tiles + p.sig_base[layer] + wave + WAVES * i) * MT + ((b >> 1) & 1)) * 64 + 32 * h + 16 * (b & 1) + j) * 16;
+              const size_t wg64 = size_t(row) * size_t((n_pts + 63) >> 6) + size_t(base >> 6);
+              float* so = p.sig_out + (((wg64 * p.sig_tiles + p.sig_base[layer] + wave + WAVES * i) * 2 + ((base >> 5) & 1)) * 64 + 32 * h + int(base & 31) + j) * 16;
 #pragma unroll
               for (int r = 0; r < 16; r += 4) {
                 float4 sg = make_float4(sigmoid2(acc[i][0][r]), sigmoid2(acc[i][0][r + 1]), sigmoid2(acc[i][0][r + 2]), sigmoid2(acc[i][0][r + 3]));
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
         const int m = e / p.out_dim, c = e % p.out_dim;
         const int stream = m / PTS;                       // 0 unless JVP
         const int64_t i = base + m % PTS;
-        if (i < n_pts) {
+        if (i < n_end) {
           float v = 0.f;
 #pragma unroll
           for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
@@ -770,10 +774,24 @@ using nphm::mlp::Plan;
 // bits 8.. = mask of the hidden layers that run the two-term product (bit l = linear layer l; layer 0 and the last never)
 static bool mlp_numerics_ok(int numerics) { return (numerics & 0xff) <= 1 && numerics >= 0; }
 
+// `columns` (value + Jacobian launches, hidden <= 512): 64 = 16 points per workgroup (default), 32 = 8 points per workgroup
+// (64 KiB of LDS, two workgroups per CU) - the caller splits a launch whose 16-point workgroups would fill 1.2 rounds of the
+// chip into one full round of them and a round of the small ones over the remaining points (a.point_base / a.point_end)
 template <int MODE, int KIND = 0>
-static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st, int numerics = 0) {
+static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st, int numerics = 0,
+                       int columns = 64) {
   using namespace nphm::mlp;
   const bool f16 = (numerics & 0xff) == 1;
+  if (MODE == 0) {
+    if (a.point_end == 0 && a.point_base == 0) a.point_end = a.n_points;                 // the whole row
+    if (a.point_base < 0 || a.point_end > a.n_points || a.point_base >= a.point_end)
+      return nphm_fail_msg("nphm_mlp_eval: bad point range");
+    n_pts = a.point_end - a.point_base;                                                  // points per row of THIS launch
+  }
+  constexpr bool JVPK = KIND == 1 || KIND == 4;
+  if (columns != 64 && !(JVPK && columns == 32 && plan.variant == 0))
+    return nphm_fail_msg("nphm_mlp_eval: 32-column workgroups exist for the value + Jacobian launches of hidden <= 512 nets");
+  if (JVPK && (a.point_base % (columns / 4)) != 0) return nphm_fail_msg("nphm_mlp_eval: point_base must be a multiple of the workgroup's points");
   for (int l = 0; l < plan.n_linear; ++l) {
     a.layer[l].n_tiles = plan.layer[l].n_tiles;
     a.layer[l].k_steps = plan.layer[l].k_steps;
@@ -789,8 +807,8 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   for (int l = 0; l < plan.n_linear - 1; ++l) { a.sig_base[l] = a.sig_tiles; a.sig_tiles += plan.layer[l].n_tiles; }
   // Small Broyden batches of the hidden <= 512 nets (the fitting loop: 5 x 1000 points) run 32 points per workgroup:
   // twice the workgroups (the 64-point form occupies 79 of the 256 CUs) at 64 KiB of LDS: 272 -> 205 us.
-  constexpr bool SMALL_OK = KIND == 2 && MODE == 0;      // (the value+Jacobian launch measured 244 us with 32 columns, 213 with 64)
-  const bool small = SMALL_OK && plan.variant == 0 && n_pts * int64_t(n_rows) * (KIND == 1 ? 4 : 1) <= 64 * 1024
+  constexpr bool SMALL_OK = (KIND == 2 || JVPK) && MODE == 0;      // (a whole value+Jacobian launch measured 244 us with 32 columns, 213 with 64)
+  const bool small = SMALL_OK && plan.variant == 0 && (JVPK ? columns == 32 : n_pts * int64_t(n_rows) <= 64 * 1024)
 #ifdef NPHM_MLP_NO_SMALL
                      && false
 #endif
@@ -949,7 +967,7 @@ int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int ou
 int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                                     const void* packed, const void* latent_state,
                                     const float* xyz, int n_rows, int64_t n_points, int add_input,
-                                    float* out, void* saved, int numerics, void* stream) {
+                                    float* out, void* saved, int numerics, int64_t point_base, int64_t point_count, int columns, void* stream) {
   Plan plan;
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: unsupported architecture");
   if (!packed || !latent_state || !xyz || !out || !saved) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: null pointer");
@@ -965,13 +983,15 @@ int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, in
   a.n_points = n_points;
   a.sig_out = static_cast<float*>(saved);
   if (!mlp_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: unknown numerics format");
-  return launch_eval<0, 4>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream), numerics);
+  a.point_base = point_base;
+  a.point_end = point_count > 0 ? point_base + point_count : (point_base == 0 ? 0 : n_points);
+  return launch_eval<0, 4>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream), numerics, columns == 0 ? 64 : columns);
 }
 
 int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                              const void* packed, const void* latent_state,
                              const float* xyz, int n_rows, int64_t n_points, int add_input,
-                             float* out, int numerics, void* stream) {
+                             float* out, int numerics, int64_t point_base, int64_t point_count, int columns, void* stream) {
   Plan plan;
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points_jvp: unsupported architecture");
   if (!packed || !latent_state || !xyz || !out) return nphm_fail_msg("nphm_mlp_eval_points_jvp: null pointer");
@@ -986,7 +1006,9 @@ int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_d
   a.xyz = xyz;
   a.n_points = n_points;
   if (!mlp_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_points_jvp: unknown numerics format");
-  return launch_eval<0, 1>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream), numerics);
+  a.point_base = point_base;
+  a.point_end = point_count > 0 ? point_base + point_count : (point_base == 0 ? 0 : n_points);
+  return launch_eval<0, 1>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream), numerics, columns == 0 ? 64 : columns);
 }
 
 int nphm_mlp_broyden(int lat_dim, int hidden_dim, int nlayers, int out_dim,

@@ -53,9 +53,11 @@ class _MlpCondFn(torch.autograd.Function):
         code = module._fit_code(packed, state, xyz_c)
         if with_jacobian:
             out = torch.empty(R, n, 4, module.n_out, dtype=torch.float32, device=dev)
-            _lib.check(lib.nphm_mlp_eval_points_jvp_saving(*module._arch(), packed.data_ptr(), state.data_ptr(),
-                                                           xyz_c.data_ptr(), R, n, int(bool(add_input)), out.data_ptr(),
-                                                           saved.data_ptr(), code, stream), "nphm_mlp_eval_points_jvp_saving")
+            for p0, cnt, cols in module._jvp_split(R, n, dev, 64):
+                _lib.check(lib.nphm_mlp_eval_points_jvp_saving(*module._arch(), packed.data_ptr(), state.data_ptr(),
+                                                               xyz_c.data_ptr(), R, n, int(bool(add_input)), out.data_ptr(),
+                                                               saved.data_ptr(), code, p0, cnt, cols, stream),
+                           "nphm_mlp_eval_points_jvp_saving")
         else:
             out = torch.empty(R, n, module.n_out, dtype=torch.float32, device=dev)
             _lib.check(lib.nphm_mlp_eval_points_saving(*module._arch(), packed.data_ptr(), state.data_ptr(), xyz_c.data_ptr(),
@@ -366,6 +368,23 @@ class DeepSDF(nn.Module):
                                       recalibrated_for_conditioning=True)
         return fmt | (mask << 8)
 
+    def _jvp_split(self, R, n, device, align):
+        """How a value+Jacobian launch over R rows x n points is cut: [(point_base, point_count, columns)].  Its workgroups
+        hold 16 points (64 columns: value + three tangents); when they would fill between 1 and 1.5 rounds of the chip (the
+        fitting loop: 5 x 1000 points = 315 workgroups on 256 CUs, the second round a fifth full) the first round takes as
+        many whole rows-of-16 as fit and the REST runs as 8-point workgroups (32 columns, half the LDS: two per CU), whose
+        round is shorter.  ``align``: granularity of the cut (16; 64 for the sigma'-saving form)."""
+        if self.hidden_dim > 512 or os.environ.get("NPHM_AMD_JVP_SPLIT", "1") in ("0", ""):
+            return [(0, 0, 64)]
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        wgs = R * ((n + 15) // 16)
+        if not (cus < wgs <= cus + cus // 2):
+            return [(0, 0, 64)]
+        n_a = ((cus // R) * 16) // align * align
+        if n_a <= 0 or n_a >= n:
+            return [(0, 0, 64)]
+        return [(0, n_a, 64), (n_a, n - n_a, 32)]
+
     def _fit_code(self, packed, state, xyz):
         """`numerics` argument of the tangent / Broyden / saving launches (``fit_numerics``).  xyz [B,N,3]: this call's points."""
         if self.fit_numerics not in ("auto", "bf16x3", "f16x3"):
@@ -415,8 +434,10 @@ class DeepSDF(nn.Module):
         xyz = xyz.contiguous().float()
         out = torch.empty(B, N, 4, self.n_out, dtype=torch.float32, device=xyz.device)
         stream = torch.cuda.current_stream(xyz.device).cuda_stream
-        _lib.check(lib.nphm_mlp_eval_points_jvp(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(),
-                                                B, N, int(bool(add_input)), out.data_ptr(), self._fit_code(packed, state, xyz), stream),
+        code = self._fit_code(packed, state, xyz)
+        for p0, cnt, cols in self._jvp_split(B, N, xyz.device, 16):
+            _lib.check(lib.nphm_mlp_eval_points_jvp(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(),
+                                                    B, N, int(bool(add_input)), out.data_ptr(), code, p0, cnt, cols, stream),
                    "nphm_mlp_eval_points_jvp")
         return out
 

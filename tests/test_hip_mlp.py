@@ -438,10 +438,12 @@ def test_npm_full_size_64_cubed_vs_reference_sequence(npm, dev):
 # ---------------------------------------------------------------------------------------------
 # hand-written backward of the deformation backbone w.r.t. its conditioning (fitting loop)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 64, 777])
+@pytest.mark.parametrize("n", [1, 64, 777, 4133, 9000])
 def test_backward_wrt_conditioning_matches_autograd(dev, n):
     """d/d(lat_rep, anchors) of sum(offsets * cotangent) through DeformationNetwork with frozen parameters and
-    detached points: HIP forward + mlp_bwd_kernel vs autograd through the composite formulation."""
+    detached points: HIP forward + mlp_bwd_kernel vs autograd through the composite formulation.  (2 x n points: up to
+    2 x 4096 run as 32-point workgroups - one round of 256 CUs -, beyond as 64-point ones; 4133 ends inside the first
+    tile of a 64-point group, 777 inside the first tile of an odd 32-point workgroup's group.)"""
     net = _exact(U.build_deformation(device=dev).eval())
     for p in net.parameters():
         p.requires_grad_(False)
@@ -662,3 +664,44 @@ def test_fit_tier_two_term_layers_against_the_three_term_launches(dev):
     mlp.fit_numerics = "bf16x3"                        # rounds 1-3: still available, three-term on bf16 halves
     p_b, J_b, g_b = run()
     assert float((p_b - p_x).abs().max()) < 3e-6 and float((J_b - J_x).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("tier", ["f16x3", "auto"])
+def test_value_jacobian_launch_cut_in_16_and_8_point_workgroups_is_bitwise_the_single_launch(dev, tier, monkeypatch):
+    """The fitting batch (5 x 1000 points) runs its value+Jacobian launches as one chip-filling round of 16-point
+    workgroups + the rest as 8-point workgroups (DeepSDF._jvp_split): values, Jacobians, and the conditioning gradient
+    the saved state yields are bit-identical to the single 16-point launch (same per-point arithmetic, other geometry)."""
+    net = U.build_deformation(device=dev).eval()
+    net.defDeepSDF.fit_numerics = tier
+    for p in net.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(33)
+    R, n = 5, 1000
+    xyz = ((torch.rand(R, n, 3, generator=g) - 0.5) * 0.6).to(dev)
+    cot = torch.randn(R, n, 3, generator=g).to(dev)
+    lat0 = (torch.randn(R, 1, 1544, generator=g) * 0.05).to(dev)
+    anc = (torch.from_numpy(U.anchors_mean()).float()[None] + 0.01 * torch.randn(R, 39, 3, generator=g)).to(dev)
+    mlp = net.defDeepSDF
+    res = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("NPHM_AMD_JVP_SPLIT", split)
+        cuts = mlp._jvp_split(R, n, dev, 64)
+        assert (len(cuts) == 2 and cuts[0][2] == 64 and cuts[1][2] == 32 and cuts[0][1] + cuts[1][1] == n
+                and cuts[0][1] % 64 == 0) if split == "1" else cuts == [(0, 0, 64)]
+        lat = lat0.clone().requires_grad_(True)
+        # the saved-state buffer comes from the caching allocator unwritten past each row's end: hand it NaNs
+        from nphm_amd import _lib
+        nbytes = _lib.load().nphm_mlp_saved_bytes(*mlp._arch(), R, n)
+        poison = torch.full((nbytes // 4,), float("nan"), device=dev)
+        del poison
+        posed, J = net.posed_and_jacobian(xyz, lat, anc)
+        (posed * cot).sum().backward()
+        assert bool(torch.isfinite(lat.grad).all())
+        _, J2 = net.jacobian(xyz, lat0, anc)
+        res[split] = (posed.detach().clone(), J.clone(), lat.grad.clone(), J2.clone())
+    (p1, j1, g1, jj1), (p0, j0, g0, jj0) = res["1"], res["0"]
+    assert torch.equal(p1, p0) and torch.equal(j1, j0) and torch.equal(jj1, jj0)
+    # (the conditioning gradient sums the saved state over the row's points with float atomics: equal up to their order)
+    assert float((g1 - g0).abs().max()) < 2e-6 * float(g0.abs().max())
+    # a launch too small or too large for the cut keeps the single form
+    assert mlp._jvp_split(1, 1000, dev, 16) == [(0, 0, 64)] and mlp._jvp_split(64, 1000, dev, 16) == [(0, 0, 64)]
