@@ -27,6 +27,10 @@
 
 #include "member_common.h"
 
+#ifndef NPHM_BWD_RING
+#define NPHM_BWD_RING 4        // K-steps of weight fragments a wavefront of the backward kernel keeps in flight (LDS ring)
+#endif
+
 namespace nphm {
 namespace bwd {
 
@@ -114,33 +118,77 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
   const float sign_x = (k < 2 * N_SYMM && (k & 1)) ? -1.f : 1.f;
   const float w_bg = expf(-0.2f / 0.01f);
 
-  // ---- per point (threads < M): coordinates, blend weights --------------------------------------
+  const uint16_t* fw = p.packed_bf16 + size_t(set) * BF_SET_STRIDE;
+  const uint16_t* bw = p.packed_bwd + size_t(set) * BWD_SET_STRIDE;
+  // The backward variant streams its weights through the per-wavefront LDS ring (member_common.h): RING K-steps in
+  // flight, prologue of a stage issued as soon as the previous stage's K loop is done (weights do not depend on
+  // activations), fully unrolled K loop so that every vmcnt count is an immediate.  prefetch + run must be paired.
+  constexpr int RING = BWD ? NPHM_BWD_RING : 0;
+  __shared__ __attribute__((aligned(16))) char wring[RING ? WAVES * RING * 2048 : 16];
+  const unsigned ring_lds = lds_addr_of(wring) + unsigned(wave) * (RING * 2048);
+  const bf16x8* const R = reinterpret_cast<const bf16x8*>(wring + wave * (RING * 2048)) + lane;
+  const unsigned voff = unsigned(lane) * 16u;
+  auto ring_prefetch = [&](const uint16_t* frag_base, int n, auto ks_c) __attribute__((always_inline)) {
+    constexpr int KS = decltype(ks_c)::value;
+    static_assert(RING == 0 || KS >= RING, "a stage fills the ring");
+    const v4i rs = raw_rsrc(frag_base);
+    const unsigned s0 = unsigned(n * KS) * 2048u;
+#pragma unroll
+    for (int u = 0; u < RING; ++u) dma_kstep(rs, voff, s0 + unsigned(u) * 2048u, ring_lds + unsigned(u) * 2048u);
+  };
+  if constexpr (RING) {                  // the first stage this wavefront runs (4 .. 6 sit out lin1)
+    if (wave < L1_OB) ring_prefetch(fw + BF_OFF_L1A, wave, std::integral_constant<int, L1_KS16>{});
+    else if (wave < 7) ring_prefetch(fw + BF_OFF_L2A, wave, std::integral_constant<int, L2_KS16>{});
+  }
+  // ---- per point: coordinates, blend weights --------------------------------------------------------
+  // backward: the denominator sum_a w_a of the point in lane m, the 39 anchors dealt over the 8 wavefronts (5 steps instead
+  // of 39 on one wavefront while seven wait at the barrier); the forward-only kernel needs no blend weight at all
+  if (BWD) {
+    const int m = lane;
+    const int n = p.list[off + (m < cnt ? m : cnt - 1)];
+    const float* q = p.xyz + (int64_t(row) * p.n_points + n) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    float s = 0.f;
+#pragma unroll 1
+    for (int a = wave; a < N_LOC; a += WAVES) {
+      const float dx = anch[3 * a] - qx, dy = anch[3 * a + 1] - qy, dz = anch[3 * a + 2] - qz;
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-5f;
+      s += expf(-(d * d) / 0.01f);
+    }
+    part[wave][m] = s;
+    __syncthreads();
+  }
   if (threadIdx.x < M) {
     const int m = threadIdx.x;
     const bool ok = m < cnt;
     const int n = p.list[off + (ok ? m : cnt - 1)];
     const float* q = p.xyz + (int64_t(row) * p.n_points + n) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
-    float S = w_bg, wk = w_bg, dk = 0.f, nk = 1.f, ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll 1
-    for (int a = 0; a < N_LOC; ++a) {
-      const float dx = anch[3 * a] - qx, dy = anch[3 * a + 1] - qy, dz = anch[3 * a + 2] - qz;
-      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-      const float d = nrm + 1e-5f;
-      const float w = expf(-(d * d) / 0.01f);
-      S += w;
-      if (a == k) { wk = w; dk = d; nk = nrm; ax = anch[3 * a]; ay = anch[3 * a + 1]; az = anch[3 * a + 2]; }
+    float wk = w_bg, dk = 0.f, nk = 1.f, ax = 0.f, ay = 0.f, az = 0.f;
+    if (k < N_LOC) {
+      ax = anch[3 * k]; ay = anch[3 * k + 1]; az = anch[3 * k + 2];
+      if (BWD) {
+        const float dx = ax - qx, dy = ay - qy, dz = az - qz;
+        nk = sqrtf(dx * dx + dy * dy + dz * dz);
+        dk = nk + 1e-5f;
+        wk = expf(-(dk * dk) / 0.01f);
+      }
     }
-    const float denom = S + 1e-6f;
-    const float g = ok ? p.gout[int64_t(row) * p.n_points + n] : 0.f;
     pt_idx[m] = ok ? n : -1;
     pt_q[m][0] = qx; pt_q[m][1] = qy; pt_q[m][2] = qz; pt_q[m][3] = nk;
     pt_c[m][0] = sign_x * (qx - ax); pt_c[m][1] = qy - ay; pt_c[m][2] = qz - az; pt_c[m][3] = 0.f;
-    pt_g[m][0] = g * wk / denom;                                       // d L / d f_k
-    // d L / d w_k * d w_k / d d  (without the (f_k - sdf) factor, which needs the forward value)
-    pt_g[m][1] = (k < N_LOC) ? g / denom * wk * (-2.f * dk / 0.01f) : 0.f;
-    pt_g[m][2] = ok ? p.sdf[int64_t(row) * p.n_points + n] : 0.f;
-    pt_g[m][3] = 0.f;
+    if (BWD) {
+      float S = w_bg;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) S += part[w][m];
+      const float denom = S + 1e-6f;
+      const float g = ok ? p.gout[int64_t(row) * p.n_points + n] : 0.f;
+      pt_g[m][0] = g * wk / denom;                                       // d L / d f_k
+      // d L / d w_k * d w_k / d d  (without the (f_k - sdf) factor, which needs the forward value)
+      pt_g[m][1] = (k < N_LOC) ? g / denom * wk * (-2.f * dk / 0.01f) : 0.f;
+      pt_g[m][2] = ok ? p.sdf[int64_t(row) * p.n_points + n] : 0.f;
+      pt_g[m][3] = 0.f;
+    }
   }
   __syncthreads();
 
@@ -154,8 +202,6 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
     bv[t] = coord_operand(cx[t], cy[t], cz[t], h);
   }
 
-  const uint16_t* fw = p.packed_bf16 + size_t(set) * BF_SET_STRIDE;
-  const uint16_t* bw = p.packed_bwd + size_t(set) * BWD_SET_STRIDE;
   const float* tails = st + LS_OFF_TAIL + size_t(k) * GEMM_CHUNKS * TAIL_FLOATS;
   const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
   const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
@@ -190,6 +236,35 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
       if (s + 2 < ks) load(0, s + 2);
       if (s + 1 < ks) mma(1);
     }
+  };
+  auto gemm_ring = [&](f32x16 (&acc)[MT], const uint16_t* frag_base, int n, auto ks_c) __attribute__((always_inline)) {
+    constexpr int KS = decltype(ks_c)::value;
+    constexpr int RG = RING ? RING : 1;
+    const v4i rs = raw_rsrc(frag_base);
+    const unsigned s0 = unsigned(n * KS) * 2048u;
+    bf16x8 ah[2], al[2], bh[MT], bl[MT];               // A: two K-steps; B: one per point tile, reloaded behind its MFMAs
+    wait_vm<2 * (RG - 1)>();                           // K-step 0 has landed
+    ah[0] = R[0]; al[0] = R[64];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { bh[t] = Bh[32 * t]; bl[t] = Bl[32 * t]; }
+    static_for<KS>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value, cur = S & 1, nxt = cur ^ 1;
+      if constexpr (S + 1 < KS) {
+        // K-steps issued so far: 0 .. min(S + RING, KS) - 1; those after S + 1 may still be in flight
+        constexpr int issued = S + RG < KS ? S + RG : KS;
+        wait_vm<2 * (issued - 1 - (S + 1))>();
+        ah[nxt] = R[((S + 1) % RG) * 128]; al[nxt] = R[((S + 1) % RG) * 128 + 64];
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[t], acc[t], 0, 0, 0);
+        if constexpr (S + 1 < KS) { bh[t] = Bh[2 * (S + 1) * M + 32 * t]; bl[t] = Bl[2 * (S + 1) * M + 32 * t]; }
+      }
+      // slot of K-step S: its fragments went to registers one step ago and have just been consumed
+      if constexpr (S + RG < KS) dma_kstep(rs, voff, s0 + unsigned(S + RG) * 2048u, ring_lds + unsigned(S % RG) * 2048u);
+    });
   };
   // D tile n -> LDS K chunks 4n + 2*half + h of the points
   auto store_tile = [&](int n, const f32x16 (&v)[MT]) __attribute__((always_inline)) {
@@ -230,7 +305,8 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
   if (wave < L1_OB) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = load_frag16(tails + wave * TAIL_FLOATS + h * 16);
-    gemm_tile(acc, fw + BF_OFF_L1A, wave, L1_KS16);
+    if constexpr (RING) { gemm_ring(acc, fw + BF_OFF_L1A, wave, std::integral_constant<int, L1_KS16>{}); ring_prefetch(fw + BF_OFF_L2A, wave, std::integral_constant<int, L2_KS16>{}); }
+    else gemm_tile(acc, fw + BF_OFF_L1A, wave, L1_KS16);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -249,7 +325,8 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
   if (wave < 7) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = load_frag16(tails + (L1_OB + wave) * TAIL_FLOATS + h * 16);
-    gemm_tile(acc, fw + BF_OFF_L2A, wave, L2_KS16);
+    if constexpr (RING) { gemm_ring(acc, fw + BF_OFF_L2A, wave, std::integral_constant<int, L2_KS16>{}); ring_prefetch(fw + BF_OFF_L3A, wave, std::integral_constant<int, L3_KS16>{}); }
+    else gemm_tile(acc, fw + BF_OFF_L2A, wave, L2_KS16);
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -264,7 +341,8 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
     const float* tl = tails + (L1_OB + L2_OB + wave) * TAIL_FLOATS;
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = load_frag16(tl + h * 16);
-    gemm_tile(acc, fw + BF_OFF_L3A, wave, L3_KS16);
+    if constexpr (RING) { gemm_ring(acc, fw + BF_OFF_L3A, wave, std::integral_constant<int, L3_KS16>{}); ring_prefetch(bw + OFF_A, wave, std::integral_constant<int, A_KS>{}); }
+    else gemm_tile(acc, fw + BF_OFF_L3A, wave, L3_KS16);
     w4v = load_frag16(tl + 32 + h * 16);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -288,7 +366,7 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
       if (pt_idx[m] >= 0) p.fmem[(int64_t(row) * p.n_points + pt_idx[m]) * N_MEMBERS + k] = f;
     }
     // blend-weight term: d L / d q += g (f_k - sdf) / denom * d w_k / d d * (q - a_k) / |q - a_k|
-    pt_g[m][3] = pt_g[m][1] * (f - pt_g[m][2]);
+    if (BWD) pt_g[m][3] = pt_g[m][1] * (f - pt_g[m][2]);
   }
   if (!BWD) return;
   __syncthreads();
@@ -309,7 +387,8 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
   if (wave < 7) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = zero16;
-    gemm_tile(acc, bw + OFF_A, wave, A_KS);
+    gemm_ring(acc, bw + OFF_A, wave, std::integral_constant<int, A_KS>{});
+    if (wave < B_OB) ring_prefetch(bw + OFF_B, wave, std::integral_constant<int, B_KS>{}); else ring_prefetch(bw + OFF_C, wave, std::integral_constant<int, C_KS>{});
     float* gb = p.gb2 + (size_t(row) * N_MEMBERS + k) * HID;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -328,7 +407,8 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
   if (wave < B_OB) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = zero16;
-    gemm_tile(acc, bw + OFF_B, wave, B_KS);
+    gemm_ring(acc, bw + OFF_B, wave, std::integral_constant<int, B_KS>{});
+    ring_prefetch(bw + OFF_C, wave, std::integral_constant<int, C_KS>{});
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -348,7 +428,8 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
   if (wave < 7) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = zero16;
-    gemm_tile(acc, bw + OFF_C, wave, C_KS);
+    gemm_ring(acc, bw + OFF_C, wave, std::integral_constant<int, C_KS>{});
+    if (wave == 0) ring_prefetch(bw + OFF_D, 0, std::integral_constant<int, D_KS>{});
     float* gb = p.gb0 + (size_t(row) * N_MEMBERS + k) * HID;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -367,7 +448,7 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
   if (wave == 0) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = zero16;
-    gemm_tile(acc, bw + OFF_D, 0, D_KS);
+    gemm_ring(acc, bw + OFF_D, 0, std::integral_constant<int, D_KS>{});
     if (h == 0) {
 #pragma unroll
       for (int t = 0; t < MT; ++t) {

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "layout.h"
 
@@ -113,6 +114,45 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 #endif
+}
+
+// ---- per-wavefront LDS ring of weight K-steps, filled by LDS-DMA ------------------------------------------------------
+// The member-centric kernels give every wavefront its own output tile, so a weight fragment is read by ONE wavefront, once
+// per tile: through VGPRs (two K-steps in flight: all the registers left next to the sweep's sigma' state) every K-step
+// waits for most of an L2 round trip - 0.6 us x 13 K-steps x 8 GEMM stages is the 58 us a tile took on a CU that needs 12 us
+// of MFMA time for it.  MUBUF loads with the LDS destination (buffer_load ... lds, the fused kernel's weight path,
+// eval_kernel.hip) cost no VGPRs and are not tracked by the compiler: a wavefront keeps RING K-steps (2 KiB each: hi | lo
+// fragments, contiguous in both packs) in flight into its private slice of LDS and waits with explicit vmcnt counts.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i raw_rsrc(const void* base) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  v4i r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));   // stride 0: raw buffer
+  r[2] = 0x7fffffff;
+  r[3] = 0x00020000;                                                             // gfx950 raw-buffer descriptor word
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* q) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)q;
+}
+// one K-step: 2 x 1 KiB (lane's 16 bytes at voff = 16 lane), memory offset soff (SGPR), LDS destination lds_dst (M0 is
+// reserved for hipcc: saved and restored inside the statement)
+__device__ __forceinline__ void dma_kstep(const v4i& rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+               "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 }  // namespace bwd

@@ -298,7 +298,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
       const unsigned w_lane = lane * 16;
       const bf16x8* Bh = reinterpret_cast<const bf16x8*>(act_hi) + h * M + j;
       const bf16x8* Bl = reinterpret_cast<const bf16x8*>(act_lo) + h * M + j;
-      bf16x8 ah[2][NTW], al[2][NTW], bh[2][MT], bl[2][MT];
+      // A fragments: NS K-steps in flight (32-point workgroups: 6 MFMAs per step and registers to spare - four; mlp_kernel.hip)
+      constexpr int NS = MT == 1 ? 4 : 2;
+      bf16x8 ah[NS][NTW], al[NS][NTW], bh[2][MT], bl[2][MT];
       auto load_a = [&](int slot, int k) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
@@ -316,33 +318,36 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
           bl[slot][t] = Bl[2 * k * M + 32 * t];
         }
       };
-      auto mma = [&](int slot) __attribute__((always_inline)) {
+      auto mma = [&](int sa, int sb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
           if (i < ni) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot][i], bh[slot][t], acc[i][t], 0, 0, 0);
-              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot][i], bl[slot][t], acc[i][t], 0, 0, 0);
-              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot][i], bh[slot][t], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sa][i], bh[sb][t], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sa][i], bl[sb][t], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[sa][i], bh[sb][t], acc[i][t], 0, 0, 0);
             }
           }
         }
       };
-      load_a(0, 0);
-      load_a(1, 1);
+#pragma unroll
+      for (int u = 0; u < NS; ++u) if (u < 2 || u < ks) load_a(u, u);
       load_b(0, 0);
+      // slot u holds K-step k + u; the B operand alternates its two slots (k_steps is even: the steps u >= 2 of the last
+      // round may not exist)
 #pragma unroll 1
-      for (int k = 0; k < ks; k += 2) {
-        load_b(1, k + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 2 < ks) { load_a(0, k + 2); load_b(0, k + 2); }
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 3 < ks) load_a(1, k + 3);
+      for (int k = 0; k < ks; k += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          if (u < 2 || k + u < ks) {
+            if (k + u + 1 < ks) load_b((u + 1) & 1, k + u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(u, u & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + u + NS < ks) load_a(u, k + u + NS);
+          }
+        }
       }
     }
     finish(s, ni);

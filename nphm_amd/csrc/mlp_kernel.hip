@@ -511,7 +511,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #define NPHM_MLP_XPREFETCH 1
 #endif
   const unsigned w_lane = lane * 16;
-  frag_t ah[2][NTW], al[2][NTW];
+  // K-steps of A fragments in flight per wavefront.  A K-step of the 32-column workgroups (MT = 1: the small launches of the
+  // fitting loop) is 4 - 6 MFMAs: two steps ahead cover a third of an L2 round trip, and these variants leave > 100 VGPRs
+  // unused - they keep four.  (NTW = 4 or MT = 2: no registers to spare.)
+#ifndef NPHM_MLP_SLOTS_SMALL
+#define NPHM_MLP_SLOTS_SMALL 4
+#endif
+  constexpr int NS = (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
+  static_assert(NS % 2 == 0, "the B operand's two slots alternate with the K-step");
+  frag_t ah[NS][NTW], al[NS][NTW];
   // Terms of the split product of a layer: three = xh wh + xl wh + xh wl, two = without the wl term (EvalArgs::two_pass_mask).
   // One loop body serves both (two specialised loops under a branch made hipcc spill 60-250 VGPRs): the wl fragments of a
   // two-term layer are requested out of the buffer's range (lo_lane: the range check covers the VGPR offset; such a load
@@ -531,8 +539,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     const LayerDev& L1 = p.layer[1];
     const int n1 = tiles_of(L1.n_tiles);
     const unsigned lo1 = lo_lane_of(1);
-    load_a(L1, n1, 0, 0, lo1);
-    load_a(L1, n1, 1, 1, lo1);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) if (u < 2 || u < L1.k_steps) load_a(L1, n1, u, u, lo1);
   }
 #pragma unroll 1
   for (int l = 1; l < p.n_linear - 1; ++l) {
@@ -554,14 +562,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           bl[slot][t] = Bl[2 * s * M + 32 * t];
         }
       };
-      auto mma = [&](int slot) __attribute__((always_inline)) {
+      auto mma = [&](int sa, int sb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
           if (i < ni) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-              acc[i][t] = mfma16<F16>(ah[slot][i], bh[slot][t], acc[i][t]);
-              acc[i][t] = mfma16<F16>(ah[slot][i], bl[slot][t], acc[i][t]);
+              acc[i][t] = mfma16<F16>(ah[sa][i], bh[sb][t], acc[i][t]);
+              acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]);
             }
           }
         }
@@ -570,35 +578,38 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           for (int i = 0; i < NTW; ++i) {
             if (i < ni) {
 #pragma unroll
-              for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(al[slot][i], bh[slot][t], acc[i][t]);
+              for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(al[sa][i], bh[sb][t], acc[i][t]);
             }
           }
         }
       };
       if (!NPHM_MLP_XPREFETCH) {
-        load_a(L, ni, 0, 0, lo_lane);
-        load_a(L, ni, 1, 1, lo_lane);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) if (u < 2 || u < ks) load_a(L, ni, u, u, lo_lane);
       }
       load_b(0, 0);
+      // slot u holds K-step s + u, the B operand alternates its two slots (k_steps is even, mlp_layout.h: the steps
+      // u >= 2 of the last round may not exist)
 #pragma unroll 1
-      for (int s = 0; s < ks; s += 2) {
-        load_b(1, s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < ks) { load_a(L, ni, 0, s + 2, lo_lane); load_b(0, s + 2); }
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 3 < ks) load_a(L, ni, 1, s + 3, lo_lane);
+      for (int s = 0; s < ks; s += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          if (u < 2 || s + u < ks) {
+            if (s + u + 1 < ks) load_b((u + 1) & 1, s + u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(u, u & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + u + NS < ks) load_a(L, ni, u, s + u + NS, lo_lane);
+          }
+        }
       }
     }
     if (NPHM_MLP_XPREFETCH && l + 1 < p.n_linear - 1) {
       const LayerDev& Ln = p.layer[l + 1];
       const int nn = tiles_of(Ln.n_tiles);
       const unsigned lon = lo_lane_of(l + 1);
-      load_a(Ln, nn, 0, 0, lon);
-      load_a(Ln, nn, 1, 1, lon);
+#pragma unroll
+      for (int u = 0; u < NS; ++u) if (u < 2 || u < Ln.k_steps) load_a(Ln, nn, u, u, lon);
       __builtin_amdgcn_sched_barrier(0);
     }
     activate(ni, l);

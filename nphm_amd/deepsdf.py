@@ -72,11 +72,14 @@ class _MlpCondFn(torch.autograd.Function):
         # backward below would copy the slice out again
         jac = out[:, :, 1:]
         ctx.mark_non_differentiable(jac)
+        ctx.set_materialize_grads(False)       # (no zeros [R,n,3,out] + fill launch for the Jacobian's absent gradient)
         return out[:, :, 0], jac
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out, _grad_jac=None):
+        if grad_out is None:
+            return None, None, None, None, None
         lib = _lib.load()
         module = ctx.module
         (saved,) = ctx.saved_tensors

@@ -294,11 +294,14 @@ class _FitLossFn(torch.autograd.Function):
         ctx.save_for_backward(sdf_c, valid_c, zs, ze, obs_idx, thr, lam6)
         ctx.shapes = (sdf.shape, z_shape.shape, None if z_expr is None else z_expr.shape)
         ctx.mark_non_differentiable(row)
+        ctx.set_materialize_grads(False)       # (no zeros [8] + fill launch for the report row's absent gradient)
         return buf[8], row
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_total, _g_row):
+        if g_total is None:
+            return None, None, None, None, None, None, None
         from . import _lib
         lib = _lib.load()
         sdf_c, valid_c, zs, ze, obs_idx, thr, lam6 = ctx.saved_tensors
