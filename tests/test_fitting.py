@@ -406,11 +406,12 @@ def test_joint_fit_on_trained_identity_and_deformation_weights_gpu():
     print(f"trained pair, 60 steps: surface trace max abs {d.max():.2e}, max rel {(d / rsurf).max():.2e}, first 10 steps rel "
           f"{(d / rsurf)[:10].max():.2e}; end of fit {surf[-10:].mean():.4e} vs {rsurf[-10:].mean():.4e}; fit-tier mask "
           f"{None if fc is None else hex(fc[1])}")
-    # The first steps separate tier accuracy from the loop's own sensitivity: steps 0-3 repeat to < 2e-4 of the reference;
-    # from step 4 on the trace of the SAME build differs run to run (the backward kernels sum with float atomics; ten runs
-    # on one box, either workgroup shape of the conditioning backward: 2.0e-3 ... 1.1e-2 over steps 4-9,
+    # The first steps separate tier accuracy from the loop's own sensitivity: steps 0-2 repeat to 3e-6 / 2e-5 / 2e-4 of the
+    # reference in every run; from step 3 on the trace of the SAME build differs run to run (the backward kernels sum with
+    # float atomics and Adam's first updates normalise noise-level gradient components to +-lr; twelve runs, either workgroup
+    # shape of the conditioning backward: step 3 between 3e-5 and 1.2e-3, steps 4-9 between 2.0e-3 and 1.1e-2,
     # tools/ab_fitting.sh) - the band there is that spread, not a tier error.
-    assert d.max() < 1e-4 and (d / rsurf).max() < 0.05 and (d / rsurf)[:4].max() < 1e-3 and (d / rsurf)[:10].max() < 2.5e-2
+    assert d.max() < 1e-4 and (d / rsurf).max() < 0.05 and (d / rsurf)[:3].max() < 5e-4 and (d / rsurf)[:10].max() < 2.5e-2
     assert abs(surf[-10:].mean() / rsurf[-10:].mean() - 1) < 3e-2
     for k in ("reg_expr", "reg_global", "reg_loc"):
         a, b = table[-10:, keys.index(k)].mean(), ref[-10:, keys.index(k)].mean()
