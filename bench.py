@@ -359,6 +359,15 @@ def _mlp_exec_flops(mlp, mask):
     return total, passes
 
 
+def _mlp_kernel_name(mlp, shape, num):
+    """symbol of the lattice launch (csrc/mlp_kernel.hip launch_eval): format and, when every hidden GEMM layer runs the two-term
+    product, the variant that keeps four K-steps of wh in flight"""
+    f16 = mlp.precision == "f16x3"
+    n_hidden = len(num["passes_per_layer"]) - 2
+    all2 = f16 and n_hidden > 0 and all(p == 2 for p in num["passes_per_layer"][1:-1])
+    return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,{'true' if f16 else 'false'}{',true' if all2 else ''}>"
+
+
 def _mlp_numerics_report(mlp):
     r = dict(mlp.last_numerics or {})
     mask = int(r.get("mask", 0))
@@ -384,7 +393,7 @@ def two_stage_record(args, dev, steps, warmup):
     _, k_ms = _timed(lambda: R.evaluate_grid_mlp(mlp, cond, axes, add_input=True), steps, 1)
     num, flops = _mlp_numerics_report(mlp)
     ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
-    kname = "nphm::mlp::mlp_eval_kernel<2,2,1,0,true>" if mlp.precision == 'f16x3' else "nphm::mlp::mlp_eval_kernel<2,2,1,0,false>"
+    kname = _mlp_kernel_name(mlp, "2,2", num)
     return {"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice",
             "value": n * steps / dt / 1e6, "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "dtype": f"{mlp.precision} (split-f16 MFMA, fp32 accumulate; {num['passes_per_layer']} product terms per layer, calibrated) deformation + "
@@ -412,7 +421,7 @@ def npm_record(args, dev, steps, warmup, cpu):
     dt, k_ms = _timed(lambda: R.evaluate_grid_mlp(npm, lat, axes_dev), steps, warmup)
     num, flops = _mlp_numerics_report(npm)
     ach = flops * n / (np.mean(k_ms) * 1e-3) / 1e12
-    kname = "nphm::mlp::mlp_eval_kernel<1,4,1,0,true>" if npm.precision == 'f16x3' else "nphm::mlp::mlp_eval_kernel<1,4,1,0,false>"
+    kname = _mlp_kernel_name(npm, "1,4", num)
     out = {"metric": "SDF query throughput, NPM global DeepSDF, dense lattice", "value": n * steps / dt / 1e6,
            "unit": "Mpoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "dtype": f"{npm.precision} (split-f16 MFMA, fp32 accumulate; {num['passes_per_layer']} product terms per layer, calibrated)",

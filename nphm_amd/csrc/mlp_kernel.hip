@@ -319,7 +319,11 @@ __device__ __forceinline__ frag_t unit_operand(int c) {
 // the two-term product of the layers in two_pass_mask is 8x closer to fp32 than its bf16 form); every entry point takes the
 // format in its `numerics` argument (tangent streams: k d a / d x stays far inside the binary16 range for fields with
 // |d a / d x| < 400, and the hi half saturates instead of overflowing, see split8)
-template <int MT, int NTW, int MODE, int KIND, bool F16 = false>
+// ALL2: every hidden GEMM layer runs the two-term product (EvalArgs::two_pass_mask names them all - what the calibration finds
+// for both lattice nets): no wl fragment is ever requested, and the registers that would hold them hold two more K-steps of wh -
+// four in flight instead of two.  (The 32-point workgroups of the hidden-1024 net stream a 16 MB pack out of the Infinity
+// Cache: with 64 KB in flight per CU they ran at that latency's 74 GB/s per CU, a third of the matrix pipe.)
+template <int MT, int NTW, int MODE, int KIND, bool F16 = false, bool ALL2 = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   constexpr bool JVP = KIND == 1 || KIND == 4, BROY = KIND == 2, SAVE = KIND == 3 || KIND == 4;   // 4: value+Jacobian, sigma' saved
   constexpr int M = 32 * MT;               // columns per workgroup
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #ifndef NPHM_MLP_SLOTS_SMALL
 #define NPHM_MLP_SLOTS_SMALL 4
 #endif
-  constexpr int NS = (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
+  constexpr int NS = ALL2 ? 4 : (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
   static_assert(NS % 2 == 0, "the B operand's two slots alternate with the K-step");
   frag_t ah[NS][NTW], al[NS][NTW];
   // Terms of the split product of a layer: three = xh wh + xl wh + xh wl, two = without the wl term (EvalArgs::two_pass_mask).
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       if (i < ni) {
         const unsigned o = __builtin_amdgcn_readfirstlane(L.w_off + (unsigned(wave + WAVES * i) * unsigned(L.k_steps) + unsigned(s)) * 2048u);
         ah[slot][i] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o, 0));
-        al[slot][i] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lo_lane, o + 1024u, 0));
+        if constexpr (!ALL2) al[slot][i] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lo_lane, o + 1024u, 0));
       }
     }
   };
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     const LayerDev& L = p.layer[l];
     const int ni = tiles_of(L.n_tiles);
     const int ks = L.k_steps;
-    const bool three = !((p.two_pass_mask >> l) & 1u);
+    const bool three = !ALL2 && !((p.two_pass_mask >> l) & 1u);
     const unsigned lo_lane = lo_lane_of(l);
     coord_step(L, ni);       // (requesting these fragments a layer ahead as well: +-0, and the Broyden variants spill)
     __syncthreads();                                  // the previous layer's tile is complete
@@ -573,12 +577,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
             }
           }
         }
-        if (three) {
+        if constexpr (!ALL2) {
+          if (three) {
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) {
-            if (i < ni) {
+            for (int i = 0; i < NTW; ++i) {
+              if (i < ni) {
 #pragma unroll
-              for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(al[sa][i], bh[sb][t], acc[i][t]);
+                for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(al[sa][i], bh[sb][t], acc[i][t]);
+              }
             }
           }
         }
@@ -814,6 +820,13 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   a.state_row_bytes = 2 * plan.state_row_bytes;
   if (f16) { a.packed += plan.packed_bytes; a.state += plan.state_row_bytes; }
   a.two_pass_mask = (unsigned(numerics) >> 8) & ((1u << (plan.n_linear - 1)) - 2u);     // hidden GEMM layers 1 .. n_linear - 2
+  // every hidden GEMM layer two-term (split-f16 only): the variant without wl fragments (mlp_eval_kernel, ALL2)
+  const unsigned hidden_mask = (1u << (plan.n_linear - 1)) - 2u;
+  const bool all2 = KIND == 0 && f16 && plan.n_linear > 2 && a.two_pass_mask == hidden_mask
+#ifdef NPHM_MLP_NO_ALL2
+                    && false
+#endif
+      ;
   a.sig_tiles = 0;
   for (int l = 0; l < plan.n_linear - 1; ++l) { a.sig_base[l] = a.sig_tiles; a.sig_tiles += plan.layer[l].n_tiles; }
   // Small Broyden batches of the hidden <= 512 nets (the fitting loop: 5 x 1000 points) run 32 points per workgroup:
@@ -840,11 +853,19 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
       if (f16 ? go(mlp_eval_kernel<1, 2, MODE, KIND, true>, lds_bytes<1, 2>()) : go(mlp_eval_kernel<1, 2, MODE, KIND, false>, lds_bytes<1, 2>())) return -2;
     }
   } else if (plan.variant == 0) {
+    if constexpr (KIND == 0) {
+      if (all2) {
+        if (go(mlp_eval_kernel<2, 2, MODE, 0, true, true>, lds_bytes<2, 2>())) return -2;
+        e = hipGetLastError();
+        return e == hipSuccess ? 0 : nphm_fail("nphm_mlp_eval launch", e);
+      }
+    }
     if (f16 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true>, lds_bytes<2, 2>()) : go(mlp_eval_kernel<2, 2, MODE, KIND, false>, lds_bytes<2, 2>())) return -2;
   } else if constexpr (KIND == 3 || KIND == 4) {
     return nphm_fail_msg("nphm_mlp_eval_points_saving: only the hidden <= 512 variant has a backward kernel");
   } else if constexpr (KIND == 0) {
-    if (f16 ? go(mlp_eval_kernel<1, 4, MODE, 0, true>, lds_bytes<1, 4>()) : go(mlp_eval_kernel<1, 4, MODE, 0, false>, lds_bytes<1, 4>())) return -2;
+    if (all2 ? go(mlp_eval_kernel<1, 4, MODE, 0, true, true>, lds_bytes<1, 4>())
+             : f16 ? go(mlp_eval_kernel<1, 4, MODE, 0, true>, lds_bytes<1, 4>()) : go(mlp_eval_kernel<1, 4, MODE, 0, false>, lds_bytes<1, 4>())) return -2;
   } else {
     // the hidden <= 1024 variant (NPM) keeps bf16 halves for its tangent / Broyden forms (nothing drives them hard: the
     // fitting loop's expression decoder is the hidden <= 512 one)
