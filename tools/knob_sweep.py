@@ -27,7 +27,9 @@ def run(knobs, steps=8):
 _, ref = run((-1.0, net.precision_code("f16x3", None, None, None)), 1)
 base = None
 L, M_, P = c["light_tol"], c["mid_tol"], c["prune_tol"]
-cands = [(L, M_, P), (L, M_, P)]
+cands = [(L, M_, P)]
+for fl, fm, fp in itertools.product((0.71, 1, 1.41, 2), (0.25, 0.5, 1, 2), (1, 2)):
+    if (fl, fm, fp) != (1, 1, 1): cands.append((L * fl, M_ * fm, P * fp))
 for light, mid, prune in cands:
     code = net.precision_code("f16x3a2", light, mid, c.get("refine_band"))
     dt, vol = run((float(prune), code))
