@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 7
+#define NPHM_AMD_ABI_VERSION 8
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -210,30 +210,44 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *     d f_k / d xyz for the listed triples (others untouched).
  *   nphm_identity_train_backward : seeds grad_member_sdf = dL/df_k and grad_member_grad = dL/d(d f_k/d xyz) (NULL:
  *     zero) -> ACCUMULATES grad_xyz, grad_anchors (as nphm_identity_backward, for
- *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k) and stores the operands of the weight gradients into
- *     saved (nphm_identity_train_saved_bytes(n_tiles, operands_bf16) bytes; per tile [1409 rows][64 columns] fp32 - or,
- *     with operands_bf16 != 0, bf16: half the operand traffic of both kernels, the weight-gradient products then
- *     carry 8-bit mantissas (opt-in; same flag in all three calls) -, column =
- *     32 * stream + point with stream 0 = value, 1 = tangent along the seed direction; rows = inputs of lin0..lin4
- *     followed by the adjoints of the pre-activations of lin0..lin3 and the output seeds, scaled domain).
- *   nphm_identity_train_weight_grads : contracts those operands over the columns, ADDING into parameter-shaped
- *     gradients grad_weight[l] (shape of lin<l>.weight; the latent columns of lin0 / lin2 are not touched - they
- *     receive theirs through grad_b0 / grad_b2), grad_bias1/3/4, and grad_b0 / grad_b2 [n_rows,40,200] =
- *     dL/d(folded bias of lin0 / of the skip layer) per (row, member) as in nphm_identity_backward (row sums of the
- *     stored adjoints; tiles = the backward kernel's tile table).  chunks [n_chunks][4] = (weight set, first
- *     tile, number of tiles, 0): consecutive tiles of ONE weight set each (the host cuts the member-ordered tile
- *     table; a few dozen tiles per chunk keeps the atomics negligible). */
+ *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k), stores the operands of the weight gradients of lin1 .. lin3
+ *     into saved (nphm_identity_train_saved_bytes(n_tiles, operands_bf16) bytes; per tile [1005 rows][64 columns] fp32 -
+ *     or, with operands_bf16 != 0, bf16: half the operand traffic of both kernels, the weight-gradient products then
+ *     carry 8-bit mantissas (opt-in; same flag in all three calls) -, column = 32 * stream + point with stream 0 = value,
+ *     1 = tangent along the seed direction; rows = inputs of lin1..lin3 followed by the adjoints of their
+ *     pre-activations, scaled domain) and WRITES edge (nphm_identity_train_edge_bytes(n_tiles); ABI 8): per tile 1024
+ *     floats = the tile's contribution to the gradients of lin0 (3 input columns + folded bias) and lin4 (one output) -
+ *     contractions thin enough to be summed over the tile's columns in registers instead of travelling as 404 more rows.
+ *   nphm_identity_train_weight_grads : contracts the stored operands over the columns, ADDING into parameter-shaped
+ *     gradients grad_weight[1..3] (shape of lin<l>.weight; the latent columns of lin2 are not touched - they receive theirs
+ *     through grad_b2; grad_weight[0] / [4] are not written), grad_bias1/3, and grad_b2 [n_rows,40,200] = dL/d(folded bias
+ *     of the skip layer) per (row, member) as in nphm_identity_backward (row sums of the stored adjoints; tiles = the
+ *     backward kernel's tile table).  chunks [n_chunks][4] = (weight set, first tile, number of tiles, 0): consecutive
+ *     tiles of ONE weight set each (the host cuts the member-ordered tile table; a few dozen tiles per chunk keeps the
+ *     atomics negligible).
+ *   nphm_identity_train_edge_grads (ABI 8) : sums the edge records of ALL n_tiles tiles (every piece of the backward
+ *     pass written at its tile's index) in table order, no atomics (bitwise reproducible; three small launches: per chunk,
+ *     per weight set, per (member, row) pair) - ADDING into grad_weight0 (lin0.weight [sets,200,99]: columns 0..2),
+ *     grad_weight4 (lin4.weight [sets,200]), grad_bias4 [sets] and grad_b0 [n_rows,40,200] (folded bias of lin0).
+ *     chunks [n_chunks][4] = the weight-gradient work list of ALL pieces (weight set, first tile relative to its piece,
+ *     tiles, piece), ordered by tile; ring_tiles = tiles per piece; set_chunk_first [sets + 1] = first chunk of every weight
+ *     set; pair_first [40 * n_rows + 1] = first tile of every (member, row) pair in table order (pair = member * n_rows +
+ *     row); scratch = n_chunks * nphm_identity_train_edge_bytes(1) bytes. */
 size_t nphm_identity_train_saved_bytes(int n_tiles, int operands_bf16);
+size_t nphm_identity_train_edge_bytes(int n_tiles);
 int nphm_identity_train_forward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                 int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                 float* member_sdf, float* member_grad, void* stream);
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, float* grad_anchors, void* saved, int operands_bf16, void* stream);
+                                 float* grad_xyz, float* grad_anchors, void* saved, void* edge, int operands_bf16, void* stream);
 int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* tiles, const int* chunks, int n_chunks,
-                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_bias4,
-                                     float* grad_b0, float* grad_b2, void* stream);
+                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_b2,
+                                     void* stream);
+int nphm_identity_train_edge_grads(const void* edge, int n_tiles, const int* chunks, int n_chunks, int ring_tiles,
+                                   const int* set_chunk_first, const int* pair_first, int n_rows, void* scratch,
+                                   float* grad_weight0, float* grad_weight4, float* grad_bias4, float* grad_b0, void* stream);
 
 /* The Gaussian blend of the training tier WITH its spatial gradient, for callers that need both (compute_loss:
  * decoder(...) followed by gradient(pred, x), loss_functions.py:36-49) without a graph-recording backward pass:

@@ -65,10 +65,13 @@ SYMBOLS = {
     "nphm_identity_train_saved_bytes": (c_size_t, [c_int, c_int]),
     "nphm_identity_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_train_edge_bytes": (c_size_t, [c_int]),
     "nphm_identity_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, _PtrArr5, c_void_p, c_void_p, c_void_p,
-                                                 c_void_p, c_void_p, c_void_p]),
+                                                 c_void_p]),
+    "nphm_identity_train_edge_grads": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_blend_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_blend_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -144,7 +147,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 7:
+    if lib.nphm_abi_version() != 8:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -48,26 +48,27 @@ using namespace nphm::bwd;
 
 constexpr float LN2 = 0.6931471805599453f;
 
-// saved operands of the weight gradients: per tile [SV_ROWS][64] fp32, column = 32 * stream + point
-enum { SV_IN0 = 0,    // 3   local coordinates | tangent direction
-       SV_IN1,        // 200 h0' | u0'
+// saved operands of the weight gradients of lin1 .. lin3: per tile [SV_ROWS][64] fp32, column = 32 * stream + point.
+// (Round 4: lin0 and lin4 left the table - their gradients are 3- and 1-column contractions, which the reverse kernel
+// reduces over its 64 columns in registers and hands to edge_grads_kernel as 1001 floats per tile instead of 404 rows
+// x 256 bytes: 1409 -> 1005 rows, -29 % of the bytes both kernels move.)
+enum { SV_IN1 = 0,    // 200 h0' | u0'
        SV_IN2,        // 104 h1' | u1'  (rows 101..103: coordinates | direction)
        SV_IN3,        // 200 h2' | u2'
-       SV_IN4,        // 200 h3' | u3'
-       SV_D0,         // 200 D0 | T0
        SV_D1,         // 101 D1 | T1
        SV_D2,         // 200 D2 | T2
        SV_D3,         // 200 D3 | T3
-       SV_SEED,       // 1   sbar | 1 (valid points)
        SV_COUNT };
-constexpr int SV_ROWS = 3 + HID + L2_IN + HID + HID + HID + L1_OUT + HID + HID + 1;      // 1409
+constexpr int SV_ROWS = HID + L2_IN + HID + L1_OUT + HID + HID;      // 1005
 __host__ __device__ constexpr int sv_offset(int which) {
-  constexpr int off[SV_COUNT] = {0, 3, 3 + HID, 3 + HID + L2_IN, 3 + 2 * HID + L2_IN, 3 + 3 * HID + L2_IN,
-                                 3 + 4 * HID + L2_IN, 3 + 4 * HID + L2_IN + L1_OUT, 3 + 5 * HID + L2_IN + L1_OUT,
-                                 3 + 6 * HID + L2_IN + L1_OUT};
+  constexpr int off[SV_COUNT] = {0, HID, HID + L2_IN, 2 * HID + L2_IN, 2 * HID + L2_IN + L1_OUT, 3 * HID + L2_IN + L1_OUT};
   return off[which];
 }
-static_assert(sv_offset(SV_SEED) + 1 == SV_ROWS, "saved-operand rows");
+static_assert(sv_offset(SV_D3) + HID == SV_ROWS, "saved-operand rows");
+// per tile, from the reverse kernel: sums over the tile's 64 columns (scaled domain; edge_grads_kernel applies the scales)
+//   [0, 600)  dW0[f][c] = sum D0[f] c_in[c] + T0[f] v[c]      [600, 800)  sum of D0[f]'s value columns (folded bias of lin0)
+//   [800, 1000)  dW4[f] = sum h3'[f] sbar + u3'[f] valid        [1000]  sum of sbar (lin4's bias)
+constexpr int EDGE_FLOATS = 1024, EDGE_W0 = 0, EDGE_B0 = 3 * HID, EDGE_W4 = 4 * HID, EDGE_B4 = 5 * HID;
 
 struct TrainArgs {
   const uint16_t* packed_bf16;
@@ -86,6 +87,7 @@ struct TrainArgs {
   float* gxyz;                    // [n_rows, n_points, 3]  (+=)
   float* ganch;                   // [n_rows, 39, 3]        (+=)
   float* save;                    // backward: [n_tiles][SV_ROWS][64]
+  float* edge;                    // backward: [n_tiles][EDGE_FLOATS]
 };
 
 // coord_operand without the constant slots: the B operand of the tangent stream at lin0 (no bias)
@@ -333,14 +335,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   f32x16 acc[NT], val[NT], s0, s1, s2, s3, q0, q1, q2, q3;
   s0 = zero16; s1 = zero16; s2 = zero16; s3 = zero16; q0 = zero16; q1 = zero16; q2 = zero16; q3 = zero16;
 
-  if (SECOND && wave == 7) {                       // lin0's own inputs and the output seeds, as saved operands
-    if (h == 0) {
-      char* b = save + (sv_offset(SV_IN0) * 64 + j) * ES;
-      put(b, cx); put(b + 64 * ES, cy); put(b + 128 * ES, cz);
-      put(b + 32 * ES, vx); put(b + (64 + 32) * ES, vy); put(b + (128 + 32) * ES, vz);
-      char* sd = save + (sv_offset(SV_SEED) * 64 + j) * ES;
-      put(sd, seed); put(sd + 32 * ES, valid);
-    }
+  float* const edge = SECOND ? p.edge + size_t(tile_index) * EDGE_FLOATS : nullptr;
+  if (SECOND && wave == 7 && h == 0) {             // lin4's bias gradient: the value seeds of the tile
+    const float sb = half_wave_sum(seed);
+    if (j == 0) edge[EDGE_B4] = sb;
   }
 
   // ================================ forward =======================================================
@@ -400,14 +398,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
         partial += __shfl_xor(partial, 32);
         if (h == 0) part[wave][32 * t + j] = partial;
       }
+    } else {
+      // lin4's weight gradient: dW4[f] = sum over the points of h3'[f] sbar + u3'[f] (valid): this lane holds point j.
+      // The sum of register r is kept by lane j = r: one store of 16 lanes per half-wave instead of sixteen of one lane.
+      float o4 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sum = half_wave_sum(fmaf(val[0][r], seed, val[1][r] * valid));
+        o4 = j == r ? sum : o4;
+      }
+      const int f4 = feat_of(wave, j & 15, h);
+      if (j < 16 && f4 < HID) edge[EDGE_W4 + f4] = o4;
     }
   }
-  if (SECOND) {                          // wavefront 7 has finished copying h2' | u2' out of the staging buffer
-    __syncthreads();
-    if (wave < 7) save_tile(val);
-  }
   __syncthreads();
-  copy_out(SV_IN4, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   if (!SECOND && threadIdx.x < 64) {
     const int m = threadIdx.x;
     float f = p.packed_f32[size_t(set) * SET_STRIDE + OFF_L4B];
@@ -472,11 +476,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     for (int t = 0; t < NT; ++t) acc[t] = zero16;
     gemm_tile(acc, bw + OFF_C, wave, std::integral_constant<int, C_KS>{});
     deactivate(acc, s0, q0, val);
+    if (SECOND) {
+      // lin0: dW0[f][c] = sum over the points of D0[f] c_in[c] + T0[f] v[c]; folded bias: sum of D0[f]
+      float ox = 0.f, oy = 0.f, oz = 0.f, ob = 0.f;          // (lane j = r keeps register r's sums, as for lin4)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = val[0][r], t = val[1][r];
+        const float sx = half_wave_sum(fmaf(d, cx, t * vx)), sy = half_wave_sum(fmaf(d, cy, t * vy));
+        const float sz = half_wave_sum(fmaf(d, cz, t * vz)), sb = half_wave_sum(d);
+        ox = j == r ? sx : ox; oy = j == r ? sy : oy; oz = j == r ? sz : oz; ob = j == r ? sb : ob;
+      }
+      const int f0 = feat_of(wave, j & 15, h);
+      if (j < 16 && f0 < HID) {
+        edge[EDGE_W0 + 3 * f0] = ox; edge[EDGE_W0 + 3 * f0 + 1] = oy; edge[EDGE_W0 + 3 * f0 + 2] = oz;
+        edge[EDGE_B0 + f0] = ob;
+      }
+    }
   }
   __syncthreads();
-  if (wave < 7) { store_tile(wave, val); save_tile(val); }
+  if (wave < 7) store_tile(wave, val);
   __syncthreads();
-  copy_out(SV_D0, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   // stage D: d phi / d coords (lin0 path) = (k lin0[:, :3])^T D0 ; one tile, wavefront 0
   if (wave == 0) {
 #pragma unroll
@@ -523,7 +542,7 @@ namespace nphm {
 namespace train {
 
 // ---- weight gradients ---------------------------------------------------------------------------------------
-// One workgroup = one chunk (<= a few dozen tiles of ONE weight set) x one layer.  Per tile: the layer's INPUT
+// One workgroup = one chunk (<= a few dozen tiles of ONE weight set) x one of lin1 .. lin3 (lin0 / lin4: edge_grads_kernel).  Per tile: the layer's INPUT
 // operand [rows_in][64 columns] goes through LDS as split-bf16 (every wavefront needs all of it), the ADJOINT
 // operand rows of wavefront w (output block w) come straight from HBM as the MFMA A fragments (lane = row, 8
 // consecutive columns); acc[b] += A x B over the tile's 4 K-steps of 16 columns for the 7 input blocks b.
@@ -531,9 +550,9 @@ struct WgradArgs {
   const float* saved;         // [n_tiles][SV_ROWS][64]
   const int* chunks;          // [n_chunks][4] = weight set, first tile, number of tiles, -
   const int* tiles;           // the backward kernel's tile table of this piece (row, member of every tile)
-  float* gW[5];               // parameter-shaped gradients of lin0..lin4.weight  (+=)
-  float* gb1; float* gb3; float* gb4;    // of lin1/lin3/lin4.bias  (+=)
-  float* gb0; float* gb2;     // of the folded biases of lin0 / the skip layer [n_rows, 40, 200]  (+=)
+  float* gW[5];               // parameter-shaped gradients of lin0..lin4.weight  (+=; [1] .. [3] are written here)
+  float* gb1; float* gb3;     // of lin1/lin3.bias  (+=)
+  float* gb2;                 // of the folded bias of the skip layer [n_rows, 40, 200]  (+=)
 };
 
 constexpr int WG_ROW_BYTES = 64 * 2 + 16;            // bf16 row of 64 columns, padded against bank conflicts
@@ -550,41 +569,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
   __shared__ __attribute__((aligned(16))) char in_hi[WG_PLANE];
   __shared__ __attribute__((aligned(16))) char in_lo[O16 ? 16 : WG_PLANE];
   const char* const saved = reinterpret_cast<const char*>(p.saved);
-  auto get = [&](const char* at) __attribute__((always_inline)) -> float {
-    return O16 ? (float)*reinterpret_cast<const __bf16*>(at) : *reinterpret_cast<const float*>(at);
-  };
   const int* ch = p.chunks + 4 * blockIdx.x;
   const int set = ch[0], tile0 = ch[1], n_tiles = ch[2];
-  const int layer = blockIdx.y;
+  const int layer = blockIdx.y + 1;          // lin1 .. lin3
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, j = lane & 31;
 
-  if (layer == 4) {           // lin4: dW4[f] = sum_cols h3'|u3' [f][col] * seed[col] / k ; db4 = sum of the value seeds
-    if (tid <= HID) {
-      float acc = 0.f;
-      for (int t = 0; t < n_tiles; ++t) {
-        const char* blk = saved + size_t(tile0 + t) * SV_ROWS * 64 * ES;
-        const char* sd = blk + sv_offset(SV_SEED) * 64 * ES;
-        if (tid < HID) {
-          const char* r = blk + (sv_offset(SV_IN4) + tid) * 64 * ES;
-          for (int c = 0; c < 64; ++c) acc = fmaf(get(r + c * ES), get(sd + c * ES), acc);
-        } else {
-          for (int c = 0; c < 32; ++c) acc += get(sd + c * ES);
-        }
-      }
-      if (tid < HID) atomicAdd(p.gW[4] + size_t(set) * HID + tid, acc / SP_SCALE);
-      else atomicAdd(p.gb4 + set, acc);
-    }
-    return;
-  }
-
   // layer geometry
-  const int d_which = layer == 0 ? SV_D0 : layer == 1 ? SV_D1 : layer == 2 ? SV_D2 : SV_D3;
-  const int i_which = layer == 0 ? SV_IN0 : layer == 1 ? SV_IN1 : layer == 2 ? SV_IN2 : SV_IN3;
+  const int d_which = layer == 1 ? SV_D1 : layer == 2 ? SV_D2 : SV_D3;
+  const int i_which = layer == 1 ? SV_IN1 : layer == 2 ? SV_IN2 : SV_IN3;
   const int rows_out = layer == 1 ? L1_OUT : HID;
-  const int rows_in = layer == 0 ? 3 : layer == 2 ? L2_IN : HID;
-  const int ld = layer == 0 ? D_IN : HID;                    // row length of the parameter
+  const int rows_in = layer == 2 ? L2_IN : HID;
+  const int ld = HID;                                        // row length of the parameter
   const int nb_in = (rows_in + 31) / 32;
   const bool active = 32 * wave < rows_out;
   const int orow = 32 * wave + j;                            // this lane's adjoint row (A operand)
@@ -624,9 +621,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
   };
 
   // bias gradients = k * row sums of the adjoints' value columns: per weight set for lin1 / lin3, per (batch row,
-  // member) for the folded biases of lin0 / the skip layer - the tile table is ordered by (member, row), so a chunk
+  // member) for the folded bias of the skip layer - the tile table is ordered by (member, row), so a chunk
   // crosses few pairs: the running sum is flushed whenever the pair changes
-  float* const gb_pair = layer == 0 ? p.gb0 : layer == 2 ? p.gb2 : nullptr;
+  float* const gb_pair = layer == 2 ? p.gb2 : nullptr;
   int pair = -1;
   auto flush_pair = [&]() __attribute__((always_inline)) {
     const float total = bsum + __shfl_xor(bsum, 32);
@@ -702,7 +699,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
     if (b < nb_in) {
       const int icol = 32 * b + j;
       float scale = 1.f;
-      if (layer == 0) scale = SP_SCALE;
       if (layer == 2) scale = (icol >= L1_OUT ? SP_SCALE : 1.f) / INV_SQRT2_DIV;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -716,6 +712,78 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
     bsum += __shfl_xor(bsum, 32);
     if (h == 0 && row_ok) atomicAdd(gb + size_t(set) * rows_out + orow, bsum * SP_SCALE);
   }
+}
+
+// ---- lin0 / lin4: the reverse kernel's per-tile sums -> parameter gradients -----------------------------------------------
+// Fixed summation order, no atomics (bitwise reproducible), three small launches:
+//   edge_chunk_kernel : one workgroup per chunk of the weight-gradient work list (<= 32 consecutive tiles of ONE weight set)
+//                       adds the chunk's records in tile order -> part[chunk][EDGE_FLOATS]            (~900 workgroups)
+//   edge_set_kernel   : one workgroup per weight set adds its chunks' partial sums in chunk order (the chunk table is ordered
+//                       by tile index: a set's chunks are consecutive) into lin0.weight[:, :3], lin4.weight, lin4.bias
+//   edge_pair_kernel  : one workgroup per (member, row) pair adds the folded-bias sums of the pair's tiles (consecutive in
+//                       the member-ordered table) into grad_b0[row, member]
+// (A first form - one workgroup per weight set walking its ~1 200 records alone - took 0.44 ms: 24 latency-bound workgroups.)
+struct EdgeArgs {
+  const float* edge;          // [n_tiles][EDGE_FLOATS]
+  const int* chunks;          // [n_chunks][4] = weight set, first tile relative to its piece, tiles, piece
+  int ring_tiles;             // tiles per piece
+  float* part;                // [n_chunks][EDGE_FLOATS]
+  const int* set_chunk_first; // [N_SETS + 1]
+  const int* pair_first;      // [n_pairs + 1] first tile of pair (member * n_rows + row)
+  int n_rows;
+  float* gW0; float* gW4; float* gb4;   // lin0.weight [sets, 200, 99] (columns 0..2), lin4.weight [sets, 200], lin4.bias [sets]  (+=)
+  float* gb0;                 // folded bias of lin0 [n_rows, 40, 200]  (+=)
+};
+__device__ __forceinline__ bool edge_set_level(int e) { return e < EDGE_B0 || (e >= EDGE_W4 && e <= EDGE_B4); }
+__global__ __launch_bounds__(1024) void edge_chunk_kernel(EdgeArgs p) {
+  const int e = threadIdx.x;
+  if (!edge_set_level(e)) return;
+  const int* ch = p.chunks + 4 * blockIdx.x;
+  const int t0 = ch[3] * p.ring_tiles + ch[1], n = ch[2];
+  const float* src = p.edge + size_t(t0) * EDGE_FLOATS + e;
+  float acc = 0.f;
+  for (int t = 0; t < n; t += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = t + i < n ? src[size_t(t + i) * EDGE_FLOATS] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += v[i];
+  }
+  p.part[size_t(blockIdx.x) * EDGE_FLOATS + e] = acc;
+}
+__global__ __launch_bounds__(1024) void edge_set_kernel(EdgeArgs p) {
+  const int set = blockIdx.x, e = threadIdx.x;
+  const int c0 = p.set_chunk_first[set], c1 = p.set_chunk_first[set + 1];
+  if (!edge_set_level(e) || c0 >= c1) return;
+  const float* src = p.part + size_t(c0) * EDGE_FLOATS + e;
+  const int n = c1 - c0;
+  float acc = 0.f;
+  for (int c = 0; c < n; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = c + i < n ? src[size_t(c + i) * EDGE_FLOATS] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += v[i];
+  }
+  if (e < EDGE_B0) p.gW0[(size_t(set) * HID + e / 3) * D_IN + e % 3] += acc * SP_SCALE;
+  else if (e < EDGE_B4) p.gW4[size_t(set) * HID + (e - EDGE_W4)] += acc / SP_SCALE;
+  else p.gb4[set] += acc;
+}
+__global__ __launch_bounds__(256) void edge_pair_kernel(EdgeArgs p) {
+  const int pair = blockIdx.x, f = threadIdx.x;            // pair = member * n_rows + row (table order)
+  const int t0 = p.pair_first[pair], n = p.pair_first[pair + 1] - t0;
+  if (f >= HID || n <= 0) return;
+  const float* src = p.edge + size_t(t0) * EDGE_FLOATS + EDGE_B0 + f;
+  float acc = 0.f;
+  for (int t = 0; t < n; t += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = t + i < n ? src[size_t(t + i) * EDGE_FLOATS] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += v[i];
+  }
+  const int member = pair / p.n_rows, row = pair % p.n_rows;
+  p.gb0[(size_t(row) * N_MEMBERS + member) * HID + f] += acc * SP_SCALE;
 }
 
 // ---- the Gaussian blend with its spatial gradient, and their backward ------------------------------------------
@@ -848,6 +916,7 @@ extern "C" {
 size_t nphm_identity_train_saved_bytes(int n_tiles, int operands_bf16) {
   return n_tiles <= 0 ? 0 : size_t(n_tiles) * nphm::train::SV_ROWS * 64 * (operands_bf16 ? 2 : 4);
 }
+size_t nphm_identity_train_edge_bytes(int n_tiles) { return n_tiles <= 0 ? 0 : size_t(n_tiles) * nphm::train::EDGE_FLOATS * 4; }
 
 static int train_common(nphm::train::TrainArgs& a, const void* packed, const void* packed_bwd, const void* latent_state,
                         const float* xyz, int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
@@ -882,14 +951,15 @@ int nphm_identity_train_forward(const void* packed, const void* packed_bwd, cons
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, float* grad_anchors, void* saved, int operands_bf16, void* stream) {
+                                 float* grad_xyz, float* grad_anchors, void* saved, void* edge, int operands_bf16, void* stream) {
   nphm::train::TrainArgs a;
   if (train_common(a, packed, packed_bwd, latent_state, xyz, n_points, tiles, n_tiles, point_list,
                    "nphm_identity_train_backward: null pointer or bad sizes")) return 1;
-  if (!grad_member_sdf || !grad_xyz || !grad_anchors || !saved)
+  if (!grad_member_sdf || !grad_xyz || !grad_anchors || !saved || !edge)
     return nphm_fail_msg("nphm_identity_train_backward: null pointer");
   if (n_tiles == 0) return 0;
   a.save = static_cast<float*>(saved);
+  a.edge = static_cast<float*>(edge);
   a.g_sdf = grad_member_sdf; a.g_grad = grad_member_grad;
   a.gxyz = grad_xyz; a.ganch = grad_anchors;
   if (operands_bf16)
@@ -904,28 +974,48 @@ int nphm_identity_train_backward(const void* packed, const void* packed_bwd, con
 }
 
 int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* tiles, const int* chunks, int n_chunks,
-                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_bias4,
-                                     float* grad_b0, float* grad_b2, void* stream) {
-  if (!saved || !tiles || !chunks || !grad_weight || !grad_bias1 || !grad_bias3 || !grad_bias4 || !grad_b0 || !grad_b2)
+                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_b2,
+                                     void* stream) {
+  if (!saved || !tiles || !chunks || !grad_weight || !grad_bias1 || !grad_bias3 || !grad_b2)
     return nphm_fail_msg("nphm_identity_train_weight_grads: null pointer");
   if (n_chunks < 0) return nphm_fail_msg("nphm_identity_train_weight_grads: bad sizes");
   if (n_chunks == 0) return 0;
   nphm::train::WgradArgs a;
   a.saved = static_cast<const float*>(saved); a.chunks = chunks; a.tiles = tiles;
-  a.gb0 = grad_b0; a.gb2 = grad_b2;
+  a.gb2 = grad_b2;
   for (int i = 0; i < 5; ++i) {
     if (!grad_weight[i]) return nphm_fail_msg("nphm_identity_train_weight_grads: null gradient pointer");
     a.gW[i] = grad_weight[i];
   }
-  a.gb1 = grad_bias1; a.gb3 = grad_bias3; a.gb4 = grad_bias4;
+  a.gb1 = grad_bias1; a.gb3 = grad_bias3;
   if (operands_bf16)
-    hipLaunchKernelGGL(nphm::train::wgrad_kernel<true>, dim3(n_chunks, 5), dim3(64 * nphm::bwd::WAVES), 0,
+    hipLaunchKernelGGL(nphm::train::wgrad_kernel<true>, dim3(n_chunks, 3), dim3(64 * nphm::bwd::WAVES), 0,
                        static_cast<hipStream_t>(stream), a);
   else
-    hipLaunchKernelGGL(nphm::train::wgrad_kernel<false>, dim3(n_chunks, 5), dim3(64 * nphm::bwd::WAVES), 0,
+    hipLaunchKernelGGL(nphm::train::wgrad_kernel<false>, dim3(n_chunks, 3), dim3(64 * nphm::bwd::WAVES), 0,
                        static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_train_weight_grads launch", e);
+  return 0;
+}
+
+int nphm_identity_train_edge_grads(const void* edge, int n_tiles, const int* chunks, int n_chunks, int ring_tiles,
+                                   const int* set_chunk_first, const int* pair_first, int n_rows, void* scratch,
+                                   float* grad_weight0, float* grad_weight4, float* grad_bias4, float* grad_b0, void* stream) {
+  if (!edge || !chunks || !set_chunk_first || !pair_first || !scratch || !grad_weight0 || !grad_weight4 || !grad_bias4 || !grad_b0)
+    return nphm_fail_msg("nphm_identity_train_edge_grads: null pointer");
+  if (n_tiles < 0 || n_chunks < 0 || ring_tiles <= 0 || n_rows <= 0) return nphm_fail_msg("nphm_identity_train_edge_grads: bad sizes");
+  if (n_tiles == 0 || n_chunks == 0) return 0;
+  nphm::train::EdgeArgs a;
+  a.edge = static_cast<const float*>(edge); a.chunks = chunks; a.ring_tiles = ring_tiles; a.part = static_cast<float*>(scratch);
+  a.set_chunk_first = set_chunk_first; a.pair_first = pair_first; a.n_rows = n_rows;
+  a.gW0 = grad_weight0; a.gW4 = grad_weight4; a.gb4 = grad_bias4; a.gb0 = grad_b0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(nphm::train::edge_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(nphm::train::edge_set_kernel, dim3(nphm::N_SETS), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(nphm::train::edge_pair_kernel, dim3(nphm::N_MEMBERS * n_rows), dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_train_edge_grads launch", e);
   return 0;
 }
 

@@ -207,7 +207,9 @@ def _train_member_lists(mask, sets):
     the tile table is cut into pieces of <= _TRAIN_RING_TILES tiles (the backward kernel's stored operands of one
     piece live in a ring buffer that fits the Infinity Cache), every piece into chunks of <= _WGRAD_CHUNK tiles of
     ONE weight set for the weight-gradient kernel: ``pieces`` = list of (first tile, tiles, first chunk, chunks),
-    chunk table int32 [C,4] = (weight set, first tile RELATIVE to its piece, tiles, 0).  One host sync."""
+    chunk table int32 [C,4] = (weight set, first tile RELATIVE to its piece, tiles, piece), and the tables of
+    nphm_identity_train_edge_grads: int32 [sets + 1 | A * B + 1] = first chunk of every weight set (the chunk table is ordered
+    by tile, hence by set) | first backward tile of every (member, row) pair, and the tiles per piece.  One host sync."""
     B, N, A = mask.shape
     with torch.no_grad():
         idx = mask.permute(2, 0, 1).nonzero()                  # sorted by (member, row, point)
@@ -218,11 +220,11 @@ def _train_member_lists(mask, sets):
         n_t = (counts + width - 1) // width
         pair = np.repeat(np.arange(A * B), n_t)
         within = np.arange(int(n_t.sum())) - np.repeat(np.cumsum(n_t) - n_t, n_t)
-        return pair, np.stack([pair % B, pair // B, offs[pair] + width * within,
-                               np.minimum(width, counts[pair] - width * within)], axis=1).astype(np.int32)
+        return pair, n_t, np.stack([pair % B, pair // B, offs[pair] + width * within,
+                                    np.minimum(width, counts[pair] - width * within)], axis=1).astype(np.int32)
 
-    _, tiles_fwd = cut(64)
-    pair, tiles = cut(32)
+    _, _, tiles_fwd = cut(64)
+    pair, tiles_per_pair, tiles = cut(32)
     T = tiles.shape[0]
     set_of_tile = sets.cpu().numpy()[pair // B]
     ring = _TRAIN_RING_TILES if _TRAIN_RING_TILES > 0 else max(T, 1)
@@ -243,9 +245,12 @@ def _train_member_lists(mask, sets):
         pieces = [(int(pi * ring), int(min(ring, T - pi * ring)), int(c0), int(nc)) for pi, (c0, nc) in enumerate(zip(c_first, c_count))]
     else:
         chunks, pieces = np.zeros((0, 4), np.int32), []
+    n_sets = int(sets.max().item()) + 1
+    edge_tabs = np.concatenate([np.searchsorted(chunks[:, 0], np.arange(n_sets + 1), side="left"),
+                                np.r_[0, np.cumsum(tiles_per_pair)]]).astype(np.int32)
     dev = mask.device
     return (torch.from_numpy(tiles_fwd).to(dev), torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(),
-            torch.from_numpy(chunks).to(dev), pieces)
+            torch.from_numpy(chunks).to(dev), pieces, (torch.from_numpy(edge_tabs).to(dev), n_sets, int(ring)))
 
 
 def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
@@ -446,7 +451,7 @@ class _MemberFieldFn(torch.autograd.Function):
         # members the pruning rule keeps per point: the list kernel's normalised blend weights (0 where pruned)
         tol = module._train_tol()
         what = _member_point_lists_device(state, xyz_c, tol, A, stream)[0]
-        tiles_fwd, tiles, plist, chunks, pieces = _train_member_lists(what > 0, module.ensembled_deep_sdf.lin0._sets)
+        tiles_fwd, tiles, plist, chunks, pieces, (edge_tabs, n_sets, ring) = _train_member_lists(what > 0, module.ensembled_deep_sdf.lin0._sets)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
         _lib.check(lib.nphm_identity_train_forward(
@@ -458,7 +463,8 @@ class _MemberFieldFn(torch.autograd.Function):
         ctx.module = module
         ctx.pieces = pieces
         ctx.shapes = [t.shape for t in (W0, W1, W2, W3, W4, b1, b3, b4)]
-        ctx.save_for_backward(xyz_c, packed, packed_bwd, state, tiles, plist, chunks)
+        ctx.edge_meta = (n_sets, ring)
+        ctx.save_for_backward(xyz_c, packed, packed_bwd, state, tiles, plist, chunks, edge_tabs)
         ctx.set_materialize_grads(False)
         return S, G
 
@@ -507,7 +513,7 @@ class _MemberFieldFn(torch.autograd.Function):
             return tuple(out)
         lib = _lib.load()
         module = ctx.module
-        xyz, packed, packed_bwd, state, tiles, plist, chunks = ctx.saved_tensors
+        xyz, packed, packed_bwd, state, tiles, plist, chunks, edge_tabs = ctx.saved_tensors
         B, N, _ = xyz.shape
         dev = xyz.device
         A, H, K = module.num_kps + 1, module.hidden_dim, module.num_kps
@@ -523,6 +529,9 @@ class _MemberFieldFn(torch.autograd.Function):
             o16 = {"f32": 0, "bf16": 1}[module.train_operands]
             saved = torch.empty(lib.nphm_identity_train_saved_bytes(max(n for _, n, _, _ in ctx.pieces), o16),
                                 dtype=torch.uint8, device=dev)
+            # per tile: its share of the lin0 / lin4 gradients, summed over the tile's columns in the reverse kernel
+            edge = torch.empty(lib.nphm_identity_train_edge_bytes(T), dtype=torch.uint8, device=dev)
+            edge_tile = lib.nphm_identity_train_edge_bytes(1)
             stream = torch.cuda.current_stream(dev).cuda_stream
             gws = _lib.ptr_array5([gW0, gW1, gW2, gW3, gW4])
             timing = getattr(module, "_train_backward_events", None)       # bench.py: HIP events around the two kernels
@@ -533,11 +542,17 @@ class _MemberFieldFn(torch.autograd.Function):
                 _lib.check(lib.nphm_identity_train_backward(
                     packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N,
                     tiles.data_ptr() + 16 * t0, nt, plist.data_ptr(), gS_c.data_ptr(),
-                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), ga.data_ptr(), saved.data_ptr(), o16, stream),
-                    "nphm_identity_train_backward")
+                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), ga.data_ptr(), saved.data_ptr(),
+                    edge.data_ptr() + edge_tile * t0, o16, stream), "nphm_identity_train_backward")
                 _lib.check(lib.nphm_identity_train_weight_grads(
                     saved.data_ptr(), o16, tiles.data_ptr() + 16 * t0, chunks.data_ptr() + 16 * c0, nc, gws, gb1.data_ptr(),
-                    gb3.data_ptr(), gb4.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_train_weight_grads")
+                    gb3.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_train_weight_grads")
+            n_sets, ring = ctx.edge_meta
+            scratch = torch.empty(chunks.shape[0] * edge_tile, dtype=torch.uint8, device=dev)
+            _lib.check(lib.nphm_identity_train_edge_grads(
+                edge.data_ptr(), T, chunks.data_ptr(), chunks.shape[0], ring, edge_tabs.data_ptr(),
+                edge_tabs.data_ptr() + 4 * (n_sets + 1), B, scratch.data_ptr(), gW0.data_ptr(), gW4.data_ptr(), gb4.data_ptr(),
+                gb0.data_ptr(), stream), "nphm_identity_train_edge_grads")
             if timing is not None:
                 ev[1].record()
                 timing.append((ev[0], ev[1], 2 * T * lib.nphm_identity_train_saved_bytes(1, o16)))   # bytes written + read back

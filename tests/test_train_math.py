@@ -86,8 +86,8 @@ def test_training_work_lists_cover_every_kept_pair_once(monkeypatch):
     anch, xyz = torch.randn(B, 39, 3) * 0.1, torch.randn(B, N, 3) * 0.15
     sets = E._member_sets(A, 16)
     _, mask = E._blend_mask(anch, xyz, 1e-7, A)
-    tiles_fwd, tiles, plist, chunks, pieces = E._train_member_lists(mask, sets)
-    tiles_fwd, tiles, plist, chunks = (t.numpy() for t in (tiles_fwd, tiles, plist, chunks))
+    tiles_fwd, tiles, plist, chunks, pieces, (edge_tabs, n_sets, ring) = E._train_member_lists(mask, sets)
+    tiles_fwd, tiles, plist, chunks, edge_tabs = (t.numpy() for t in (tiles_fwd, tiles, plist, chunks, edge_tabs))
     for tab, width in ((tiles_fwd, 64), (tiles, 32)):
         seen = np.zeros((B, N, A), int)
         assert (tab[:, 3] > 0).all() and (tab[:, 3] <= width).all()
@@ -105,6 +105,18 @@ def test_training_work_lists_cover_every_kept_pair_once(monkeypatch):
             assert (sets.numpy()[tiles[t0 + rel:t0 + rel + n, 1]] == s_).all()
             cover[t0 + rel:t0 + rel + n] += 1
     assert (cover == 1).all()
+    # the tables of the edge-gradient kernels: a set's chunks are consecutive in the chunk table, a pair's tiles in the tile table
+    assert ring == 7 and n_sets == int(sets.max()) + 1
+    set_chunk_first, pair_first = edge_tabs[:n_sets + 1], edge_tabs[n_sets + 1:]
+    assert set_chunk_first[0] == 0 and set_chunk_first[-1] == len(chunks) and (np.diff(set_chunk_first) >= 0).all()
+    for s_ in range(n_sets):
+        assert (chunks[set_chunk_first[s_]:set_chunk_first[s_ + 1], 0] == s_).all()
+    first_abs = chunks[:, 3] * ring + chunks[:, 1]
+    assert (np.diff(first_abs) > 0).all()                                   # ordered by tile
+    assert len(pair_first) == A * B + 1 and pair_first[0] == 0 and pair_first[-1] == T
+    for pr in range(A * B):
+        sub = tiles[pair_first[pr]:pair_first[pr + 1]]
+        assert (sub[:, 1] == pr // B).all() and (sub[:, 0] == pr % B).all()
 
 
 def test_fused_blend_backward_formulas():
