@@ -209,30 +209,33 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *   nphm_identity_train_forward : member_sdf [n_rows,n_points,40] = f_k, member_grad [n_rows,n_points,40,3] =
  *     d f_k / d xyz for the listed triples (others untouched).
  *   nphm_identity_train_backward : seeds grad_member_sdf = dL/df_k and grad_member_grad = dL/d(d f_k/d xyz) (NULL:
- *     zero) -> ACCUMULATES grad_xyz, grad_anchors (as nphm_identity_backward, for
- *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k), stores the operands of the weight gradients of lin1 .. lin3
+ *     zero) -> ACCUMULATES grad_xyz (as nphm_identity_backward, for
+ *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k; float atomics over the members of a point - the one output of the
+ *     training tier that is not bitwise reproducible, and the one a training step never uses), stores the operands of the weight gradients of lin1 .. lin3
  *     into saved (nphm_identity_train_saved_bytes(n_tiles, operands_bf16) bytes; per tile [1005 rows][64 columns] fp32 -
  *     or, with operands_bf16 != 0, bf16: half the operand traffic of both kernels, the weight-gradient products then
  *     carry 8-bit mantissas (opt-in; same flag in all three calls) -, column = 32 * stream + point with stream 0 = value,
  *     1 = tangent along the seed direction; rows = inputs of lin1..lin3 followed by the adjoints of their
- *     pre-activations, scaled domain) and WRITES edge (nphm_identity_train_edge_bytes(n_tiles); ABI 8): per tile 1024
+ *     pre-activations, scaled domain) and WRITES edge (nphm_identity_train_edge_bytes(n_tiles); ABI 8): per tile 1600
  *     floats = the tile's contribution to the gradients of lin0 (3 input columns + folded bias) and lin4 (one output) -
  *     contractions thin enough to be summed over the tile's columns in registers instead of travelling as 404 more rows.
- *   nphm_identity_train_weight_grads : contracts the stored operands over the columns, ADDING into parameter-shaped
- *     gradients grad_weight[1..3] (shape of lin<l>.weight; the latent columns of lin2 are not touched - they receive theirs
- *     through grad_b2; grad_weight[0] / [4] are not written), grad_bias1/3, and grad_b2 [n_rows,40,200] = dL/d(folded bias
- *     of the skip layer) per (row, member) as in nphm_identity_backward (row sums of the stored adjoints; tiles = the
- *     backward kernel's tile table).  chunks [n_chunks][4] = (weight set, first tile, number of tiles, 0): consecutive
- *     tiles of ONE weight set each (the host cuts the member-ordered tile table; a few dozen tiles per chunk keeps the
- *     atomics negligible).
- *   nphm_identity_train_edge_grads (ABI 8) : sums the edge records of ALL n_tiles tiles (every piece of the backward
- *     pass written at its tile's index) in table order, no atomics (bitwise reproducible; three small launches: per chunk,
- *     per weight set, per (member, row) pair) - ADDING into grad_weight0 (lin0.weight [sets,200,99]: columns 0..2),
- *     grad_weight4 (lin4.weight [sets,200]), grad_bias4 [sets] and grad_b0 [n_rows,40,200] (folded bias of lin0).
- *     chunks [n_chunks][4] = the weight-gradient work list of ALL pieces (weight set, first tile relative to its piece,
- *     tiles, piece), ordered by tile; ring_tiles = tiles per piece; set_chunk_first [sets + 1] = first chunk of every weight
- *     set; pair_first [40 * n_rows + 1] = first tile of every (member, row) pair in table order (pair = member * n_rows +
- *     row); scratch = n_chunks * nphm_identity_train_edge_bytes(1) bytes. */
+ *     The record also carries the row sums of the adjoints' value columns = the bias gradients of lin1, lin3 and the
+ *     folded bias of the skip layer.
+ *   nphm_identity_train_weight_grads : contracts the stored operands over the columns: every chunk's share of the
+ *     gradients of lin1 / lin2[:, :104] / lin3 (scaled back to the parameters' units) is WRITTEN to wpart
+ *     (nphm_identity_train_wpart_bytes(n_chunks); chunk c of this call at wpart + c * nphm_identity_train_wpart_bytes(1)).
+ *     chunks [n_chunks][4] = (weight set, first tile relative to its piece, number of tiles, piece): consecutive tiles of
+ *     ONE weight set each (the host cuts the member-ordered tile table).
+ *   nphm_identity_train_reduce_grads (ABI 8) : after ALL pieces - sums the edge records (n_tiles, every piece written at its
+ *     tile's index) and the chunk shares (n_chunks, every piece's chunks at their index in the whole work list) in table
+ *     order, no atomics: the parameter gradients are bitwise reproducible (round 3 added per-chunk partial sums with float
+ *     atomics) - ADDING into grad_weight[l] (shape of lin<l>.weight; lin0: columns 0..2, lin2: columns 0..103 - the latent
+ *     columns receive theirs through grad_b0 / grad_b2), grad_bias1/3/4 and grad_b0 / grad_b2 [n_rows,40,200] = dL/d(folded
+ *     bias of lin0 / of the skip layer) per (row, member) as in nphm_identity_backward, and grad_anchors [n_rows,39,3] (the
+ *     tiles' anchor terms, per pair in table order).  chunks = the work list of ALL pieces
+ *     ordered by tile; ring_tiles = tiles per piece; set_chunk_first [sets + 1] = first chunk of every weight set; pair_first
+ *     [40 * n_rows + 1] = first tile of every (member, row) pair in table order (pair = member * n_rows + row); scratch =
+ *     n_chunks * nphm_identity_train_edge_bytes(1) bytes. */
 size_t nphm_identity_train_saved_bytes(int n_tiles, int operands_bf16);
 size_t nphm_identity_train_edge_bytes(int n_tiles);
 int nphm_identity_train_forward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
@@ -241,13 +244,14 @@ int nphm_identity_train_forward(const void* packed, const void* packed_bwd, cons
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, float* grad_anchors, void* saved, void* edge, int operands_bf16, void* stream);
-int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* tiles, const int* chunks, int n_chunks,
-                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_b2,
+                                 float* grad_xyz, void* saved, void* edge, int operands_bf16, void* stream);
+int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* chunks, int n_chunks, void* wpart,
                                      void* stream);
-int nphm_identity_train_edge_grads(const void* edge, int n_tiles, const int* chunks, int n_chunks, int ring_tiles,
-                                   const int* set_chunk_first, const int* pair_first, int n_rows, void* scratch,
-                                   float* grad_weight0, float* grad_weight4, float* grad_bias4, float* grad_b0, void* stream);
+size_t nphm_identity_train_wpart_bytes(int n_chunks);
+int nphm_identity_train_reduce_grads(const void* edge, int n_tiles, const void* wpart, const int* chunks, int n_chunks,
+                                     int ring_tiles, const int* set_chunk_first, const int* pair_first, int n_rows, void* scratch,
+                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_bias4,
+                                     float* grad_b0, float* grad_b2, float* grad_anchors, void* stream);
 
 /* The Gaussian blend of the training tier WITH its spatial gradient, for callers that need both (compute_loss:
  * decoder(...) followed by gradient(pred, x), loss_functions.py:36-49) without a graph-recording backward pass:
@@ -255,13 +259,15 @@ int nphm_identity_train_edge_grads(const void* edge, int n_tiles, const int* chu
  * from the member values / gradients of nphm_identity_train_forward (EnsembledDeepSDF.py:129-150 for the weights; the
  * anchors are the second forward output).  The backward takes dL/dpred and dL/dgrad (NULL: zero), WRITES
  * grad_member_sdf / grad_member_grad (the seeds of nphm_identity_train_backward) and ACCUMULATES the blend's own
- * terms into grad_xyz / grad_anchors. */
+ * terms into grad_xyz (one thread per point: plain adds) / grad_anchors (ABI 8: per-block sums into anchor_partials
+ * [nphm_identity_blend_partial_bytes(n_rows, n_points)], added per row in block order by a second small launch - no atomics). */
+size_t nphm_identity_blend_partial_bytes(int n_rows, int64_t n_points);
 int nphm_identity_blend_forward(const float* xyz, const float* anchors, const float* member_sdf, const float* member_grad,
                                 int n_rows, int64_t n_points, float* pred, float* grad, void* stream);
 int nphm_identity_blend_backward(const float* xyz, const float* anchors, const float* member_sdf, const float* member_grad,
                                  const float* grad_pred, const float* grad_grad, int n_rows, int64_t n_points,
                                  float* grad_member_sdf, float* grad_member_grad, float* grad_xyz, float* grad_anchors,
-                                 void* stream);
+                                 void* anchor_partials, void* stream);
 
 /* Second stage of the two-stage evaluation get_logits_backward (src/NPHM/models/reconstruction.py:28-56):
  * the identity field at displaced lattice points.  xyz_slab [(ix1-ix0)*ry*rz, 3] holds the canonical

@@ -67,14 +67,15 @@ SYMBOLS = {
                                             c_void_p, c_void_p, c_void_p]),
     "nphm_identity_train_edge_bytes": (c_size_t, [c_int]),
     "nphm_identity_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, _PtrArr5, c_void_p, c_void_p, c_void_p,
-                                                 c_void_p]),
-    "nphm_identity_train_edge_grads": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "nphm_identity_train_wpart_bytes": (c_size_t, [c_int]),
+    "nphm_identity_train_reduce_grads": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                                 _PtrArr5, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_blend_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_blend_partial_bytes": (c_size_t, [c_int, c_int64]),
     "nphm_identity_blend_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_eval_grid_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                                c_void_p]),

@@ -65,10 +65,17 @@ __host__ __device__ constexpr int sv_offset(int which) {
   return off[which];
 }
 static_assert(sv_offset(SV_D3) + HID == SV_ROWS, "saved-operand rows");
-// per tile, from the reverse kernel: sums over the tile's 64 columns (scaled domain; edge_grads_kernel applies the scales)
+// per tile, from the reverse kernel: sums over the tile's 64 columns (scaled domain; the edge kernels apply the scales)
 //   [0, 600)  dW0[f][c] = sum D0[f] c_in[c] + T0[f] v[c]      [600, 800)  sum of D0[f]'s value columns (folded bias of lin0)
 //   [800, 1000)  dW4[f] = sum h3'[f] sbar + u3'[f] valid        [1000]  sum of sbar (lin4's bias)
-constexpr int EDGE_FLOATS = 1024, EDGE_W0 = 0, EDGE_B0 = 3 * HID, EDGE_W4 = 4 * HID, EDGE_B4 = 5 * HID;
+//   [1024, 1125) / [1152, 1352) / [1352, 1552)  sums of the value columns of D1 / D2 / D3: bias of lin1, folded bias of the
+//   skip layer, bias of lin3 (the weight-gradient kernel then has no bias work and no per-pair bookkeeping)
+constexpr int EDGE_FLOATS = 1600, EDGE_W0 = 0, EDGE_B0 = 3 * HID, EDGE_W4 = 4 * HID, EDGE_B4 = 5 * HID;
+constexpr int EDGE_B1 = 1024, EDGE_B2 = 1152, EDGE_B3 = 1352;
+constexpr int EDGE_GA = 1008;     // [1008, 1011): the tile's share of d phi / d anchor_k (minus the sum of its points' d phi / d x)
+static_assert(EDGE_B4 < EDGE_B1 && EDGE_B1 + L1_OUT <= EDGE_B2 && EDGE_B2 + HID == EDGE_B3 && EDGE_B3 + HID <= EDGE_FLOATS, "edge record");
+// per chunk, from the weight-gradient kernel: its share of lin1 / lin2[:, :104] / lin3 (wgrad_set_kernel sums the chunks of a set)
+constexpr int WPART_W1 = 0, WPART_W2 = L1_OUT * HID, WPART_W3 = WPART_W2 + HID * L2_IN, WPART_FLOATS = WPART_W3 + HID * HID;
 
 struct TrainArgs {
   const uint16_t* packed_bf16;
@@ -336,6 +343,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   s0 = zero16; s1 = zero16; s2 = zero16; s3 = zero16; q0 = zero16; q1 = zero16; q2 = zero16; q3 = zero16;
 
   float* const edge = SECOND ? p.edge + size_t(tile_index) * EDGE_FLOATS : nullptr;
+  // sum over the tile's value columns of the 16 rows this lane's registers hold (bias gradients): lane j = r keeps row r's
+  auto edge_row_sums = [&](const f32x16& v, int off, int limit) __attribute__((always_inline)) {
+    float o = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sum = half_wave_sum(v[r]);
+      o = j == r ? sum : o;
+    }
+    const int f = feat_of(wave, j & 15, h);
+    if (j < 16 && f < limit) edge[off + f] = o;
+  };
   if (SECOND && wave == 7 && h == 0) {             // lin4's bias gradient: the value seeds of the tile
     const float sb = half_wave_sum(seed);
     if (j == 0) edge[EDGE_B4] = sb;
@@ -435,8 +453,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
       }
     }
     store_tile(wave, val);               // a2 is no longer needed (every wavefront passed the barriers above)
+    if (SECOND) edge_row_sums(val[0], EDGE_B3, HID);
   }
-  if (SECOND) {                          // ... and h3' | u3' have left the staging buffer
+  if (SECOND) {                          // ... and h2' | u2' have left the staging buffer
     __syncthreads();
     if (wave < 7) save_tile(val);
   }
@@ -448,6 +467,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     for (int t = 0; t < NT; ++t) acc[t] = zero16;
     gemm_tile(acc, bw + OFF_A, wave, std::integral_constant<int, A_KS>{});
     deactivate(acc, s2, q2, val);
+    if (SECOND) edge_row_sums(val[0], EDGE_B2, HID);
   }
   __syncthreads();
   if (wave < 7) { store_tile(wave, val); save_tile(val); }
@@ -465,6 +485,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) { val[t][1] = 0.f; val[t][2] = 0.f; val[t][3] = 0.f; }
     }
+    if (SECOND) edge_row_sums(val[0], EDGE_B1, L1_OUT);
   }
   __syncthreads();
   if (wave < B_OB) { store_tile(wave, val); save_tile(val); }
@@ -527,10 +548,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
       float sx = gq[0], sy = gq[1], sz = gq[2];      // anchor gradient: minus the sum over the tile's points
 #pragma unroll
       for (int o2 = 16; o2 > 0; o2 >>= 1) { sx += __shfl_xor(sx, o2); sy += __shfl_xor(sy, o2); sz += __shfl_xor(sz, o2); }
-      if (m == 0 && k < N_LOC) {
-        float* o = p.ganch + (size_t(row) * N_LOC + k) * 3;
-        atomicAdd(o, -sx); atomicAdd(o + 1, -sy); atomicAdd(o + 2, -sz);
-      }
+      // (per-tile record, summed per (member, row) pair in table order by edge_pair_kernel: no atomics on the anchors, whose
+      // gradient reaches mlp_pos and the latent codes)
+      if (m == 0) { edge[EDGE_GA] = -sx; edge[EDGE_GA + 1] = -sy; edge[EDGE_GA + 2] = -sz; }
     }
   }
 }
@@ -549,10 +569,7 @@ namespace train {
 struct WgradArgs {
   const float* saved;         // [n_tiles][SV_ROWS][64]
   const int* chunks;          // [n_chunks][4] = weight set, first tile, number of tiles, -
-  const int* tiles;           // the backward kernel's tile table of this piece (row, member of every tile)
-  float* gW[5];               // parameter-shaped gradients of lin0..lin4.weight  (+=; [1] .. [3] are written here)
-  float* gb1; float* gb3;     // of lin1/lin3.bias  (+=)
-  float* gb2;                 // of the folded bias of the skip layer [n_rows, 40, 200]  (+=)
+  float* part;                // [n_chunks][WPART_FLOATS]: every chunk's share of lin1 / lin2[:, :104] / lin3 (written in full)
 };
 
 constexpr int WG_ROW_BYTES = 64 * 2 + 16;            // bf16 row of 64 columns, padded against bank conflicts
@@ -581,7 +598,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
   const int i_which = layer == 1 ? SV_IN1 : layer == 2 ? SV_IN2 : SV_IN3;
   const int rows_out = layer == 1 ? L1_OUT : HID;
   const int rows_in = layer == 2 ? L2_IN : HID;
-  const int ld = HID;                                        // row length of the parameter
   const int nb_in = (rows_in + 31) / 32;
   const bool active = 32 * wave < rows_out;
   const int orow = 32 * wave + j;                            // this lane's adjoint row (A operand)
@@ -590,7 +606,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
   f32x16 acc[7];
 #pragma unroll
   for (int b = 0; b < 7; ++b) acc[b] = f32x16{};
-  float bsum = 0.f;
 
   // staging registers: the tile's input operand (7 passes of 32 rows x 16 float4) and this lane's adjoint row
   // (bf16 operands: 4 columns = 8 bytes per thread of the input operand, 8 columns = one 16-byte A fragment per K-step)
@@ -620,23 +635,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
     }
   };
 
-  // bias gradients = k * row sums of the adjoints' value columns: per weight set for lin1 / lin3, per (batch row,
-  // member) for the folded bias of the skip layer - the tile table is ordered by (member, row), so a chunk
-  // crosses few pairs: the running sum is flushed whenever the pair changes
-  float* const gb_pair = layer == 2 ? p.gb2 : nullptr;
-  int pair = -1;
-  auto flush_pair = [&]() __attribute__((always_inline)) {
-    const float total = bsum + __shfl_xor(bsum, 32);
-    if (pair >= 0 && h == 0 && row_ok) atomicAdd(gb_pair + size_t(pair) * HID + orow, total * SP_SCALE);
-    bsum = 0.f;
-  };
   if (n_tiles > 0) fetch(0);
   for (int t = 0; t < n_tiles; ++t) {
-    if (gb_pair) {
-      const int* tl = p.tiles + 4 * (tile0 + t);
-      const int pr = tl[0] * N_MEMBERS + tl[1];
-      if (pr != pair) { flush_pair(); pair = pr; }
-    }
     __syncthreads();                                   // the previous tile's LDS operand has been consumed
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
@@ -654,19 +654,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
     Split8 a[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (O16) {
-        a[s].hi = d_reg16[s];
-        if (s < 2) {                                   // bias gradient: the value columns are columns 0..31
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum += (float)d_reg16[s][e];
-        }
-      } else {
-        a[s] = split8v(d_reg[2 * s], d_reg[2 * s + 1]);
-        if (s < 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bsum += d_reg[2 * s][e] + d_reg[2 * s + 1][e];
-        }
-      }
+      if (O16) a[s].hi = d_reg16[s];
+      else a[s] = split8v(d_reg[2 * s], d_reg[2 * s + 1]);
     }
     __syncthreads();
     if (t + 1 < n_tiles) fetch(t + 1);                 // next tile's operands fly during the MFMAs
@@ -689,11 +678,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
       }
     }
   }
-  if (gb_pair) flush_pair();
   if (!active) return;
 
-  // scaled-domain products -> parameter gradients
-  float* gw = p.gW[layer] + size_t(set) * rows_out * ld;
+  // scaled-domain products -> this chunk's share of the parameter gradient (plain stores: wgrad_set_kernel adds the chunks
+  // of a weight set in chunk order - no atomics, bitwise reproducible)
+  float* gw = p.part + size_t(blockIdx.x) * WPART_FLOATS + (layer == 1 ? WPART_W1 : layer == 2 ? WPART_W2 : WPART_W3);
 #pragma unroll
   for (int b = 0; b < 7; ++b) {
     if (b < nb_in) {
@@ -703,15 +692,34 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < rows_out && icol < rows_in) atomicAdd(gw + size_t(row) * ld + icol, acc[b][r] * scale);
+        if (row < rows_out && icol < rows_in) gw[size_t(row) * rows_in + icol] = acc[b][r] * scale;
       }
     }
   }
-  float* gb = layer == 1 ? p.gb1 : layer == 3 ? p.gb3 : nullptr;
-  if (gb) {
-    bsum += __shfl_xor(bsum, 32);
-    if (h == 0 && row_ok) atomicAdd(gb + size_t(set) * rows_out + orow, bsum * SP_SCALE);
+}
+
+// sums the chunks' shares of lin1 / lin2[:, :104] / lin3 per weight set, in chunk order, into the parameter-shaped gradients
+struct WsetArgs {
+  const float* part;          // [n_chunks][WPART_FLOATS]
+  const int* set_chunk_first; // [N_SETS + 1]
+  float* gW1; float* gW2; float* gW3;   // lin1.weight [sets,101,200], lin2.weight [sets,200,200] (columns 0..103), lin3.weight [sets,200,200]  (+=)
+};
+__global__ __launch_bounds__(256) void wgrad_set_kernel(WsetArgs p) {
+  const int set = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = p.set_chunk_first[set], n = p.set_chunk_first[set + 1] - c0;
+  if (e >= WPART_FLOATS || n <= 0) return;
+  const float* src = p.part + size_t(c0) * WPART_FLOATS + e;
+  float acc = 0.f;
+  for (int c = 0; c < n; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = c + i < n ? src[size_t(c + i) * WPART_FLOATS] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += v[i];
   }
+  if (e < WPART_W2) p.gW1[size_t(set) * L1_OUT * HID + e] += acc;
+  else if (e < WPART_W3) { const int x = e - WPART_W2; p.gW2[(size_t(set) * HID + x / L2_IN) * HID + x % L2_IN] += acc; }
+  else p.gW3[size_t(set) * HID * HID + (e - WPART_W3)] += acc;
 }
 
 // ---- lin0 / lin4: the reverse kernel's per-tile sums -> parameter gradients -----------------------------------------------
@@ -732,58 +740,78 @@ struct EdgeArgs {
   const int* pair_first;      // [n_pairs + 1] first tile of pair (member * n_rows + row)
   int n_rows;
   float* gW0; float* gW4; float* gb4;   // lin0.weight [sets, 200, 99] (columns 0..2), lin4.weight [sets, 200], lin4.bias [sets]  (+=)
-  float* gb0;                 // folded bias of lin0 [n_rows, 40, 200]  (+=)
+  float* gb1; float* gb3;     // lin1.bias [sets, 101], lin3.bias [sets, 200]  (+=)
+  float* gb0; float* gb2;     // folded biases of lin0 / the skip layer [n_rows, 40, 200]  (+=)
+  float* ganch;               // [n_rows, 39, 3]  (+=)
 };
-__device__ __forceinline__ bool edge_set_level(int e) { return e < EDGE_B0 || (e >= EDGE_W4 && e <= EDGE_B4); }
+// elements of the record that belong to the weight set (the folded biases belong to a (row, member) pair)
+__device__ __forceinline__ bool edge_set_level(int e) {
+  return e < EDGE_B0 || (e >= EDGE_W4 && e <= EDGE_B4) || (e >= EDGE_B1 && e < EDGE_B1 + L1_OUT) || (e >= EDGE_B3 && e < EDGE_B3 + HID);
+}
 __global__ __launch_bounds__(1024) void edge_chunk_kernel(EdgeArgs p) {
-  const int e = threadIdx.x;
-  if (!edge_set_level(e)) return;
   const int* ch = p.chunks + 4 * blockIdx.x;
   const int t0 = ch[3] * p.ring_tiles + ch[1], n = ch[2];
-  const float* src = p.edge + size_t(t0) * EDGE_FLOATS + e;
-  float acc = 0.f;
-  for (int t = 0; t < n; t += 8) {
-    float v[8];
+  for (int e = threadIdx.x; e < EDGE_FLOATS; e += blockDim.x) {
+    if (!edge_set_level(e)) continue;
+    const float* src = p.edge + size_t(t0) * EDGE_FLOATS + e;
+    float acc = 0.f;
+    for (int t = 0; t < n; t += 8) {
+      float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = t + i < n ? src[size_t(t + i) * EDGE_FLOATS] : 0.f;
+      for (int i = 0; i < 8; ++i) v[i] = t + i < n ? src[size_t(t + i) * EDGE_FLOATS] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc += v[i];
+      for (int i = 0; i < 8; ++i) acc += v[i];
+    }
+    p.part[size_t(blockIdx.x) * EDGE_FLOATS + e] = acc;
   }
-  p.part[size_t(blockIdx.x) * EDGE_FLOATS + e] = acc;
 }
 __global__ __launch_bounds__(1024) void edge_set_kernel(EdgeArgs p) {
-  const int set = blockIdx.x, e = threadIdx.x;
-  const int c0 = p.set_chunk_first[set], c1 = p.set_chunk_first[set + 1];
-  if (!edge_set_level(e) || c0 >= c1) return;
-  const float* src = p.part + size_t(c0) * EDGE_FLOATS + e;
-  const int n = c1 - c0;
-  float acc = 0.f;
-  for (int c = 0; c < n; c += 8) {
-    float v[8];
+  const int set = blockIdx.x;
+  const int c0 = p.set_chunk_first[set], n = p.set_chunk_first[set + 1] - c0;
+  if (n <= 0) return;
+  for (int e = threadIdx.x; e < EDGE_FLOATS; e += blockDim.x) {
+    if (!edge_set_level(e)) continue;
+    const float* src = p.part + size_t(c0) * EDGE_FLOATS + e;
+    float acc = 0.f;
+    for (int c = 0; c < n; c += 8) {
+      float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = c + i < n ? src[size_t(c + i) * EDGE_FLOATS] : 0.f;
+      for (int i = 0; i < 8; ++i) v[i] = c + i < n ? src[size_t(c + i) * EDGE_FLOATS] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc += v[i];
+      for (int i = 0; i < 8; ++i) acc += v[i];
+    }
+    if (e < EDGE_B0) p.gW0[(size_t(set) * HID + e / 3) * D_IN + e % 3] += acc * SP_SCALE;
+    else if (e < EDGE_B4) p.gW4[size_t(set) * HID + (e - EDGE_W4)] += acc / SP_SCALE;
+    else if (e == EDGE_B4) p.gb4[set] += acc;
+    else if (e < EDGE_B2) p.gb1[size_t(set) * L1_OUT + (e - EDGE_B1)] += acc * SP_SCALE;
+    else p.gb3[size_t(set) * HID + (e - EDGE_B3)] += acc * SP_SCALE;
   }
-  if (e < EDGE_B0) p.gW0[(size_t(set) * HID + e / 3) * D_IN + e % 3] += acc * SP_SCALE;
-  else if (e < EDGE_B4) p.gW4[size_t(set) * HID + (e - EDGE_W4)] += acc / SP_SCALE;
-  else p.gb4[set] += acc;
 }
 __global__ __launch_bounds__(256) void edge_pair_kernel(EdgeArgs p) {
   const int pair = blockIdx.x, f = threadIdx.x;            // pair = member * n_rows + row (table order)
   const int t0 = p.pair_first[pair], n = p.pair_first[pair + 1] - t0;
   if (f >= HID || n <= 0) return;
-  const float* src = p.edge + size_t(t0) * EDGE_FLOATS + EDGE_B0 + f;
-  float acc = 0.f;
-  for (int t = 0; t < n; t += 8) {
-    float v[8];
+  const float* src = p.edge + size_t(t0) * EDGE_FLOATS + f;
+  float a0 = 0.f, a2 = 0.f;
+  for (int t = 0; t < n; t += 4) {
+    float v0[4], v2[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = t + i < n ? src[size_t(t + i) * EDGE_FLOATS] : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      v0[i] = t + i < n ? src[size_t(t + i) * EDGE_FLOATS + EDGE_B0] : 0.f;
+      v2[i] = t + i < n ? src[size_t(t + i) * EDGE_FLOATS + EDGE_B2] : 0.f;
+    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc += v[i];
+    for (int i = 0; i < 4; ++i) { a0 += v0[i]; a2 += v2[i]; }
   }
   const int member = pair / p.n_rows, row = pair % p.n_rows;
-  p.gb0[(size_t(row) * N_MEMBERS + member) * HID + f] += acc * SP_SCALE;
+  const size_t o = (size_t(row) * N_MEMBERS + member) * HID + f;
+  p.gb0[o] += a0 * SP_SCALE;
+  p.gb2[o] += a2 * SP_SCALE;
+  if (f < 3 && member < N_LOC) {                          // the pair's anchor gradient
+    float g = 0.f;
+    for (int t = 0; t < n; ++t) g += src[size_t(t) * EDGE_FLOATS + EDGE_GA];
+    p.ganch[(size_t(row) * N_LOC + member) * 3 + f] += g;
+  }
 }
 
 // ---- the Gaussian blend with its spatial gradient, and their backward ------------------------------------------
@@ -803,6 +831,7 @@ struct BlendArgs {
   float* pred; float* grad;                      // forward
   const float* g_pred; const float* g_grad;      // backward seeds (g_grad may be NULL)
   float* gS; float* gG; float* gxyz; float* ganch;
+  float* ga_part;                                // backward: [n_rows][blocks][39 * 3] per-block anchor gradients
 };
 
 constexpr float BL_SIGMA = 0.01f, BL_EPS = 1e-5f;
@@ -810,9 +839,9 @@ constexpr float BL_SIGMA = 0.01f, BL_EPS = 1e-5f;
 template <bool BWD>
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs p) {
   __shared__ float anch[N_LOC * 3];
-  __shared__ float ga[N_LOC * 3];
+  __shared__ float ga[4][N_LOC * 3];          // per wavefront: the block's anchor gradient is their sum in wavefront order
   const int row = blockIdx.y;
-  for (int i = threadIdx.x; i < N_LOC * 3; i += blockDim.x) { anch[i] = p.anchors[size_t(row) * N_LOC * 3 + i]; ga[i] = 0.f; }
+  for (int i = threadIdx.x; i < N_LOC * 3; i += blockDim.x) anch[i] = p.anchors[size_t(row) * N_LOC * 3 + i];
   __syncthreads();
   const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool live = n < p.n_points;
@@ -897,12 +926,21 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs p) {
       float sx = dx, sy = dy, sz = dz;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
-      if ((threadIdx.x & 63) == 0) { atomicAdd(&ga[3 * k], -sx); atomicAdd(&ga[3 * k + 1], -sy); atomicAdd(&ga[3 * k + 2], -sz); }
+      if ((threadIdx.x & 63) == 0) { float* o = ga[threadIdx.x >> 6] + 3 * k; o[0] = -sx; o[1] = -sy; o[2] = -sz; }
     }
   }
-  if (live) { atomicAdd(p.gxyz + pt * 3, xbx); atomicAdd(p.gxyz + pt * 3 + 1, xby); atomicAdd(p.gxyz + pt * 3 + 2, xbz); }
+  if (live) { p.gxyz[pt * 3] += xbx; p.gxyz[pt * 3 + 1] += xby; p.gxyz[pt * 3 + 2] += xbz; }     // (this thread owns the point)
   __syncthreads();
-  for (int i = threadIdx.x; i < N_LOC * 3; i += blockDim.x) atomicAdd(p.ganch + size_t(row) * N_LOC * 3 + i, ga[i]);
+  // the block's anchor gradient -> its slot of the partial table (blend_anchor_kernel adds the blocks of a row in order)
+  for (int i = threadIdx.x; i < N_LOC * 3; i += blockDim.x)
+    p.ga_part[(size_t(row) * gridDim.x + blockIdx.x) * (N_LOC * 3) + i] = (ga[0][i] + ga[1][i]) + (ga[2][i] + ga[3][i]);
+}
+__global__ __launch_bounds__(128) void blend_anchor_kernel(const float* ga_part, int n_blocks, float* ganch) {
+  const int row = blockIdx.x, i = threadIdx.x;
+  if (i >= N_LOC * 3) return;
+  float acc = 0.f;
+  for (int b = 0; b < n_blocks; ++b) acc += ga_part[(size_t(row) * n_blocks + b) * (N_LOC * 3) + i];
+  ganch[size_t(row) * N_LOC * 3 + i] += acc;
 }
 
 }  // namespace train
@@ -951,17 +989,17 @@ int nphm_identity_train_forward(const void* packed, const void* packed_bwd, cons
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, float* grad_anchors, void* saved, void* edge, int operands_bf16, void* stream) {
+                                 float* grad_xyz, void* saved, void* edge, int operands_bf16, void* stream) {
   nphm::train::TrainArgs a;
   if (train_common(a, packed, packed_bwd, latent_state, xyz, n_points, tiles, n_tiles, point_list,
                    "nphm_identity_train_backward: null pointer or bad sizes")) return 1;
-  if (!grad_member_sdf || !grad_xyz || !grad_anchors || !saved || !edge)
+  if (!grad_member_sdf || !grad_xyz || !saved || !edge)
     return nphm_fail_msg("nphm_identity_train_backward: null pointer");
   if (n_tiles == 0) return 0;
   a.save = static_cast<float*>(saved);
   a.edge = static_cast<float*>(edge);
   a.g_sdf = grad_member_sdf; a.g_grad = grad_member_grad;
-  a.gxyz = grad_xyz; a.ganch = grad_anchors;
+  a.gxyz = grad_xyz;
   if (operands_bf16)
     hipLaunchKernelGGL((nphm::train::train_kernel<true, true>), dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
                        static_cast<hipStream_t>(stream), a);
@@ -973,21 +1011,15 @@ int nphm_identity_train_backward(const void* packed, const void* packed_bwd, con
   return 0;
 }
 
-int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* tiles, const int* chunks, int n_chunks,
-                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_b2,
+size_t nphm_identity_train_wpart_bytes(int n_chunks) { return n_chunks <= 0 ? 0 : size_t(n_chunks) * nphm::train::WPART_FLOATS * 4; }
+
+int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* chunks, int n_chunks, void* wpart,
                                      void* stream) {
-  if (!saved || !tiles || !chunks || !grad_weight || !grad_bias1 || !grad_bias3 || !grad_b2)
-    return nphm_fail_msg("nphm_identity_train_weight_grads: null pointer");
+  if (!saved || !chunks || !wpart) return nphm_fail_msg("nphm_identity_train_weight_grads: null pointer");
   if (n_chunks < 0) return nphm_fail_msg("nphm_identity_train_weight_grads: bad sizes");
   if (n_chunks == 0) return 0;
   nphm::train::WgradArgs a;
-  a.saved = static_cast<const float*>(saved); a.chunks = chunks; a.tiles = tiles;
-  a.gb2 = grad_b2;
-  for (int i = 0; i < 5; ++i) {
-    if (!grad_weight[i]) return nphm_fail_msg("nphm_identity_train_weight_grads: null gradient pointer");
-    a.gW[i] = grad_weight[i];
-  }
-  a.gb1 = grad_bias1; a.gb3 = grad_bias3;
+  a.saved = static_cast<const float*>(saved); a.chunks = chunks; a.part = static_cast<float*>(wpart);
   if (operands_bf16)
     hipLaunchKernelGGL(nphm::train::wgrad_kernel<true>, dim3(n_chunks, 3), dim3(64 * nphm::bwd::WAVES), 0,
                        static_cast<hipStream_t>(stream), a);
@@ -999,23 +1031,32 @@ int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const
   return 0;
 }
 
-int nphm_identity_train_edge_grads(const void* edge, int n_tiles, const int* chunks, int n_chunks, int ring_tiles,
-                                   const int* set_chunk_first, const int* pair_first, int n_rows, void* scratch,
-                                   float* grad_weight0, float* grad_weight4, float* grad_bias4, float* grad_b0, void* stream) {
-  if (!edge || !chunks || !set_chunk_first || !pair_first || !scratch || !grad_weight0 || !grad_weight4 || !grad_bias4 || !grad_b0)
-    return nphm_fail_msg("nphm_identity_train_edge_grads: null pointer");
-  if (n_tiles < 0 || n_chunks < 0 || ring_tiles <= 0 || n_rows <= 0) return nphm_fail_msg("nphm_identity_train_edge_grads: bad sizes");
+int nphm_identity_train_reduce_grads(const void* edge, int n_tiles, const void* wpart, const int* chunks, int n_chunks,
+                                     int ring_tiles, const int* set_chunk_first, const int* pair_first, int n_rows, void* scratch,
+                                     float* const grad_weight[5], float* grad_bias1, float* grad_bias3, float* grad_bias4,
+                                     float* grad_b0, float* grad_b2, float* grad_anchors, void* stream) {
+  if (!edge || !wpart || !chunks || !set_chunk_first || !pair_first || !scratch || !grad_weight || !grad_bias1 || !grad_bias3 ||
+      !grad_bias4 || !grad_b0 || !grad_b2 || !grad_anchors)
+    return nphm_fail_msg("nphm_identity_train_reduce_grads: null pointer");
+  for (int i = 0; i < 5; ++i)
+    if (!grad_weight[i]) return nphm_fail_msg("nphm_identity_train_reduce_grads: null gradient pointer");
+  if (n_tiles < 0 || n_chunks < 0 || ring_tiles <= 0 || n_rows <= 0) return nphm_fail_msg("nphm_identity_train_reduce_grads: bad sizes");
   if (n_tiles == 0 || n_chunks == 0) return 0;
   nphm::train::EdgeArgs a;
   a.edge = static_cast<const float*>(edge); a.chunks = chunks; a.ring_tiles = ring_tiles; a.part = static_cast<float*>(scratch);
   a.set_chunk_first = set_chunk_first; a.pair_first = pair_first; a.n_rows = n_rows;
-  a.gW0 = grad_weight0; a.gW4 = grad_weight4; a.gb4 = grad_bias4; a.gb0 = grad_b0;
+  a.gW0 = grad_weight[0]; a.gW4 = grad_weight[4]; a.gb4 = grad_bias4; a.gb1 = grad_bias1; a.gb3 = grad_bias3;
+  a.gb0 = grad_b0; a.gb2 = grad_b2; a.ganch = grad_anchors;
+  nphm::train::WsetArgs w;
+  w.part = static_cast<const float*>(wpart); w.set_chunk_first = set_chunk_first;
+  w.gW1 = grad_weight[1]; w.gW2 = grad_weight[2]; w.gW3 = grad_weight[3];
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(nphm::train::edge_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(nphm::train::edge_set_kernel, dim3(nphm::N_SETS), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(nphm::train::edge_pair_kernel, dim3(nphm::N_MEMBERS * n_rows), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(nphm::train::wgrad_set_kernel, dim3((nphm::train::WPART_FLOATS + 255) / 256, nphm::N_SETS), dim3(256), 0, st, w);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return nphm_fail("nphm_identity_train_edge_grads launch", e);
+  if (e != hipSuccess) return nphm_fail("nphm_identity_train_reduce_grads launch", e);
   return 0;
 }
 
@@ -1035,12 +1076,16 @@ int nphm_identity_blend_forward(const float* xyz, const float* anchors, const fl
   return 0;
 }
 
+size_t nphm_identity_blend_partial_bytes(int n_rows, int64_t n_points) {
+  return n_rows <= 0 || n_points <= 0 ? 0 : size_t(n_rows) * size_t((n_points + 255) / 256) * nphm::N_LOC * 3 * 4;
+}
+
 int nphm_identity_blend_backward(const float* xyz, const float* anchors, const float* member_sdf, const float* member_grad,
                                  const float* grad_pred, const float* grad_grad, int n_rows, int64_t n_points,
                                  float* grad_member_sdf, float* grad_member_grad, float* grad_xyz, float* grad_anchors,
-                                 void* stream) {
+                                 void* anchor_partials, void* stream) {
   if (!xyz || !anchors || !member_sdf || !member_grad || !grad_pred || !grad_member_sdf || !grad_member_grad || !grad_xyz ||
-      !grad_anchors)
+      !grad_anchors || !anchor_partials)
     return nphm_fail_msg("nphm_identity_blend_backward: null pointer");
   if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_identity_blend_backward: bad sizes");
   nphm::train::BlendArgs a;
@@ -1048,8 +1093,11 @@ int nphm_identity_blend_backward(const float* xyz, const float* anchors, const f
   a.xyz = xyz; a.anchors = anchors; a.S = member_sdf; a.G = member_grad; a.n_points = n_points;
   a.g_pred = grad_pred; a.g_grad = grad_grad;
   a.gS = grad_member_sdf; a.gG = grad_member_grad; a.gxyz = grad_xyz; a.ganch = grad_anchors;
-  hipLaunchKernelGGL(nphm::train::blend_kernel<true>, dim3(unsigned((n_points + 255) / 256), n_rows), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a);
+  a.ga_part = static_cast<float*>(anchor_partials);
+  const unsigned blocks = unsigned((n_points + 255) / 256);
+  hipLaunchKernelGGL(nphm::train::blend_kernel<true>, dim3(blocks, n_rows), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(nphm::train::blend_anchor_kernel, dim3(n_rows), dim3(128), 0, static_cast<hipStream_t>(stream),
+                     a.ga_part, int(blocks), grad_anchors);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_blend_backward launch", e);
   return 0;

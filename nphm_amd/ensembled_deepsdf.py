@@ -208,7 +208,7 @@ def _train_member_lists(mask, sets):
     piece live in a ring buffer that fits the Infinity Cache), every piece into chunks of <= _WGRAD_CHUNK tiles of
     ONE weight set for the weight-gradient kernel: ``pieces`` = list of (first tile, tiles, first chunk, chunks),
     chunk table int32 [C,4] = (weight set, first tile RELATIVE to its piece, tiles, piece), and the tables of
-    nphm_identity_train_edge_grads: int32 [sets + 1 | A * B + 1] = first chunk of every weight set (the chunk table is ordered
+    nphm_identity_train_reduce_grads: int32 [sets + 1 | A * B + 1] = first chunk of every weight set (the chunk table is ordered
     by tile, hence by set) | first backward tile of every (member, row) pair, and the tiles per piece.  One host sync."""
     B, N, A = mask.shape
     with torch.no_grad():
@@ -538,21 +538,25 @@ class _MemberFieldFn(torch.autograd.Function):
             if timing is not None:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 ev[0].record()
+            n_sets, ring = ctx.edge_meta
+            C = chunks.shape[0]
+            # every chunk's share of lin1 .. lin3 (written by the weight-gradient kernel, summed per weight set afterwards)
+            wpart = torch.empty(lib.nphm_identity_train_wpart_bytes(C), dtype=torch.uint8, device=dev)
+            wpart_chunk = lib.nphm_identity_train_wpart_bytes(1)
             for t0, nt, c0, nc in ctx.pieces:
                 _lib.check(lib.nphm_identity_train_backward(
                     packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N,
                     tiles.data_ptr() + 16 * t0, nt, plist.data_ptr(), gS_c.data_ptr(),
-                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), ga.data_ptr(), saved.data_ptr(),
+                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), saved.data_ptr(),
                     edge.data_ptr() + edge_tile * t0, o16, stream), "nphm_identity_train_backward")
                 _lib.check(lib.nphm_identity_train_weight_grads(
-                    saved.data_ptr(), o16, tiles.data_ptr() + 16 * t0, chunks.data_ptr() + 16 * c0, nc, gws, gb1.data_ptr(),
-                    gb3.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_train_weight_grads")
-            n_sets, ring = ctx.edge_meta
-            scratch = torch.empty(chunks.shape[0] * edge_tile, dtype=torch.uint8, device=dev)
-            _lib.check(lib.nphm_identity_train_edge_grads(
-                edge.data_ptr(), T, chunks.data_ptr(), chunks.shape[0], ring, edge_tabs.data_ptr(),
-                edge_tabs.data_ptr() + 4 * (n_sets + 1), B, scratch.data_ptr(), gW0.data_ptr(), gW4.data_ptr(), gb4.data_ptr(),
-                gb0.data_ptr(), stream), "nphm_identity_train_edge_grads")
+                    saved.data_ptr(), o16, chunks.data_ptr() + 16 * c0, nc, wpart.data_ptr() + wpart_chunk * c0, stream),
+                    "nphm_identity_train_weight_grads")
+            scratch = torch.empty(C * edge_tile, dtype=torch.uint8, device=dev)
+            _lib.check(lib.nphm_identity_train_reduce_grads(
+                edge.data_ptr(), T, wpart.data_ptr(), chunks.data_ptr(), C, ring, edge_tabs.data_ptr(),
+                edge_tabs.data_ptr() + 4 * (n_sets + 1), B, scratch.data_ptr(), gws, gb1.data_ptr(), gb3.data_ptr(), gb4.data_ptr(),
+                gb0.data_ptr(), gb2.data_ptr(), ga.data_ptr(), stream), "nphm_identity_train_reduce_grads")
             if timing is not None:
                 ev[1].record()
                 timing.append((ev[0], ev[1], 2 * T * lib.nphm_identity_train_saved_bytes(1, o16)))   # bytes written + read back
@@ -615,9 +619,10 @@ class _BlendFn(torch.autograd.Function):
         gp = torch.zeros(B, N, dtype=torch.float32, device=dev) if g_pred is None else g_pred.contiguous().float()
         gg = None if g_grad is None else g_grad.contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
+        part = torch.empty(lib.nphm_identity_blend_partial_bytes(B, N), dtype=torch.uint8, device=dev)
         _lib.check(lib.nphm_identity_blend_backward(
             xyz.data_ptr(), anchors.data_ptr(), S.data_ptr(), G.data_ptr(), gp.data_ptr(), None if gg is None else gg.data_ptr(),
-            B, N, gS.data_ptr(), gG.data_ptr(), gx.data_ptr(), ga.data_ptr(), stream), "nphm_identity_blend_backward")
+            B, N, gS.data_ptr(), gG.data_ptr(), gx.data_ptr(), ga.data_ptr(), part.data_ptr(), stream), "nphm_identity_blend_backward")
         return gx.view(B, N, 3), ga.view_as(anchors), gS, gG
 
 

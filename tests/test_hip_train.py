@@ -290,3 +290,45 @@ def test_graph_recording_pass_refuses_latent_and_parameter_gradients(dev):
         assert gw1 is not None and gw1.shape == w1.shape and bool(torch.isnan(gw1).all())
     except RuntimeError as e:
         assert "graph-recording" in str(e)
+
+
+@pytest.mark.parametrize("fused_blend", [False, True])
+def test_parameter_and_latent_gradients_are_bitwise_reproducible(dev, monkeypatch, fused_blend):
+    """Every parameter and latent gradient of a training step comes from fixed-order sums (per-tile records and per-chunk
+    shares added in table order: nphm_identity_train_reduce_grads; the fused blend's anchor terms per block), not from float
+    atomics: two backward passes on the same inputs agree bit for bit - also across the pieces of the work list (ring of 300
+    tiles, chunks of 7).  (d/dxyz, which a training step does not use, still adds over the members with float atomics.)"""
+    import nphm_amd.ensembled_deepsdf as E
+    monkeypatch.setattr(E, "_TRAIN_RING_TILES", 300)
+    monkeypatch.setattr(E, "_WGRAD_CHUNK", 7)
+    net = U.build_identity(device=dev).train()
+    net.train_prune_tol = 1e-8             # (the default budget follows the previous step's member values: _train_tol)
+    lat, xyz, nrm = _batch(dev, 3, 700)
+    run = _run_fused if fused_blend else _run
+    a = run(net, "hip", lat, xyz, nrm)
+    b = run(net, "hip", lat, xyz, nrm)
+    assert torch.equal(a["pred"], b["pred"]) and torch.equal(a["grad"], b["grad"])
+    names = [n for n, _ in net.named_parameters()] + ["lat"]
+    assert len(names) >= 17
+    for n in names:
+        assert a[n].abs().max() > 0 and torch.equal(a[n], b[n]), n
+    # ... and they are the composite tier's gradients
+    c = _run(net, "composite", lat, xyz, nrm)
+    for n in names:
+        assert _rel(a[n], c[n]) < 1e-3, (n, _rel(a[n], c[n]))
+
+
+def _run_fused(net, backend, lat0, xyz, nrm):
+    """_run with decoder.value_and_gradient (the fused blend + its first-order backward, what the mirrored compute_loss calls)"""
+    net.train_backend = backend
+    net.zero_grad(set_to_none=True)
+    lat = lat0.clone().requires_grad_()
+    pred, grad, anchors = net.value_and_gradient(xyz, lat)
+    loss = (2.0 * pred.abs().mean() + 0.3 * (grad - nrm).norm(2, dim=-1).mean()
+            + 0.1 * (grad.norm(dim=-1) - 1).abs().mean() + 0.01 * torch.exp(-1e1 * pred.abs()).mean()
+            + 7.5 * anchors.square().mean() + 0.01 * (lat.norm(dim=-1) ** 2).mean())
+    loss.backward()
+    out = {"pred": pred.detach(), "grad": grad.detach(), "lat": lat.grad.detach().clone(), "loss": loss.detach()}
+    for name, p in net.named_parameters():
+        out[name] = p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
+    return out
