@@ -238,6 +238,7 @@ BOUND_SAFETY = 2.0
 PRUNE_LADDER = (1e-6, 5e-7, 2e-7, 1e-7, 5e-8, 2e-8, 1e-8, 5e-9, 2e-9, 1e-9, -1.0)
 TIER_LADDER = tuple((2.0 ** (-5 - 0.5 * i), 2.0 ** (-2 - 0.5 * i)) for i in range(20)) + ((None, None),)
 MID_WIDEN = (2.0, 4.0, 8.0)
+PRUNE_SHARE_MAX = 0.8      # a pruning rung is a candidate while its error alone stays below this share of the target
 
 
 def fit_member_bounds(decoder, lat: torch.Tensor, n: int = 1 << 16, seed: int = 0) -> torch.Tensor:
@@ -297,7 +298,7 @@ def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int =
     ``latents`` [R, lat_dim]: the codes to
     calibrate with (``kernel_knobs`` passes the code of the call that triggers it; default: the zero code = mean
     anchors).  Returns {"precision", "light_tol", "mid_tol", "prune_tol", "bounds" [40,4] or None, "error",
-    "searched": [(setting, error)]}; what the inference entry points use when ``decoder.numerics == "auto"``."""
+    "terms_per_point", "searched": [(setting, error, product terms per sample point)]}; what the inference entry points use when ``decoder.numerics == "auto"``."""
     lib = _lib.load()
     dev = torch.device(device) if device is not None else next(decoder.parameters()).device
     if dev.type != "cuda" or not decoder.hip_supported():
@@ -318,9 +319,16 @@ def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int =
             cases.append((packed, state, xyz, dims))
         stream = torch.cuda.current_stream(dev).cuda_stream
 
-        def run(case, code, prune):
+        stats = torch.zeros(16, dtype=torch.int64, device=dev)
+
+        def run(case, code, prune, count=False):
             packed, state, xyz, dims = case
-            return _eval_tiles(lib, decoder, packed, state, xyz, dims, code, prune, stream)
+            rx, ry, rz = dims
+            out = torch.empty(rx * ry * rz, dtype=torch.float32, device=xyz.device)
+            _lib.check(lib.nphm_identity_eval_grid_points(packed.data_ptr(), state.data_ptr(), xyz.data_ptr(), rx, ry, rz, 0, rx, 0,
+                                                          float(prune), code, out.data_ptr(), stats.data_ptr() if count else None,
+                                                          None, 0, stream), "nphm_identity_eval_grid_points")
+            return out
         dense = [run(c, _lib.NPHM_PREC_F32, -1.0) for c in cases]
         surf = [_tile_surface_weights(d, c[3]) for c, d in zip(cases, dense)]
         scale = target / target_surface          # errors are compared in units of `target`
@@ -328,40 +336,60 @@ def calibrate_numerics(decoder, latents: Optional[torch.Tensor] = None, n: int =
         band = target if refine_band is None else refine_band
 
         def err_of(precision, light, mid, prune):
+            """(error, cost) of a setting; cost = product terms per sample point from the kernel's own counters: 3 x three-pass +
+            2 x two-pass + 1 x one-pass (point, member) pairs, + 1 per pair for its fixed work"""
             code = decoder.precision_code(precision, light, mid, band)
             e = 0.0
+            stats.zero_()
             for c, d, (near, inv_g) in zip(cases, dense, surf):
-                diff = (run(c, code, prune) - d).abs()
+                diff = (run(c, code, prune, count=True) - d).abs()
                 e = max(e, float(diff.max()))
                 if int(near.sum()) >= 64:
                     e = max(e, scale * float((diff * inv_g)[near].mean()))
-            searched.append(({"precision": precision, "light_tol": light, "mid_tol": mid, "prune_tol": prune}, e))
-            return e
-        # 1. pruning budget, three-pass product everywhere: half of the target
-        prune, e_prune = PRUNE_LADDER[-1], None
-        for cand in PRUNE_LADDER:
-            e = err_of("f16x3", None, None, cand)
-            if e <= 0.5 * target or cand == PRUNE_LADDER[-1]:
-                prune, e_prune = cand, e
-                break
-        # 2. tier thresholds at that budget: the whole target
-        choice, e_choice = ("f16x3", None, None), e_prune
-        for light, mid in TIER_LADDER[:-1]:
-            e = err_of("f16x3a2", light, mid, prune)
-            if e <= target:
-                choice, e_choice = ("f16x3a2", light, mid), e
-                break
-        # 3. the two-pass tier alone, wider (its members then stop running the third pass), under the same bound
-        if choice[0] == "f16x3a2":
-            light, mid0 = choice[1], choice[2]
-            for f in MID_WIDEN:
-                e = err_of("f16x3a2", light, mid0 * f, prune)
-                if e > target:
+            st = stats.cpu().numpy()
+            total, pts, two, one = int(st[0]), max(int(st[1]), 1), int(st[14]), int(st[15])
+            cost = (3 * (total - two - one) + 2 * two + one + total) / pts      # (+ one term per pair: its weight stream and epilogue)
+            searched.append(({"precision": precision, "light_tol": light, "mid_tol": mid, "prune_tol": prune}, e, cost))
+            return e, cost
+
+        def tiers_at(prune, e_prune, cost_prune):
+            """tier thresholds at a pruning budget: the coarsest rung inside the whole target, then the two-pass tier alone,
+            wider (its members stop running the third pass), under the same bound"""
+            choice, e_choice, cost = ("f16x3", None, None), e_prune, cost_prune
+            for light, mid in TIER_LADDER[:-1]:
+                e, c = err_of("f16x3a2", light, mid, prune)
+                if e <= target:
+                    choice, e_choice, cost = ("f16x3a2", light, mid), e, c
                     break
-                choice, e_choice = ("f16x3a2", light, mid0 * f), e
+            if choice[0] == "f16x3a2":
+                light, mid0 = choice[1], choice[2]
+                for f in MID_WIDEN:
+                    e, c = err_of("f16x3a2", light, mid0 * f, prune)
+                    if e > target:
+                        break
+                    choice, e_choice, cost = ("f16x3a2", light, mid0 * f), e, c
+            return choice, e_choice, cost
+        # 1. candidates for the pruning budget (three-pass product everywhere): the coarsest rungs that leave the tiers a fifth
+        #    of the target, down to the first that leaves them half of it (round 4: the greedy "half" rule passed over a rung
+        #    that is faster AND more accurate in the end - a 2e-7 budget with a half-octave smaller one-pass threshold)
+        rungs = []
+        for cand in PRUNE_LADDER:
+            e, c = err_of("f16x3", None, None, cand)
+            if e <= PRUNE_SHARE_MAX * target or cand == PRUNE_LADDER[-1]:
+                rungs.append((cand, e, c))
+                if e <= 0.5 * target or len(rungs) == 3 or cand == PRUNE_LADDER[-1]:
+                    break
+        # 2. the tiers at every candidate; the cheapest setting (product terms per sample point) wins
+        best = None
+        for cand, e, c in rungs:
+            choice, e_choice, cost = tiers_at(cand, e, c)
+            if best is None or cost < best[3]:
+                best = (cand, choice, e_choice, cost)
+        prune, choice, e_choice, cost_choice = best
     return {"precision": choice[0], "light_tol": choice[1], "mid_tol": choice[2], "prune_tol": prune, "bounds": bounds,
             "refine_band": band, "latents": latents.detach().clone(),
-            "error": e_choice, "target": target, "n_points": int(n), "n_latents": int(latents.shape[0]), "searched": searched}
+            "error": e_choice, "terms_per_point": cost_choice, "target": target, "n_points": int(n), "n_latents": int(latents.shape[0]),
+            "searched": searched}
 
 
 def sample_error(decoder, lat: torch.Tensor, *, precision, light_tol, mid_tol, prune_tol, refine_band=None, bounds=None,
