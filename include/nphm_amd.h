@@ -445,8 +445,10 @@ int nphm_mlp_broyden_from(int lat_dim, int hidden_dim, int nlayers, int out_dim,
  *     `saved` (nphm_mlp_saved_bytes(..., n_rows, n_points) bytes);
  *   nphm_mlp_pack_bwd           : transposed split-bf16 pack of lin1..lin_last (nphm_mlp_bwd_packed_bytes);
  *   nphm_mlp_backward_cond      : grad_out [n_rows, n_points, out_dim] -> bias gradients of lin0 and of the skip
- *     layer, grad_bias0 / grad_bias_skip [n_rows, hidden_dim] (ACCUMULATED into: zero them first).  The caller maps
- *     them onto the conditioning: d L / d cond = grad_bias0 W0[:, 3:] + grad_bias_skip W_skip[:, K+3:] / sqrt(2). */
+ *     layer as per-slot sums bias_partials [n_rows][ceil(n_points / 32)][2][hidden_dim] (nphm_mlp_bwd_partial_bytes; ABI 8:
+ *     every slot is WRITTEN - no zero fill, no atomics); their sums over the slots of a row, g0 and gs, map onto the
+ *     conditioning as d L / d cond = g0 W0[:, 3:] + gs W_skip[:, K+3:] / sqrt(2) (nphm_mlp_cond_grad adds the slots in
+ *     order: bitwise reproducible). */
 size_t nphm_mlp_saved_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows, int64_t n_points);
 int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                                 const void* packed, const void* latent_state,
@@ -462,9 +464,10 @@ int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, in
 size_t nphm_mlp_bwd_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim);
 int nphm_mlp_pack_bwd(int lat_dim, int hidden_dim, int nlayers, int out_dim, const float* const* lin_weight,
                       void* packed_bwd, void* stream);
+size_t nphm_mlp_bwd_partial_bytes(int hidden_dim, int n_rows, int64_t n_points);
 int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim, const void* packed_bwd,
                            const void* saved, const float* grad_out, int n_rows, int64_t n_points,
-                           float* grad_bias0, float* grad_bias_skip, void* stream);
+                           void* bias_partials, void* stream);
 
 /* Batched inverse of n row-major 3x3 matrices (adjugate formula, one thread each): the `.inverse()` calls on
  * the deformation Jacobians in the correspondence search and the implicit differentiation of the fitting loop
@@ -476,10 +479,11 @@ int nphm_inverse3x3(const float* matrices, float* inverses, int64_t n, void* str
  * (diff_operators.jac's layout), is inverted where it lies; inverses row-major [n, 3, 3] (ABI 6). */
 int nphm_inverse3x3_strided(const float* matrices, int64_t matrix_stride, int64_t row_stride, int64_t col_stride,
                             float* inverses, int64_t n, void* stream);
-/* d L / d cond [n_rows, lat_dim] = grad_bias0 W0[:, off0 : off0 + lat_dim] + grad_bias_skip W_skip[:, off_skip : off_skip +
- * lat_dim] / sqrt(2) from nphm_mlp_backward_cond's outputs [n_rows, hidden_dim] and the row-major fp32 weights of lin0 /
- * the skip layer (leading dimensions ld0 / ld_skip = their in_features) in one launch (ABI 6). */
-int nphm_mlp_cond_grad(const float* grad_bias0, const float* grad_bias_skip, int n_rows, int hidden_dim,
+/* d L / d cond [n_rows, lat_dim] = g0 W0[:, off0 : off0 + lat_dim] + gs W_skip[:, off_skip : off_skip + lat_dim] / sqrt(2)
+ * from nphm_mlp_backward_cond's per-slot sums (g0, gs = their sums over the ceil(n_points / 32) slots of a row, in slot
+ * order) and the row-major fp32 weights of lin0 / the skip layer (leading dimensions ld0 / ld_skip = their in_features) in
+ * one launch (ABI 6; ABI 8: the partials instead of zero-filled accumulators; hidden_dim <= 512). */
+int nphm_mlp_cond_grad(const void* bias_partials, int64_t n_points, int n_rows, int hidden_dim,
                        const float* lin0_weight, int ld0, int off0, const float* skip_weight, int ld_skip, int off_skip,
                        int lat_dim, float* grad_cond, void* stream);
 

@@ -99,8 +99,8 @@ SYMBOLS = {
                                                                c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "nphm_mlp_bwd_packed_bytes": (c_size_t, [c_int] * 4),
     "nphm_mlp_pack_bwd": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
-    "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
-                                                      c_void_p]),
+    "nphm_mlp_bwd_partial_bytes": (c_size_t, [c_int, c_int, c_int64]),
+    "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "nphm_inverse3x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nphm_train_loss_blocks": (c_int, []),
     "nphm_train_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
@@ -112,7 +112,7 @@ SYMBOLS = {
                                c_void_p]),
     "nphm_identity_blend_members": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "nphm_inverse3x3_strided": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
-    "nphm_mlp_cond_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+    "nphm_mlp_cond_grad": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                    c_void_p, c_void_p]),
     "nphm_mlp_eval_grid": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

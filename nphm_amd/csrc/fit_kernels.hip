@@ -245,21 +245,32 @@ __global__ __launch_bounds__(256) void inverse3x3_strided_kernel(const float* __
   o[6] = c02 * r; o[7] = (a[1] * a[6] - a[0] * a[7]) * r; o[8] = (a[0] * a[4] - a[1] * a[3]) * r;
 }
 
-// d L / d cond [R][lat] of the dense skip-MLP from the bias gradients of lin0 and of the skip layer [R][H]
-// (nphm_mlp_backward_cond): g0 W0[:, off0:] + gs Ws[:, offs:] / sqrt2 - two [R,H]x[H,lat] products on 5 rows, for which the
-// library launched two GEMMs, a divide and an add.  Block = 64 columns x 16 slices of H, slices combined through LDS.
-constexpr int CG_PARTS = 16;
-__global__ __launch_bounds__(64 * CG_PARTS) void cond_grad_kernel(const float* __restrict__ g0, const float* __restrict__ gs, int H,
+// d L / d cond [R][lat] of the dense skip-MLP from the bias gradients of lin0 and of the skip layer
+// (nphm_mlp_backward_cond's per-slot sums [R][n_slots][2][H], added here per row in slot order: fixed order, no atomics):
+// g0 W0[:, off0:] + gs Ws[:, offs:] / sqrt2 - two [R,H]x[H,lat] products on 5 rows, for which the library launched two GEMMs,
+// a divide and an add.  Block = 64 columns x 16 slices of H, slices combined through LDS.
+constexpr int CG_PARTS = 16, CG_HMAX = 512;
+__global__ __launch_bounds__(64 * CG_PARTS) void cond_grad_kernel(const float* __restrict__ parts, int n_slots, int H,
                                                                    const float* __restrict__ w0, int ld0, int off0,
                                                                    const float* __restrict__ ws, int lds_, int offs, int lat,
                                                                    float* __restrict__ out) {
   __shared__ float part[CG_PARTS][64];
+  __shared__ float gsum[2][CG_HMAX];
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6, r = blockIdx.y;
+  for (int e = threadIdx.x; e < 2 * H; e += blockDim.x) {         // (which, h) = (e / H, e % H): the row's slots in order
+    const float* src = parts + size_t(r) * n_slots * 2 * H + e;
+    float t = 0.f;
+    for (int q = 0; q < n_slots; ++q) t += src[size_t(q) * 2 * H];
+    gsum[e / H][e % H] = t;
+  }
+  __syncthreads();
+  const float* g0 = gsum[0];
+  const float* gs = gsum[1];
   float acc0 = 0.f, acc1 = 0.f;
   if (j < lat)
     for (int h = s; h < H; h += CG_PARTS) {
-      acc0 = fmaf(g0[size_t(r) * H + h], w0[size_t(h) * ld0 + off0 + j], acc0);
-      acc1 = fmaf(gs[size_t(r) * H + h], ws[size_t(h) * lds_ + offs + j], acc1);
+      acc0 = fmaf(g0[h], w0[size_t(h) * ld0 + off0 + j], acc0);
+      acc1 = fmaf(gs[h], ws[size_t(h) * lds_ + offs + j], acc1);
     }
   part[s][threadIdx.x & 63] = acc0 + acc1 * 0.70710678118654752440f;
   __syncthreads();
@@ -592,16 +603,17 @@ int nphm_inverse3x3_strided(const float* matrices, int64_t matrix_stride, int64_
   return e == hipSuccess ? 0 : nphm_fail("nphm_inverse3x3_strided launch", e);
 }
 
-int nphm_mlp_cond_grad(const float* grad_bias0, const float* grad_bias_skip, int n_rows, int hidden_dim,
+int nphm_mlp_cond_grad(const void* bias_partials, int64_t n_points, int n_rows, int hidden_dim,
                        const float* lin0_weight, int ld0, int off0, const float* skip_weight, int ld_skip, int off_skip,
                        int lat_dim, float* grad_cond, void* stream) {
-  if (!grad_bias0 || !grad_bias_skip || !lin0_weight || !skip_weight || !grad_cond)
+  if (!bias_partials || !lin0_weight || !skip_weight || !grad_cond)
     return nphm_fail_msg("nphm_mlp_cond_grad: null pointer");
-  if (n_rows <= 0 || hidden_dim <= 0 || lat_dim <= 0 || off0 < 0 || off_skip < 0 || off0 + lat_dim > ld0 ||
-      off_skip + lat_dim > ld_skip)
+  if (n_rows <= 0 || n_points <= 0 || hidden_dim <= 0 || hidden_dim > nphm::fit::CG_HMAX || lat_dim <= 0 || off0 < 0 || off_skip < 0 ||
+      off0 + lat_dim > ld0 || off_skip + lat_dim > ld_skip)
     return nphm_fail_msg("nphm_mlp_cond_grad: bad sizes");
   hipLaunchKernelGGL(nphm::fit::cond_grad_kernel, dim3((lat_dim + 63) / 64, n_rows), dim3(64 * nphm::fit::CG_PARTS), 0,
-                     static_cast<hipStream_t>(stream), grad_bias0, grad_bias_skip, hidden_dim, lin0_weight, ld0, off0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(bias_partials), int((n_points + 31) / 32), hidden_dim,
+                     lin0_weight, ld0, off0,
                      skip_weight, ld_skip, off_skip, lat_dim, grad_cond);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_mlp_cond_grad launch", e);

@@ -132,9 +132,11 @@ struct Args {
   int sig_tiles;
   int sig_base[MAX_LINEAR];
   int skip;                    // layer whose bias gradient is returned besides layer 0's
-  int hidden;                  // row stride of gb0 / gb_skip
-  float* gb0;                  // [n_rows, hidden]  (+=)
-  float* gb_skip;              // [n_rows, hidden]  (+=)
+  int hidden;
+  int n_slots;                 // ceil(n_points / 32): 32-point slots per row
+  float* part;                 // [n_rows][n_slots][2][hidden]: per slot the bias gradients of layer 0 | of the skip layer.  Every
+                               // slot is WRITTEN (a 64-point workgroup writes its sums to slot 2b and zeros to 2b + 1): no zero
+                               // fill, no atomics - nphm_mlp_cond_grad adds the slots of a row in order
 };
 
 struct Split8 { bf16x8 hi, lo; };
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
 
   // G tile (n, t) of stage s: accumulators x sigma'_s; bias gradients of layer 0 / the skip layer on the way
   auto finish = [&](int s, int ni) __attribute__((always_inline)) {
-    float* gb = s == 0 ? p.gb0 : (s == p.skip ? p.gb_skip : nullptr);
+    const int slot = MT == 1 ? int(blockIdx.x) : 2 * int(blockIdx.x);
+    float* gb = (s == 0 || s == p.skip) ? p.part + ((size_t(row) * p.n_slots + slot) * 2 + (s == 0 ? 0 : 1)) * p.hidden : nullptr;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
@@ -229,7 +232,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
             for (int t = 0; t < MT; ++t) sum += v[t][r];
             sum = half_wave_sum(sum);
             const int f = 32 * n + feat_local(r, h);
-            if (j == 0 && f < p.hidden) atomicAdd(gb + size_t(row) * p.hidden + f, sum * SP_SCALE);
+            if (j == 0 && f < p.hidden) {
+              gb[f] = sum * SP_SCALE;
+              if (MT == 2 && slot + 1 < p.n_slots) gb[size_t(2) * p.hidden + f] = 0.f;
+            }
           }
         }
       }
@@ -401,14 +407,18 @@ int nphm_mlp_pack_bwd(int lat_dim, int hidden_dim, int nlayers, int out_dim, con
   return 0;
 }
 
+size_t nphm_mlp_bwd_partial_bytes(int hidden_dim, int n_rows, int64_t n_points) {
+  return hidden_dim <= 0 || n_rows <= 0 || n_points <= 0 ? 0 : size_t(n_rows) * size_t((n_points + 31) / 32) * 2 * size_t(hidden_dim) * 4;
+}
+
 int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim, const void* packed_bwd,
                            const void* saved, const float* grad_out, int n_rows, int64_t n_points,
-                           float* grad_bias0, float* grad_bias_skip, void* stream) {
+                           void* bias_partials, void* stream) {
   Plan plan;
   nphm::mlp::bwd::BwdPlan b;
   if (!bwd_plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan, b))
     return nphm_fail_msg("nphm_mlp_backward_cond: unsupported architecture (backward covers hidden <= 512, out_dim <= 3)");
-  if (!packed_bwd || !saved || !grad_out || !grad_bias0 || !grad_bias_skip) return nphm_fail_msg("nphm_mlp_backward_cond: null pointer");
+  if (!packed_bwd || !saved || !grad_out || !bias_partials) return nphm_fail_msg("nphm_mlp_backward_cond: null pointer");
   if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_mlp_backward_cond: empty input");
   nphm::mlp::bwd::Args a;
   memset(&a, 0, sizeof(a));
@@ -425,8 +435,8 @@ int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim
   }
   a.skip = nlayers / 2;
   a.hidden = hidden_dim;
-  a.gb0 = grad_bias0;
-  a.gb_skip = grad_bias_skip;
+  a.n_slots = int((n_points + 31) / 32);
+  a.part = static_cast<float*>(bias_partials);
   // 64-point workgroups unless their 32-point halves still fit one round of the chip (see part_bytes)
   int cus = 0, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;

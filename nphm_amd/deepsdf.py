@@ -86,12 +86,12 @@ class _MlpCondFn(torch.autograd.Function):
         R, n = ctx.shape
         dev = grad_out.device
         H = module.hidden_dim
-        gb0, gbs = torch.zeros(2, R, H, dtype=torch.float32, device=dev).unbind(0)     # accumulated into: one zero-fill
+        # per 32-point slot of every row the bias gradients of lin0 | the skip layer (every slot written: no zero fill)
+        parts = torch.empty(lib.nphm_mlp_bwd_partial_bytes(H, R, n) // 4, dtype=torch.float32, device=dev)
         g = grad_out.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.nphm_mlp_backward_cond(*module._arch(), module._packed_bwd(dev).data_ptr(), saved.data_ptr(),
-                                              g.data_ptr(), R, n, gb0.data_ptr(), gbs.data_ptr(), stream),
-                   "nphm_mlp_backward_cond")
+                                              g.data_ptr(), R, n, parts.data_ptr(), stream), "nphm_mlp_backward_cond")
         d = module.input_dim
         skip = module.skip_in[0]
         W0 = module.lin0.weight                                   # [H, d + lat]
@@ -101,10 +101,11 @@ class _MlpCondFn(torch.autograd.Function):
         if W0.dtype == torch.float32 and W0.is_contiguous() and Ws.is_contiguous():
             # gb0 W0[:, d:] + gbs Ws[:, k_act + d:] / sqrt2 in one launch (two library GEMMs on 5 rows, a divide, an add)
             grad_cond = torch.empty(R, lat, dtype=torch.float32, device=dev)
-            _lib.check(lib.nphm_mlp_cond_grad(gb0.data_ptr(), gbs.data_ptr(), R, H, W0.detach().data_ptr(), W0.shape[1], d,
+            _lib.check(lib.nphm_mlp_cond_grad(parts.data_ptr(), n, R, H, W0.detach().data_ptr(), W0.shape[1], d,
                                               Ws.detach().data_ptr(), Ws.shape[1], k_act + d, lat, grad_cond.data_ptr(), stream),
                        "nphm_mlp_cond_grad")
         else:
+            gb0, gbs = parts.view(R, -1, 2, H).sum(dim=1).unbind(1)
             grad_cond = gb0 @ W0[:, d:] + (gbs @ Ws[:, k_act + d:]) / _SQRT2
         return None, None, grad_cond, None, None
 

@@ -303,11 +303,15 @@ def test_fused_step_pieces_match_the_pytorch_formulation():
     H, lat, d, k_act = 512, 232, 3, 277
     W0 = torch.randn(H, d + lat, generator=g).to(dev) * 0.1
     Ws = torch.randn(H, k_act + d + lat, generator=g).to(dev) * 0.1
-    q0, qs = torch.randn(B, H, generator=g).to(dev), torch.randn(B, H, generator=g).to(dev)
+    # (per 32-point slot of each row: [B][slots][lin0 | skip][H]; 1000 points = 32 slots, summed in slot order by the kernel)
+    n_pts = 1000
+    assert lib.nphm_mlp_bwd_partial_bytes(H, B, n_pts) == B * 32 * 2 * H * 4
+    parts = torch.randn(B, 32, 2, H, generator=g).to(dev)
+    q0, qs = parts.double().sum(dim=1).unbind(1)
     got = torch.empty(B, lat, device=dev)
-    _lib.check(lib.nphm_mlp_cond_grad(q0.data_ptr(), qs.data_ptr(), B, H, W0.data_ptr(), W0.shape[1], d, Ws.data_ptr(), Ws.shape[1],
+    _lib.check(lib.nphm_mlp_cond_grad(parts.data_ptr(), n_pts, B, H, W0.data_ptr(), W0.shape[1], d, Ws.data_ptr(), Ws.shape[1],
                                       k_act + d, lat, got.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "cond_grad")
-    want = (q0.double() @ W0[:, d:].double() + (qs.double() @ Ws[:, k_act + d:].double()) / 2 ** 0.5).float()
+    want = (q0 @ W0[:, d:].double() + (qs @ Ws[:, k_act + d:].double()) / 2 ** 0.5).float()
     assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
 
 
