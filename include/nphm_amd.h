@@ -169,10 +169,13 @@ int nphm_identity_eval_grid_planes(const void* packed, const void* latent_state,
  *   nphm_identity_backward : the caller lists, per (batch row, member), the points whose normalised
  *     blend weight exceeds its pruning tolerance: tiles [n_tiles][4] = (row, member, offset into
  *     point_list, count <= 64), point_list = point indices inside the row.  sdf = forward values,
- *     grad_sdf = dL/dsdf, both [n_rows, n_points].  ACCUMULATES (+=) into
+ *     grad_sdf = dL/dsdf, both [n_rows, n_points].  WRITES (ABI 8; rounds 1-3 accumulated with float atomics)
  *       grad_xyz [n_rows,n_points,3], grad_anchors [n_rows,39,3] (anchors = second forward output),
  *       grad_b0 / grad_b2 [n_rows,40,200] = dL/d(b0 + W0[:,3:] cond_k), dL/d(b2 + W2[:,104:] cond_k / sqrt2),
- *     which the host chains through mlp_pos and the latent columns.  No weight gradients.
+ *     which the host chains through mlp_pos and the latent columns.  No weight gradients.  Two launches: the member kernel
+ *     leaves per-tile / per-(point, member) records in scratch (nphm_identity_backward_scratch_bytes; n_tiles = the table's
+ *     capacity), a second one adds a pair's tiles in table order and a point's members in member order (blend_weights
+ *     [n_rows,n_points,40] != 0 marks the listed pairs - what nphm_identity_build_lists returns): bitwise reproducible.
  *   nphm_identity_member_forward : the forward half on the same (row, member) point lists: the member
  *     predictions f_k into member_sdf [n_rows, n_points, 40] (entries of unlisted pairs are left
  *     untouched); the host blends them.  Serves the forward of the autograd tier, whose query points are
@@ -193,9 +196,11 @@ int nphm_identity_member_forward(const void* packed, const void* packed_bwd, con
                                  const float* xyz, int64_t n_points, const int* tiles, int n_tiles,
                                  const int* n_tiles_dev, const int* point_list, float* member_sdf, void* stream);
 int nphm_identity_pack_bwd(const float* const lin_weight[5], void* packed_bwd, void* stream);
+size_t nphm_identity_backward_scratch_bytes(int n_rows, int64_t n_points, int n_tiles);
 int nphm_identity_backward(const void* packed, const void* packed_bwd, const void* latent_state,
-                           const float* xyz, const float* sdf, const float* grad_sdf, int64_t n_points,
+                           const float* xyz, const float* sdf, const float* grad_sdf, int n_rows, int64_t n_points,
                            const int* tiles, int n_tiles, const int* n_tiles_dev, const int* point_list,
+                           const float* blend_weights, void* scratch,
                            float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2, void* stream);
 
 /* Training tier of the identity ensemble: what compute_loss needs from the 40 member MLPs

@@ -60,8 +60,10 @@ SYMBOLS = {
                                           c_void_p]),
     "nphm_identity_member_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nphm_identity_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_backward_scratch_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "nphm_identity_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_train_saved_bytes": (c_size_t, [c_int, c_int]),
     "nphm_identity_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),

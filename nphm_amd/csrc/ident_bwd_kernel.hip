@@ -84,10 +84,10 @@ struct BwdArgs {
   int n_tiles;                    // tiles in the table ...
   const int* n_tiles_dev;         // ... or, if not NULL, their number in device memory (tables built on the device)
   int64_t n_points;
-  float* gxyz;                    // [n_rows, n_points, 3]   (+=)
-  float* ganch;                   // [n_rows, 39, 3]         (+=)
-  float* gb0;                     // [n_rows, 40, 200]       (+=)
-  float* gb2;                     // [n_rows, 40, 200]       (+=)
+  // backward kernel: per-tile / per-pair records (no atomics; ident_bwd_reduce_kernel adds them in table / member order)
+  float* gbp;                     // [n_tiles][2][200]  bias gradients of lin0 | the skip layer from the tile's points
+  float* gap;                     // [n_tiles][4]       the tile's share of d L / d anchor_k
+  float* gxm;                     // [n_rows, n_points, 40, 3]  member k's share of d L / d xyz of a listed point
   float* fmem;                    // forward-only kernel: [n_rows, n_points, 40] member predictions
 };
 
@@ -389,7 +389,7 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
     for (int t = 0; t < MT; ++t) acc[t] = zero16;
     gemm_ring(acc, bw + OFF_A, wave, std::integral_constant<int, A_KS>{});
     if (wave < B_OB) ring_prefetch(bw + OFF_B, wave, std::integral_constant<int, B_KS>{}); else ring_prefetch(bw + OFF_C, wave, std::integral_constant<int, C_KS>{});
-    float* gb = p.gb2 + (size_t(row) * N_MEMBERS + k) * HID;
+    float* gb = p.gbp + (size_t(tile_index) * 2 + 1) * HID;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float sum = 0.f;
@@ -397,7 +397,7 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
       for (int t = 0; t < MT; ++t) { val[t][r] = acc[t][r] * s2[t][r]; sum += val[t][r]; }
       sum = half_wave_sum(sum);
       const int f = feat_of(wave, r, h);
-      if (j == 0 && f < HID) atomicAdd(gb + f, sum * SP_SCALE);
+      if (j == 0 && f < HID) gb[f] = sum * SP_SCALE;
     }
   }
   __syncthreads();
@@ -430,7 +430,7 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
     for (int t = 0; t < MT; ++t) acc[t] = zero16;
     gemm_ring(acc, bw + OFF_C, wave, std::integral_constant<int, C_KS>{});
     if (wave == 0) ring_prefetch(bw + OFF_D, 0, std::integral_constant<int, D_KS>{});
-    float* gb = p.gb0 + (size_t(row) * N_MEMBERS + k) * HID;
+    float* gb = p.gbp + size_t(tile_index) * 2 * HID;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float sum = 0.f;
@@ -438,7 +438,7 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
       for (int t = 0; t < MT; ++t) { val[t][r] = acc[t][r] * s0[t][r]; sum += val[t][r]; }
       sum = half_wave_sum(sum);
       const int f = feat_of(wave, r, h);
-      if (j == 0 && f < HID) atomicAdd(gb + f, sum * SP_SCALE);
+      if (j == 0 && f < HID) gb[f] = sum * SP_SCALE;
     }
   }
   __syncthreads();
@@ -480,8 +480,8 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
       } else {
         gq[0] = pt_dc[m][0];      // the background member sees global coordinates (no anchor)
       }
-      float* o = p.gxyz + (int64_t(row) * p.n_points + n) * 3;
-      atomicAdd(o, gq[0]); atomicAdd(o + 1, gq[1]); atomicAdd(o + 2, gq[2]);
+      float* o = p.gxm + ((int64_t(row) * p.n_points + n) * N_MEMBERS + k) * 3;
+      o[0] = gq[0]; o[1] = gq[1]; o[2] = gq[2];
       pt_q[m][0] = ga[0]; pt_q[m][1] = ga[1]; pt_q[m][2] = ga[2];
     } else {
       pt_q[m][0] = 0.f; pt_q[m][1] = 0.f; pt_q[m][2] = 0.f;
@@ -490,11 +490,53 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
     float sx = pt_q[m][0], sy = pt_q[m][1], sz = pt_q[m][2];
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) { sx += __shfl_xor(sx, o2); sy += __shfl_xor(sy, o2); sz += __shfl_xor(sz, o2); }
-    if (m == 0 && k < N_LOC) {
-      float* o = p.ganch + (size_t(row) * N_LOC + k) * 3;
-      atomicAdd(o, sx); atomicAdd(o + 1, sy); atomicAdd(o + 2, sz);
-    }
+    if (m == 0) { float* o = p.gap + size_t(tile_index) * 4; o[0] = sx; o[1] = sy; o[2] = sz; }
   }
+}
+
+// The records of the backward kernel -> d L / d (folded biases, anchors) per (row, member) and d L / d xyz per point, fixed
+// order, every output element WRITTEN (no zero fill).  Blocks [0, n_rows * 40): pair (row, member) walks the tile table in
+// order and adds its tiles' records (a pair's tiles are few; the table is ~12 KB); the rest: one thread per point adds the
+// shares of the members that listed it (blend weight != 0), member ascending.
+struct ReduceArgs {
+  const int* tiles; int n_tiles; const int* n_tiles_dev;
+  const float* gbp; const float* gap; const float* gxm; const float* what;
+  int n_rows; int64_t n_points;
+  float* gxyz; float* ganch; float* gb0; float* gb2;
+};
+__global__ __launch_bounds__(256) void ident_bwd_reduce_kernel(ReduceArgs p) {
+  const int n_pairs = p.n_rows * N_MEMBERS;
+  if (int(blockIdx.x) < n_pairs) {
+    const int row = blockIdx.x / N_MEMBERS, k = blockIdx.x % N_MEMBERS, f = threadIdx.x;
+    const int nt = p.n_tiles_dev ? min(*p.n_tiles_dev, p.n_tiles) : p.n_tiles;
+    // the pair's tiles are consecutive in the table (ordered by row, member, tile): find the run with all threads (a
+    // one-thread walk over ~750 entries was 100 us of dependent loads), then add its records in order
+    __shared__ int first, count;
+    if (threadIdx.x == 0) { first = 0x7fffffff; count = 0; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+      const int4 tl = reinterpret_cast<const int4*>(p.tiles)[t];
+      if (tl.x == row && tl.y == k && tl.w > 0) { atomicMin(&first, t); atomicAdd(&count, 1); }
+    }
+    __syncthreads();
+    float a0 = 0.f, a2 = 0.f, ga = 0.f;
+    for (int i = 0; i < count; ++i) {
+      const int t = first + i;
+      if (f < HID) { a0 += p.gbp[size_t(t) * 2 * HID + f]; a2 += p.gbp[(size_t(t) * 2 + 1) * HID + f]; }
+      else if (f < HID + 3) ga += p.gap[size_t(t) * 4 + (f - HID)];
+    }
+    if (f < HID) { p.gb0[size_t(blockIdx.x) * HID + f] = a0; p.gb2[size_t(blockIdx.x) * HID + f] = a2; }
+    else if (f < HID + 3 && k < N_LOC) p.ganch[(size_t(row) * N_LOC + k) * 3 + (f - HID)] = ga;
+    return;
+  }
+  const int64_t pt = int64_t(blockIdx.x - n_pairs) * blockDim.x + threadIdx.x;
+  if (pt >= int64_t(p.n_rows) * p.n_points) return;
+  const float* w = p.what + pt * N_MEMBERS;
+  const float* g = p.gxm + pt * N_MEMBERS * 3;
+  float x = 0.f, y = 0.f, z = 0.f;
+  for (int k = 0; k < N_MEMBERS; ++k)
+    if (w[k] != 0.f) { x += g[3 * k]; y += g[3 * k + 1]; z += g[3 * k + 2]; }
+  p.gxyz[pt * 3] = x; p.gxyz[pt * 3 + 1] = y; p.gxyz[pt * 3 + 2] = z;
 }
 
 // Workgroups walk the tile table with a grid stride.  A table built on the device has a fixed capacity and its
@@ -686,15 +728,20 @@ int nphm_identity_build_lists(const void* latent_state, const float* xyz, int n_
   return 0;
 }
 
+size_t nphm_identity_backward_scratch_bytes(int n_rows, int64_t n_points, int n_tiles) {
+  if (n_rows <= 0 || n_points <= 0 || n_tiles < 0) return 0;
+  return (size_t(n_tiles) * (2 * nphm::HID + 4) + size_t(n_rows) * size_t(n_points) * nphm::N_MEMBERS * 3) * 4;
+}
+
 int nphm_identity_backward(const void* packed, const void* packed_bwd, const void* latent_state,
-                           const float* xyz, const float* sdf, const float* grad_sdf, int64_t n_points,
+                           const float* xyz, const float* sdf, const float* grad_sdf, int n_rows, int64_t n_points,
                            const int* tiles, int n_tiles, const int* n_tiles_dev, const int* point_list,
+                           const float* blend_weights, void* scratch,
                            float* grad_xyz, float* grad_anchors, float* grad_b0, float* grad_b2, void* stream) {
-  if (!packed || !packed_bwd || !latent_state || !xyz || !sdf || !grad_sdf || !tiles || !point_list || !grad_xyz ||
-      !grad_anchors || !grad_b0 || !grad_b2)
+  if (!packed || !packed_bwd || !latent_state || !xyz || !sdf || !grad_sdf || !tiles || !point_list || !blend_weights || !scratch ||
+      !grad_xyz || !grad_anchors || !grad_b0 || !grad_b2)
     return nphm_fail_msg("nphm_identity_backward: null pointer");
-  if (n_points <= 0 || n_tiles < 0) return nphm_fail_msg("nphm_identity_backward: bad sizes");
-  if (n_tiles == 0) return 0;
+  if (n_rows <= 0 || n_points <= 0 || n_tiles < 0) return nphm_fail_msg("nphm_identity_backward: bad sizes");
   nphm::bwd::BwdArgs a;
   a.packed_f32 = static_cast<const float*>(packed);
   a.packed_bf16 = reinterpret_cast<const uint16_t*>(static_cast<const char*>(packed) + nphm::PACKED_F32_FLOATS * 4);
@@ -703,10 +750,20 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
   a.xyz = xyz; a.sdf = sdf; a.gout = grad_sdf;
   a.tiles = tiles; a.list = point_list; a.n_points = n_points;
   a.n_tiles = n_tiles; a.n_tiles_dev = n_tiles_dev;
-  a.gxyz = grad_xyz; a.ganch = grad_anchors; a.gb0 = grad_b0; a.gb2 = grad_b2;
+  a.gbp = static_cast<float*>(scratch);
+  a.gap = a.gbp + size_t(n_tiles) * 2 * nphm::HID;
+  a.gxm = a.gap + size_t(n_tiles) * 4;
   a.fmem = nullptr;
-  hipLaunchKernelGGL(nphm::bwd::ident_member_kernel<true>, dim3(member_grid(n_tiles, n_tiles_dev)), dim3(64 * nphm::bwd::WAVES), 0,
-                     static_cast<hipStream_t>(stream), a);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_tiles > 0)
+    hipLaunchKernelGGL(nphm::bwd::ident_member_kernel<true>, dim3(member_grid(n_tiles, n_tiles_dev)), dim3(64 * nphm::bwd::WAVES), 0, st, a);
+  nphm::bwd::ReduceArgs r;
+  r.tiles = tiles; r.n_tiles = n_tiles; r.n_tiles_dev = n_tiles_dev;
+  r.gbp = a.gbp; r.gap = a.gap; r.gxm = a.gxm; r.what = blend_weights;
+  r.n_rows = n_rows; r.n_points = n_points;
+  r.gxyz = grad_xyz; r.ganch = grad_anchors; r.gb0 = grad_b0; r.gb2 = grad_b2;
+  const int64_t pts = int64_t(n_rows) * n_points;
+  hipLaunchKernelGGL(nphm::bwd::ident_bwd_reduce_kernel, dim3(unsigned(n_rows * nphm::N_MEMBERS + (pts + 255) / 256)), dim3(256), 0, st, r);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_backward launch", e);
   return 0;

@@ -374,7 +374,7 @@ class _IdentityFieldFn(torch.autograd.Function):
         _lib.check(lib.nphm_identity_blend_members(what.data_ptr(), fmem.data_ptr(), B * N, out.data_ptr(), stream),
                    "nphm_identity_blend_members")                        # reads fmem only where the blend weight is not 0
         ctx.module = module
-        ctx.save_for_backward(xyz_c, out, packed, state, tiles, n_used, plist)
+        ctx.save_for_backward(xyz_c, out, packed, state, tiles, n_used, plist, what)
         return out
 
     @staticmethod
@@ -385,23 +385,24 @@ class _IdentityFieldFn(torch.autograd.Function):
         # on the composite tier (module.backend = "composite", or parameters that require grad)
         lib = _lib.load()
         module = ctx.module
-        xyz, out, packed, state, tiles, n_used, plist = ctx.saved_tensors
+        xyz, out, packed, state, tiles, n_used, plist, what = ctx.saved_tensors
         B, N, _ = xyz.shape
         dev = xyz.device
         A = module.num_kps + 1
-        # the kernel accumulates into all four: ONE zero-fill, four views
+        # all four are WRITTEN by the kernels (per-tile records added in fixed order: no zero fill, no atomics)
         H, K = module.hidden_dim, module.num_kps
         sizes = [B * N * 3, B * K * 3, B * A * H, B * A * H]
-        parts = torch.zeros(sum(sizes), dtype=torch.float32, device=dev).split(sizes)
+        parts = torch.empty(sum(sizes), dtype=torch.float32, device=dev).split(sizes)
         gx, ga = parts[0].view(B, N, 3), parts[1].view(B, K, 3)
         gb0, gb2 = parts[2].view(B, A, H), parts[3].view(B, A, H)
-        if tiles.shape[0]:
-            g = grad_out.detach().reshape(B, N).contiguous().float()
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(lib.nphm_identity_backward(
-                packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz.data_ptr(),
-                out.data_ptr(), g.data_ptr(), N, tiles.data_ptr(), tiles.shape[0], n_used.data_ptr(), plist.data_ptr(), gx.data_ptr(),
-                ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream), "nphm_identity_backward")
+        g = grad_out.detach().reshape(B, N).contiguous().float()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        scratch = torch.empty(lib.nphm_identity_backward_scratch_bytes(B, N, tiles.shape[0]), dtype=torch.uint8, device=dev)
+        _lib.check(lib.nphm_identity_backward(
+            packed.data_ptr(), module._packed_bwd(dev).data_ptr(), state.data_ptr(), xyz.data_ptr(),
+            out.data_ptr(), g.data_ptr(), B, N, tiles.data_ptr(), tiles.shape[0], n_used.data_ptr(), plist.data_ptr(),
+            what.data_ptr(), scratch.data_ptr(), gx.data_ptr(), ga.data_ptr(), gb0.data_ptr(), gb2.data_ptr(), stream),
+            "nphm_identity_backward")
         # folded bias of member k: W0[k][:, lat] cond_k + b (lin0), W2[k][:, lat] cond_k / sqrt2 + b (skip layer), with
         # cond_k = [z_glob | z_k]: d/dcond_k = gb0_k W0_lat[k] + gb2_k W2_lat[k] / sqrt2, then back onto the latent layout
         # (one launch through the latent columns of lin0 / lin2 in place of a batched GEMM over the 40 members + cat / sum)
