@@ -298,7 +298,10 @@ class IdentityBench:
         return {"mode": "auto (calibrated per checkpoint against the dense exact-fp32 kernel)", "precision": c["precision"],
                 "light_tol": c["light_tol"], "mid_tol": c["mid_tol"], "prune_tol": c["prune_tol"], "refine_band": c["refine_band"],
                 "member_bounds": c["bounds"] is not None,
-                "sample_max_abs_err": c["error"], "target": c["target"], "sample_points": c["n_points"]}
+                "sample_max_abs_err": c["error"], "target": c["target"], "sample_points": c["n_points"],
+                "terms_per_sample_point": c.get("terms_per_point"), "settings_searched": len(c.get("searched", ())),
+                # one-off per weight version, outside the timed region (bounds fit + search + verification of this latent)
+                "calibration_ms": round(self.calibration_ms, 1)}
 
     def mesh_extract(self, precision, binned):
         """second half of the BASELINE metric: latent -> SDF volume (all ranks) -> marching cubes -> vertices/faces,
