@@ -705,3 +705,43 @@ def test_value_jacobian_launch_cut_in_16_and_8_point_workgroups_is_bitwise_the_s
     assert torch.equal(g1, g0)
     # a launch too small or too large for the cut keeps the single form
     assert mlp._jvp_split(1, 1000, dev, 16) == [(0, 0, 64)] and mlp._jvp_split(64, 1000, dev, 16) == [(0, 0, 64)]
+
+
+@pytest.mark.parametrize("hidden", [96, 400])
+def test_k_loops_with_partial_last_round(dev, hidden, monkeypatch):
+    """Hidden widths whose K-step count is not a multiple of four (96 -> 6, 400 -> 26): the four-slot register rings - the
+    32-column value+Jacobian workgroups and the variant for all-two-term hidden layers - skip the slots of their last round
+    that do not exist.  Value and Jacobian of the cut launch against the whole one (bitwise) and against autograd on the
+    composite tier; the all-two-term lattice variant against the three-term kernel."""
+    torch.manual_seed(hidden)
+    net = nphm_amd.DeepSDF(lat_dim=29, hidden_dim=hidden, nlayers=4, geometric_init=False, out_dim=3).to(dev).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.5)
+    net.fit_numerics = "f16x3"
+    g = torch.Generator().manual_seed(3)
+    R, n = 5, 1000
+    x = ((torch.rand(R, n, 3, generator=g) - 0.5) * 0.8).to(dev)
+    cond = (torch.randn(R, 29, generator=g) * 0.3).to(dev)
+    outs = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("NPHM_AMD_JVP_SPLIT", split)
+        assert len(net._jvp_split(R, n, dev, 16)) == (2 if split == "1" else 1)
+        outs[split] = net.forward_hip_jvp(x, cond)
+    assert torch.equal(outs["1"], outs["0"])
+    net.backend = "composite"
+    xg = x.clone().requires_grad_(True)
+    val, _ = net(xg, cond[:, None, :].expand(R, n, 29))
+    jac = torch.stack([torch.autograd.grad(val[..., i].sum(), xg, retain_graph=True)[0] for i in range(3)], dim=-1)   # [R,n,3(x),3(out)]
+    net.backend = "hip"
+    scale = float(jac.abs().max())
+    assert U.maxdiff(outs["1"][:, :, 0].cpu().numpy(), val.detach().cpu().numpy()) < 2e-5 * max(1.0, float(val.detach().abs().max()))
+    assert U.maxdiff(outs["1"][:, :, 1:].cpu().numpy(), jac.cpu().numpy()) < 5e-5 * max(1.0, scale)
+    # lattice-sized evaluation: every hidden layer two-term (the ALL2 variant) against three terms everywhere
+    big = ((torch.rand(1, 1 << 18, 3, generator=g) - 0.5) * 0.8).to(dev)
+    net.numerics, net.two_pass_mask = "fixed", 0
+    ref = net.forward_hip(big, cond[:1])
+    net.two_pass_mask = (1 << 4) - 2                                   # hidden GEMM layers 1 .. 3 of the 5 linear layers
+    two = net.forward_hip(big, cond[:1])
+    err = float((two - ref).abs().max())
+    assert 0 < err < 2e-4 * max(1.0, float(ref.abs().max())), err
