@@ -320,8 +320,9 @@ __device__ __forceinline__ frag_t unit_operand(int c) {
 // format in its `numerics` argument (tangent streams: k d a / d x stays far inside the binary16 range for fields with
 // |d a / d x| < 400, and the hi half saturates instead of overflowing, see split8)
 // ALL2: every hidden GEMM layer runs the two-term product (EvalArgs::two_pass_mask names them all - what the calibration finds
-// for both lattice nets): no wl fragment is ever requested, and the registers that would hold them hold two more K-steps of wh -
-// four in flight instead of two.  (The 32-point workgroups of the hidden-1024 net stream a 16 MB pack out of the Infinity
+// for both lattice nets and for the fitting launches of the expression decoder): no wl fragment is ever requested, and the
+// registers that would hold them hold two more K-steps of wh - four in flight instead of two.  (Fitting step, all six launch
+// shapes: 1 116 -> 1 142 steps/s, same bits.)  (The 32-point workgroups of the hidden-1024 net stream a 16 MB pack out of the Infinity
 // Cache: with 64 KB in flight per CU they ran at that latency's 74 GB/s per CU, a third of the matrix pipe.)
 template <int MT, int NTW, int MODE, int KIND, bool F16 = false, bool ALL2 = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
@@ -822,7 +823,7 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   a.two_pass_mask = (unsigned(numerics) >> 8) & ((1u << (plan.n_linear - 1)) - 2u);     // hidden GEMM layers 1 .. n_linear - 2
   // every hidden GEMM layer two-term (split-f16 only): the variant without wl fragments (mlp_eval_kernel, ALL2)
   const unsigned hidden_mask = (1u << (plan.n_linear - 1)) - 2u;
-  const bool all2 = KIND == 0 && f16 && plan.n_linear > 2 && a.two_pass_mask == hidden_mask
+  const bool all2 = f16 && plan.n_linear > 2 && a.two_pass_mask == hidden_mask && (KIND == 0 || plan.variant == 0)
 #ifdef NPHM_MLP_NO_ALL2
                     && false
 #endif
@@ -850,17 +851,12 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   };
   if (small) {
     if constexpr (SMALL_OK) {
-      if (f16 ? go(mlp_eval_kernel<1, 2, MODE, KIND, true>, lds_bytes<1, 2>()) : go(mlp_eval_kernel<1, 2, MODE, KIND, false>, lds_bytes<1, 2>())) return -2;
+      if (all2 ? go(mlp_eval_kernel<1, 2, MODE, KIND, true, true>, lds_bytes<1, 2>())
+               : f16 ? go(mlp_eval_kernel<1, 2, MODE, KIND, true>, lds_bytes<1, 2>()) : go(mlp_eval_kernel<1, 2, MODE, KIND, false>, lds_bytes<1, 2>())) return -2;
     }
   } else if (plan.variant == 0) {
-    if constexpr (KIND == 0) {
-      if (all2) {
-        if (go(mlp_eval_kernel<2, 2, MODE, 0, true, true>, lds_bytes<2, 2>())) return -2;
-        e = hipGetLastError();
-        return e == hipSuccess ? 0 : nphm_fail("nphm_mlp_eval launch", e);
-      }
-    }
-    if (f16 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true>, lds_bytes<2, 2>()) : go(mlp_eval_kernel<2, 2, MODE, KIND, false>, lds_bytes<2, 2>())) return -2;
+    if (all2 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true, true>, lds_bytes<2, 2>())
+             : f16 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true>, lds_bytes<2, 2>()) : go(mlp_eval_kernel<2, 2, MODE, KIND, false>, lds_bytes<2, 2>())) return -2;
   } else if constexpr (KIND == 3 || KIND == 4) {
     return nphm_fail_msg("nphm_mlp_eval_points_saving: only the hidden <= 512 variant has a backward kernel");
   } else if constexpr (KIND == 0) {
