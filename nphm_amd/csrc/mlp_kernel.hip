@@ -522,7 +522,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #ifndef NPHM_MLP_SLOTS_SMALL
 #define NPHM_MLP_SLOTS_SMALL 4
 #endif
-  constexpr int NS = ALL2 ? 4 : (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
+#ifndef NPHM_MLP_SLOTS_ALL2_SMALL
+#define NPHM_MLP_SLOTS_ALL2_SMALL 4
+#endif
+  constexpr int NS = ALL2 ? ((MT == 1 && NTW == 2) ? NPHM_MLP_SLOTS_ALL2_SMALL : 4) : (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
   static_assert(NS % 2 == 0, "the B operand's two slots alternate with the K-step");
   frag_t ah[NS][NTW], al[NS][NTW];
   // Terms of the split product of a layer: three = xh wh + xl wh + xh wl, two = without the wl term (EvalArgs::two_pass_mask).
