@@ -260,7 +260,13 @@ __global__ __launch_bounds__(64 * CG_PARTS) void cond_grad_kernel(const float* _
   for (int e = threadIdx.x; e < 2 * H; e += blockDim.x) {         // (which, h) = (e / H, e % H): the row's slots in order
     const float* src = parts + size_t(r) * n_slots * 2 * H + e;
     float t = 0.f;
-    for (int q = 0; q < n_slots; ++q) t += src[size_t(q) * 2 * H];
+    for (int q = 0; q < n_slots; q += 8) {                         // eight loads in flight, added in slot order
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = q + i < n_slots ? src[size_t(q + i) * 2 * H] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += v[i];
+    }
     gsum[e / H][e % H] = t;
   }
   __syncthreads();
