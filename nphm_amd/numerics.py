@@ -259,15 +259,19 @@ def fit_member_bounds(decoder, lat: torch.Tensor, n: int = 1 << 16, seed: int = 
         _lib.check(lib.nphm_identity_member_forward(packed.data_ptr(), decoder._packed_bwd(dev).data_ptr(), state.data_ptr(),
                                                     pts.data_ptr(), N, tiles.data_ptr(), tiles.shape[0], None, plist.data_ptr(),
                                                     fmem.data_ptr(), stream), "nphm_identity_member_forward")
-        f = fmem[0].abs().cpu().numpy()                                               # [N, 40]
-        d = (pts[0][:, None, :] - anchors[0][None]).norm(dim=-1).cpu().numpy()       # [N, 39]
+        f = fmem[0].abs()                                                             # [N, 40]
+        d = (pts[0][:, None, :] - anchors[0][None]).norm(dim=-1)                      # [N, 39]
+        # maxima of |f_k| over 24 distance bins of width 0.1, on the device (39 x np.maximum.at over 65 536 points was
+        # most of the 0.13 s this function took): only the [39, 24] table travels
+        bins = torch.clamp((d.double() / 0.1).floor().long(), 0, 23)                  # = np.digitize(d, linspace(0, 2.4, 25)) - 1
+        table = torch.zeros(A - 1, 24, dtype=torch.float32, device=dev)
+        table.scatter_reduce_(1, bins.t().contiguous(), f[:, :A - 1].t().contiguous(), reduce="amax", include_self=True)
+        table = table.double().cpu().numpy()
+        f_bg = float(f[:, A - 1].max())
     out = np.zeros((A, 4), np.float32)
     edges = np.linspace(0.0, 2.4, 25)
     for k in range(A - 1):
-        b = np.clip(np.digitize(d[:, k], edges) - 1, 0, 23)
-        m = np.zeros(24)
-        np.maximum.at(m, b, f[:, k])
-        m = np.maximum.accumulate(m)                         # non-decreasing envelope of the bin maxima
+        m = np.maximum.accumulate(table[k])                  # non-decreasing envelope of the bin maxima
         x = edges[1:]                                        # evaluated at the far edge of a bin
         # non-negative least squares on (1, d, d^2), then lifted onto the envelope
         from scipy.optimize import nnls
@@ -276,7 +280,7 @@ def fit_member_bounds(decoder, lat: torch.Tensor, n: int = 1 << 16, seed: int = 
         lift = float(np.max(m - Amat @ c))
         c[0] += max(lift, 0.0)
         out[k, :3] = BOUND_SAFETY * c
-    out[A - 1, 0] = BOUND_SAFETY * float(f[:, A - 1].max())
+    out[A - 1, 0] = BOUND_SAFETY * f_bg
     out[:, 0] = np.maximum(out[:, 0], 1e-6)
     return torch.from_numpy(out).to(dev)
 
