@@ -188,7 +188,8 @@ size_t nphm_identity_bwd_packed_bytes(void);
  * (prune_tol < 0: nothing dropped; EnsembledDeepSDF.py:129-150 for the weights); tiles = room for
  * 2 * n_rows * 40 * T entries of 4 ints (the used tiles end up compacted at the front, the second half is
  * scratch); *n_tiles_used (device int) = their number; point_list [n_rows * 40 * 64 T].  The kernels take the
- * capacity n_rows * 40 * T as n_tiles and the device count as n_tiles_dev. */
+ * capacity n_rows * 40 * T as n_tiles and the device count as n_tiles_dev.  tiles = n_tiles_used = point_list = NULL: the
+ * blend weights alone (one launch). */
 int nphm_identity_list_tiles(int64_t n_points);
 int nphm_identity_build_lists(const void* latent_state, const float* xyz, int n_rows, int64_t n_points, float prune_tol,
                               float* blend_weights, int* tiles, int* n_tiles_used, int* point_list, void* stream);

@@ -723,7 +723,9 @@ int nphm_identity_list_tiles(int64_t n_points) { return n_points <= 0 ? 0 : int(
 
 int nphm_identity_build_lists(const void* latent_state, const float* xyz, int n_rows, int64_t n_points, float prune_tol,
                               float* blend_weights, int* tiles, int* n_tiles_used, int* point_list, void* stream) {
-  if (!latent_state || !xyz || !blend_weights || !tiles || !n_tiles_used || !point_list)
+  // (tiles = n_tiles_used = point_list = NULL: the blend weights alone - the training tier cuts its own, member-ordered lists)
+  const bool weights_only = !tiles && !n_tiles_used && !point_list;
+  if (!latent_state || !xyz || !blend_weights || (!weights_only && (!tiles || !n_tiles_used || !point_list)))
     return nphm_fail_msg("nphm_identity_build_lists: null pointer");
   if (n_rows <= 0 || n_points <= 0 || n_points > 0x7fffff00LL / (nphm::N_MEMBERS * int64_t(n_rows)) - 64)
     return nphm_fail_msg("nphm_identity_build_lists: bad sizes");
@@ -732,9 +734,13 @@ int nphm_identity_build_lists(const void* latent_state, const float* xyz, int n_
   a.xyz = xyz; a.n_rows = n_rows; a.n_points = n_points; a.prune_tol = prune_tol;
   a.T = nphm_identity_list_tiles(n_points);
   const int n_slots = n_rows * nphm::N_MEMBERS * a.T;
-  a.what = blend_weights; a.tiles = tiles + 4 * size_t(n_slots); a.list = point_list;     // slot table: second half
+  a.what = blend_weights; a.tiles = weights_only ? nullptr : tiles + 4 * size_t(n_slots); a.list = point_list;     // slot table: second half
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(nphm::bwd::weights_kernel, dim3(unsigned((n_points + 255) / 256), n_rows), dim3(256), 0, st, a);
+  if (weights_only) {
+    hipError_t e0 = hipGetLastError();
+    return e0 == hipSuccess ? 0 : nphm_fail("nphm_identity_build_lists launch", e0);
+  }
   // a block per (row, member) walks the row's points: 1024 threads when the rows are long (one row of 5 000 points in the
   // fitting step: 5 rounds instead of 20 on the step's serial chain)
   hipLaunchKernelGGL(nphm::bwd::lists_kernel, dim3(n_rows * nphm::N_MEMBERS), dim3(n_points > 512 ? 1024 : 256), 0, st, a);

@@ -272,6 +272,17 @@ def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
     return what, tiles[: B * n_members * T], n_used, plist
 
 
+def _blend_weights_device(state, xyz, prune_tol, n_members, stream):
+    """Normalised blend weights [B,N,A], zero where the pruning rule drops the member (the first launch of
+    nphm_identity_build_lists alone: the training tier cuts its own member-ordered lists from them)."""
+    lib = _lib.load()
+    B, N, _ = xyz.shape
+    what = torch.empty(B, N, n_members, dtype=torch.float32, device=xyz.device)
+    _lib.check(lib.nphm_identity_build_lists(state.data_ptr(), xyz.data_ptr(), B, N, float(prune_tol), what.data_ptr(),
+                                             None, None, None, stream), "nphm_identity_build_lists")
+    return what
+
+
 class _FrozenHeadFn(torch.autograd.Function):
     """y = head(x) for a small nn.Sequential of Linear / ReLU layers whose parameters are CONSTANTS (latent fitting:
     ``mlp_pos``, the deformation field's compressor): the whole chain in one launch, the gradient w.r.t. x in one launch
@@ -451,7 +462,7 @@ class _MemberFieldFn(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         # members the pruning rule keeps per point: the list kernel's normalised blend weights (0 where pruned)
         tol = module._train_tol()
-        what = _member_point_lists_device(state, xyz_c, tol, A, stream)[0]
+        what = _blend_weights_device(state, xyz_c, tol, A, stream)
         tiles_fwd, tiles, plist, chunks, pieces, (edge_tabs, n_sets, ring) = _train_member_lists(what > 0, module.ensembled_deep_sdf.lin0._sets)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
