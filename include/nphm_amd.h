@@ -391,7 +391,7 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
  *   checkpoint: the host module measures it against the three-term product (nphm_amd/deepsdf.py, calibrate).
  * The value+Jacobian, Broyden and saving entry points below take the same argument (hidden_dim <= 512: both formats;
  * the 1024-wide variant runs them on bf16 halves only).
- * The two value+Jacobian entry points also take a point RANGE and a workgroup width (ABI 7): the launch covers points
+ * The two value+Jacobian entry points also take a point RANGE and a workgroup width (ABI 8): the launch covers points
  * [point_base, point_base + point_count) of every row (0, 0 = all; point_base a multiple of 16, of 64 for the saving form)
  * with `columns` = 64 (16 points per workgroup; 0 = default) or 32 (8 points per workgroup, hidden_dim <= 512) - a batch whose
  * 16-point workgroups fill 1.2 rounds of the chip runs as one full round of them plus a round of 8-point workgroups over the
