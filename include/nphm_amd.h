@@ -244,6 +244,13 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *     n_chunks * nphm_identity_train_edge_bytes(1) bytes. */
 size_t nphm_identity_train_saved_bytes(int n_tiles, int operands_bf16);
 size_t nphm_identity_train_edge_bytes(int n_tiles);
+/* HOST helper (no device work; ABI 8): the tables above from counts [40 * n_rows] = listed points of every (member, row) pair
+ * (pair = member * n_rows + row, the order of the point list); member_set [40] = weight set of every member (non-decreasing),
+ * ring_tiles = backward tiles per piece (<= 0: one piece), chunk_tiles = tiles per weight-gradient chunk.  Capacities the caller
+ * provides: tiles_fwd 4 * (sum(counts) / 64 + pairs), tiles_bwd and chunks 4 * (sum(counts) / 32 + pairs) ints, set_chunk_first
+ * [n_sets + 1], pair_first [pairs + 1]; sizes[4] = forward tiles, backward tiles, chunks, tiles per piece. */
+int nphm_identity_train_tables(const long long* counts, int n_rows, const int* member_set, int n_sets, int ring_tiles, int chunk_tiles,
+                               int* tiles_fwd, int* tiles_bwd, int* chunks, int* set_chunk_first, int* pair_first, int* sizes);
 int nphm_identity_train_forward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                 int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                 float* member_sdf, float* member_grad, void* stream);

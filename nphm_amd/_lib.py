@@ -68,6 +68,8 @@ SYMBOLS = {
     "nphm_identity_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
     "nphm_identity_train_edge_bytes": (c_size_t, [c_int]),
+    "nphm_identity_train_tables": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     "nphm_identity_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

@@ -213,44 +213,51 @@ def _train_member_lists(mask, sets):
     B, N, A = mask.shape
     with torch.no_grad():
         idx = mask.permute(2, 0, 1).nonzero()                  # sorted by (member, row, point)
-        counts = torch.bincount(idx[:, 0] * B + idx[:, 1], minlength=A * B).cpu().numpy()
-    offs = np.concatenate([[0], np.cumsum(counts)])
-
-    def cut(width):            # tiles of <= width consecutive list entries of one (member, row) pair
-        n_t = (counts + width - 1) // width
-        pair = np.repeat(np.arange(A * B), n_t)
-        within = np.arange(int(n_t.sum())) - np.repeat(np.cumsum(n_t) - n_t, n_t)
-        return pair, n_t, np.stack([pair % B, pair // B, offs[pair] + width * within,
-                                    np.minimum(width, counts[pair] - width * within)], axis=1).astype(np.int32)
-
-    _, _, tiles_fwd = cut(64)
-    pair, tiles_per_pair, tiles = cut(32)
-    T = tiles.shape[0]
-    set_of_tile = sets.cpu().numpy()[pair // B]
-    ring = _TRAIN_RING_TILES if _TRAIN_RING_TILES > 0 else max(T, 1)
-    # chunk boundaries: every _WGRAD_CHUNK tiles inside a run of one weight set inside one piece
-    piece_of_tile = np.arange(T) // ring
-    if T:
-        run_start = np.flatnonzero(np.r_[True, (np.diff(set_of_tile) != 0) | (np.diff(piece_of_tile) != 0)])
-        run_len = np.diff(np.r_[run_start, T])
-        n_ch = (run_len + _WGRAD_CHUNK - 1) // _WGRAD_CHUNK                       # chunks per run
-        run = np.repeat(np.arange(len(run_start)), n_ch)
-        k_in_run = np.arange(int(n_ch.sum())) - np.repeat(np.cumsum(n_ch) - n_ch, n_ch)
-        first = run_start[run] + _WGRAD_CHUNK * k_in_run                          # first tile of every chunk
-        piece = first // ring
-        chunks = np.stack([set_of_tile[first], first - piece * ring,
-                           np.minimum(_WGRAD_CHUNK, run_start[run] + run_len[run] - first), piece], axis=1).astype(np.int32)
-        c_first = np.searchsorted(piece, np.arange(piece[-1] + 1), side="left")
-        c_count = np.diff(np.r_[c_first, len(piece)])
+        counts = torch.bincount(idx[:, 0] * B + idx[:, 1], minlength=A * B).cpu().numpy().astype(np.int64)   # the one sync
+    sets_np = _sets_on_host(sets)
+    n_sets = int(sets_np.max()) + 1
+    # the tables on the host in C (nphm_identity_train_tables; numpy took 0.5 ms per step with the GPU idle), in ONE buffer
+    # that travels to the device in one copy: [forward tiles | backward tiles | chunks | first chunk per set | first tile per pair]
+    lib = _lib.load()
+    total = int(counts.sum())
+    cap64, cap32 = total // 64 + A * B, total // 32 + A * B
+    o_fwd, o_bwd, o_ch = 0, 4 * cap64, 4 * cap64 + 4 * cap32
+    o_set = o_ch + 4 * cap32
+    o_pair = o_set + n_sets + 1
+    buf = np.empty(o_pair + A * B + 1, np.int32)
+    sizes = np.zeros(4, np.int32)
+    base = buf.ctypes.data
+    _lib.check(lib.nphm_identity_train_tables(counts.ctypes.data, B, sets_np.ctypes.data, n_sets, int(_TRAIN_RING_TILES), int(_WGRAD_CHUNK),
+                                              base + 4 * o_fwd, base + 4 * o_bwd, base + 4 * o_ch, base + 4 * o_set, base + 4 * o_pair,
+                                              sizes.ctypes.data), "nphm_identity_train_tables")
+    t64, T, C, ring = (int(v) for v in sizes)
+    piece_of_chunk = buf[o_ch:o_ch + 4 * C].reshape(C, 4)[:, 3]
+    pieces = []
+    if C:
+        c_first = np.searchsorted(piece_of_chunk, np.arange(int(piece_of_chunk[-1]) + 1), side="left")
+        c_count = np.diff(np.r_[c_first, C])
         pieces = [(int(pi * ring), int(min(ring, T - pi * ring)), int(c0), int(nc)) for pi, (c0, nc) in enumerate(zip(c_first, c_count))]
-    else:
-        chunks, pieces = np.zeros((0, 4), np.int32), []
-    n_sets = int(sets.max().item()) + 1
-    edge_tabs = np.concatenate([np.searchsorted(chunks[:, 0], np.arange(n_sets + 1), side="left"),
-                                np.r_[0, np.cumsum(tiles_per_pair)]]).astype(np.int32)
     dev = mask.device
-    return (torch.from_numpy(tiles_fwd).to(dev), torch.from_numpy(tiles).to(dev), idx[:, 2].to(torch.int32).contiguous(),
-            torch.from_numpy(chunks).to(dev), pieces, (torch.from_numpy(edge_tabs).to(dev), n_sets, int(ring)))
+    d = torch.from_numpy(buf).to(dev)
+    tiles_fwd = d[o_fwd:o_fwd + 4 * t64].view(t64, 4)
+    tiles = d[o_bwd:o_bwd + 4 * T].view(T, 4)
+    chunks = d[o_ch:o_ch + 4 * C].view(C, 4)
+    edge_tabs = d[o_set:]                                      # [n_sets + 1 | A * B + 1], contiguous
+    return tiles_fwd, tiles, idx[:, 2].to(torch.int32).contiguous(), chunks, pieces, (edge_tabs, n_sets, ring)
+
+
+_SETS_HOST = {}
+
+
+def _sets_on_host(sets):
+    """member -> weight set as a contiguous int32 host array (a constant of the architecture: read from the device once)"""
+    key = (sets.data_ptr(), sets._version, sets.numel())
+    hit = _SETS_HOST.get(key)
+    if hit is None:
+        if len(_SETS_HOST) > 8:
+            _SETS_HOST.clear()
+        hit = _SETS_HOST[key] = np.ascontiguousarray(sets.detach().cpu().numpy().astype(np.int32))
+    return hit
 
 
 def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
