@@ -439,7 +439,9 @@ _WGRAD_CHUNK = int(os.environ.get("NPHM_AMD_WGRAD_CHUNK", "32"))     # tiles per
 # operands of a piece into a buffer the weight-gradient kernel consumes before the next piece reuses it - a cap on the
 # memory of large batches (pieces of 512 tiles that would stay in the Infinity Cache measured 15-25 % SLOWER than
 # one piece: launch gaps and tail effects outweigh the saved HBM traffic)
-_TRAIN_RING_TILES = int(os.environ.get("NPHM_AMD_TRAIN_RING_TILES", "16384"))       # 5.5 GiB
+# (round 4: 65 536 tiles = 16 GiB of 257 KiB records - the nphm.yaml batch, 28.6 k tiles, is ONE piece: 9.64 -> 9.47 ms per step
+# against two pieces of 16 384; the cap only matters for batches several times that size on a 288 GB device)
+_TRAIN_RING_TILES = int(os.environ.get("NPHM_AMD_TRAIN_RING_TILES", "65536"))
 
 
 class _MemberFieldFn(torch.autograd.Function):
