@@ -435,7 +435,7 @@ class _IdentityFieldFn(torch.autograd.Function):
 
 
 _WGRAD_CHUNK = int(os.environ.get("NPHM_AMD_WGRAD_CHUNK", "32"))     # tiles per workgroup of the weight-gradient kernel
-# tiles per piece of the backward pass (352 KiB of stored operands each; 0 = one piece): the reverse kernel writes the
+# tiles per piece of the backward pass (257 KiB of stored operands each; 0 = one piece): the reverse kernel writes the
 # operands of a piece into a buffer the weight-gradient kernel consumes before the next piece reuses it - a cap on the
 # memory of large batches (pieces of 512 tiles that would stay in the Infinity Cache measured 15-25 % SLOWER than
 # one piece: launch gaps and tail effects outweigh the saved HBM traffic)
