@@ -256,8 +256,9 @@ def _sets_on_host(sets):
     if hit is None:
         if len(_SETS_HOST) > 8:
             _SETS_HOST.clear()
-        hit = _SETS_HOST[key] = np.ascontiguousarray(sets.detach().cpu().numpy().astype(np.int32))
-    return hit
+        # (the entry holds the tensor: an address that is still referenced cannot be handed to another decoder's table)
+        hit = _SETS_HOST[key] = (sets, np.ascontiguousarray(sets.detach().cpu().numpy().astype(np.int32)))
+    return hit[1]
 
 
 def _member_point_lists_device(state, xyz, prune_tol, n_members, stream):
