@@ -346,17 +346,18 @@ class IdentityBench:
 # ------------------------------------------------------------------------------------------------------
 # configs[2], configs[0], configs[4]
 # ------------------------------------------------------------------------------------------------------
-def _mlp_exec_flops(mlp, mask):
-    """executed MFMA FLOPs per point of the dense skip-MLP kernel: hidden GEMM layer l runs 2 terms of the split product if
-    bit l of ``mask`` is set (DeepSDF.two_pass tier, calibrated per checkpoint) else 3; lin0's coordinate step and the
-    (folded) last layer always 3.  Also returns the per-layer pass list."""
+def _mlp_exec_flops(mlp, mask, single=False):
+    """executed MFMA FLOPs per point of the dense skip-MLP kernel: hidden GEMM layer l runs 1 term of the split product in the
+    single-term tier, 2 if bit l of ``mask`` is set (DeepSDF's calibrated tiers) else 3; lin0's coordinate step always 3, the
+    (folded) last layer 3 (2 in the single-term tier).  Also returns the per-layer pass list."""
     d_in = mlp.lat_dim + mlp.input_dim
     total, passes = 0.0, []
     for l in range(mlp.num_layers - 1):
         W = getattr(mlp, f"lin{l}").weight
         out_f, in_f = W.shape
         k = 3 if l == 0 else (in_f - d_in if l in mlp.skip_in else in_f) + (3 if l in mlp.skip_in else 0)
-        p = 2 if (0 < l < mlp.num_layers - 2 and (mask >> l) & 1) else 3
+        hidden = 0 < l < mlp.num_layers - 2
+        p = (1 if hidden else 2 if l > 0 else 3) if single else 2 if (hidden and (mask >> l) & 1) else 3
         passes.append(p)
         total += p * 2.0 * out_f * k
     return total, passes
@@ -368,15 +369,23 @@ def _mlp_kernel_name(mlp, shape, num):
     f16 = mlp.precision == "f16x3"
     n_hidden = len(num["passes_per_layer"]) - 2
     all2 = f16 and n_hidden > 0 and all(p == 2 for p in num["passes_per_layer"][1:-1])
-    return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,{'true' if f16 else 'false'}{',true' if all2 else ''}>"
+    asym = os.environ.get("NPHM_AMD_MLP_ASYM", "1") not in ("0", "")
+    if not f16:
+        return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,false>"
+    if num.get("single_term"):
+        shape = {"2,2": "4,2", "1,4": "2,4"}[shape]          # twice the points per workgroup
+        return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,false,true,{'true' if asym else 'false'}>"
+    return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,{'true' if all2 else 'false'},false,{'true' if asym else 'false'}>"
 
 
 def _mlp_numerics_report(mlp):
     r = dict(mlp.last_numerics or {})
     mask = int(r.get("mask", 0))
-    flops, passes = _mlp_exec_flops(mlp, mask)
-    return {"precision": mlp.precision, "numerics": mlp.numerics, "two_pass_mask": mask, "passes_per_layer": passes,
-            "target": r.get("target"), "sample_err": r.get("err"), "verified_err": r.get("verified_err")}, flops
+    single = bool(r.get("single_term", False))
+    flops, passes = _mlp_exec_flops(mlp, mask, single)
+    return {"precision": mlp.precision, "numerics": mlp.numerics, "single_term": single, "two_pass_mask": mask,
+            "passes_per_layer": passes, "target": r.get("target"), "sample_err": r.get("err"),
+            "verified_err": r.get("verified_err"), "single_term_err": r.get("single_term_err")}, flops
 
 
 def two_stage_record(args, dev, steps, warmup):

@@ -19,6 +19,7 @@
 //     fixed order (bitwise reproducible).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -258,6 +259,24 @@ __device__ __forceinline__ Split8 split8(const float* x) {
   return o;
 }
 
+// 8 values -> ONE binary16 operand, rounded to nearest (v_cvt_pk_f16_f32; +inf clamped to the largest finite value): the
+// B operand of a single-term layer (ONE below).  Truncation (split8's hi half) would shrink every product of the non-negative
+// activations by 2^-12 on average - a coherent 1.2e-4 relative error of the layer instead of a random one
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ frag_t pack8_rn(const float* x) {
+  frag_t o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2_t v = {x[2 * q], x[2 * q + 1]};
+    f16x2_t hv = __builtin_convertvector(v, f16x2_t);
+    const f16x2_t top = {(_Float16)65504.f, (_Float16)65504.f};
+    hv = __builtin_elementwise_min(hv, top);
+    o[q] = __builtin_bit_cast(unsigned, hv);
+  }
+  return o;
+}
+
 // B operand of the coordinate K-step for one point (see mlp_layout.h)
 template <bool F16>
 __device__ __forceinline__ frag_t coord_operand(float x, float y, float z, int h) {
@@ -324,9 +343,22 @@ __device__ __forceinline__ frag_t unit_operand(int c) {
 // registers that would hold them hold two more K-steps of wh - four in flight instead of two.  (Fitting step, all six launch
 // shapes: 1 116 -> 1 142 steps/s, same bits.)  (The 32-point workgroups of the hidden-1024 net stream a 16 MB pack out of the Infinity
 // Cache: with 64 KB in flight per CU they ran at that latency's 74 GB/s per CU, a third of the matrix pipe.)
-template <int MT, int NTW, int MODE, int KIND, bool F16 = false, bool ALL2 = false>
+// ONE (split-f16, plain evaluation only): every hidden GEMM layer runs the SINGLE-term product rn(x) wh on binary16 operands
+// with fp32 accumulation - no lo plane in LDS, so a workgroup holds TWICE the points (128 at hidden <= 512) per weight pass:
+// half the L2 -> register weight bytes per point and half the MFMAs of the two-term product.  Chosen per checkpoint by the
+// calibration of DeepSDF._numerics_code (measured against the three-term product; the trained deformation net sits at 2e-6).
+// ASYM (plain evaluation): the two wavefronts of a SIMD run half a layer out of phase instead of in lockstep.  Wavefronts
+// 0..3 (one per SIMD, s_setprio 1) own the matrix pipe first: they finish their GEMM, run their softplus / re-split
+// epilogue while wavefronts 4..7 have the pipe, and start the next layer on the K-steps whose input tiles THEY produced while
+// wavefronts 4..7 run their epilogue.  One s_barrier per layer is left (all reads of the old tile done -> the in-place store is
+// safe); "the new tile is complete" became two LDS flag groups (tiles of wavefronts 0..3 / 4..7 stored), and the K loop
+// visits the K-steps of the first group's tiles first (kstep_of).  Lockstep had both wavefronts of a SIMD in their MFMA
+// segment and then both in their VALU segment (MI355X_MICROARCH.md, "Two waves per SIMD": matrix beside matrix nets nothing).
+template <int MT, int NTW, int MODE, int KIND, bool F16 = false, bool ALL2 = false, bool ONE = false, bool ASYM = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   constexpr bool JVP = KIND == 1 || KIND == 4, BROY = KIND == 2, SAVE = KIND == 3 || KIND == 4;   // 4: value+Jacobian, sigma' saved
+  static_assert(!ONE || (F16 && KIND == 0), "the single-term product serves the plain split-f16 evaluation");
+  static_assert(!ASYM || KIND == 0, "the phase-shifted schedule serves the plain evaluation (one pass over the network)");
   constexpr int M = 32 * MT;               // columns per workgroup
   constexpr int PTS = JVP ? M / 4 : M;     // points per workgroup
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
@@ -334,9 +366,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   constexpr int PART_BYTES = NCH * M * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act_hi = smem;
-  char* act_lo = smem + PART_BYTES;
-  float* partial = reinterpret_cast<float*>(smem + 2 * PART_BYTES);   // [WAVES][M][4]
+  char* act_lo = smem + PART_BYTES;                                   // (ONE: no lo plane; never addressed)
+  float* partial = reinterpret_cast<float*>(smem + (ONE ? 1 : 2) * PART_BYTES);   // [WAVES][M][4]
   float* xs = partial + WAVES * M * 4;                                // [M][4] current iterate (KIND 2)
+  volatile unsigned* flags = reinterpret_cast<volatile unsigned*>(xs + M * 4);   // [WAVES] layers whose tiles wavefront w has stored (ASYM)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -345,6 +378,33 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   const int64_t n_pts = MODE == 0 ? p.n_points : int64_t(p.ix1 - p.ix0) * p.ry * p.rz;
   const int64_t base = (MODE == 0 ? p.point_base : 0) + int64_t(blockIdx.x) * PTS;
   const int64_t n_end = MODE == 0 ? p.point_end : n_pts;          // first point of the row this launch does not own
+  const bool lead = wave < WAVES / 2;      // ASYM: the wavefronts that own the matrix pipe first (one per SIMD)
+  if constexpr (ASYM) {
+    if (threadIdx.x < WAVES) flags[threadIdx.x] = 0;
+    if (lead) __builtin_amdgcn_s_setprio(1);
+    __syncthreads();
+  }
+  // ASYM: flags[w] >= v for the four wavefronts from `first` on (their tiles of layer v - 1 are in LDS)
+  auto wait_flags = [&](int first, unsigned v) __attribute__((always_inline)) {
+    for (;;) {
+      const volatile unsigned* f = flags + first;
+      const unsigned a = f[0], b = f[1], c = f[2], d = f[3];
+      const unsigned m = a < b ? a : b, n = c < d ? c : d;
+      if (__builtin_amdgcn_readfirstlane(m < n ? m : n) >= v) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");          // no tile read moves above the flag reads
+  };
+  // ASYM: the K loop's s-th step is K-step kstep_of(s): the steps of the tiles wavefronts 0..3 produced (tiles n with
+  // (n & 4) == 0) first, then the others.  kt = input tiles of the layer (k_steps / 2), lead_tiles(kt) of them from wavefronts 0..3
+  auto lead_tiles = [](int kt) { const int r = kt & 7; return (kt >> 3) * 4 + (r < 4 ? r : 4); };
+  auto kstep_of = [&](int sidx, int ch) __attribute__((always_inline)) {
+    if constexpr (!ASYM) return sidx;
+    const int q = sidx >> 1;
+    const int m = q < ch ? q : q - ch;
+    const int n = ((m >> 2) << 3) | (m & 3) | (q < ch ? 0 : 4);
+    return 2 * n + (sidx & 1);
+  };
 
   auto point_coords = [&](int64_t i, float& x, float& y, float& z) {
     const int64_t ic = i < n_pts ? i : n_pts - 1;
@@ -403,7 +463,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, 0x7fffffff, 0x00020000);
   const f32x16 zero16 = {};
   f32x16 acc[NTW][MT];
+#ifndef NPHM_MLP_ALIAS
+#define NPHM_MLP_ALIAS 1
+#endif
+#if !NPHM_MLP_ALIAS
   Split8 packed_out[NTW][MT][2];
+#endif
 
   // epilogue of the wavefront's tiles: softplus, re-split (registers only)
   auto activate = [&](int ni, int layer) __attribute__((always_inline)) {
@@ -448,8 +513,29 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
               v[r] = softplus2(acc[i][t][r]);
             }
           }
-          packed_out[i][t][0] = split8<F16>(v);
-          packed_out[i][t][1] = split8<F16>(v + 8);
+          // the operands take the place of the accumulators they came from (registers 8 half .. 8 half + 3: hi fragment of
+          // values 8 half .. 8 half + 7, the next four: lo fragment) - no second register set lives beside the tile.
+          // (__uint_as_float, NOT __builtin_bit_cast: the builtin applied to an ext-vector ELEMENT reads element 0.)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+#if NPHM_MLP_ALIAS
+            if constexpr (ONE) {
+              const frag_t o = pack8_rn(v + 8 * half);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[i][t][8 * half + q] = __uint_as_float(o[q]);
+            } else {
+              const Split8 o = split8<F16>(v + 8 * half);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                acc[i][t][8 * half + q] = __uint_as_float(o.hi[q]);
+                acc[i][t][8 * half + 4 + q] = __uint_as_float(o.lo[q]);
+              }
+            }
+#else
+            if constexpr (ONE) packed_out[i][t][half].hi = pack8_rn(v + 8 * half);
+            else packed_out[i][t][half] = split8<F16>(v + 8 * half);
+#endif
+          }
         }
       }
     }
@@ -465,8 +551,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int off = ((4 * n + 2 * half + h) * M + 32 * t + j) * 16;
-            *reinterpret_cast<frag_t*>(act_hi + off) = packed_out[i][t][half].hi;
-            *reinterpret_cast<frag_t*>(act_lo + off) = packed_out[i][t][half].lo;
+            frag_t fh, fl;
+#if NPHM_MLP_ALIAS
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              fh[q] = __float_as_uint(acc[i][t][8 * half + q]);
+              fl[q] = __float_as_uint(acc[i][t][8 * half + 4 + q]);
+            }
+#else
+            fh = packed_out[i][t][half].hi;
+            fl = packed_out[i][t][half].lo;
+#endif
+            *reinterpret_cast<frag_t*>(act_hi + off) = fh;
+            if constexpr (!ONE) *reinterpret_cast<frag_t*>(act_lo + off) = fl;
           }
         }
       }
@@ -503,6 +600,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     coord_step(L, ni);
     activate(ni, 0);
     store_tiles(ni);
+    if constexpr (ASYM) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) flags[wave] = 1u;
+    }
   }
 
   // ---- hidden layers ---------------------------------------------------------------------------
@@ -525,20 +626,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #ifndef NPHM_MLP_SLOTS_ALL2_SMALL
 #define NPHM_MLP_SLOTS_ALL2_SMALL 4
 #endif
-  constexpr int NS = ALL2 ? ((MT == 1 && NTW == 2) ? NPHM_MLP_SLOTS_ALL2_SMALL : 4) : (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
+#ifndef NPHM_MLP_SLOTS_ONE
+#define NPHM_MLP_SLOTS_ONE 4
+#endif
+  constexpr bool NO_WL = ALL2 || ONE;      // no wl fragment is ever requested
+  constexpr int NS = ONE ? NPHM_MLP_SLOTS_ONE : ALL2 ? ((MT == 1 && NTW == 2) ? NPHM_MLP_SLOTS_ALL2_SMALL : 4) : (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
   static_assert(NS % 2 == 0, "the B operand's two slots alternate with the K-step");
   frag_t ah[NS][NTW], al[NS][NTW];
   // Terms of the split product of a layer: three = xh wh + xl wh + xh wl, two = without the wl term (EvalArgs::two_pass_mask).
   // One loop body serves both (two specialised loops under a branch made hipcc spill 60-250 VGPRs): the wl fragments of a
   // two-term layer are requested out of the buffer's range (lo_lane: the range check covers the VGPR offset; such a load
   // returns zeros without a memory request - half the L2 bytes of the layer) and their MFMAs sit under one wave-uniform branch.
+  // `s` = the K-step in PACKED order (kstep_of of the loop's counter)
   auto load_a = [&](const LayerDev& L, int ni, int slot, int s, unsigned lo_lane) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
         const unsigned o = __builtin_amdgcn_readfirstlane(L.w_off + (unsigned(wave + WAVES * i) * unsigned(L.k_steps) + unsigned(s)) * 2048u);
         ah[slot][i] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, o, 0));
-        if constexpr (!ALL2) al[slot][i] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lo_lane, o + 1024u, 0));
+        if constexpr (!NO_WL) al[slot][i] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lo_lane, o + 1024u, 0));
       }
     }
   };
@@ -547,18 +653,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     const LayerDev& L1 = p.layer[1];
     const int n1 = tiles_of(L1.n_tiles);
     const unsigned lo1 = lo_lane_of(1);
+    const int ch1 = lead_tiles(L1.k_steps >> 1);
 #pragma unroll
-    for (int u = 0; u < NS; ++u) if (u < 2 || u < L1.k_steps) load_a(L1, n1, u, u, lo1);
+    for (int u = 0; u < NS; ++u) if (u < 2 || u < L1.k_steps) load_a(L1, n1, u, kstep_of(u, ch1), lo1);
   }
 #pragma unroll 1
   for (int l = 1; l < p.n_linear - 1; ++l) {
     const LayerDev& L = p.layer[l];
     const int ni = tiles_of(L.n_tiles);
     const int ks = L.k_steps;
-    const bool three = !ALL2 && !((p.two_pass_mask >> l) & 1u);
+    const bool three = !NO_WL && !((p.two_pass_mask >> l) & 1u);
     const unsigned lo_lane = lo_lane_of(l);
+    const int ch = lead_tiles(ks >> 1);               // input tiles that wavefronts 0..3 produced: their K-steps come first (ASYM)
     coord_step(L, ni);       // (requesting these fragments a layer ahead as well: +-0, and the Broyden variants spill)
-    __syncthreads();                                  // the previous layer's tile is complete
+    if constexpr (ASYM) wait_flags(0, unsigned(l));   // the previous layer's tiles of wavefronts 0..3 are in LDS
+    else __syncthreads();                             // the previous layer's tile is complete
     if (ni > 0) {
       const frag_t* Bh = reinterpret_cast<const frag_t*>(act_hi) + h * M + j;
       const frag_t* Bl = reinterpret_cast<const frag_t*>(act_lo) + h * M + j;
@@ -567,9 +676,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           bh[slot][t] = Bh[2 * s * M + 32 * t];
-          bl[slot][t] = Bl[2 * s * M + 32 * t];
+          if constexpr (!ONE) bl[slot][t] = Bl[2 * s * M + 32 * t];
         }
       };
+      // (every accumulator's hi product before any lo product: a wavefront that has the matrix pipe to itself - ASYM - would
+      // otherwise issue each dependent pair back to back)
+#ifndef NPHM_MLP_HI_THEN_LO
+#define NPHM_MLP_HI_THEN_LO 1
+#endif
       auto mma = [&](int sa, int sb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
@@ -577,11 +691,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
               acc[i][t] = mfma16<F16>(ah[sa][i], bh[sb][t], acc[i][t]);
-              acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]);
+              if constexpr (!ONE && !NPHM_MLP_HI_THEN_LO) acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]);
             }
           }
         }
-        if constexpr (!ALL2) {
+        if constexpr (!ONE && NPHM_MLP_HI_THEN_LO) {
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (i < ni) {
+#pragma unroll
+              for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]);
+            }
+          }
+        }
+        if constexpr (!NO_WL) {
           if (three) {
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
@@ -595,9 +718,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       };
       if (!NPHM_MLP_XPREFETCH) {
 #pragma unroll
-        for (int u = 0; u < NS; ++u) if (u < 2 || u < ks) load_a(L, ni, u, u, lo_lane);
+        for (int u = 0; u < NS; ++u) if (u < 2 || u < ks) load_a(L, ni, u, kstep_of(u, ch), lo_lane);
       }
-      load_b(0, 0);
+      load_b(0, kstep_of(0, ch));
       // slot u holds K-step s + u, the B operand alternates its two slots (k_steps is even, mlp_layout.h: the steps
       // u >= 2 of the last round may not exist)
 #pragma unroll 1
@@ -605,11 +728,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
           if (u < 2 || s + u < ks) {
-            if (s + u + 1 < ks) load_b((u + 1) & 1, s + u + 1);
+            if (s + u + 1 < ks) {
+              if constexpr (ASYM) { if (s + u + 1 == 2 * ch) wait_flags(WAVES / 2, unsigned(l)); }   // ... and those of wavefronts 4..7
+              load_b((u + 1) & 1, kstep_of(s + u + 1, ch));
+            }
             __builtin_amdgcn_sched_barrier(0);
             mma(u, u & 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + u + NS < ks) load_a(L, ni, u, s + u + NS, lo_lane);
+            if (s + u + NS < ks) load_a(L, ni, u, kstep_of(s + u + NS, ch), lo_lane);
           }
         }
       }
@@ -618,13 +744,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       const LayerDev& Ln = p.layer[l + 1];
       const int nn = tiles_of(Ln.n_tiles);
       const unsigned lon = lo_lane_of(l + 1);
+      const int chn = lead_tiles(Ln.k_steps >> 1);
 #pragma unroll
-      for (int u = 0; u < NS; ++u) if (u < 2 || u < Ln.k_steps) load_a(Ln, nn, u, u, lon);
+      for (int u = 0; u < NS; ++u) if (u < 2 || u < Ln.k_steps) load_a(Ln, nn, u, kstep_of(u, chn), lon);
       __builtin_amdgcn_sched_barrier(0);
     }
-    activate(ni, l);
-    __syncthreads();                                  // every wavefront has read the old tile
-    store_tiles(ni);
+    if constexpr (ASYM) {
+      // one code copy of the epilogue, in front of the barrier for wavefronts 0..3 and behind it for wavefronts 4..7
+#pragma unroll 1
+      for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 1) __syncthreads();                 // every wavefront has read the old tile
+        if (lead == (ph == 0)) activate(ni, l);
+      }
+      store_tiles(ni);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) flags[wave] = unsigned(l + 1);
+    } else {
+      activate(ni, l);
+      __syncthreads();                                  // every wavefront has read the old tile
+      store_tiles(ni);
+    }
   }
 
   // ---- last layer: K split over the wavefronts, one output tile --------------------------------
@@ -637,7 +776,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
       for (int t = 0; t < MT; ++t) acc[0][t] = zero16;
     }
-    __syncthreads();
+    if constexpr (ASYM) {
+      wait_flags(0, unsigned(p.n_linear - 1));
+      wait_flags(WAVES / 2, unsigned(p.n_linear - 1));
+    } else {
+      __syncthreads();
+    }
     const frag_t* W = reinterpret_cast<const frag_t*>(p.packed + L.w_off) + lane;
     const frag_t* Bh = reinterpret_cast<const frag_t*>(act_hi) + h * M + j;
     const frag_t* Bl = reinterpret_cast<const frag_t*>(act_lo) + h * M + j;
@@ -646,9 +790,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       const frag_t wh = W[size_t(s) * 128], wl = W[size_t(s) * 128 + 64];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const frag_t xh = Bh[2 * s * M + 32 * t], xl = Bl[2 * s * M + 32 * t];
+        const frag_t xh = Bh[2 * s * M + 32 * t];
         acc[0][t] = mfma16<F16>(wh, xh, acc[0][t]);
-        acc[0][t] = mfma16<F16>(wh, xl, acc[0][t]);
+        if constexpr (!ONE) acc[0][t] = mfma16<F16>(wh, Bl[2 * s * M + 32 * t], acc[0][t]);
         acc[0][t] = mfma16<F16>(wl, xh, acc[0][t]);
       }
     }
@@ -779,8 +923,8 @@ __global__ __launch_bounds__(256) void inverse3x3_kernel(const float* __restrict
   o[6] = c02 * r; o[7] = (a[1] * a[6] - a[0] * a[7]) * r; o[8] = (a[0] * a[4] - a[1] * a[3]) * r;
 }
 
-template <int MT, int NTW>
-constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) * 16 * 2 + (WAVES + 1) * 32 * MT * 4 * 4; }
+template <int MT, int NTW, bool ONE = false>
+constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) * 16 * (ONE ? 1 : 2) + (WAVES + 1) * 32 * MT * 4 * 4 + 64; }
 
 }  // namespace mlp
 }  // namespace nphm
@@ -794,6 +938,14 @@ using nphm::mlp::Plan;
 // `numerics` of the plain evaluation entry points (include/nphm_amd.h): low byte = operand format (0 split-bf16, 1 split-f16),
 // bits 8.. = mask of the hidden layers that run the two-term product (bit l = linear layer l; layer 0 and the last never)
 static bool mlp_numerics_ok(int numerics) { return (numerics & 0xff) <= 1 && numerics >= 0; }
+// ... and of the two plain-evaluation entry points (points / lattice): also 2 = split-f16 storage, SINGLE-term product rn(x) wh
+// in every hidden GEMM layer (mlp_eval_kernel, ONE: 128 points per workgroup at hidden <= 512, 64 at hidden <= 1024)
+static bool mlp_eval_numerics_ok(int numerics) { return (numerics & 0xff) <= 2 && numerics >= 0; }
+// NPHM_AMD_MLP_ASYM=0: the plain evaluation in lockstep (both wavefronts of a SIMD in the same phase), for same-box A/B runs
+static bool mlp_asym_enabled() {
+  static const bool on = [] { const char* e = getenv("NPHM_AMD_MLP_ASYM"); return !e || atoi(e) != 0; }();
+  return on;
+}
 
 // `columns` (value + Jacobian launches, hidden <= 512): 64 = 16 points per workgroup (default), 32 = 8 points per workgroup
 // (64 KiB of LDS, two workgroups per CU) - the caller splits a launch whose 16-point workgroups would fill 1.2 rounds of the
@@ -802,7 +954,9 @@ template <int MODE, int KIND = 0>
 static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st, int numerics = 0,
                        int columns = 64) {
   using namespace nphm::mlp;
-  const bool f16 = (numerics & 0xff) == 1;
+  const bool one = (numerics & 0xff) == 2;
+  const bool f16 = (numerics & 0xff) == 1 || one;
+  if (one && KIND != 0) return nphm_fail_msg("nphm_mlp_eval: the single-term product serves the plain evaluation only");
   if (MODE == 0) {
     if (a.point_end == 0 && a.point_base == 0) a.point_end = a.n_points;                 // the whole row
     if (a.point_base < 0 || a.point_end > a.n_points || a.point_base >= a.point_end)
@@ -826,7 +980,8 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   a.two_pass_mask = (unsigned(numerics) >> 8) & ((1u << (plan.n_linear - 1)) - 2u);     // hidden GEMM layers 1 .. n_linear - 2
   // every hidden GEMM layer two-term (split-f16 only): the variant without wl fragments (mlp_eval_kernel, ALL2)
   const unsigned hidden_mask = (1u << (plan.n_linear - 1)) - 2u;
-  const bool all2 = f16 && plan.n_linear > 2 && a.two_pass_mask == hidden_mask && (KIND == 0 || plan.variant == 0)
+  if (one) a.two_pass_mask = 0;
+  const bool all2 = f16 && !one && plan.n_linear > 2 && a.two_pass_mask == hidden_mask && (KIND == 0 || plan.variant == 0)
 #ifdef NPHM_MLP_NO_ALL2
                     && false
 #endif
@@ -841,7 +996,7 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
                      && false
 #endif
       ;
-  const int M = (small ? 32 : plan.variant == 0 ? 64 : 32) / ((KIND == 1 || KIND == 4) ? 4 : 1);      // points per workgroup
+  const int M = (small ? 32 : plan.variant == 0 ? 64 : 32) * (one ? 2 : 1) / ((KIND == 1 || KIND == 4) ? 4 : 1);      // points per workgroup
   const int64_t tiles = (n_pts + M - 1) / M;
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * WAVES);
@@ -857,14 +1012,34 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
       if (all2 ? go(mlp_eval_kernel<1, 2, MODE, KIND, true, true>, lds_bytes<1, 2>())
                : f16 ? go(mlp_eval_kernel<1, 2, MODE, KIND, true>, lds_bytes<1, 2>()) : go(mlp_eval_kernel<1, 2, MODE, KIND, false>, lds_bytes<1, 2>())) return -2;
     }
+  } else if (KIND == 0 && f16) {
+    // the plain split-f16 evaluation: phase-shifted wavefront pairs (ASYM) unless NPHM_AMD_MLP_ASYM=0
+    if constexpr (KIND == 0) {
+      const bool asym = mlp_asym_enabled();
+      int r;
+      if (plan.variant == 0) {
+        r = one ? (asym ? go(mlp_eval_kernel<4, 2, MODE, 0, true, false, true, true>, lds_bytes<4, 2, true>())
+                        : go(mlp_eval_kernel<4, 2, MODE, 0, true, false, true, false>, lds_bytes<4, 2, true>()))
+          : all2 ? (asym ? go(mlp_eval_kernel<2, 2, MODE, 0, true, true, false, true>, lds_bytes<2, 2>())
+                         : go(mlp_eval_kernel<2, 2, MODE, 0, true, true>, lds_bytes<2, 2>()))
+                 : (asym ? go(mlp_eval_kernel<2, 2, MODE, 0, true, false, false, true>, lds_bytes<2, 2>())
+                         : go(mlp_eval_kernel<2, 2, MODE, 0, true>, lds_bytes<2, 2>()));
+      } else {
+        r = one ? go(mlp_eval_kernel<2, 4, MODE, 0, true, false, true, true>, lds_bytes<2, 4, true>())
+          : all2 ? (asym ? go(mlp_eval_kernel<1, 4, MODE, 0, true, true, false, true>, lds_bytes<1, 4>())
+                         : go(mlp_eval_kernel<1, 4, MODE, 0, true, true>, lds_bytes<1, 4>()))
+                 : (asym ? go(mlp_eval_kernel<1, 4, MODE, 0, true, false, false, true>, lds_bytes<1, 4>())
+                         : go(mlp_eval_kernel<1, 4, MODE, 0, true>, lds_bytes<1, 4>()));
+      }
+      if (r) return -2;
+    }
   } else if (plan.variant == 0) {
     if (all2 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true, true>, lds_bytes<2, 2>())
              : f16 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true>, lds_bytes<2, 2>()) : go(mlp_eval_kernel<2, 2, MODE, KIND, false>, lds_bytes<2, 2>())) return -2;
   } else if constexpr (KIND == 3 || KIND == 4) {
     return nphm_fail_msg("nphm_mlp_eval_points_saving: only the hidden <= 512 variant has a backward kernel");
   } else if constexpr (KIND == 0) {
-    if (all2 ? go(mlp_eval_kernel<1, 4, MODE, 0, true, true>, lds_bytes<1, 4>())
-             : f16 ? go(mlp_eval_kernel<1, 4, MODE, 0, true>, lds_bytes<1, 4>()) : go(mlp_eval_kernel<1, 4, MODE, 0, false>, lds_bytes<1, 4>())) return -2;
+    if (go(mlp_eval_kernel<1, 4, MODE, 0, false>, lds_bytes<1, 4>())) return -2;
   } else {
     // the hidden <= 1024 variant (NPM) keeps bf16 halves for its tangent / Broyden forms (nothing drives them hard: the
     // fitting loop's expression decoder is the hidden <= 512 one)
@@ -951,7 +1126,7 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points: unsupported architecture");
   if (!packed || !latent_state || !xyz || !out) return nphm_fail_msg("nphm_mlp_eval_points: null pointer");
   if (n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_mlp_eval_points: empty input");
-  if (!mlp_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_points: unknown numerics format");
+  if (!mlp_eval_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_points: unknown numerics format");
   nphm::mlp::EvalArgs a;
   memset(&a, 0, sizeof(a));
   a.packed = static_cast<const char*>(packed);
@@ -1123,7 +1298,7 @@ int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   if (!packed || !latent_state || !axis_x || !axis_y || !axis_z || !out) return nphm_fail_msg("nphm_mlp_eval_grid: null pointer");
   if (rx <= 0 || ry <= 0 || rz <= 0 || ix0 < 0 || ix1 > rx || ix0 >= ix1)
     return nphm_fail_msg("nphm_mlp_eval_grid: bad grid / slab bounds");
-  if (!mlp_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_grid: unknown numerics format");
+  if (!mlp_eval_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_grid: unknown numerics format");
   nphm::mlp::EvalArgs a;
   memset(&a, 0, sizeof(a));
   a.packed = static_cast<const char*>(packed);
