@@ -346,10 +346,11 @@ class IdentityBench:
 # ------------------------------------------------------------------------------------------------------
 # configs[2], configs[0], configs[4]
 # ------------------------------------------------------------------------------------------------------
-def _mlp_exec_flops(mlp, mask, single=False):
-    """executed MFMA FLOPs per point of the dense skip-MLP kernel: hidden GEMM layer l runs 1 term of the split product in the
-    single-term tier, 2 if bit l of ``mask`` is set (DeepSDF's calibrated tiers) else 3; lin0's coordinate step always 3, the
-    (folded) last layer 3 (2 in the single-term tier).  Also returns the per-layer pass list."""
+def _mlp_exec_flops(mlp, mask, single_mask=0):
+    """executed MFMA FLOPs per point of the dense skip-MLP kernel: hidden GEMM layer l runs 1 term of the split product if bit
+    l of ``single_mask`` is set, 2 if bit l of ``mask`` is (DeepSDF's calibrated tiers), else 3; lin0's coordinate step counts
+    3; the last linear layer (out_dim rows) runs in fp32 on the VALU since round 5 and counts as one pass of its 2 out k
+    FLOPs.  Also returns the per-layer pass list."""
     d_in = mlp.lat_dim + mlp.input_dim
     total, passes = 0.0, []
     for l in range(mlp.num_layers - 1):
@@ -357,7 +358,7 @@ def _mlp_exec_flops(mlp, mask, single=False):
         out_f, in_f = W.shape
         k = 3 if l == 0 else (in_f - d_in if l in mlp.skip_in else in_f) + (3 if l in mlp.skip_in else 0)
         hidden = 0 < l < mlp.num_layers - 2
-        p = (1 if hidden else 2 if l > 0 else 3) if single else 2 if (hidden and (mask >> l) & 1) else 3
+        p = 3 if l == 0 else 1 if (not hidden or (single_mask >> l) & 1) else 2 if (mask >> l) & 1 else 3
         passes.append(p)
         total += p * 2.0 * out_f * k
     return total, passes
@@ -367,25 +368,25 @@ def _mlp_kernel_name(mlp, shape, num):
     """symbol of the lattice launch (csrc/mlp_kernel.hip launch_eval): format and, when every hidden GEMM layer runs the two-term
     product, the variant that keeps four K-steps of wh in flight"""
     f16 = mlp.precision == "f16x3"
-    n_hidden = len(num["passes_per_layer"]) - 2
-    all2 = f16 and n_hidden > 0 and all(p == 2 for p in num["passes_per_layer"][1:-1])
-    asym = os.environ.get("NPHM_AMD_MLP_ASYM", "1") not in ("0", "")
+    hidden = num["passes_per_layer"][1:-1]
     if not f16:
         return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,false>"
-    if num.get("single_term"):
-        shape = {"2,2": "4,2", "1,4": "2,4"}[shape]          # twice the points per workgroup
-        return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,false,true,{'true' if asym else 'false'}>"
-    return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,{'true' if all2 else 'false'},false,{'true' if asym else 'false'}>"
+    if hidden and all(p == 1 for p in hidden):
+        shape = {"2,2": "4,2", "1,4": "2,4"}[shape]          # single-term everywhere: twice the points per workgroup
+        return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,false,true>"
+    no_wl = bool(hidden) and all(p <= 2 for p in hidden)     # no three-term layer: the variant without wl registers
+    return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,{'true' if no_wl else 'false'},false>"
 
 
 def _mlp_numerics_report(mlp):
     r = dict(mlp.last_numerics or {})
     mask = int(r.get("mask", 0))
-    single = bool(r.get("single_term", False))
-    flops, passes = _mlp_exec_flops(mlp, mask, single)
-    return {"precision": mlp.precision, "numerics": mlp.numerics, "single_term": single, "two_pass_mask": mask,
-            "passes_per_layer": passes, "target": r.get("target"), "sample_err": r.get("err"),
-            "verified_err": r.get("verified_err"), "single_term_err": r.get("single_term_err")}, flops
+    single_mask = int(r.get("single_mask", 0))
+    flops, passes = _mlp_exec_flops(mlp, mask, single_mask)
+    return {"precision": mlp.precision, "numerics": mlp.numerics, "single_mask": single_mask, "two_pass_mask": mask,
+            "passes_per_layer": passes, "points_per_workgroup": (2 if r.get("single_term") else 1) * (64 if mlp.hidden_dim <= 512 else 32),
+            "target": r.get("target"), "sample_err": r.get("err"), "verified_err": r.get("verified_err"),
+            "all_single_err": r.get("all_single_err")}, flops
 
 
 def two_stage_record(args, dev, steps, warmup):
@@ -548,7 +549,9 @@ def fitting_record(args, dev, with_reference_loop=True):
         tail = hist[-20:]
         fc = getattr(expr_net.defDeepSDF, "_fit_cache", None)
         fit_num = {"fit_numerics": expr_net.defDeepSDF.fit_numerics, "two_pass_mask": None if fc is None else int(fc[1]),
-                   "sample_err": None if fc is None else fc[2].get("err"), "target": expr_net.defDeepSDF.two_pass_target}
+                   "sample_err_in_units_of_targets": None if fc is None else fc[2].get("err"),
+                   "value_target": expr_net.defDeepSDF.fit_target, "jacobian_target": expr_net.defDeepSDF.fit_jacobian_target,
+                   "reverified_err": None if fc is None else fc[2].get("reverified_err"), "verify_every": expr_net.defDeepSDF.fit_verify_every}
         return {"expr_decoder_numerics": fit_num, "steps_per_s": len(hist) / dt, "ms_per_step": dt / len(hist) * 1e3, "steps": len(hist), "step_scale": step_scale,
                 "first_surface_loss": hist[0]["surface"], "final_surface_loss": float(np.mean([h["surface"] for h in tail])),
                 "final_total_loss": float(np.mean([h["loss"] for h in tail])),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 8
+#define NPHM_AMD_ABI_VERSION 9
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -396,7 +396,12 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
  *   xh wl term, i.e. runs on weights rounded to the half format - two MFMAs instead of three and half the weight bytes;
  *   a systematic 2^-12 (f16) / 2^-9 (bf16) perturbation of that layer's weights.  Which layers may is a property of the
  *   checkpoint: the host module measures it against the three-term product (nphm_amd/deepsdf.py, calibrate).
- * The value+Jacobian, Broyden and saving entry points below take the same argument (hidden_dim <= 512: both formats;
+ *   NPHM_MLP_ONE_PASS(mask) (ABI 9; NPHM_MLP_F16X3, nphm_mlp_eval_points / nphm_mlp_eval_grid only): bit l = hidden GEMM
+ *   layer l runs the SINGLE-term product rn(x) wh - one MFMA per tile and K-step, no read of the activations' lo plane; all
+ *   hidden layers: a variant without the lo plane that holds twice the points per workgroup (128 at hidden_dim <= 512), i.e.
+ *   half the weight bytes per point.  Error ~2^-12 relative per product on both operands, random in the activations: again
+ *   measured per checkpoint against the three-term product before it is used (nphm_amd/deepsdf.py, calibrate_numerics).
+ * The value+Jacobian, Broyden and saving entry points below take format and two-pass mask (hidden_dim <= 512: both formats;
  * the 1024-wide variant runs them on bf16 halves only).
  * The two value+Jacobian entry points also take a point RANGE and a workgroup width (ABI 8): the launch covers points
  * [point_base, point_base + point_count) of every row (0, 0 = all; point_base a multiple of 16, of 64 for the saving form)
@@ -405,7 +410,8 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
  * rest (nphm_amd/deepsdf.py: _jvp_split). */
 #define NPHM_MLP_BF16X3 0
 #define NPHM_MLP_F16X3 1
-#define NPHM_MLP_TWO_PASS(mask) ((int)((unsigned)(mask) << 8))
+#define NPHM_MLP_TWO_PASS(mask) ((int)(((unsigned)(mask) & 0xfffu) << 8))
+#define NPHM_MLP_ONE_PASS(mask) ((int)(((unsigned)(mask) & 0x7ffu) << 20))
 
 /* DeepSDF.forward (deepSDF.py:64-89) for row-constant latents: out[b,n,:out_dim] for xyz[b,n,:3].
  * add_input != 0 adds xyz to the first 3 outputs: canonical points x + F_ex(x) of get_logits_backward

@@ -36,6 +36,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_CACHE, exist_ok=True)
     # every translation unit sees every header: one digest of them + the flags, then one of the source per object
     common = hashlib.sha256(" ".join(FLAGS).encode())
+    try:                                                    # a toolchain upgrade invalidates every cached object
+        common.update(subprocess.run([hipcc, "--version"], capture_output=True, check=True).stdout)
+    except Exception:                                       # noqa: BLE001
+        pass
     for f in sorted(os.listdir(CSRC)):
         if f.endswith(".h"):
             common.update(open(os.path.join(CSRC, f), "rb").read())
@@ -48,22 +52,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if os.path.exists(obj) and not force:
             continue
-        cmd = [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
+        tmp = f"{obj}.{os.getpid()}.tmp"                    # (two builds at once - ranks, xdist workers - never share a temp file)
+        cmd = [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, src), "-o", tmp]
         if verbose:
             print(" ".join(cmd))
-        jobs.append((cmd, obj, subprocess.Popen(cmd)))
-    for cmd, obj, proc in jobs:
+        jobs.append((cmd, obj, tmp, subprocess.Popen(cmd)))
+    for cmd, obj, tmp, proc in jobs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-        os.replace(obj + ".tmp", obj)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", OUT + ".tmp"]
+        os.replace(tmp, obj)
+    out_tmp = f"{OUT}.{os.getpid()}.tmp"
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", out_tmp]
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True)
-    os.replace(OUT + ".tmp", OUT)
-    keep = set(objs)
-    for f in os.listdir(OBJ_CACHE):                         # objects of older source versions
-        if os.path.join(OBJ_CACHE, f) not in keep:
+    os.replace(out_tmp, OUT)
+    # objects of older versions of OUR sources only (another build's in-flight temp files are not ours to delete)
+    keep = {os.path.basename(o) for o in objs}
+    stems = {os.path.splitext(src)[0] for src in SOURCES}
+    for f in os.listdir(OBJ_CACHE):
+        if f.endswith(".o") and f not in keep and f.rsplit("-", 1)[0] in stems:
             os.remove(os.path.join(OBJ_CACHE, f))
     return OUT
 

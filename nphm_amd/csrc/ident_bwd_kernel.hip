@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void ident_bwd_reduce_kernel(ReduceArgs p) {
     const int q = e / (N_MEMBERS * 3), r = e % (N_MEMBERS * 3);
     const int64_t pt = pt0 + q;
     float v = 0.f;
-    if (pt < total && p.what[pt * N_MEMBERS + r / 3] != 0.f) v = p.gxm[pt * N_MEMBERS * 3 + r];
+    if (pt < total && p.what[pt * N_MEMBERS + r / 3] > 0.f) v = p.gxm[pt * N_MEMBERS * 3 + r];
     sh[q][r] = v;
   }
   __syncthreads();

@@ -68,6 +68,25 @@ struct PackArgs {
 };
 
 __global__ void mlp_pack_kernel(PackArgs a) {
+  if (blockIdx.y == a.plan.n_linear - 1) {            // extra grid row: the fp32 table of the last layer (mlp_layout.h)
+    const Layer& LL = a.plan.layer[a.plan.n_linear - 1];
+    float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(a.out) + 2 * a.plan.packed_bytes);
+    const int kt = LL.k_steps / 2;
+    const size_t total = last_table_floats(kt);
+    for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += size_t(gridDim.x) * blockDim.x) {
+      float v = 0.f;
+      if (e >= total - 4) {
+        const int c = int(e - (total - 4));
+        if (c < LL.out_dim) v = a.t.b[a.plan.n_linear - 1][c];
+      } else {
+        const int r = e & 15, c = (e >> 4) & 3, hh = (e >> 6) & 1, n = int(e >> 7);
+        const int f = 32 * n + feat_local(r, hh);
+        if (c < LL.out_dim && f < LL.k_act) v = a.t.w[a.plan.n_linear - 1][size_t(c) * LL.in_dim + f];
+      }
+      tab[e] = v;
+    }
+    return;
+  }
   const int l = blockIdx.y + 1;                       // layer 0 has no activation columns
   const Layer& L = a.plan.layer[l];
   const size_t total = size_t(L.n_tiles) * L.k_steps * 2 * 64 * 8;
@@ -179,6 +198,8 @@ struct LayerDev {
 
 struct EvalArgs {
   const char* packed;
+  const float* last_tab;   // fp32 table of the last linear layer (mlp_layout.h: last_table_floats), behind both fragment formats
+  int last_tiles;          // its input tiles
   const char* state;
   size_t state_row_bytes;
   float* out;             // [n_rows, n_points, out_dim]
@@ -186,6 +207,7 @@ struct EvalArgs {
   int add_input;          // out[..., c] += xyz[..., c] (c < 3): canonical / posed points
   int n_linear;
   unsigned two_pass_mask;  // bit l: hidden layer l runs the two-term product xh wh + xl wh (weights rounded to the half format)
+  unsigned one_pass_mask;  // bit l: hidden layer l runs the single-term product xh wh (split-f16 only; xh = rn(x))
   LayerDev layer[MAX_LINEAR];
   // MODE 0
   const float* xyz;       // [n_rows, n_points, 3]
@@ -226,6 +248,8 @@ __device__ __forceinline__ float softplus2(float d) {
 }
 
 struct Split8 { frag_t hi, lo; };
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -234,16 +258,21 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 // 8 values -> hi | lo operands.  bf16: per pair one packed convert, a shift / a mask back to fp32, the residuals through a
-// second packed convert (the generic __bf16 casts made hipcc convert every value twice).  binary16 (eval_kernel.hip,
-// pack_pair): hi by v_cvt_pkrtz_f16_f32 (round toward zero: beyond the f16 range it saturates at 65504 and the lo half carries
-// the rest instead of becoming inf), lo = x - hi straight into its packed half by v_fma_mixlo / mixhi_f16.
+// second packed convert (the generic __bf16 casts made hipcc convert every value twice).  binary16: hi = rn(x) by
+// v_cvt_pk_f16_f32, clamped to the largest finite value (beyond the f16 range it saturates at 65504 and the lo half carries the
+// rest instead of hi becoming inf), lo = x - hi straight into its packed half by v_fma_mixlo / mixhi_f16.  (Rounds 1-4 took
+// hi by round-toward-zero, v_cvt_pkrtz: one instruction less per pair, but a single-term layer - which reads hi alone - then
+// sees every non-negative activation shrunk by 2^-12 on average, a coherent 1.2e-4 relative error; with hi to nearest the lo
+// half is a bit smaller as well.)
 template <bool F16>
 __device__ __forceinline__ Split8 split8(const float* x) {
   Split8 o;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if constexpr (F16) {
-      const unsigned ph = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]));
+      const f32x2_t xv = {x[2 * q], x[2 * q + 1]};
+      const f16x2_t top = {(_Float16)65504.f, (_Float16)65504.f};
+      const unsigned ph = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_convertvector(xv, f16x2_t), top));
       unsigned pl;
       asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(pl) : "v"(ph), "v"(x[2 * q]));
       asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(pl) : "v"(ph), "v"(x[2 * q + 1]));
@@ -259,11 +288,7 @@ __device__ __forceinline__ Split8 split8(const float* x) {
   return o;
 }
 
-// 8 values -> ONE binary16 operand, rounded to nearest (v_cvt_pk_f16_f32; +inf clamped to the largest finite value): the
-// B operand of a single-term layer (ONE below).  Truncation (split8's hi half) would shrink every product of the non-negative
-// activations by 2^-12 on average - a coherent 1.2e-4 relative error of the layer instead of a random one
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// 8 values -> ONE binary16 operand (split8's hi half alone): the B operand of the all-single-term variant (ONE below)
 __device__ __forceinline__ frag_t pack8_rn(const float* x) {
   frag_t o;
 #pragma unroll
@@ -343,22 +368,17 @@ __device__ __forceinline__ frag_t unit_operand(int c) {
 // registers that would hold them hold two more K-steps of wh - four in flight instead of two.  (Fitting step, all six launch
 // shapes: 1 116 -> 1 142 steps/s, same bits.)  (The 32-point workgroups of the hidden-1024 net stream a 16 MB pack out of the Infinity
 // Cache: with 64 KB in flight per CU they ran at that latency's 74 GB/s per CU, a third of the matrix pipe.)
-// ONE (split-f16, plain evaluation only): every hidden GEMM layer runs the SINGLE-term product rn(x) wh on binary16 operands
-// with fp32 accumulation - no lo plane in LDS, so a workgroup holds TWICE the points (128 at hidden <= 512) per weight pass:
-// half the L2 -> register weight bytes per point and half the MFMAs of the two-term product.  Chosen per checkpoint by the
-// calibration of DeepSDF._numerics_code (measured against the three-term product; the trained deformation net sits at 2e-6).
-// ASYM (plain evaluation): the two wavefronts of a SIMD run half a layer out of phase instead of in lockstep.  Wavefronts
-// 0..3 (one per SIMD, s_setprio 1) own the matrix pipe first: they finish their GEMM, run their softplus / re-split
-// epilogue while wavefronts 4..7 have the pipe, and start the next layer on the K-steps whose input tiles THEY produced while
-// wavefronts 4..7 run their epilogue.  One s_barrier per layer is left (all reads of the old tile done -> the in-place store is
-// safe); "the new tile is complete" became two LDS flag groups (tiles of wavefronts 0..3 / 4..7 stored), and the K loop
-// visits the K-steps of the first group's tiles first (kstep_of).  Lockstep had both wavefronts of a SIMD in their MFMA
-// segment and then both in their VALU segment (MI355X_MICROARCH.md, "Two waves per SIMD": matrix beside matrix nets nothing).
-template <int MT, int NTW, int MODE, int KIND, bool F16 = false, bool ALL2 = false, bool ONE = false, bool ASYM = false>
+// Per-layer tiers of the split-f16 product (EvalArgs::two_pass_mask / one_pass_mask, calibrated per checkpoint by
+// DeepSDF._numerics_code): three terms xh wh + xl wh + xh wl | two terms (weights rounded) | ONE term rn(x) wh.
+// ONE (template): EVERY hidden GEMM layer single-term - no lo plane in LDS, so a workgroup holds TWICE the points (128 at
+// hidden <= 512) per weight pass: half the L2 -> register weight bytes per point and half the MFMAs of the two-term product.
+// (Round 5 also built a phase-shifted schedule - wavefronts 0..3 half a layer ahead of 4..7, LDS flags instead of the second
+// barrier, so that one wavefront of a SIMD runs its epilogue while the other owns the matrix pipe: correct, and 3-5 % SLOWER
+// on all three tiers; the kernel sits at the board's power limit, a denser MFMA stream is a lower clock.  profiles/NOTES.md.)
+template <int MT, int NTW, int MODE, int KIND, bool F16 = false, bool ALL2 = false, bool ONE = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   constexpr bool JVP = KIND == 1 || KIND == 4, BROY = KIND == 2, SAVE = KIND == 3 || KIND == 4;   // 4: value+Jacobian, sigma' saved
   static_assert(!ONE || (F16 && KIND == 0), "the single-term product serves the plain split-f16 evaluation");
-  static_assert(!ASYM || KIND == 0, "the phase-shifted schedule serves the plain evaluation (one pass over the network)");
   constexpr int M = 32 * MT;               // columns per workgroup
   constexpr int PTS = JVP ? M / 4 : M;     // points per workgroup
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
@@ -369,7 +389,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   char* act_lo = smem + PART_BYTES;                                   // (ONE: no lo plane; never addressed)
   float* partial = reinterpret_cast<float*>(smem + (ONE ? 1 : 2) * PART_BYTES);   // [WAVES][M][4]
   float* xs = partial + WAVES * M * 4;                                // [M][4] current iterate (KIND 2)
-  volatile unsigned* flags = reinterpret_cast<volatile unsigned*>(xs + M * 4);   // [WAVES] layers whose tiles wavefront w has stored (ASYM)
+  float* wlast = xs + M * 4;                                          // fp32 table of the last linear layer (mlp_layout.h)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -378,34 +398,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   const int64_t n_pts = MODE == 0 ? p.n_points : int64_t(p.ix1 - p.ix0) * p.ry * p.rz;
   const int64_t base = (MODE == 0 ? p.point_base : 0) + int64_t(blockIdx.x) * PTS;
   const int64_t n_end = MODE == 0 ? p.point_end : n_pts;          // first point of the row this launch does not own
-  const bool lead = wave < WAVES / 2;      // ASYM: the wavefronts that own the matrix pipe first (one per SIMD)
-  if constexpr (ASYM) {
-    if (threadIdx.x < WAVES) flags[threadIdx.x] = 0;
-    if (lead) __builtin_amdgcn_s_setprio(1);
-    __syncthreads();
-  }
-  // ASYM: flags[w] >= v for the four wavefronts from `first` on (their tiles of layer v - 1 are in LDS)
-  auto wait_flags = [&](int first, unsigned v) __attribute__((always_inline)) {
-    for (;;) {
-      const volatile unsigned* f = flags + first;
-      const unsigned a = f[0], b = f[1], c = f[2], d = f[3];
-      const unsigned m = a < b ? a : b, n = c < d ? c : d;
-      if (__builtin_amdgcn_readfirstlane(m < n ? m : n) >= v) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");          // no tile read moves above the flag reads
-  };
-  // ASYM: the K loop's s-th step is K-step kstep_of(s): the steps of the tiles wavefronts 0..3 produced (tiles n with
-  // (n & 4) == 0) first, then the others.  kt = input tiles of the layer (k_steps / 2), lead_tiles(kt) of them from wavefronts 0..3
-  auto lead_tiles = [](int kt) { const int r = kt & 7; return (kt >> 3) * 4 + (r < 4 ? r : 4); };
-  auto kstep_of = [&](int sidx, int ch) __attribute__((always_inline)) {
-    if constexpr (!ASYM) return sidx;
-    const int q = sidx >> 1;
-    const int m = q < ch ? q : q - ch;
-    const int n = ((m >> 2) << 3) | (m & 3) | (q < ch ? 0 : 4);
-    return 2 * n + (sidx & 1);
-  };
-
   auto point_coords = [&](int64_t i, float& x, float& y, float& z) {
     const int64_t ic = i < n_pts ? i : n_pts - 1;
     if (MODE == 0) {
@@ -418,6 +410,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       x = p.ax[ix]; y = p.ay[rem / p.rz]; z = p.az[rem % p.rz];
     }
   };
+
+  // the last layer's fp32 weights into LDS (first use: behind the barriers of the hidden layers)
+  {
+    const int n4 = p.last_tiles * 32 + 1;                             // float4 entries
+    for (int e = threadIdx.x; e < n4; e += blockDim.x)
+      reinterpret_cast<float4*>(wlast)[e] = reinterpret_cast<const float4*>(p.last_tab)[e];
+  }
 
   // ---- KIND 2: solver state of point threadIdx.x (threads < M) -----------------------------------
   float bx[3] = {0, 0, 0}, bobs[3] = {0, 0, 0}, bgx[3] = {0, 0, 0}, bdx[3] = {0, 0, 0}, bdgx[3] = {0, 0, 0};
@@ -441,6 +440,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   const bool given0 = BROY && it == 0 && p.posed0 != nullptr;
   if (!given0) {
   frag_t bv[MT];
+  // this wavefront's slot of the last layer's partial sums (activate, `last`, adds its tiles' shares in tile order)
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+    if (h == 0) *reinterpret_cast<float4*>(partial + (wave * M + 32 * t + j) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   if (BROY) __syncthreads();                // the iterate written by the owners is visible
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -463,18 +466,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, 0x7fffffff, 0x00020000);
   const f32x16 zero16 = {};
   f32x16 acc[NTW][MT];
-#ifndef NPHM_MLP_ALIAS
-#define NPHM_MLP_ALIAS 1
-#endif
-#if !NPHM_MLP_ALIAS
-  Split8 packed_out[NTW][MT][2];
-#endif
 
-  // epilogue of the wavefront's tiles: softplus, re-split (registers only)
-  auto activate = [&](int ni, int layer) __attribute__((always_inline)) {
+  // epilogue of the wavefront's tiles: softplus, then either the re-split operands of the next layer (registers only) or -
+  // `last`, the last hidden layer - this wavefront's share of the last linear layer in fp32, straight from the registers
+  // (rounds 1-4 stored the tile and ran the out_dim <= 4 rows as a K-split MFMA layer on split operands: one more store,
+  // barrier and operand rounding; the single-term variant has no lo plane to run it on)
+  auto activate = [&](int ni, int layer, bool last) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
+        float sgv[JVP ? 16 : 1];                        // sigma' of the value stream (point tile 0), read before the tile is overwritten
+        if constexpr (JVP) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sgv[r] = sigmoid2(acc[i][0][r]);
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           if constexpr (SAVE && !JVP) {
@@ -506,11 +511,31 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             if (JVP) {
-              const float sig = __shfl(sigmoid2(acc[i][0][r]), value_lane[t]);
+              const float sig = __shfl(sgv[r], value_lane[t]);
               const bool is_value = 32 * t + j < PTS;
               v[r] = is_value ? softplus2(acc[i][t][r]) : sig * acc[i][t][r];
             } else {
               v[r] = softplus2(acc[i][t][r]);
+            }
+          }
+          if (last) {
+            const float4* wt = reinterpret_cast<const float4*>(wlast) + ((wave + WAVES * i) * 2 + h) * 16;
+            float* yq = partial + (wave * M + 32 * t + j) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (c < p.out_dim) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float4 w4 = wt[c * 4 + q];
+                  sacc = fmaf(w4.x, v[4 * q], sacc);
+                  sacc = fmaf(w4.y, v[4 * q + 1], sacc);
+                  sacc = fmaf(w4.z, v[4 * q + 2], sacc);
+                  sacc = fmaf(w4.w, v[4 * q + 3], sacc);
+                }
+                sacc += __shfl_xor(sacc, 32);                          // the two halves of the tile's 32 rows
+                if (h == 0) yq[c] += sacc;                             // (own slot, in program order: no atomics, fixed order)
+              }
             }
           }
           // the operands take the place of the accumulators they came from (registers 8 half .. 8 half + 3: hi fragment of
@@ -518,7 +543,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           // (__uint_as_float, NOT __builtin_bit_cast: the builtin applied to an ext-vector ELEMENT reads element 0.)
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
-#if NPHM_MLP_ALIAS
             if constexpr (ONE) {
               const frag_t o = pack8_rn(v + 8 * half);
 #pragma unroll
@@ -531,10 +555,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
                 acc[i][t][8 * half + 4 + q] = __uint_as_float(o.lo[q]);
               }
             }
-#else
-            if constexpr (ONE) packed_out[i][t][half].hi = pack8_rn(v + 8 * half);
-            else packed_out[i][t][half] = split8<F16>(v + 8 * half);
-#endif
           }
         }
       }
@@ -552,16 +572,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           for (int half = 0; half < 2; ++half) {
             const int off = ((4 * n + 2 * half + h) * M + 32 * t + j) * 16;
             frag_t fh, fl;
-#if NPHM_MLP_ALIAS
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               fh[q] = __float_as_uint(acc[i][t][8 * half + q]);
               fl[q] = __float_as_uint(acc[i][t][8 * half + 4 + q]);
             }
-#else
-            fh = packed_out[i][t][half].hi;
-            fl = packed_out[i][t][half].lo;
-#endif
             *reinterpret_cast<frag_t*>(act_hi + off) = fh;
             if constexpr (!ONE) *reinterpret_cast<frag_t*>(act_lo + off) = fl;
           }
@@ -598,12 +613,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     const LayerDev& L = p.layer[0];
     const int ni = tiles_of(L.n_tiles);
     coord_step(L, ni);
-    activate(ni, 0);
+    activate(ni, 0, false);
     store_tiles(ni);
-    if constexpr (ASYM) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) flags[wave] = 1u;
-    }
   }
 
   // ---- hidden layers ---------------------------------------------------------------------------
@@ -627,17 +638,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #define NPHM_MLP_SLOTS_ALL2_SMALL 4
 #endif
 #ifndef NPHM_MLP_SLOTS_ONE
-#define NPHM_MLP_SLOTS_ONE 4
+#define NPHM_MLP_SLOTS_ONE 2       // (a K-step of the 128-point variant is 8 MFMAs; four slots: 8 spilled VGPRs and 1.5 % slower)
+#endif
+#ifndef NPHM_MLP_SLOTS_ALL2
+#define NPHM_MLP_SLOTS_ALL2 4
 #endif
   constexpr bool NO_WL = ALL2 || ONE;      // no wl fragment is ever requested
-  constexpr int NS = ONE ? NPHM_MLP_SLOTS_ONE : ALL2 ? ((MT == 1 && NTW == 2) ? NPHM_MLP_SLOTS_ALL2_SMALL : 4) : (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
+  constexpr int NS = ONE ? NPHM_MLP_SLOTS_ONE : ALL2 ? ((MT == 1 && NTW == 2) ? NPHM_MLP_SLOTS_ALL2_SMALL : NPHM_MLP_SLOTS_ALL2) : (MT == 1 && NTW == 2 && !BROY) ? NPHM_MLP_SLOTS_SMALL : 2;    // (the fused solver: 240 VGPRs with four, and no faster)
   static_assert(NS % 2 == 0, "the B operand's two slots alternate with the K-step");
   frag_t ah[NS][NTW], al[NS][NTW];
   // Terms of the split product of a layer: three = xh wh + xl wh + xh wl, two = without the wl term (EvalArgs::two_pass_mask).
   // One loop body serves both (two specialised loops under a branch made hipcc spill 60-250 VGPRs): the wl fragments of a
   // two-term layer are requested out of the buffer's range (lo_lane: the range check covers the VGPR offset; such a load
   // returns zeros without a memory request - half the L2 bytes of the layer) and their MFMAs sit under one wave-uniform branch.
-  // `s` = the K-step in PACKED order (kstep_of of the loop's counter)
   auto load_a = [&](const LayerDev& L, int ni, int slot, int s, unsigned lo_lane) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -648,26 +661,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       }
     }
   };
-  auto lo_lane_of = [&](int l) { return ((p.two_pass_mask >> l) & 1u) ? (w_lane | 0x80000000u) : w_lane; };
+  auto lo_lane_of = [&](int l) { return (((p.two_pass_mask | p.one_pass_mask) >> l) & 1u) ? (w_lane | 0x80000000u) : w_lane; };
   if (NPHM_MLP_XPREFETCH && p.n_linear > 2) {
     const LayerDev& L1 = p.layer[1];
     const int n1 = tiles_of(L1.n_tiles);
     const unsigned lo1 = lo_lane_of(1);
-    const int ch1 = lead_tiles(L1.k_steps >> 1);
 #pragma unroll
-    for (int u = 0; u < NS; ++u) if (u < 2 || u < L1.k_steps) load_a(L1, n1, u, kstep_of(u, ch1), lo1);
+    for (int u = 0; u < NS; ++u) if (u < 2 || u < L1.k_steps) load_a(L1, n1, u, u, lo1);
   }
 #pragma unroll 1
   for (int l = 1; l < p.n_linear - 1; ++l) {
     const LayerDev& L = p.layer[l];
     const int ni = tiles_of(L.n_tiles);
     const int ks = L.k_steps;
-    const bool three = !NO_WL && !((p.two_pass_mask >> l) & 1u);
+    const bool single = ONE || ((p.one_pass_mask >> l) & 1u);             // xh wh alone (wave-uniform)
+    const bool three = !NO_WL && !(((p.two_pass_mask | p.one_pass_mask) >> l) & 1u);
     const unsigned lo_lane = lo_lane_of(l);
-    const int ch = lead_tiles(ks >> 1);               // input tiles that wavefronts 0..3 produced: their K-steps come first (ASYM)
     coord_step(L, ni);       // (requesting these fragments a layer ahead as well: +-0, and the Broyden variants spill)
-    if constexpr (ASYM) wait_flags(0, unsigned(l));   // the previous layer's tiles of wavefronts 0..3 are in LDS
-    else __syncthreads();                             // the previous layer's tile is complete
+    __syncthreads();                                  // the previous layer's tile is complete
     if (ni > 0) {
       const frag_t* Bh = reinterpret_cast<const frag_t*>(act_hi) + h * M + j;
       const frag_t* Bl = reinterpret_cast<const frag_t*>(act_lo) + h * M + j;
@@ -676,11 +687,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           bh[slot][t] = Bh[2 * s * M + 32 * t];
-          if constexpr (!ONE) bl[slot][t] = Bl[2 * s * M + 32 * t];
+          if constexpr (!ONE) { if (!single) bl[slot][t] = Bl[2 * s * M + 32 * t]; }
         }
       };
-      // (every accumulator's hi product before any lo product: a wavefront that has the matrix pipe to itself - ASYM - would
-      // otherwise issue each dependent pair back to back)
+      // (every accumulator's hi product before any lo product: no dependent pair back to back)
 #ifndef NPHM_MLP_HI_THEN_LO
 #define NPHM_MLP_HI_THEN_LO 1
 #endif
@@ -691,16 +701,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
               acc[i][t] = mfma16<F16>(ah[sa][i], bh[sb][t], acc[i][t]);
-              if constexpr (!ONE && !NPHM_MLP_HI_THEN_LO) acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]);
+              if constexpr (!ONE && !NPHM_MLP_HI_THEN_LO) { if (!single) acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]); }
             }
           }
         }
         if constexpr (!ONE && NPHM_MLP_HI_THEN_LO) {
+          if (!single) {
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) {
-            if (i < ni) {
+            for (int i = 0; i < NTW; ++i) {
+              if (i < ni) {
 #pragma unroll
-              for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]);
+                for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]);
+              }
             }
           }
         }
@@ -718,9 +730,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       };
       if (!NPHM_MLP_XPREFETCH) {
 #pragma unroll
-        for (int u = 0; u < NS; ++u) if (u < 2 || u < ks) load_a(L, ni, u, kstep_of(u, ch), lo_lane);
+        for (int u = 0; u < NS; ++u) if (u < 2 || u < ks) load_a(L, ni, u, u, lo_lane);
       }
-      load_b(0, kstep_of(0, ch));
+      load_b(0, 0);
       // slot u holds K-step s + u, the B operand alternates its two slots (k_steps is even, mlp_layout.h: the steps
       // u >= 2 of the last round may not exist)
 #pragma unroll 1
@@ -728,14 +740,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
           if (u < 2 || s + u < ks) {
-            if (s + u + 1 < ks) {
-              if constexpr (ASYM) { if (s + u + 1 == 2 * ch) wait_flags(WAVES / 2, unsigned(l)); }   // ... and those of wavefronts 4..7
-              load_b((u + 1) & 1, kstep_of(s + u + 1, ch));
-            }
+            if (s + u + 1 < ks) load_b((u + 1) & 1, s + u + 1);
             __builtin_amdgcn_sched_barrier(0);
             mma(u, u & 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + u + NS < ks) load_a(L, ni, u, kstep_of(s + u + NS, ch), lo_lane);
+            if (s + u + NS < ks) load_a(L, ni, u, s + u + NS, lo_lane);
           }
         }
       }
@@ -744,66 +753,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       const LayerDev& Ln = p.layer[l + 1];
       const int nn = tiles_of(Ln.n_tiles);
       const unsigned lon = lo_lane_of(l + 1);
-      const int chn = lead_tiles(Ln.k_steps >> 1);
 #pragma unroll
-      for (int u = 0; u < NS; ++u) if (u < 2 || u < Ln.k_steps) load_a(Ln, nn, u, kstep_of(u, chn), lon);
+      for (int u = 0; u < NS; ++u) if (u < 2 || u < Ln.k_steps) load_a(Ln, nn, u, u, lon);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (ASYM) {
-      // one code copy of the epilogue, in front of the barrier for wavefronts 0..3 and behind it for wavefronts 4..7
-#pragma unroll 1
-      for (int ph = 0; ph < 2; ++ph) {
-        if (ph == 1) __syncthreads();                 // every wavefront has read the old tile
-        if (lead == (ph == 0)) activate(ni, l);
-      }
-      store_tiles(ni);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) flags[wave] = unsigned(l + 1);
-    } else {
-      activate(ni, l);
-      __syncthreads();                                  // every wavefront has read the old tile
-      store_tiles(ni);
-    }
+    // (the last hidden layer feeds the last linear layer from its registers; its operands are packed and stored like the
+    // others' - unused - because a second code path here costs hipcc's register allocation far more than the stores)
+    activate(ni, l, l == p.n_linear - 2);
+    __syncthreads();                                  // every wavefront has read the old tile
+    store_tiles(ni);
   }
 
-  // ---- last layer: K split over the wavefronts, one output tile --------------------------------
+  // ---- last linear layer: the wavefronts' shares (activate, `last`) lie in LDS and are added in wavefront order ----------------
   {
-    const LayerDev& L = p.layer[p.n_linear - 1];
-    const int ks = L.k_steps;
-    if (wave == 0) {
-      coord_step(L, 1);
-    } else {
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[0][t] = zero16;
-    }
-    if constexpr (ASYM) {
-      wait_flags(0, unsigned(p.n_linear - 1));
-      wait_flags(WAVES / 2, unsigned(p.n_linear - 1));
-    } else {
-      __syncthreads();
-    }
-    const frag_t* W = reinterpret_cast<const frag_t*>(p.packed + L.w_off) + lane;
-    const frag_t* Bh = reinterpret_cast<const frag_t*>(act_hi) + h * M + j;
-    const frag_t* Bl = reinterpret_cast<const frag_t*>(act_lo) + h * M + j;
-#pragma unroll 1
-    for (int s = wave; s < ks; s += WAVES) {
-      const frag_t wh = W[size_t(s) * 128], wl = W[size_t(s) * 128 + 64];
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const frag_t xh = Bh[2 * s * M + 32 * t];
-        acc[0][t] = mfma16<F16>(wh, xh, acc[0][t]);
-        if constexpr (!ONE) acc[0][t] = mfma16<F16>(wh, Bl[2 * s * M + 32 * t], acc[0][t]);
-        acc[0][t] = mfma16<F16>(wl, xh, acc[0][t]);
-      }
-    }
-    // rows 0..3 of the tile are registers 0..3 of the lanes with h == 0
-    if (h == 0) {
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        float* q = partial + (wave * M + 32 * t + j) * 4;
-        q[0] = acc[0][t][0]; q[1] = acc[0][t][1]; q[2] = acc[0][t][2]; q[3] = acc[0][t][3];
-      }
-    }
     __syncthreads();
     if (!BROY) {
       for (int e = threadIdx.x; e < M * p.out_dim; e += blockDim.x) {
@@ -814,7 +776,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           float v = 0.f;
 #pragma unroll
           for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
-          v *= 1.f / SP_SCALE;                                // the last layer's 1 / k (see mlp_pack_kernel)
+          v *= 1.f / SP_SCALE;                                // the activations carry k (mlp_layout.h)
+          if (stream == 0) v += wlast[p.last_tiles * 128 + c];  // bias (the tangent streams have none)
           if (p.add_input && c < 3) {
             if (stream == 0) {
               float x, y, z;
@@ -849,7 +812,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) v += partial[(w * M + m) * 4 + c];
-        gnew[c] = (v * (1.f / SP_SCALE) + bx[c]) - bobs[c];     // residual (x + F(x)) - obs
+        gnew[c] = (v * (1.f / SP_SCALE) + wlast[p.last_tiles * 128 + c] + bx[c]) - bobs[c];     // residual (x + F(x)) - obs
       }
     }
     if (it == 0) {
@@ -924,7 +887,9 @@ __global__ __launch_bounds__(256) void inverse3x3_kernel(const float* __restrict
 }
 
 template <int MT, int NTW, bool ONE = false>
-constexpr size_t lds_bytes() { return size_t(32 * WAVES * NTW / 8) * (32 * MT) * 16 * (ONE ? 1 : 2) + (WAVES + 1) * 32 * MT * 4 * 4 + 64; }
+constexpr size_t lds_bytes() {
+  return size_t(32 * WAVES * NTW / 8) * (32 * MT) * 16 * (ONE ? 1 : 2) + (WAVES + 1) * 32 * MT * 4 * 4 + last_table_floats(WAVES * NTW) * sizeof(float);
+}
 
 }  // namespace mlp
 }  // namespace nphm
@@ -938,25 +903,14 @@ using nphm::mlp::Plan;
 // `numerics` of the plain evaluation entry points (include/nphm_amd.h): low byte = operand format (0 split-bf16, 1 split-f16),
 // bits 8.. = mask of the hidden layers that run the two-term product (bit l = linear layer l; layer 0 and the last never)
 static bool mlp_numerics_ok(int numerics) { return (numerics & 0xff) <= 1 && numerics >= 0; }
-// ... and of the two plain-evaluation entry points (points / lattice): also 2 = split-f16 storage, SINGLE-term product rn(x) wh
-// in every hidden GEMM layer (mlp_eval_kernel, ONE: 128 points per workgroup at hidden <= 512, 64 at hidden <= 1024)
-static bool mlp_eval_numerics_ok(int numerics) { return (numerics & 0xff) <= 2 && numerics >= 0; }
-// NPHM_AMD_MLP_ASYM=0: the plain evaluation in lockstep (both wavefronts of a SIMD in the same phase), for same-box A/B runs
-static bool mlp_asym_enabled() {
-  static const bool on = [] { const char* e = getenv("NPHM_AMD_MLP_ASYM"); return !e || atoi(e) != 0; }();
-  return on;
-}
-
-// `columns` (value + Jacobian launches, hidden <= 512): 64 = 16 points per workgroup (default), 32 = 8 points per workgroup
-// (64 KiB of LDS, two workgroups per CU) - the caller splits a launch whose 16-point workgroups would fill 1.2 rounds of the
-// chip into one full round of them and a round of the small ones over the remaining points (a.point_base / a.point_end)
+// bits 20.. (split-f16, plain evaluation entry points - points / lattice - only) = mask of the hidden layers that run the
+// SINGLE-term product rn(x) wh; all of them: the 128-points-per-workgroup variant (mlp_eval_kernel, ONE)
+static bool mlp_eval_numerics_ok(int numerics) { return mlp_numerics_ok(numerics) && ((numerics >> 20) == 0 || (numerics & 0xff) == 1); }
 template <int MODE, int KIND = 0>
 static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, int n_rows, hipStream_t st, int numerics = 0,
                        int columns = 64) {
   using namespace nphm::mlp;
-  const bool one = (numerics & 0xff) == 2;
-  const bool f16 = (numerics & 0xff) == 1 || one;
-  if (one && KIND != 0) return nphm_fail_msg("nphm_mlp_eval: the single-term product serves the plain evaluation only");
+  const bool f16 = (numerics & 0xff) == 1;
   if (MODE == 0) {
     if (a.point_end == 0 && a.point_base == 0) a.point_end = a.n_points;                 // the whole row
     if (a.point_base < 0 || a.point_end > a.n_points || a.point_base >= a.point_end)
@@ -976,12 +930,21 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   a.n_linear = plan.n_linear;
   // both buffers hold the two formats back to back: [bf16 fragments | f16 fragments], per state row [bf16 | f16]
   a.state_row_bytes = 2 * plan.state_row_bytes;
+  a.last_tab = reinterpret_cast<const float*>(a.packed + 2 * plan.packed_bytes);
+  a.last_tiles = plan.layer[plan.n_linear - 1].k_steps / 2;
   if (f16) { a.packed += plan.packed_bytes; a.state += plan.state_row_bytes; }
-  a.two_pass_mask = (unsigned(numerics) >> 8) & ((1u << (plan.n_linear - 1)) - 2u);     // hidden GEMM layers 1 .. n_linear - 2
-  // every hidden GEMM layer two-term (split-f16 only): the variant without wl fragments (mlp_eval_kernel, ALL2)
-  const unsigned hidden_mask = (1u << (plan.n_linear - 1)) - 2u;
-  if (one) a.two_pass_mask = 0;
-  const bool all2 = f16 && !one && plan.n_linear > 2 && a.two_pass_mask == hidden_mask && (KIND == 0 || plan.variant == 0)
+  const unsigned hidden_mask = (1u << (plan.n_linear - 1)) - 2u;                        // hidden GEMM layers 1 .. n_linear - 2
+  a.one_pass_mask = (unsigned(numerics) >> 20) & hidden_mask;
+  a.two_pass_mask = (unsigned(numerics) >> 8) & hidden_mask & ~a.one_pass_mask;
+  if (a.one_pass_mask && (KIND != 0 || !f16)) return nphm_fail_msg("nphm_mlp_eval: the single-term product serves the plain split-f16 evaluation only");
+  // every hidden GEMM layer single-term: the variant without a lo plane (mlp_eval_kernel, ONE)
+  const bool one = KIND == 0 && f16 && plan.n_linear > 2 && a.one_pass_mask == hidden_mask
+#ifdef NPHM_MLP_NO_ONE
+                   && false
+#endif
+      ;
+  // no hidden GEMM layer three-term (split-f16 only): the variant without wl fragments (mlp_eval_kernel, ALL2)
+  const bool all2 = f16 && !one && plan.n_linear > 2 && (a.two_pass_mask | a.one_pass_mask) == hidden_mask && (KIND == 0 || plan.variant == 0)
 #ifdef NPHM_MLP_NO_ALL2
                     && false
 #endif
@@ -1012,26 +975,10 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
       if (all2 ? go(mlp_eval_kernel<1, 2, MODE, KIND, true, true>, lds_bytes<1, 2>())
                : f16 ? go(mlp_eval_kernel<1, 2, MODE, KIND, true>, lds_bytes<1, 2>()) : go(mlp_eval_kernel<1, 2, MODE, KIND, false>, lds_bytes<1, 2>())) return -2;
     }
-  } else if (KIND == 0 && f16) {
-    // the plain split-f16 evaluation: phase-shifted wavefront pairs (ASYM) unless NPHM_AMD_MLP_ASYM=0
+  } else if (one) {
     if constexpr (KIND == 0) {
-      const bool asym = mlp_asym_enabled();
-      int r;
-      if (plan.variant == 0) {
-        r = one ? (asym ? go(mlp_eval_kernel<4, 2, MODE, 0, true, false, true, true>, lds_bytes<4, 2, true>())
-                        : go(mlp_eval_kernel<4, 2, MODE, 0, true, false, true, false>, lds_bytes<4, 2, true>()))
-          : all2 ? (asym ? go(mlp_eval_kernel<2, 2, MODE, 0, true, true, false, true>, lds_bytes<2, 2>())
-                         : go(mlp_eval_kernel<2, 2, MODE, 0, true, true>, lds_bytes<2, 2>()))
-                 : (asym ? go(mlp_eval_kernel<2, 2, MODE, 0, true, false, false, true>, lds_bytes<2, 2>())
-                         : go(mlp_eval_kernel<2, 2, MODE, 0, true>, lds_bytes<2, 2>()));
-      } else {
-        r = one ? go(mlp_eval_kernel<2, 4, MODE, 0, true, false, true, true>, lds_bytes<2, 4, true>())
-          : all2 ? (asym ? go(mlp_eval_kernel<1, 4, MODE, 0, true, true, false, true>, lds_bytes<1, 4>())
-                         : go(mlp_eval_kernel<1, 4, MODE, 0, true, true>, lds_bytes<1, 4>()))
-                 : (asym ? go(mlp_eval_kernel<1, 4, MODE, 0, true, false, false, true>, lds_bytes<1, 4>())
-                         : go(mlp_eval_kernel<1, 4, MODE, 0, true>, lds_bytes<1, 4>()));
-      }
-      if (r) return -2;
+      if (plan.variant == 0 ? go(mlp_eval_kernel<4, 2, MODE, 0, true, false, true>, lds_bytes<4, 2, true>())
+                            : go(mlp_eval_kernel<2, 4, MODE, 0, true, false, true>, lds_bytes<2, 4, true>())) return -2;
     }
   } else if (plan.variant == 0) {
     if (all2 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true, true>, lds_bytes<2, 2>())
@@ -1039,7 +986,8 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
   } else if constexpr (KIND == 3 || KIND == 4) {
     return nphm_fail_msg("nphm_mlp_eval_points_saving: only the hidden <= 512 variant has a backward kernel");
   } else if constexpr (KIND == 0) {
-    if (go(mlp_eval_kernel<1, 4, MODE, 0, false>, lds_bytes<1, 4>())) return -2;
+    if (all2 ? go(mlp_eval_kernel<1, 4, MODE, 0, true, true>, lds_bytes<1, 4>())
+             : f16 ? go(mlp_eval_kernel<1, 4, MODE, 0, true>, lds_bytes<1, 4>()) : go(mlp_eval_kernel<1, 4, MODE, 0, false>, lds_bytes<1, 4>())) return -2;
   } else {
     // the hidden <= 1024 variant (NPM) keeps bf16 halves for its tangent / Broyden forms (nothing drives them hard: the
     // fitting loop's expression decoder is the hidden <= 512 one)
@@ -1066,7 +1014,7 @@ int nphm_mlp_supported(int lat_dim, int hidden_dim, int nlayers, int out_dim, in
 
 size_t nphm_mlp_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim) {
   Plan plan;
-  return plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) ? 2 * plan.packed_bytes : 0;      // [split-bf16 | split-f16] fragments
+  return plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan) ? 2 * plan.packed_bytes + plan.last_bytes : 0;      // [split-bf16 | split-f16] fragments | fp32 last layer
 }
 
 size_t nphm_mlp_latent_state_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows) {
@@ -1092,7 +1040,7 @@ int nphm_mlp_pack(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   if (!packed) return nphm_fail_msg("nphm_mlp_pack: null packed buffer");
   if (fill_table(a.t, a.plan, lin_weight, lin_bias, "nphm_mlp_pack: null weight/bias pointer")) return -2;
   a.out = static_cast<uint16_t*>(packed);
-  hipLaunchKernelGGL(nphm::mlp::mlp_pack_kernel, dim3(1024, a.plan.n_linear - 1), dim3(256), 0,
+  hipLaunchKernelGGL(nphm::mlp::mlp_pack_kernel, dim3(1024, a.plan.n_linear), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_mlp_pack launch", e);

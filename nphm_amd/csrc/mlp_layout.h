@@ -64,9 +64,15 @@ struct Plan {
   int n_linear;
   int variant;      // 0: 64 points x 512 features per workgroup, 1: 32 points x 1024 features
   Layer layer[MAX_LINEAR];
-  size_t packed_bytes;
+  size_t packed_bytes;       // A fragments of one operand format; the packed buffer = [bf16 | f16 | last-layer table]
   size_t state_row_bytes;
+  size_t last_bytes;         // fp32 table of the LAST linear layer (see last_table_floats)
 };
+
+// The last linear layer (out_dim <= 4 rows) is applied in fp32 by the epilogue of the last hidden layer, straight from the
+// activations in registers: per input tile n (32 features) and lane half h the 4 x 16 weights W[c][32 n + feat_local(r, h)]
+// ([n][h][c][r] floats, zero-padded), then the 4 biases.
+__host__ __device__ constexpr size_t last_table_floats(int k_tiles) { return size_t(k_tiles) * 2 * 4 * 16 + 4; }
 
 __host__ __device__ constexpr int feat_local(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -103,6 +109,7 @@ inline bool make_plan(const Config& c, Plan& p) {
   }
   p.packed_bytes = w;
   p.state_row_bytes = s;
+  p.last_bytes = (last_table_floats(p.layer[p.n_linear - 1].k_steps / 2) * sizeof(float) + 15) / 16 * 16;
   return w < (size_t(1) << 32);
 }
 

@@ -134,13 +134,13 @@ class DeepSDF(nn.Module):
         #   precision "f16x3" (default) | "bf16x3": operand format of the split products;
         #   numerics "auto": on evaluations of >= two_pass_min_points points the cheapest tier whose output stays within
         #   `numerics_target` of the three-term product on a sample (calibrate_numerics / _numerics_code below; verified on a
-        #   sample of every such call): the SINGLE-term product rn(x) wh in every hidden layer (split-f16 only; twice the
-        #   points per weight pass), else the two-term product xh wh + xl wh in the layers of a calibrated mask;
-        #   "fixed": exactly `single_term` / `two_pass_mask` (False / 0 = the three-term product everywhere).
+        #   sample of every such call): per hidden layer the single-term product rn(x) wh (split-f16 only; in EVERY layer:
+        #   twice the points per weight pass), the two-term product xh wh + xl wh, or all three terms;
+        #   "fixed": exactly `single_mask` / `two_pass_mask` (0 / 0 = the three-term product everywhere).
         self.precision = os.environ.get("NPHM_AMD_MLP_PRECISION", "f16x3")
         self.numerics = os.environ.get("NPHM_AMD_MLP_NUMERICS", "auto")
         self.two_pass_mask = 0
-        self.single_term = False
+        self.single_mask = 0            # ("fixed") hidden layers on the single-term product; all of them: 128 points per workgroup
         # max |tier - three-term| allowed on the calibration / verification sample (output units).  5e-6 = the bar of the
         # identity field's calibrated tiers (numerics.py); rounds 3-4 used 2e-6 here, which the two-term tier meets
         # (0.7 - 1.3e-6 on the seeded and trained-like nets) and the single-term tier misses by a hair (2.1e-6)
@@ -154,7 +154,11 @@ class DeepSDF(nn.Module):
         # a sample of its points and its first conditioning row; nothing can be re-measured inside the replayed graph) |
         # "f16x3" | "bf16x3" (rounds 1-3): three terms everywhere
         self.fit_numerics = os.environ.get("NPHM_AMD_FIT_NUMERICS", "auto")
+        self.fit_target = 2e-6          # bound on the value of those launches (two-term against three-term), output units
+        self.fit_jacobian_target = 2e-5  # ... and on their Jacobian entries
+        self.fit_verify_every = 100     # fitting steps between two re-measurements on the current codes (reverify_fit)
         self._fit_cache = None          # (weight key, mask, report)
+        self._fit_last = None
         self.last_numerics = None       # what the most recent large evaluation ran (for bench.py / diagnostics)
         self._state_scope = None        # inside DeformationNetwork.condition_scope(): {cond tensor key: (tensor, state)}
         print(d_in)
@@ -328,19 +332,23 @@ class DeepSDF(nn.Module):
                    "nphm_mlp_eval_points")
         return out
 
-    def calibrate_two_pass(self, packed, state, sample_xyz):
+    def calibrate_two_pass(self, packed, state, sample_xyz, err_of=None, target=None):
         """Which hidden layers may run the two-term product xh wh + xl wh (weights rounded to the half format) on THIS
-        checkpoint: the largest set whose output stays within ``two_pass_target`` of the three-term product on
+        checkpoint: the largest set whose output stays within ``numerics_target`` of the three-term product on
         ``sample_xyz`` [1,n,3] with the conditioning in ``state`` (row 0).  All layers at once if that holds; otherwise
         the layers are added in the order of their individual errors while the measured error of the set stays inside.
-        Synchronises (one scalar per candidate); ~2 (best case) .. 2 nlayers small launches.  Returns (mask, report)."""
+        Synchronises (one scalar per candidate); ~2 (best case) .. 2 nlayers small launches.  Returns (mask, report).
+        ``err_of(mask) -> float`` / ``target``: another error measure and its bound (the fitting launches: value AND Jacobian
+        on every conditioning row, _fit_err)."""
         fmt = self._format_code()
-        ref = self._eval_points_raw(packed, state, sample_xyz, False, fmt)
-        err_of = lambda m: float((self._eval_points_raw(packed, state, sample_xyz, False, fmt | (m << 8)) - ref).abs().max())
+        if err_of is None:
+            ref = self._eval_points_raw(packed, state, sample_xyz, False, fmt)
+            err_of = lambda m: float((self._eval_points_raw(packed, state, sample_xyz, False, fmt | (m << 8)) - ref).abs().max())
+        tgt = self.numerics_target if target is None else float(target)
         full = self._hidden_mask()
         e_all = err_of(full)
-        report = {"target": self.two_pass_target, "all_layers_err": e_all, "sample_points": int(sample_xyz.shape[1])}
-        if e_all <= self.two_pass_target:
+        report = {"target": tgt, "all_layers_err": e_all, "sample_points": int(sample_xyz.shape[1])}
+        if e_all <= tgt:
             report.update(mask=full, err=e_all)
             return full, report
         layers = [l for l in range(1, self.nlayers) if (full >> l) & 1]
@@ -348,47 +356,66 @@ class DeepSDF(nn.Module):
         report["per_layer_err"] = {l: e for e, l in single}
         mask, err = 0, 0.0
         for e, l in single:
-            if e > self.two_pass_target:
+            if e > tgt:
                 break
             trial = mask | (1 << l)
             et = err_of(trial)
-            if et > self.two_pass_target:
+            if et > tgt:
                 break
             mask, err = trial, et
         report.update(mask=mask, err=err)
         return mask, report
 
-    _SINGLE = 2      # `numerics` format byte: split-f16 storage, single-term product in every hidden layer (mlp_kernel.hip, ONE)
-
     def _single_ok(self) -> bool:
         return self.allow_single_term and self.precision == "f16x3" and self.nlayers >= 2
 
+    def _code(self, two_mask: int, one_mask: int = 0) -> int:
+        """`numerics` argument (include/nphm_amd.h): format byte | two-term layer mask << 8 | single-term layer mask << 20"""
+        hid = self._hidden_mask()
+        one_mask &= hid
+        return self._format_code() | ((two_mask & hid & ~one_mask) << 8) | (one_mask << 20)
+
     def calibrate_numerics(self, packed, state, sample_xyz):
-        """The cheapest tier of the plain evaluation that stays within ``numerics_target`` of the three-term product on
-        ``sample_xyz``: -> (numerics code, report).  Order: single-term everywhere (half the MFMAs and half the weight bytes
-        per point of the two-term tier), then ``calibrate_two_pass``."""
+        """The cheapest per-layer tiers of the plain evaluation that stay within ``numerics_target`` of the three-term product
+        on ``sample_xyz``: -> (numerics code, report).  Order: the single-term product rn(x) wh in EVERY hidden layer (half
+        the MFMAs of the two-term tier and, with twice the points per workgroup, half its weight bytes per point); else the
+        two-term layers of ``calibrate_two_pass`` and, of those, single-term layers added in the order of their individual
+        errors while the measured error of the whole setting stays inside."""
         fmt = self._format_code()
-        if self._single_ok():
-            ref = self._eval_points_raw(packed, state, sample_xyz, False, fmt)
-            e1 = float((self._eval_points_raw(packed, state, sample_xyz, False, self._SINGLE) - ref).abs().max())
-            if e1 <= self.numerics_target:
-                return self._SINGLE, {"target": self.numerics_target, "single_term": True, "mask": 0, "err": e1,
-                                      "sample_points": int(sample_xyz.shape[1])}
-        else:
-            e1 = None
+        hid = self._hidden_mask()
+        if not self._single_ok():
+            mask, report = self.calibrate_two_pass(packed, state, sample_xyz)
+            report.update(single_mask=0, single_term=False)
+            return self._code(mask), report
+        ref = self._eval_points_raw(packed, state, sample_xyz, False, fmt)
+        err_of = lambda two, one: float((self._eval_points_raw(packed, state, sample_xyz, False, self._code(two, one)) - ref).abs().max())
+        e_all = err_of(0, hid)
+        if e_all <= self.numerics_target:
+            return self._code(0, hid), {"target": self.numerics_target, "single_term": True, "single_mask": hid, "mask": 0,
+                                        "err": e_all, "sample_points": int(sample_xyz.shape[1])}
         mask, report = self.calibrate_two_pass(packed, state, sample_xyz)
-        report.update(single_term=False, single_term_err=e1)
-        return fmt | (mask << 8), report
+        report["all_single_err"] = e_all
+        layers = [l for l in range(1, self.nlayers) if (mask >> l) & 1]
+        per_layer = sorted((err_of(mask, 1 << l), l) for l in layers)
+        report["per_layer_single_err"] = {l: e for e, l in per_layer}
+        one, err = 0, report.get("err", 0.0)
+        for e, l in per_layer:
+            if e > self.numerics_target:
+                break
+            et = err_of(mask, one | (1 << l))
+            if et > self.numerics_target:
+                continue
+            one, err = one | (1 << l), et
+        report.update(single_mask=one, single_term=False, err=err)
+        return self._code(mask, one), report
 
     def _numerics_code(self, packed, state, n_points, sample_fn):
         """`numerics` argument of this evaluation.  ``sample_fn()`` -> [1,n,3] points of THIS call (a strided subsample)."""
         fmt = self._format_code()
         if self.numerics == "fixed":
-            if self.single_term:
-                if self.precision != "f16x3":
-                    raise ValueError("DeepSDF.single_term needs precision 'f16x3'")
-                return self._SINGLE
-            return fmt | ((int(self.two_pass_mask) & self._hidden_mask()) << 8)
+            if self.single_mask and self.precision != "f16x3":
+                raise ValueError("DeepSDF.single_mask needs precision 'f16x3'")
+            return self._code(int(self.two_pass_mask), int(self.single_mask))
         if self.numerics != "auto":
             raise ValueError(f"DeepSDF.numerics must be 'auto' or 'fixed', got {self.numerics!r}")
         if n_points < self.two_pass_min_points or torch.cuda.is_current_stream_capturing():
@@ -434,8 +461,39 @@ class DeepSDF(nn.Module):
             return [(0, 0, 64)]
         return [(0, n_a, 64), (n_a, n - n_a, 32)]
 
+    def _eval_jvp_raw(self, packed, state, xyz, code):
+        lib = _lib.load()
+        B, N, _ = xyz.shape
+        out = torch.empty(B, N, 4, self.n_out, dtype=torch.float32, device=xyz.device)
+        stream = torch.cuda.current_stream(xyz.device).cuda_stream
+        _lib.check(lib.nphm_mlp_eval_points_jvp(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(), B, N, 0,
+                                                out.data_ptr(), int(code), 0, 0, 64, stream), "nphm_mlp_eval_points_jvp")
+        return out
+
+    def _fit_err(self, packed, state, sample):
+        """-> err_of(mask): deviation of the value + Jacobian launch with the two-term layers of ``mask`` from its three-term
+        form on ``sample`` [B,n,3] (every conditioning row of ``state``), in units of the bounds: max(|d value| / fit_target,
+        |d Jacobian| / fit_jacobian_target).  The fitting loop differentiates through these launches (Broyden's start
+        Jacobian, the implicit-function gradient, fitting.py:99-106): the tangents are part of the criterion."""
+        ref = self._eval_jvp_raw(packed, state, sample, 1)
+
+        def err_of(mask):
+            d = (self._eval_jvp_raw(packed, state, sample, 1 | (mask << 8)) - ref).abs()
+            return max(float(d[:, :, 0].max()) / self.fit_target, float(d[:, :, 1:].max()) / self.fit_jacobian_target)
+        return err_of
+
+    @staticmethod
+    def _fit_sample(xyz):
+        n = xyz.shape[1]
+        per_row = max(256, 4096 // max(1, xyz.shape[0]))
+        return xyz[:, :: max(1, n // per_row)][:, :per_row].contiguous().float()
+
     def _fit_code(self, packed, state, xyz):
-        """`numerics` argument of the tangent / Broyden / saving launches (``fit_numerics``).  xyz [B,N,3]: this call's points."""
+        """`numerics` argument of the tangent / Broyden / saving launches (``fit_numerics``).  xyz [B,N,3]: this call's points.
+        "auto": split-f16 operands with the two-term layers of a mask calibrated per weight version on a sample of the first
+        such call's points under ALL of its conditioning rows, value and Jacobian both (_fit_err); re-measured on the
+        conditioning of the day by ``reverify_fit`` (the fitting loop calls it every ``fit_verify_every`` steps, outside the
+        replayed graph, and re-captures when the mask shrank)."""
         if self.fit_numerics not in ("auto", "bf16x3", "f16x3"):
             raise ValueError(f"DeepSDF.fit_numerics must be 'auto', 'f16x3' or 'bf16x3', got {self.fit_numerics!r}")
         if self.hidden_dim > 512 or self.fit_numerics == "bf16x3":
@@ -443,21 +501,45 @@ class DeepSDF(nn.Module):
         if self.fit_numerics == "f16x3":
             return 1
         ws, bs = self._lin_params()
-        key = tuple((t.data_ptr(), t._version) for t in ws + bs) + (float(self.two_pass_target),)
+        key = tuple((t.data_ptr(), t._version) for t in ws + bs) + (float(self.fit_target), float(self.fit_jacobian_target))
         c = self._fit_cache
+        self._fit_last = (packed, state, xyz)          # what reverify_fit measures on (inside a capture: the static tensors)
         if c is None or c[0] != key:
             if torch.cuda.is_current_stream_capturing() or xyz.shape[0] * xyz.shape[1] < 1024:
                 return 1                      # nothing measured yet for these weights: three terms (split-f16)
-            keep, self.precision = self.precision, "f16x3"
-            try:
-                n = xyz.shape[1]
-                sample = xyz[:1, :: max(1, n // 4096)][:, :4096].contiguous().float()
-                mask, report = self.calibrate_two_pass(packed, state, sample)
-            finally:
-                self.precision = keep
+            sample = self._fit_sample(xyz)
+            mask, report = self.calibrate_two_pass(packed, state, sample, err_of=self._fit_err(packed, state, sample), target=1.0)
+            report.update(value_target=self.fit_target, jacobian_target=self.fit_jacobian_target, rows=int(xyz.shape[0]))
             c = (key, mask, report)
             self._fit_cache = c
+            self._fit_calls = 0
+        elif c[1] and not torch.cuda.is_current_stream_capturing():
+            # eager loops: the same re-measurement the graphed loop triggers (a fitting step issues ~6 of these launches)
+            self._fit_calls = getattr(self, "_fit_calls", 0) + 1
+            if self._fit_calls % (6 * max(1, int(self.fit_verify_every))) == 0 and xyz.shape[0] * xyz.shape[1] >= 1024:
+                self.reverify_fit()
+                c = self._fit_cache
         return 1 | (c[1] << 8)
+
+    def reverify_fit(self) -> bool:
+        """Measure the cached fitting mask on the most recent fitting launch's points and CURRENT conditioning rows (outside
+        any capture); if it no longer holds, re-calibrate there and keep the intersection.  -> True if the mask changed (a
+        captured step that baked it in must be recorded again)."""
+        c, last = self._fit_cache, getattr(self, "_fit_last", None)
+        if c is None or last is None or c[1] == 0 or self.fit_numerics != "auto" or torch.cuda.is_current_stream_capturing():
+            return False
+        packed, state, xyz = last
+        sample = self._fit_sample(xyz)
+        err_of = self._fit_err(packed, state, sample)
+        e = err_of(c[1])
+        c[2]["reverified_err"] = e
+        if e <= 1.0:
+            return False
+        mask, report = self.calibrate_two_pass(packed, state, sample, err_of=err_of, target=1.0)
+        mask &= c[1]
+        report.update(value_target=self.fit_target, jacobian_target=self.fit_jacobian_target, tightened_from=c[1], mask=mask)
+        self._fit_cache = (c[0], mask, report)
+        return True
 
     def forward_hip(self, xyz, cond_rows, add_input=False):
         """xyz [B,N,3] fp32 on a ROCm device, cond_rows [B, lat_dim] -> [B,N,out_dim]

@@ -839,6 +839,8 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             _lib.check(lib.nphm_identity_prepare_latent_anchors(_lib.ptr_array5(ws), _lib.ptr_array5(bs), lat_rows.data_ptr(),
                                                                 given.data_ptr(), B, state.data_ptr(), stream),
                        "nphm_identity_prepare_latent_anchors")
+            if knobs is not None:
+                state.nphm_knobs = knobs      # (every inference launch site unpacks it)
             return packed, state, given
         anchors = torch.empty(B, self.num_kps, 3, dtype=torch.float32, device=device)
         mean = self.anchors.reshape(self.num_kps, 3).to(device=device, dtype=torch.float32).contiguous()
@@ -976,7 +978,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             if lat is not None:
                 self._verified_latents[self._latent_digest(lat)] = self._calibration[1]["error"]
         elif lat_rows is not None and n_points is not None:
-            lat = lat_rows.detach().reshape(-1, self.lat_dim)[:2]
+            lat = lat_rows.detach().reshape(-1, self.lat_dim)[:8]          # every row of the usual batches (a digest + <= 8 samples)
             if capturing:
                 return exact                  # (a digest needs a device -> host copy; captured evaluations stay exact)
             dig = self._latent_digest(lat)
@@ -1004,18 +1006,22 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         return dig
 
     def _verify_latent(self, lat, dig, device):
-        """The calibrated knobs measured on a sample of ``lat`` [R <= 2, lat_dim]; above 1.5 x target: re-calibrate on the
-        union of the calibration latents (at most 4 are kept) and this one."""
+        """The calibrated knobs measured on a sample of every row of ``lat`` [R <= 8, lat_dim]; above 1.5 x target: re-calibrate
+        on the union of the calibration latents (at most 4 are kept) and the worst rows.  A replaced calibration voids what
+        was verified under the old knobs."""
         from .numerics import calibrate_numerics, sample_error
         c = self._calibration[1]
-        err = max(sample_error(self, lat[r:r + 1], precision=c["precision"], light_tol=c["light_tol"], mid_tol=c["mid_tol"],
-                               prune_tol=c["prune_tol"], refine_band=c.get("refine_band"), bounds=c.get("bounds"))
-                  for r in range(lat.shape[0]))
+        errs = [sample_error(self, lat[r:r + 1], precision=c["precision"], light_tol=c["light_tol"], mid_tol=c["mid_tol"],
+                             prune_tol=c["prune_tol"], refine_band=c.get("refine_band"), bounds=c.get("bounds"))
+                for r in range(lat.shape[0])]
+        err = max(errs)
         if err > 1.5 * c["target"]:
-            union = torch.cat([c["latents"].to(lat), lat])[-4:]
+            worst = lat[torch.tensor(errs).argsort(descending=True)[:2].to(lat.device)]
+            union = torch.cat([c["latents"].to(lat), worst])[-4:]
             new = calibrate_numerics(self, union, device=device)
             new["recalibrated_for"] = {"digest": dig, "error_before": err}
             object.__setattr__(self, "_calibration", (self._calibration[0], new))
+            self._verified_latents.clear()               # measured with the old knobs
             err = new["error"]
         if len(self._verified_latents) >= 256:
             self._verified_latents.pop(next(iter(self._verified_latents)))

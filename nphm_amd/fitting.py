@@ -419,9 +419,13 @@ class _GraphedStep:
     its inputs from static tensors and returns static tensors; the optimizer steps stay outside.  Any failure to
     capture falls back to eager execution for the rest of the loop."""
 
-    def __init__(self, body, enabled, params, warm=3):
+    def __init__(self, body, enabled, params, warm=3, checks=(), check_every=100):
         self.body, self.enabled, self.params, self.warm = body, bool(enabled), list(params), warm
         self.calls, self.graph, self.out = 0, None, None
+        # ``checks``: callables run OUTSIDE the graph every ``check_every`` replays (numerics decisions that were baked into
+        # the recording, e.g. DeepSDF.reverify_fit); one returning True drops the recording: the next call records again
+        self.checks, self.check_every, self.replays, self.recaptures = list(checks), int(check_every), 0, 0
+        self._stale = False
 
     def zero_grad(self):
         if self.graph is None:                       # once captured, backward REWRITES the static .grad buffers
@@ -442,6 +446,12 @@ class _GraphedStep:
         if not self.enabled or (self.graph is None and self.calls < self.warm):
             self.calls += 1
             return self.body()
+        if self._stale:                              # a check invalidated the recording: backward must ASSIGN fresh .grad
+            torch.cuda.synchronize()                 # tensors again while the new graph is recorded (see zero_grad)
+            self._stale, self.graph, self.out = False, None, None
+            self.recaptures += 1
+            for p in self.params:
+                p.grad = None
         if self.graph is None:
             try:
                 torch.cuda.synchronize()
@@ -458,6 +468,10 @@ class _GraphedStep:
                     p.grad = None
                 return self.body()
         self.graph.replay()
+        self.replays += 1
+        if self.checks and self.check_every > 0 and self.replays % self.check_every == 0:
+            if any([bool(c()) for c in self.checks]):
+                self._stale = True                   # record again at the next call (this call's outputs stay valid until then)
         return self.out
 
 
@@ -607,7 +621,12 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             row = hist.row(loss_dict, loss, n_valid=valid.sum())
         return row, anchors.detach()
 
-    step = _GraphedStep(body, use_graph, [lat_rep_shape, lat_rep])
+    # the expression decoder's fitting launches run a two-term layer mask that was measured on the FIRST codes and is baked
+    # into the recording: it is measured again on the current codes every fit_verify_every steps (DeepSDF.reverify_fit)
+    mlp = getattr(decoder_expr, "defDeepSDF", None)
+    checks = [mlp.reverify_fit] if (mlp is not None and hasattr(mlp, "reverify_fit")) else []
+    step = _GraphedStep(body, use_graph, [lat_rep_shape, lat_rep], checks=checks,
+                        check_every=getattr(mlp, "fit_verify_every", 100) if mlp is not None else 0)
     anchors = None
     done = 0
     with _frozen(decoder, decoder_expr):

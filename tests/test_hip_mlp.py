@@ -397,9 +397,9 @@ def test_two_stage_full_size_256_cubed_properties(dnet, dev):
     with torch.no_grad():
         off, _ = dnet(_t(pts[None], dev), lat_ex[None, None], anchors)
     k = torch.from_numpy(keep).to(dev)
-    # (the lattice launch runs the calibrated two-term layers - DeepSDF.two_pass_target = 2e-6 on its sample - the 4 608-point
-    # call below the three-term product everywhere)
-    assert U.maxdiff(can[k].cpu().numpy(), pts + off[0].cpu().numpy()) < 3e-6
+    # (the lattice launch runs the calibrated per-layer tiers - DeepSDF.numerics_target = 5e-6 on its sample, single-term
+    # layers included - the 4 608-point call below the three-term product everywhere)
+    assert U.maxdiff(can[k].cpu().numpy(), pts + off[0].cpu().numpy()) <= 2.0 * dnet.defDeepSDF.numerics_target
     rep = dnet.defDeepSDF.last_numerics
     print("two-stage 256^3: deformation layers", rep)
     assert rep is not None and rep["verified_err"] <= dnet.defDeepSDF.two_pass_target
@@ -596,6 +596,48 @@ def test_two_term_layers_fixed_mask_and_auto(dev):
         assert torch.equal(a, b)
 
 
+def test_single_term_layers_fixed_and_auto(dev):
+    """Single-term layers rn(x) wh (ABI 9): pinned on every hidden layer (the 128-points-per-workgroup variant), pinned on
+    some (the generic kernel skips their lo products), and what `auto` settles on - each against the three-term product;
+    the lattice launch is bitwise the points launch in every tier."""
+    dnet = U.build_deformation(device=dev).eval()
+    mlp = dnet.defDeepSDF
+    cond = torch.randn(1, mlp.lat_dim, device=dev) * 0.05
+    xyz = _big_points(dev)
+    hid = mlp._hidden_mask()
+    with torch.no_grad():
+        mlp.numerics, mlp.two_pass_mask, mlp.single_mask = "fixed", 0, 0
+        ref = mlp.forward_hip(xyz, cond)
+        errs = {}
+        for name, two, one in (("all", 0, hid), ("layers 1,3 single / rest two-term", hid, 0b1010), ("layer 2 single / rest three-term", 0, 0b100)):
+            mlp.two_pass_mask, mlp.single_mask = two, one
+            out = mlp.forward_hip(xyz, cond)
+            errs[name] = float((out - ref).abs().max())
+            # ragged tail: N not a multiple of 128
+            a = mlp.forward_hip(xyz[:, :1000 + 77].contiguous(), cond)
+            assert torch.equal(a, out[:, :1077])
+        print("single-term tiers against the three-term product:", errs, "outputs up to", float(ref.abs().max()))
+        assert 0.0 < errs["layer 2 single / rest three-term"] < errs["all"] < 5e-5
+        # lattice launch = points launch, bit for bit, in the 128-point variant too
+        axes = R.grid_axes(U.MINI, U.MAXI, 20)
+        pts = torch.from_numpy(np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)).to(dev)
+        mlp.two_pass_mask, mlp.single_mask = 0, hid
+        vol = R.evaluate_grid_mlp(mlp, cond, axes, add_input=False)
+        assert torch.equal(vol.reshape(-1, 3), mlp.forward_hip(pts, cond).reshape(-1, 3))
+        # auto: whatever it picks stays within twice the target on the full set, and reports it
+        mlp.numerics, mlp.two_pass_mask, mlp.single_mask = "auto", 0, 0
+        auto = mlp.forward_hip(xyz, cond)
+        rep = mlp.last_numerics
+        e_auto = float((auto - ref).abs().max())
+        print("auto:", rep, f"full-set error {e_auto:.3e}")
+        assert rep["err"] <= mlp.numerics_target and e_auto <= 2.0 * mlp.numerics_target
+        assert rep["single_mask"] != 0                     # (the seeded net takes single-term layers at 5e-6)
+        # switched off: the two-term tier of rounds 3-4
+        mlp.allow_single_term = False
+        auto2 = mlp.forward_hip(xyz, cond)
+        assert mlp.last_numerics["single_mask"] == 0 and float((auto2 - ref).abs().max()) <= 2.0 * mlp.numerics_target
+
+
 def test_two_term_tier_on_sharp_weights_stays_inside_target(dev):
     """Weights x 2.5 (the stress model of trained sharpness): whatever mask `auto` settles on, the evaluation stays within
     twice the target of the three-term product - the tier shrinks instead of the error growing."""
@@ -655,12 +697,25 @@ def test_fit_tier_two_term_layers_against_the_three_term_launches(dev):
 
     p_a, J_a, g_a = run()
     rep = mlp._fit_cache
-    assert rep is not None and rep[2]["err"] <= mlp.two_pass_target
+    # the criterion is value AND Jacobian on all five conditioning rows, in units of (fit_target, fit_jacobian_target)
+    assert rep is not None and rep[2]["err"] <= 1.0 and rep[2]["rows"] == 5
     mlp.fit_numerics = "f16x3"
     p_x, J_x, g_x = run()
     e = (float((p_a - p_x).abs().max()), float((J_a - J_x).abs().max()), float((g_a - g_x).abs().max()) / float(g_x.abs().max()))
-    print(f"fit tier, mask {rep[1]:#x} (sample {rep[2]['err']:.2e}): posed {e[0]:.2e}, Jacobian {e[1]:.2e}, conditioning gradient (rel) {e[2]:.2e}")
-    assert e[0] < 5e-6 and e[1] < 2e-4 and e[2] < 5e-4
+    print(f"fit tier, mask {rep[1]:#x} (sample {rep[2]['err']:.2e} of the bounds): posed {e[0]:.2e}, Jacobian {e[1]:.2e}, conditioning gradient (rel) {e[2]:.2e}")
+    assert e[0] <= 2.0 * mlp.fit_target and e[1] <= 2.0 * mlp.fit_jacobian_target and e[2] < 5e-4
+    # re-measurement on the current conditioning (what the fitting loop does every fit_verify_every steps): holds here;
+    # with an unreachable bound the mask is withdrawn and the caller is told to record its graph again
+    mlp.fit_numerics = "auto"
+    run()
+    assert mlp.reverify_fit() is False and mlp._fit_cache[1] == rep[1]
+    keep = mlp.fit_target
+    try:
+        mlp.fit_target = 1e-12
+        assert mlp.reverify_fit() is True and mlp._fit_cache[1] == 0
+    finally:
+        mlp.fit_target = keep
+        mlp._fit_cache = None
     mlp.fit_numerics = "bf16x3"                        # rounds 1-3: still available, three-term on bf16 halves
     p_b, J_b, g_b = run()
     assert float((p_b - p_x).abs().max()) < 3e-6 and float((J_b - J_x).abs().max()) < 5e-5

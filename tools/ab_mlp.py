@@ -57,17 +57,27 @@ def main():
         axes = R.grid_axes(U.MINI, U.MAXI, res)
         axes_s = R.grid_axes(U.MINI, U.MAXI, 96 if name == "deformation" else 48)
         mlp.numerics = "fixed"
-        mlp.single_term, mlp.two_pass_mask = False, 0
+        mlp.single_mask, mlp.two_pass_mask = 0, 0
         ref = R.evaluate_grid_mlp(mlp, cond, axes_s, add_input=add).clone()
         rec = {}
         for tier, terms in (("three", 3), ("two", 2), ("single", 1)):
-            mlp.single_term = tier == "single"
+            mlp.single_mask = mlp._hidden_mask() if tier == "single" else 0
             mlp.two_pass_mask = mlp._hidden_mask() if tier == "two" else 0
             err = float((R.evaluate_grid_mlp(mlp, cond, axes_s, add_input=add) - ref).abs().max())
             ms = timeit(lambda: R.evaluate_grid_mlp(mlp, cond, axes, add_input=add), steps=args.steps)
             n = res ** 3
             rec[tier] = {"ms": round(ms, 3), "Mpts/s": round(n / ms / 1e3, 1), "err_vs_three": err,
                          "tflops_exec": round(flops * terms * n / ms / 1e9, 1)}
+        # the calibrated default
+        mlp.numerics, mlp.single_mask, mlp.two_pass_mask = "auto", 0, 0
+        mlp._two_pass_cache = None
+        R.evaluate_grid_mlp(mlp, cond, axes, add_input=add)
+        rep = dict(mlp.last_numerics or {})
+        err = float((R.evaluate_grid_mlp(mlp, cond, axes_s, add_input=add) - ref).abs().max()) if res > 64 else None
+        ms = timeit(lambda: R.evaluate_grid_mlp(mlp, cond, axes, add_input=add), steps=args.steps)
+        rec["auto"] = {"ms": round(ms, 3), "Mpts/s": round(res ** 3 / ms / 1e3, 1), "two_mask": rep.get("mask"), "single_mask": rep.get("single_mask"),
+                       "sample_err": rep.get("err"), "all_single_err": rep.get("all_single_err"), "per_layer_single_err": rep.get("per_layer_single_err"),
+                       "err_vs_three_small_lattice": err}
         out[name] = rec
     print(json.dumps(out))
 

@@ -23,7 +23,7 @@ def main():
     tag = f"lib={os.path.basename(os.environ.get('NPHM_AMD_LIB', 'default'))} asym={os.environ.get('NPHM_AMD_MLP_ASYM', '1')}"
     mlp.numerics = "fixed"
     for tier in ("three", "two", "single"):
-        mlp.single_term = tier == "single"
+        mlp.single_mask = mlp._hidden_mask() if tier == "single" else 0
         mlp.two_pass_mask = mlp._hidden_mask() if tier == "two" else 0
         try:
             with torch.no_grad():
@@ -41,7 +41,7 @@ def main():
     axes = R.grid_axes(U.MINI, U.MAXI, 40)
     pts = torch.from_numpy(np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)).to(dev)
     for tier in ("three", "two", "single"):
-        mlp.single_term = tier == "single"
+        mlp.single_mask = mlp._hidden_mask() if tier == "single" else 0
         mlp.two_pass_mask = mlp._hidden_mask() if tier == "two" else 0
         try:
             vol = R.evaluate_grid_mlp(m2, cond, axes, add_input=False)
