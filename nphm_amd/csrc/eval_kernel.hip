@@ -276,6 +276,41 @@ __device__ __forceinline__ void pack_pair(const f32x16& a, ActB& o) {
   }
 }
 
+// Single-pass ("light") members on the split-f16 path: the whole epilogue of a register PAIR on packed binary16 - the
+// pre-activations are converted first (v_cvt_pkrtz), then |d| (one v_and), relu (v_pk_max), the polynomial's base
+// q = clamp(a0 - a1 |d|) (v_pk_fma ... clamp) and q^2 + relu(d) (v_pk_fma): 5 VALU per pair, and the result IS the next layer's
+// B operand (round 4: polynomial in fp32 per value, then the convert: ~9 per pair).  The tier's error class is unchanged:
+// its products are hi x hi already, the polynomial's own error (4.6e-2 in the scaled domain) is 30 f16 ulps at d' = 1.
+#ifndef NPHM_LIGHT_PK
+#define NPHM_LIGHT_PK 1
+#endif
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x2 light_pair(float a, float b) {
+  const f16x2 d = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+  if (NPHM_ABLATE & (4 | 64)) return d;
+  const f16x2 zero = {(_Float16)0.f, (_Float16)0.f}, one = {(_Float16)1.f, (_Float16)1.f};
+  const f16x2 c1 = {(_Float16)-0.18805397f, (_Float16)-0.18805397f}, c0 = {(_Float16)0.9767937f, (_Float16)0.9767937f};
+  const f16x2 u = __builtin_elementwise_max(d, -d);
+  f16x2 q = __builtin_elementwise_fma(u, c1, c0);
+  q = __builtin_elementwise_min(__builtin_elementwise_max(q, zero), one);      // (folds into the fma's clamp bit: q <= a0 < 1)
+  return __builtin_elementwise_fma(q, q, __builtin_elementwise_max(d, zero));
+}
+// registers R, R+1 of an accumulator (pre-activations) -> their hi operand slot
+template <int R>
+__device__ __forceinline__ void light_pack_pair(const f32x16& a, ActB& o) {
+  constexpr int s = R >> 3, q = (R & 7) >> 1;
+  o.hi[s][q] = __builtin_bit_cast(unsigned, light_pair(a[R], a[R + 1]));
+  if constexpr (q == 3) asm volatile("" : "+v"(o.hi[s]));
+}
+
+// padding features of a layer's last block (NR real registers): zero hi operands
+template <int NR>
+__device__ __forceinline__ void zero_pad_hi(ActB& o) {
+#pragma unroll
+  for (int q = NR / 2; q < 4; ++q) o.hi[0][q] = 0u;
+  asm volatile("" : "+v"(o.hi[0]));
+}
+
 // ---- workgroup geometry ----------------------------------------------------------------------
 // NW = wavefronts per workgroup (all of them share one LDS ring): 8 -> 256 points per weight pass
 #ifndef NPHM_NW
@@ -880,6 +915,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   // A member reads its four floats back with one ds_read_b128.
   __shared__ f32x4 lane_q[64 * NW];
   __shared__ float lane_S[64 * NW];
+  // MODE 0 / 1: (output index | valid << 62 | hack << 63) of the lane's point, parked the same way (MODE 2 recomputes them from
+  // the tile id): as VGPRs that live across the member loop they were 3 spilled registers of the brick / point-set variants
+  __shared__ unsigned long long lane_w[MODE == 2 ? 1 : 64 * NW];
 
   const int lane_inv = threadIdx.x & 63;
   const int lane = lane_inv;
@@ -969,6 +1007,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     f32x4 q4 = {qx, qy, qz, denom};
     lane_q[threadIdx.x] = q4;
     lane_S[threadIdx.x] = S;
+    if (MODE != 2) lane_w[threadIdx.x] = (unsigned long long)out_idx | ((unsigned long long)valid << 62) | ((unsigned long long)hack << 63);
   }
 #endif
   const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
@@ -1093,6 +1132,30 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       (void)last_block;
       // stacked tail block of a three-term member: register r + 4 of the same lane holds the wl rows of register r's features
       if constexpr (PREC == 2 && NPHM_STACK_TAILS && is_tail_chunk(P) && decltype(LL)::value == 0 && r < LAST_BLOCK_REGS) a[r] += a[r + 4];
+      // packed-f16 epilogue of a single-pass member (light_pair): everything happens on the odd register of a pair.  (Not for
+      // lin1's tail block: three of its four registers are the skip connection's coordinates in the upper half-wave.)
+      constexpr bool PK = LIGHT && PREC == 2 && NPHM_LIGHT_PK && NPHM_LIGHT_POLY && g != L1_OB - 1;
+      if constexpr (PK) {
+        if constexpr (P >= 1 + L1_OB + L2_OB) {
+          if constexpr (r % 4 == 0) {
+            typedef __attribute__((address_space(3))) const f32x4* lds_v4;
+            const unsigned int w4a = WS::lds_addr(reinterpret_cast<const char*>(WS::tail_of(ws.slot(P)) + 32 + h * 16 + r));
+            w4q = *(lds_v4)(size_t)w4a;
+          }
+          if constexpr (r & 1) {
+            // lin4 on the pair: v_dot2c_f32_f16 (fp32 accumulate) with the two weights converted alongside
+            const f16x2 wpk = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(w4q[(r - 1) % 4], w4q[r % 4]));
+            part = __builtin_amdgcn_fdot2(light_pair(a[r - 1], a[r]), wpk, part, false);
+            asm volatile("" : "+v"(part));
+          }
+        } else {
+          Act& dst = g < L1_OB ? G[g < L1_OB ? g : 0] : H[g >= L1_OB ? g - L1_OB : 0];
+          constexpr int NR = (g == L1_OB + L2_OB - 1) ? LAST_BLOCK_REGS : 16;
+          if constexpr (r & 1) light_pack_pair<r - 1>(a, dst);
+          if constexpr (r == NR - 1 && NR < 16) zero_pad_hi<NR>(dst);
+        }
+        return;
+      }
       float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
       if constexpr (P >= 1 + L1_OB + L2_OB) {
         // lin3 block: lin4 (200 -> 1) fused; its 16 weights sit in the chunk's ring-slot tail
@@ -1139,6 +1202,11 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       constexpr bool LIGHT = decltype(LL)::value == 1;
       constexpr int NR = B == 6 ? LAST_BLOCK_REGS : 16;
       f32x16& a = l0_acc(BB);
+      if constexpr (LIGHT && PREC == 2 && NPHM_LIGHT_PK && NPHM_LIGHT_POLY) {      // packed-f16 epilogue (light_pair)
+        if constexpr (r & 1) light_pack_pair<r - 1>(a, H[B]);
+        if constexpr (r == NR - 1 && NR < 16) zero_pad_hi<NR>(H[B]);
+        return;
+      }
       const float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
       if constexpr (PREC == 0) {
         H[B][r] = x;
@@ -1321,7 +1389,14 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     // ---- does any wavefront of the workgroup sit on the zero level set? -------------------------------------------
     // (MODE 2: validity recomputed from the tile id and the lane, laundered like the final store's - `valid` as a 0/1 VGPR
     // that lives across the member loop is a scratch spill)
-    bool valid_r = valid;
+    bool valid_r = valid, hack_r = hack;
+#if NPHM_LDS_STASH
+    if (MODE != 2) {
+      const unsigned long long w3 = lane_w[my_slot()];
+      valid_r = (w3 >> 62) & 1ull;
+      hack_r = (w3 >> 63) != 0ull;
+    }
+#endif
     if (MODE == 2) {
       unsigned t3 = tile;
       int l3 = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
@@ -1330,7 +1405,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       tile_lane(p, t3, l3 & 31, lx3, iy3, iz3);
       valid_r = binned_group(blockIdx.x) * NW + wave < unsigned(p.n_tiles) && lx3 < p.ix1 - p.ix0 && iy3 < p.ry && iz3 < p.rz;
     }
-    const bool wave_near = __ballot(valid_r && !hack && fabsf(acc) < p.refine_band) != 0ull;
+    const bool wave_near = __ballot(valid_r && !hack_r && fabsf(acc) < p.refine_band) != 0ull;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) wg_mask[0] = 0u;
@@ -1349,7 +1424,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       // rarely taken path above the member loop and parks them in VGPR lanes - three VGPRs of spill storage for the loop)
       const float* anch_r = anch;
       asm volatile("" : "+s"(anch_r));
-      blend_masks<false>(anch_r, qr[0], qr[1], qr[2], valid_r, hack, p.refine_prune_tol, -1.f, -1.f, S2, denom2, wm, hm, fm);
+      blend_masks<false>(anch_r, qr[0], qr[1], qr[2], valid_r, hack_r, p.refine_prune_tol, -1.f, -1.f, S2, denom2, wm, hm, fm);
 #else
       blend_masks<false>(anch, qx, qy, qz, valid, hack, p.refine_prune_tol, -1.f, -1.f, S2, denom2, wm, hm, fm);
 #endif
@@ -1364,6 +1439,13 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
 
   // eval-mode overwrite (EnsembledDeepSDF.py:260-261): every member predicts 1 for this point
 #if NPHM_LDS_STASH
+  if (MODE != 2) {
+    const int sl = my_slot();
+    const unsigned long long w = lane_w[sl];
+    if (w >> 63) acc = lane_S[sl] / lane_q[sl][3];
+    if (((w >> 62) & 1ull) && (sl & 63) < 32) p.out[w & ((1ull << 62) - 1)] = acc;
+    return;
+  }
   if (hack) { const int sl = my_slot(); acc = lane_S[sl] / lane_q[sl][3]; }
 #else
   if (hack) acc = S / denom;

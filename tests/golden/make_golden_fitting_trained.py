@@ -8,7 +8,9 @@ Observations: three "scans" of ONE trained subject under three trained expressio
 of the subject's identity code (Newton projection through the reference network), posed by the trained deformation network
 with that expression's code (x_posed = x + F_ex(x)).  Configuration of fitting_pointclouds.py:253-276 with the reference's
 step_scale at 0.06: 60 Adam steps that still cross every transition of the schedule (steps 12 / 24 / 30 / 36 / 48).
-Stored: observations, per-step loss terms as the reference prints them, fitted codes and anchors.  ~10 minutes on 8 cores."""
+Stored: observations, per-step loss terms as the reference prints them, fitted codes and anchors, and the code gradients of
+the first three steps as the reference's autograd computed them (grad_shape [3,1,1,1344], grad_expr [3,3,1,200]).  ~10 minutes
+on 8 cores."""
 import io
 import os
 import sys
@@ -38,11 +40,12 @@ from make_golden_fitting_long import LAMBDAS, SCHEDULE, N_STEPS, level_set_point
 
 STEP_SCALE = 0.06
 SUBJECT, EXPRESSIONS, N_EXPR = 3, (2, 5, 9), 12
+GRAD_STEPS = 3          # steps whose code gradients (d loss / d z_id, d loss / d z_ex) are stored
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(HERE)), "gpurun_out", "r4", "trained_expr.npz")
-    z_all = torch.from_numpy(np.load(src)["z_ex"]).float()
+    import _sources
+    z_all = torch.from_numpy(_sources.load("expr")[0]["z_ex"]).float()     # (gpurun_out/r4/trained_expr.npz, or the committed codes)
     mean_anchors = torch.from_numpy(np.load(os.path.join(G.ASSETS, "anchors_39.npy"))).float()[None, None]
     ick = np.load(os.path.join(HERE, "trained_state.npz"))
     shape_net = FastEnsembleDeepSDFMirrored(lat_dim_glob=64, lat_dim_loc=32, n_loc=39, n_symm_pairs=16, anchors=mean_anchors,
@@ -71,10 +74,23 @@ def main():
     t0 = time.time()
     torch.manual_seed(0)
     buf = io.StringIO()
-    with redirect_stdout(buf):
-        lat_e, lat_s, anc_f = inference_iterative_root_finding_joint(
-            shape_net, expr_net, [o.clone() for o in obs], dict(LAMBDAS), N_STEPS,
-            {k: dict(v) for k, v in SCHEDULE.items()}, step_scale=STEP_SCALE)
+    # the gradients the reference's autograd hands its two optimizers in the first GRAD_STEPS steps (opt.step(), then
+    # opt_expr.step(), fitting.py:166-167): recorded at the optimizers' door, the loop itself is untouched
+    grads = []
+    adam_step = torch.optim.Adam.step
+
+    def recording_step(self, *a, **k):
+        if len(grads) < 2 * GRAD_STEPS:
+            grads.append([p.grad.detach().clone() for grp in self.param_groups for p in grp["params"]][0])
+        return adam_step(self, *a, **k)
+    torch.optim.Adam.step = recording_step
+    try:
+        with redirect_stdout(buf):
+            lat_e, lat_s, anc_f = inference_iterative_root_finding_joint(
+                shape_net, expr_net, [o.clone() for o in obs], dict(LAMBDAS), N_STEPS,
+                {k: dict(v) for k, v in SCHEDULE.items()}, step_scale=STEP_SCALE)
+    finally:
+        torch.optim.Adam.step = adam_step
     hist = parse_history(buf.getvalue(), keys)
     n_iter = int(N_STEPS * STEP_SCALE)
     assert hist.shape == (n_iter, len(keys) + 1), hist.shape
@@ -82,6 +98,7 @@ def main():
     out = dict(obs0=obs[0].numpy(), obs1=obs[1].numpy(), obs2=obs[2].numpy(), lat_gt=lat_gt.numpy(),
                n_steps=np.int64(N_STEPS), step_scale=np.float64(STEP_SCALE), keys=np.array(keys), history=hist,
                lat_expr=lat_e.detach().numpy(), lat_shape=lat_s.detach().numpy(), anchors=anc_f.detach().numpy(),
+               grad_shape=torch.stack(grads[0::2]).numpy(), grad_expr=torch.stack(grads[1::2]).numpy(),
                shape_sha256=G.state_hash(shape_net), expr_sha256=G.state_hash(expr_net),
                torch_threads=np.int64(torch.get_num_threads()))
     np.savez_compressed(os.path.join(HERE, "fitting_trained.npz"), **out)

@@ -54,17 +54,18 @@ def state_hash(sd) -> str:
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(HERE)), "gpurun_out", "r3a",
-                                                            "trained_heads.npz")
-    ck = np.load(src)
-    sd = {k[3:]: torch.from_numpy(ck[k]) for k in ck.files if k.startswith("sd.")}
+    sys.path.insert(0, HERE)
+    import _sources
+    ck, from_scratch = _sources.load("heads")       # the training run's output, or the committed trained_state.npz
+    sd = {k[3:]: torch.from_numpy(ck[k]) for k in ck if k.startswith("sd.")}
     codes = torch.from_numpy(ck["codes"]).float()
     anchors = torch.from_numpy(np.load(os.path.join(ASSETS, "anchors_39.npy"))).float().unsqueeze(0).unsqueeze(0)
     net = FastEnsembleDeepSDFMirrored(lat_dim_glob=64, lat_dim_loc=32, n_loc=39, n_symm_pairs=16, anchors=anchors,
                                       hidden_dim=200, n_layers=4, pos_mlp_dim=256)
     net.load_state_dict(sd, strict=True)                      # the checkpoint layout of the reference
-    np.savez(os.path.join(HERE, "trained_state.npz"), **{"sd." + k: v.numpy() for k, v in net.state_dict().items()},
-             codes=codes.numpy(), trace=ck["trace"], meta=ck["meta"], subject_anchors=ck["anchors"])
+    if from_scratch:
+        np.savez(os.path.join(HERE, "trained_state.npz"), **{"sd." + k: v.numpy() for k, v in net.state_dict().items()},
+                 codes=codes.numpy(), trace=ck["trace"], meta=ck["meta"], subject_anchors=ck["anchors"])
 
     out = {"state_sha256": np.array(state_hash(net.state_dict())), "codes_used": np.array(CODES)}
     axes = [np.linspace(MINI[i], MAXI[i], RES).astype(np.float32) for i in range(3)]      # utils/reconstruction.py:10-12 -> float32

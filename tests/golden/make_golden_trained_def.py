@@ -38,9 +38,9 @@ LATTICE_RES, LATTICE_CHUNK = 20, 1500
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(HERE)), "gpurun_out", "r4", "trained_expr.npz")
-    ck = np.load(src)
-    sd = {k[3:]: torch.from_numpy(ck[k]) for k in ck.files if k.startswith("sd.")}
+    import _sources
+    ck, from_scratch = _sources.load("expr")        # the training run's output, or trained_def_state.npz + trained_expr_codes.npz
+    sd = {k[3:]: torch.from_numpy(ck[k]) for k in ck if k.startswith("sd.")}
     mean_anchors = torch.from_numpy(np.load(os.path.join(G.ASSETS, "anchors_39.npy"))).float()[None, None]
     dnet = DeformationNetwork(mode="compress", lat_dim_expr=200, lat_dim_id=32, lat_dim_glob_shape=64, lat_dim_loc_shape=32,
                               n_loc=39, anchors=mean_anchors, hidden_dim=512, nlayers=6, input_dim=3, out_dim=3)
@@ -54,8 +54,10 @@ def main():
     codes = torch.from_numpy(ick["codes"]).float()
     z_all = torch.from_numpy(ck["z_ex"]).float()
     z_pairs = torch.stack([z_all[s * N_EXPR + e] for s, e in PAIRS])
-    np.savez(os.path.join(HERE, "trained_def_state.npz"), **{"sd." + k: v.numpy() for k, v in dnet.state_dict().items()},
-             z_ex=z_pairs.numpy(), pairs=np.asarray(PAIRS), trace=ck["trace"], meta=ck["meta"])
+    if from_scratch:
+        np.savez(os.path.join(HERE, "trained_def_state.npz"), **{"sd." + k: v.numpy() for k, v in dnet.state_dict().items()},
+                 z_ex=z_pairs.numpy(), pairs=np.asarray(PAIRS), trace=ck["trace"], meta=ck["meta"])
+        np.savez_compressed(os.path.join(HERE, "trained_expr_codes.npz"), z_ex=ck["z_ex"])     # every trained expression code
     out = {"state_sha256": np.array(G.state_hash(dnet)), "pairs": np.asarray(PAIRS)}
     gen = torch.Generator().manual_seed(11)
     lo, hi = torch.tensor([-0.45, -0.50, -0.45]), torch.tensor([0.45, 0.55, 0.45])

@@ -31,14 +31,15 @@ LATTICE_RES, LATTICE_CHUNK = 16, 1000
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(HERE)), "gpurun_out", "r4", "trained_npm.npz")
-    ck = np.load(src)
+    import _sources
+    ck, from_scratch = _sources.load("npm")         # the training run's output, or the committed trained_npm_state.npz
     net = DeepSDF(lat_dim=512, hidden_dim=1024, nlayers=8, geometric_init=True)
-    net.load_state_dict({k[3:]: torch.from_numpy(ck[k]) for k in ck.files if k.startswith("sd.")}, strict=True)
+    net.load_state_dict({k[3:]: torch.from_numpy(ck[k]) for k in ck if k.startswith("sd.")}, strict=True)
     net.eval()
     codes = torch.from_numpy(ck["codes"]).float()
-    np.savez_compressed(os.path.join(HERE, "trained_npm_state.npz"), **{"sd." + k: v.numpy() for k, v in net.state_dict().items()},
-                        codes=codes[list(CODES)].numpy(), code_ids=np.asarray(CODES), meta=ck["meta"])
+    if from_scratch:
+        np.savez_compressed(os.path.join(HERE, "trained_npm_state.npz"), **{"sd." + k: v.numpy() for k, v in net.state_dict().items()},
+                            codes=codes[list(CODES)].numpy(), code_ids=np.asarray(CODES), meta=ck["meta"])
     out = {"state_sha256": np.array(G.state_hash(net)), "code_ids": np.asarray(CODES)}
     gen = torch.Generator().manual_seed(21)
     lo, hi = torch.tensor([-0.5, -0.6, -0.55]), torch.tensor([0.5, 0.6, 0.45])
