@@ -384,6 +384,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
   constexpr int NCH = HMAX / 8;            // 16-byte K chunks per point
   constexpr int PART_BYTES = NCH * M * 16;
+  constexpr bool YREG = MT <= 2;           // the last layer's per-wavefront sums live in registers (else in LDS)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act_hi = smem;
   char* act_lo = smem + PART_BYTES;                                   // (ONE: no lo plane; never addressed)
@@ -440,10 +441,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   const bool given0 = BROY && it == 0 && p.posed0 != nullptr;
   if (!given0) {
   frag_t bv[MT];
-  // this wavefront's slot of the last layer's partial sums (activate, `last`, adds its tiles' shares in tile order)
+  // this wavefront's share of the last layer's sums (activate, `last`, adds its tiles' contributions in tile order): in
+  // registers where there is room (MT <= 2), else in its LDS slot
+  float yacc[YREG ? MT : 1][4];
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
-    if (h == 0) *reinterpret_cast<float4*>(partial + (wave * M + 32 * t + j) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < MT; ++t) {
+    if constexpr (YREG) { yacc[t][0] = 0.f; yacc[t][1] = 0.f; yacc[t][2] = 0.f; yacc[t][3] = 0.f; }
+    else if (h == 0) *reinterpret_cast<float4*>(partial + (wave * M + 32 * t + j) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (BROY) __syncthreads();                // the iterate written by the owners is visible
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -533,8 +538,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
                   sacc = fmaf(w4.z, v[4 * q + 2], sacc);
                   sacc = fmaf(w4.w, v[4 * q + 3], sacc);
                 }
-                sacc += __shfl_xor(sacc, 32);                          // the two halves of the tile's 32 rows
-                if (h == 0) yq[c] += sacc;                             // (own slot, in program order: no atomics, fixed order)
+                if constexpr (YREG) {
+                  yacc[t][c] += sacc;                                  // summed over the wavefront's tiles in registers
+                } else {
+                  sacc += __shfl_xor(sacc, 32);                        // the two halves of the tile's 32 rows
+                  if (h == 0) yq[c] += sacc;                           // (own slot, in program order: no atomics, fixed order)
+                }
               }
             }
           }
@@ -757,15 +766,29 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
       for (int u = 0; u < NS; ++u) if (u < 2 || u < Ln.k_steps) load_a(Ln, nn, u, u, lon);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // (the last hidden layer feeds the last linear layer from its registers; its operands are packed and stored like the
-    // others' - unused - because a second code path here costs hipcc's register allocation far more than the stores)
-    activate(ni, l, l == p.n_linear - 2);
-    __syncthreads();                                  // every wavefront has read the old tile
-    store_tiles(ni);
+    // (the last hidden layer feeds the last linear layer from its registers: nothing to store.  Its operands are still packed
+    // like the others' - a second epilogue body here costs hipcc's register allocation far more than the dead converts)
+    const bool last = l == p.n_linear - 2;
+    activate(ni, l, last);
+    if (!last) {
+      __syncthreads();                                // every wavefront has read the old tile
+      store_tiles(ni);
+    }
   }
 
-  // ---- last linear layer: the wavefronts' shares (activate, `last`) lie in LDS and are added in wavefront order ----------------
+  // ---- last linear layer: the wavefronts' shares (activate, `last`) meet in LDS and are added in wavefront order ----------------
   {
+    if constexpr (YREG) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        float4 y4;
+        y4.x = yacc[t][0] + __shfl_xor(yacc[t][0], 32);                // the two halves of the tiles' 32 rows
+        y4.y = yacc[t][1] + __shfl_xor(yacc[t][1], 32);
+        y4.z = yacc[t][2] + __shfl_xor(yacc[t][2], 32);
+        y4.w = yacc[t][3] + __shfl_xor(yacc[t][3], 32);
+        if (h == 0) *reinterpret_cast<float4*>(partial + (wave * M + 32 * t + j) * 4) = y4;
+      }
+    }
     __syncthreads();
     if (!BROY) {
       for (int e = threadIdx.x; e < M * p.out_dim; e += blockDim.x) {

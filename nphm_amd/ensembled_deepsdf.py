@@ -911,6 +911,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     # have been VERIFIED on a sample of that call's latent
     AUTO_MIN_POINTS = 1 << 16
     _EXACT_KNOBS = (-1.0, "f16x3")
+    CHURN_USES = 3          # large evaluations a calibration must have served for the next weight version to be calibrated at once
 
     def _pinned_is_approximate(self):
         return self._prune_tol >= 0 or self._precision in ("bf16x3a", "bf16x3a2", "f16x3a2")
@@ -968,9 +969,21 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         if n_points is not None and n_points < self.AUTO_MIN_POINTS:
             return exact
         have = self._calibration is not None and self._calibration[0] == key
+        hist = self.__dict__.setdefault("_auto_hist", {"uses": 0, "pending": None})
+        if have:
+            hist["uses"] += 1
         if not have:
             if capturing:
                 return exact
+            # Weight churn (a training loop that extracts one validation mesh per epoch, training.py:312-323): a calibration
+            # costs ~0.17 s and pays for itself after ~10 volumes.  If the PREVIOUS calibration served fewer than
+            # CHURN_USES large evaluations before the weights changed, the new weights run the exact three-pass setting
+            # until a second large evaluation sees them unchanged; a first calibration in a process, or weights that
+            # replace a well-used calibration, are calibrated at once.
+            if self._calibration is not None and hist["uses"] < self.CHURN_USES and hist["pending"] != key:
+                hist["pending"] = key
+                return exact
+            hist["uses"], hist["pending"] = 1, None
             from .numerics import calibrate_numerics
             lat = None if lat_rows is None else lat_rows.detach().reshape(-1, self.lat_dim)[:2]
             object.__setattr__(self, "_calibration", (key, calibrate_numerics(self, lat, device=device)))

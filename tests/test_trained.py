@@ -406,3 +406,36 @@ def test_two_term_tier_on_trained_npm_weights(dev):
     e = float((auto - ref).abs().max())
     print(f"trained NPM checkpoint, 64^3: auto mask {rep['mask']:#x} (all-layers error {rep['all_layers_err']:.2e}), full-volume error {e:.2e}")
     assert e <= 2.0 * net.two_pass_target
+
+
+@pytest.mark.gpu
+def test_auto_defers_calibration_while_the_weights_churn(dev):
+    """A training loop that extracts one validation volume per weight version (training.py:312-323) must not pay a
+    calibration (~0.17 s, worth it after ~10 volumes) for every version: when a calibration has served fewer than CHURN_USES
+    large evaluations before the weights change, the NEW weights run the exact three-pass setting until a second large
+    evaluation sees them unchanged."""
+    net, codes = U.build_trained_identity(device=dev)
+    net.eval()
+    axes = R.grid_axes(U.MINI, U.MAXI, 48)
+    lat = codes[2]
+    exact = (net._EXACT_KNOBS[0], net.precision_code(net._EXACT_KNOBS[1]))
+    with torch.no_grad():
+        R.evaluate_grid(net, lat, axes, hack_chunk=0)                 # first weights of the process: calibrated at once
+        key0 = net._calibration[0]
+        assert net.calibration is not None and net._auto_hist["uses"] >= 1
+        net.ensembled_deep_sdf.lin4.bias.add_(1e-4)                   # "an optimizer step": a new weight version
+        n = 48 ** 3
+        assert net.kernel_knobs(dev, lat[None], n) == exact and net._calibration[0] == key0          # deferred: exact setting
+        vol_exact = R.evaluate_grid(net, lat, axes, hack_chunk=0)    # second sight of the same weights: calibrates now
+        assert net._calibration[0] != key0
+        net.precision, net.prune_tol = "f16x3", -1.0
+        ref = R.evaluate_grid(net, lat, axes, hack_chunk=0)
+        assert float((vol_exact - ref).abs().max()) <= 1e-5
+        # a well-used calibration: the next weight version is calibrated immediately
+        net.numerics = "auto"
+        for _ in range(net.CHURN_USES):
+            R.evaluate_grid(net, lat, axes, hack_chunk=0)
+        key1 = net._calibration[0]
+        net.ensembled_deep_sdf.lin4.bias.add_(1e-4)
+        R.evaluate_grid(net, lat, axes, hack_chunk=0)
+        assert net._calibration[0] != key1
