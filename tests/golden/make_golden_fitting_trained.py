@@ -9,8 +9,9 @@ of the subject's identity code (Newton projection through the reference network)
 with that expression's code (x_posed = x + F_ex(x)).  Configuration of fitting_pointclouds.py:253-276 with the reference's
 step_scale at 0.06: 60 Adam steps that still cross every transition of the schedule (steps 12 / 24 / 30 / 36 / 48).
 Stored: observations, per-step loss terms as the reference prints them, fitted codes and anchors, and the code gradients of
-the first three steps as the reference's autograd computed them (grad_shape [3,1,1,1344], grad_expr [3,3,1,200]).  ~10 minutes
-on 8 cores."""
+the first three steps as the reference's autograd computed them (grad_shape [3,1,1,1344], grad_expr [3,3,1,200]) plus those
+of ONE step started at the fitted codes (grad_fit_shape, grad_fit_expr; `start_codes`).  ~10 minutes on 8 cores;
+`--grads-only` recomputes the gradient arrays from the committed trace (1 minute)."""
 import io
 import os
 import sys
@@ -41,6 +42,42 @@ from make_golden_fitting_long import LAMBDAS, SCHEDULE, N_STEPS, level_set_point
 STEP_SCALE = 0.06
 SUBJECT, EXPRESSIONS, N_EXPR = 3, (2, 5, 9), 12
 GRAD_STEPS = 3          # steps whose code gradients (d loss / d z_id, d loss / d z_ex) are stored
+
+
+class start_codes:
+    """Both loops (the reference's and nphm_amd's mirror) create their codes with torch.zeros([n_obs, 1, 200]) and
+    torch.zeros([1, 1, lat_dim]): inside this context those two calls return the given tensors instead - the loop starts
+    its first step AT these codes."""
+
+    def __init__(self, z_expr, z_shape):
+        self.init = {tuple(z_expr.shape): z_expr, tuple(z_shape.shape): z_shape}
+
+    def __enter__(self):
+        self.zeros = torch.zeros
+        init, zeros = self.init, self.zeros
+
+        def patched(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (list, tuple)) else tuple(size)
+            if shape in init:
+                t = init[shape].detach().clone().float()
+                return t.to(kw["device"]) if kw.get("device") is not None else t
+            return zeros(*size, **kw)
+        torch.zeros = patched
+        return self
+
+    def __exit__(self, *exc):
+        torch.zeros = self.zeros
+
+
+def record_adam_grads(store, n):
+    """torch.optim.Adam.step that first copies the gradient of its (single) parameter into ``store`` (first n calls)"""
+    adam_step = torch.optim.Adam.step
+
+    def recording_step(self, *a, **k):
+        if len(store) < n:
+            store.append([p.grad.detach().clone() for grp in self.param_groups for p in grp["params"]][0])
+        return adam_step(self, *a, **k)
+    return adam_step, recording_step
 
 
 def main():
@@ -77,20 +114,44 @@ def main():
     # the gradients the reference's autograd hands its two optimizers in the first GRAD_STEPS steps (opt.step(), then
     # opt_expr.step(), fitting.py:166-167): recorded at the optimizers' door, the loop itself is untouched
     grads = []
-    adam_step = torch.optim.Adam.step
-
-    def recording_step(self, *a, **k):
-        if len(grads) < 2 * GRAD_STEPS:
-            grads.append([p.grad.detach().clone() for grp in self.param_groups for p in grp["params"]][0])
-        return adam_step(self, *a, **k)
+    grads_only = "--grads-only" in sys.argv       # reuse the committed trace / codes, (re)compute the gradient arrays only
+    if grads_only:
+        old = np.load(os.path.join(HERE, "fitting_trained.npz"))
+        lat_e, lat_s, anc_f = (torch.from_numpy(old[k]) for k in ("lat_expr", "lat_shape", "anchors"))
+    adam_step, recording_step = record_adam_grads(grads, 2 * GRAD_STEPS)
     torch.optim.Adam.step = recording_step
     try:
         with redirect_stdout(buf):
-            lat_e, lat_s, anc_f = inference_iterative_root_finding_joint(
-                shape_net, expr_net, [o.clone() for o in obs], dict(LAMBDAS), N_STEPS,
-                {k: dict(v) for k, v in SCHEDULE.items()}, step_scale=STEP_SCALE)
+            if grads_only:
+                inference_iterative_root_finding_joint(shape_net, expr_net, [o.clone() for o in obs], dict(LAMBDAS), int(np.ceil(GRAD_STEPS / STEP_SCALE)),
+                                                       {k: dict(v) for k, v in SCHEDULE.items()}, step_scale=STEP_SCALE)
+            else:
+                lat_e, lat_s, anc_f = inference_iterative_root_finding_joint(
+                    shape_net, expr_net, [o.clone() for o in obs], dict(LAMBDAS), N_STEPS,
+                    {k: dict(v) for k, v in SCHEDULE.items()}, step_scale=STEP_SCALE)
     finally:
         torch.optim.Adam.step = adam_step
+    # ... and ONE step started AT the fitted codes (same seed, same draw as step 0): the gradients of a backward pass at
+    # non-trivial codes, free of the loop's own sensitivity (after Adam's first update the two implementations' codes differ by
+    # up to 2 lr in components whose gradient is round-off, so steps 1, 2 of the trace compare trajectories, not kernels)
+    grads_fit = []
+    adam_step, recording_step = record_adam_grads(grads_fit, 2)
+    torch.optim.Adam.step = recording_step
+    try:
+        torch.manual_seed(0)
+        with redirect_stdout(io.StringIO()), start_codes(lat_e.detach(), lat_s.detach()):
+            inference_iterative_root_finding_joint(shape_net, expr_net, [o.clone() for o in obs], dict(LAMBDAS), int(np.ceil(1 / STEP_SCALE)),
+                                                   {k: dict(v) for k, v in SCHEDULE.items()}, step_scale=STEP_SCALE)
+    finally:
+        torch.optim.Adam.step = adam_step
+    assert len(grads_fit) == 2
+    if grads_only:
+        out = {k: old[k] for k in old.files}
+        assert np.array_equal(out["grad_shape"], torch.stack(grads[0::2]).numpy()) and np.array_equal(out["grad_expr"], torch.stack(grads[1::2]).numpy())
+        out.update(grad_fit_shape=grads_fit[0].numpy(), grad_fit_expr=grads_fit[1].numpy())
+        np.savez_compressed(os.path.join(HERE, "fitting_trained.npz"), **out)
+        print("fitting_trained.npz: gradient arrays refreshed", {k: getattr(v, "shape", v) for k, v in out.items()})
+        return
     hist = parse_history(buf.getvalue(), keys)
     n_iter = int(N_STEPS * STEP_SCALE)
     assert hist.shape == (n_iter, len(keys) + 1), hist.shape
@@ -99,6 +160,7 @@ def main():
                n_steps=np.int64(N_STEPS), step_scale=np.float64(STEP_SCALE), keys=np.array(keys), history=hist,
                lat_expr=lat_e.detach().numpy(), lat_shape=lat_s.detach().numpy(), anchors=anc_f.detach().numpy(),
                grad_shape=torch.stack(grads[0::2]).numpy(), grad_expr=torch.stack(grads[1::2]).numpy(),
+               grad_fit_shape=grads_fit[0].numpy(), grad_fit_expr=grads_fit[1].numpy(),
                shape_sha256=G.state_hash(shape_net), expr_sha256=G.state_hash(expr_net),
                torch_threads=np.int64(torch.get_num_threads()))
     np.savez_compressed(os.path.join(HERE, "fitting_trained.npz"), **out)
