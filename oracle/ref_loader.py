@@ -25,13 +25,23 @@ def load(name: str):
     if not available():
         raise ImportError("oracle/_ref is missing or was built by another Python version (run oracle/build_ref.py where "
                           "/root/reference exists)")
-    for missing in ("trimesh", "mcubes"):          # imported but unused by get_logits* (as tests/golden/make_golden.py)
-        sys.modules.setdefault(missing, types.ModuleType(missing))
-    path = os.path.join(REF_DIR, f"{name}.pyc")
-    loader = importlib.machinery.SourcelessFileLoader(f"_nphm_reference.{name}", path)
-    spec = importlib.util.spec_from_loader(loader.name, loader)
-    mod = importlib.util.module_from_spec(spec)
-    loader.exec_module(mod)
+    # trimesh / mcubes: imported by the reference's reconstruction.py, unused by get_logits* (as tests/golden/make_golden.py).
+    # Absent modules are stubbed for the duration of the import ONLY - a stub left in sys.modules would be what the
+    # product's own optional `import trimesh` finds afterwards
+    stubbed = []
+    for missing in ("trimesh", "mcubes"):
+        if missing not in sys.modules and importlib.util.find_spec(missing) is None:
+            sys.modules[missing] = types.ModuleType(missing)
+            stubbed.append(missing)
+    try:
+        path = os.path.join(REF_DIR, f"{name}.pyc")
+        loader = importlib.machinery.SourcelessFileLoader(f"_nphm_reference.{name}", path)
+        spec = importlib.util.spec_from_loader(loader.name, loader)
+        mod = importlib.util.module_from_spec(spec)
+        loader.exec_module(mod)
+    finally:
+        for m in stubbed:
+            sys.modules.pop(m, None)
     _cache[name] = mod
     return mod
 
