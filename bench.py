@@ -637,10 +637,11 @@ def training_record(args, dev, with_composite=True, steps=8):
     lat0 = torch.stack([U.sample_latent(10 + b) for b in range(B)])[:, None, :].to(dev)
     n_pts = sum(batch[k].shape[1] for k in ("points_face", "points_non_face", "sup_grad_near", "sup_grad_far"))
 
-    def run(backend, operands="f32"):
+    def run(backend, operands=None):
         net = U.build_identity(device=dev).train()
         net.train_backend = backend
-        net.train_operands = operands
+        if operands is not None:
+            net.train_operands = operands
         lat = lat0.clone().requires_grad_()
         opt = torch.optim.AdamW(list(net.parameters()) + [lat], lr=5e-4, weight_decay=0.01)
         torch.cuda.reset_peak_memory_stats()
@@ -661,20 +662,25 @@ def training_record(args, dev, with_composite=True, steps=8):
                    # operands of the weight gradients written once and read once / the time of the two kernels
                    "traffic": nbytes, "kernel_ms": ms}
         return {"ms_per_step": dt * 1e3, "roofline": hbm, "steps_per_s": 1.0 / dt, "first_loss": losses[0], "last_loss": float(losses[-1]),
-                "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "prune_tol": net.prune_tol}
+                "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "prune_tol": net.prune_tol,
+                # "auto" (the default) resolves by batch size (FastEnsembleDeepSDFMirrored.TRAIN_F16_MIN_POINTS)
+                "operands": (("f16" if B * n_pts >= net.TRAIN_F16_MIN_POINTS else "f32") if net.train_operands == "auto" else net.train_operands)}
 
     ours = run("hip")
     out = {"metric": "identity-decoder training steps/s (compute_loss + backward + AdamW)", "value": ours["steps_per_s"],
            "unit": "steps/s", "ms_per_step": ours["ms_per_step"], "steps": steps,
-           "dtype": "bf16x3 kernels (member MLPs, their double backward, weight gradients) + fp32 PyTorch ops (blend, losses, optimizer)",
+           "dtype": f"bf16x3 kernels (member MLPs, their double backward); weight-gradient operands stored as {ours['operands']} "
+                    "(f16: binary16 with per-stream scales, one-pass contraction; f32: split three-pass) + fp32 PyTorch ops (blend, losses, optimizer)",
            "config": {"workload": f"training step, batch {B} x {n_pts} points (nphm.yaml: 750 face + 50 non-face + 800 near + 93 far), "
                                   "loss terms of loss_functions.py:20-110 with create_graph gradients, all decoder weights + latent codes trainable "
                                   "(SURVEY 8 f4)", "prune_tol": ours["prune_tol"]},
            "first_loss": ours["first_loss"], "last_loss": ours["last_loss"], "peak_mem_gb": ours["peak_mem_gb"],
            "roofline": ours["roofline"]}
-    o16 = run("hip", "bf16")
-    out["operands_bf16"] = {"ms_per_step": o16["ms_per_step"], "roofline": o16["roofline"], "steps_per_s": o16["steps_per_s"], "last_loss": o16["last_loss"],
-                            "peak_mem_gb": o16["peak_mem_gb"]}      # opt-in: decoder.train_operands = 'bf16' (profiles/NOTES.md section 12)
+    for other in ("f32", "f16", "bf16"):                   # the other storage formats of the weight gradients' operands (opt-in)
+        if other != ours["operands"]:
+            o = run("hip", other)
+            out["operands_" + other] = {"ms_per_step": o["ms_per_step"], "roofline": o["roofline"], "steps_per_s": o["steps_per_s"],
+                                        "last_loss": o["last_loss"], "peak_mem_gb": o["peak_mem_gb"]}
     if with_composite:
         ref = run("composite")
         ref.pop("roofline", None)

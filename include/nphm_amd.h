@@ -218,9 +218,11 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *     zero) -> ACCUMULATES grad_xyz (as nphm_identity_backward, for
  *     phi = sum dL/df_k f_k + dL/d(grad f_k) . grad f_k; float atomics over the members of a point - the one output of the
  *     training tier that is not bitwise reproducible, and the one a training step never uses), stores the operands of the weight gradients of lin1 .. lin3
- *     into saved (nphm_identity_train_saved_bytes(n_tiles, operands_bf16) bytes; per tile [1005 rows][64 columns] fp32 -
- *     or, with operands_bf16 != 0, bf16: half the operand traffic of both kernels, the weight-gradient products then
- *     carry 8-bit mantissas (opt-in; same flag in all three calls) -, column = 32 * stream + point with stream 0 = value,
+ *     into saved (nphm_identity_train_saved_bytes(n_tiles, operands) bytes; per tile [1005 rows][64 columns]; `operands`,
+ *     the same in all three calls: 0 = fp32; 1 = bf16 - half the operand traffic of both kernels, the weight-gradient
+ *     products then carry 8-bit mantissas (parameter gradients to 4e-4 of their largest entry); 2 (ABI 9) = binary16 with
+ *     the per-stream power-of-two scales `operand_scales` [4] that nphm_identity_train_operand_scales derives from the
+ *     seeds of the step (11-bit mantissas: 5e-5; values beyond the format saturate) -, column = 32 * stream + point with stream 0 = value,
  *     1 = tangent along the seed direction; rows = inputs of lin1..lin3 followed by the adjoints of their
  *     pre-activations, scaled domain) and WRITES edge (nphm_identity_train_edge_bytes(n_tiles); ABI 8): per tile 1600
  *     floats = the tile's contribution to the gradients of lin0 (3 input columns + folded bias) and lin4 (one output) -
@@ -242,7 +244,11 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *     ordered by tile; ring_tiles = tiles per piece; set_chunk_first [sets + 1] = first chunk of every weight set; pair_first
  *     [40 * n_rows + 1] = first tile of every (member, row) pair in table order (pair = member * n_rows + row); scratch =
  *     n_chunks * nphm_identity_train_edge_bytes(1) bytes. */
-size_t nphm_identity_train_saved_bytes(int n_tiles, int operands_bf16);
+size_t nphm_identity_train_saved_bytes(int n_tiles, int operands);
+/* ABI 9: operand_scales [4 floats, device] of `operands` = 2 from grad_member_sdf [n_sdf] and grad_member_grad [n_grad] (NULL:
+ * none) in ONE launch; work = 16 bytes of device memory, zero before the first call (the kernel leaves them zero). */
+int nphm_identity_train_operand_scales(const float* grad_member_sdf, int64_t n_sdf, const float* grad_member_grad, int64_t n_grad,
+                                       void* work, float* operand_scales, void* stream);
 size_t nphm_identity_train_edge_bytes(int n_tiles);
 /* HOST helper (no device work; ABI 8): the tables above from counts [40 * n_rows] = listed points of every (member, row) pair
  * (pair = member * n_rows + row, the order of the point list); member_set [40] = weight set of every member (non-decreasing),
@@ -257,9 +263,9 @@ int nphm_identity_train_forward(const void* packed, const void* packed_bwd, cons
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, void* saved, void* edge, int operands_bf16, void* stream);
-int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* chunks, int n_chunks, void* wpart,
-                                     void* stream);
+                                 float* grad_xyz, void* saved, void* edge, int operands, const float* operand_scales, void* stream);
+int nphm_identity_train_weight_grads(const void* saved, int operands, const float* operand_scales, const int* chunks, int n_chunks,
+                                     void* wpart, void* stream);
 size_t nphm_identity_train_wpart_bytes(int n_chunks);
 int nphm_identity_train_reduce_grads(const void* edge, int n_tiles, const void* wpart, const int* chunks, int n_chunks,
                                      int ring_tiles, const int* set_chunk_first, const int* pair_first, int n_rows, void* scratch,

@@ -71,8 +71,9 @@ SYMBOLS = {
     "nphm_identity_train_tables": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p]),
     "nphm_identity_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nphm_identity_train_operand_scales": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nphm_identity_train_weight_grads": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nphm_identity_train_wpart_bytes": (c_size_t, [c_int]),
     "nphm_identity_train_reduce_grads": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                                  _PtrArr5, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

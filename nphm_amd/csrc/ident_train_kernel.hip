@@ -95,6 +95,8 @@ struct TrainArgs {
   float* ganch;                   // [n_rows, 39, 3]        (+=)
   float* save;                    // backward: [n_tiles][SV_ROWS][64]
   float* edge;                    // backward: [n_tiles][EDGE_FLOATS]
+  const float* op_scale;          // operands == 2: [4] = scale of the adjoints' value columns (S_d), of the inputs' tangent
+                                  // columns (S_u), of the adjoints' tangent columns (S_t = S_d / S_u), 1 / S_d
 };
 
 // coord_operand without the constant slots: the B operand of the tangent stream at lin0 (no bias)
@@ -127,11 +129,17 @@ __device__ __forceinline__ bf16x8 tangent_operand(float x, float y, float z, int
 // One workgroup per tile, tiles in table order.  Measured alternatives (32 x 1693-point batch, 28.6 k backward tiles):
 // persistent workgroups striding over the table +35 %; XCD-aware order (XCD x walks the x-th eighth of the
 // member-ordered table) +6 %; a fully unrolled K loop with 4..12 weight fragments in flight +10..30 %.
-// O16: the stored operands of the weight gradients as bf16 instead of fp32 (opt-in: half the operand traffic of the
-// reverse and the weight-gradient kernel; the products of the weight gradients then carry 8-bit mantissas).
-template <bool SECOND, bool O16 = false>
+// OM: storage of the weight gradients' operands between this kernel and wgrad_kernel: 0 = fp32; 1 = bf16 (half the operand
+// traffic of both kernels; the products then carry 8-bit mantissas: parameter gradients to 4e-4 of their largest entry);
+// 2 = binary16 with per-stream power-of-two scales (11-bit mantissas: 5e-5).  The four operand streams live 4 .. 12 decades
+// apart (inputs' value columns ~1e0, their tangent columns ~1e-9 .. 1e-3, adjoints' value columns ~1e-12 .. 1e-6, their tangent
+// columns ~1e-5 .. 1e-1), each tied to the size of the seeds of the step: the host derives S_d, S_u from the seeds' maxima
+// (operand_scales_kernel), S_t = S_d / S_u keeps both streams' products on ONE scale (D h + T u, summed over all 64 columns
+// by the same MFMAs), wgrad_kernel divides by S_d.  Values beyond the format saturate instead of becoming inf.
+template <bool SECOND, int OM = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   constexpr int NT = 2;
+  constexpr bool O16 = OM != 0;
   constexpr int ES = O16 ? 2 : 4;                    // bytes per stored operand element
   constexpr int PTS = SECOND ? 32 : 64;              // points per tile
   __shared__ __attribute__((aligned(16))) char act_hi[PLANE_BYTES];
@@ -161,8 +169,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   const float sign_x = (k < 2 * N_SYMM && (k & 1)) ? -1.f : 1.f;
   char* const save = SECOND ? reinterpret_cast<char*>(p.save) + size_t(tile_index) * SV_ROWS * 64 * ES : nullptr;
   auto put = [&](char* at, float v) __attribute__((always_inline)) {
-    if (O16) *reinterpret_cast<__bf16*>(at) = (__bf16)v; else *reinterpret_cast<float*>(at) = v;
+    if constexpr (OM == 2) *reinterpret_cast<_Float16*>(at) = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    else if constexpr (OM == 1) *reinterpret_cast<__bf16*>(at) = (__bf16)v;
+    else *reinterpret_cast<float*>(at) = v;
   };
+  // OM == 2: scales of the two streams (tile 0 = value columns, tile 1 = tangent columns) of inputs / adjoints
+  float sc_in[2] = {1.f, 1.f}, sc_adj[2] = {1.f, 1.f};
+  if constexpr (SECOND && OM == 2) { sc_in[1] = p.op_scale[1]; sc_adj[0] = p.op_scale[0]; sc_adj[1] = p.op_scale[2]; }
 
   if (threadIdx.x < 64) {
     const int m = threadIdx.x;
@@ -277,13 +290,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     }
   };
   // D tile of this wavefront -> its block of the staging buffer, row = feature - 32 * wave
-  auto save_tile = [&](const f32x16 (&v)[NT]) __attribute__((always_inline)) {
+  auto save_tile = [&](const f32x16 (&v)[NT], const float (&sc)[2]) __attribute__((always_inline)) {
     if (!SECOND) return;
     char* base = stage_buf + (wave * (32 * 64) + (4 * h) * 64 + j) * ES;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) put(base + (((r & 3) + 8 * (r >> 2)) * 64 + 32 * t) * ES, v[t][r]);
+      for (int t = 0; t < NT; ++t) put(base + (((r & 3) + 8 * (r >> 2)) * 64 + 32 * t) * ES, OM == 2 ? v[t][r] * sc[t] : v[t][r]);
     }
   };
   // wavefront 7: blocks 0..NB-1 of the staging buffer -> rows 0..ROWS-1 of a saved operand (contiguous in HBM).  All
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv[t], zero16, 0, 0, 0);
     activate(acc, s0, q0, val);
     store_tile(wave, val);
-    save_tile(val);
+    save_tile(val, sc_in);
   }
   __syncthreads();
   copy_out(SV_IN1, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     }
   }
   __syncthreads();                       // every wavefront has read a0
-  if (wave < L1_OB) { store_tile(wave, val); save_tile(val); }
+  if (wave < L1_OB) { store_tile(wave, val); save_tile(val, sc_in); }
   __syncthreads();
   copy_out(SV_IN2, std::integral_constant<int, L2_IN>{}, std::integral_constant<int, L1_OB>{});
   // L2: 104 -> 200
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     activate(acc, s2, q2, val);
   }
   __syncthreads();
-  if (wave < 7) { store_tile(wave, val); save_tile(val); }
+  if (wave < 7) { store_tile(wave, val); save_tile(val, sc_in); }
   __syncthreads();
   copy_out(SV_IN3, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   // L3: 200 -> 200, lin4 fused: f = sum h3' * w4 / k + b4
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   }
   if (SECOND) {                          // ... and h2' | u2' have left the staging buffer
     __syncthreads();
-    if (wave < 7) save_tile(val);
+    if (wave < 7) save_tile(val, sc_adj);
   }
   __syncthreads();
   copy_out(SV_D3, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     if (SECOND) edge_row_sums(val[0], EDGE_B2, HID);
   }
   __syncthreads();
-  if (wave < 7) { store_tile(wave, val); save_tile(val); }
+  if (wave < 7) { store_tile(wave, val); save_tile(val, sc_adj); }
   __syncthreads();
   copy_out(SV_D2, std::integral_constant<int, HID>{}, std::integral_constant<int, 7>{});
   // stage B: rows 0..100: [H1 | U1] = (lin2a / sqrt2)^T [D2 | T2]; rows 101..103: d phi / d coords (skip path)
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     if (SECOND) edge_row_sums(val[0], EDGE_B1, L1_OUT);
   }
   __syncthreads();
-  if (wave < B_OB) { store_tile(wave, val); save_tile(val); }
+  if (wave < B_OB) { store_tile(wave, val); save_tile(val, sc_adj); }
   __syncthreads();
   copy_out(SV_D1, std::integral_constant<int, L1_OUT>{}, std::integral_constant<int, B_OB>{});
   // stage C: [H0 | U0] = lin1^T [D1 | T1]
@@ -570,8 +583,10 @@ struct WgradArgs {
   const float* saved;         // [n_tiles][SV_ROWS][64]
   const int* chunks;          // [n_chunks][4] = weight set, first tile, number of tiles, -
   float* part;                // [n_chunks][WPART_FLOATS]: every chunk's share of lin1 / lin2[:, :104] / lin3 (written in full)
+  const float* op_scale;      // operands == 2: TrainArgs::op_scale
 };
 
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 constexpr int WG_ROW_BYTES = 64 * 2 + 16;            // bf16 row of 64 columns, padded against bank conflicts
 constexpr int WG_PLANE = 224 * WG_ROW_BYTES;
 
@@ -580,9 +595,15 @@ __device__ __forceinline__ Split8 split8v(const f32x4& a, const f32x4& b) {
   return split8(x);
 }
 
-template <bool O16>
+template <int OM>
 __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
+  constexpr bool O16 = OM != 0;
   constexpr int ES = O16 ? 2 : 4;
+  // one-pass contraction of 16-bit operands: bf16 (OM 1) or binary16 (OM 2) MFMA
+  auto mfma_o16 = [](const bf16x8& a, const bf16x8& b, const f32x16& c) __attribute__((always_inline)) {
+    if constexpr (OM == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  };
   __shared__ __attribute__((aligned(16))) char in_hi[WG_PLANE];
   __shared__ __attribute__((aligned(16))) char in_lo[O16 ? 16 : WG_PLANE];
   const char* const saved = reinterpret_cast<const char*>(p.saved);
@@ -667,7 +688,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
           for (int s = 0; s < 4; ++s) {
             const int o = (32 * b + j) * WG_ROW_BYTES + (16 * s + 8 * h) * 2;
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(in_hi + o);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].hi, bh, acc[b], 0, 0, 0);
+            if constexpr (O16) acc[b] = mfma_o16(a[s].hi, bh, acc[b]);
+            else acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].hi, bh, acc[b], 0, 0, 0);
             if (!O16) {
               const bf16x8 bl = *reinterpret_cast<const bf16x8*>(in_lo + o);
               acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s].hi, bl, acc[b], 0, 0, 0);
@@ -687,8 +709,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p) {
   for (int b = 0; b < 7; ++b) {
     if (b < nb_in) {
       const int icol = 32 * b + j;
-      float scale = 1.f;
-      if (layer == 2) scale = (icol >= L1_OUT ? SP_SCALE : 1.f) / INV_SQRT2_DIV;
+      float scale = OM == 2 ? p.op_scale[3] : 1.f;          // (binary16 operands carry S_d)
+      if (layer == 2) scale *= (icol >= L1_OUT ? SP_SCALE : 1.f) / INV_SQRT2_DIV;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -943,6 +965,44 @@ __global__ __launch_bounds__(128) void blend_anchor_kernel(const float* ga_part,
   ganch[size_t(row) * N_LOC * 3 + i] += acc;
 }
 
+// Scales of the binary16 operand storage (train_kernel, OM == 2) from the seeds of the step: max |dL/df_k| and max
+// |dL/d(grad f_k)| over the batch (one pass, atomicMax on the bit patterns of non-negative floats; the last block to finish
+// turns them into powers of two and clears the work words for the next call).  Measured on seeded and trained-like weights
+// (tools/train_operand_stats.py): adjoint value columns <= 5e-3 x the value seed, input tangent columns <= 150 x the tangent
+// seed, adjoint tangent columns 5e-4 .. 1e-1 whatever the seeds; the targets below put those maxima at ~2^11 of binary16's
+// 2^16 (a 30 x margin before saturation) and leave 2^25 below them before the format's normal range ends.
+__global__ __launch_bounds__(256) void operand_scales_kernel(const float* gs, int64_t ns, const float* gg, int64_t ng,
+                                                              unsigned* work, float* scales) {
+  __shared__ float red[2][4];
+  float ms = 0.f, mg = 0.f;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x, i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t i = i0; i < ns; i += stride) ms = fmaxf(ms, fabsf(gs[i]));
+  if (gg) for (int64_t i = i0; i < ng; i += stride) mg = fmaxf(mg, fabsf(gg[i]));
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) { ms = fmaxf(ms, __shfl_xor(ms, sft)); mg = fmaxf(mg, __shfl_xor(mg, sft)); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ms; red[1][threadIdx.x >> 6] = mg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ms = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    mg = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    atomicMax(work, __float_as_uint(ms));
+    atomicMax(work + 1, __float_as_uint(mg));
+    __threadfence();
+    if (atomicAdd(work + 2, 1u) == gridDim.x - 1) {
+      __threadfence();
+      const float smax = fmaxf(__uint_as_float(atomicMax(work, 0u)), 1e-30f);
+      const float vmax = __uint_as_float(atomicMax(work + 1, 0u));
+      auto pow2_below = [](float x) { return exp2f(fminf(fmaxf(floorf(log2f(x)), -60.f), 60.f)); };
+      const float sd = pow2_below(2048.f / (5e-3f * smax));
+      float su = vmax > 0.f ? pow2_below(2048.f / (150.f * vmax)) : 1.f;
+      const float st = fminf(fmaxf(sd / su, 4.f), 32768.f);      // adjoint tangent columns: 5e-4 .. 1e-1 -> inside the format
+      su = sd / st;
+      scales[0] = sd; scales[1] = su; scales[2] = st; scales[3] = 1.f / sd;
+      work[0] = 0u; work[1] = 0u; work[2] = 0u;
+    }
+  }
+}
+
 }  // namespace train
 }  // namespace nphm
 
@@ -951,8 +1011,8 @@ __global__ __launch_bounds__(128) void blend_anchor_kernel(const float* ga_part,
 // ============================================================================================
 extern "C" {
 
-size_t nphm_identity_train_saved_bytes(int n_tiles, int operands_bf16) {
-  return n_tiles <= 0 ? 0 : size_t(n_tiles) * nphm::train::SV_ROWS * 64 * (operands_bf16 ? 2 : 4);
+size_t nphm_identity_train_saved_bytes(int n_tiles, int operands) {
+  return n_tiles <= 0 ? 0 : size_t(n_tiles) * nphm::train::SV_ROWS * 64 * (operands ? 2 : 4);
 }
 size_t nphm_identity_train_edge_bytes(int n_tiles) { return n_tiles <= 0 ? 0 : size_t(n_tiles) * nphm::train::EDGE_FLOATS * 4; }
 
@@ -989,7 +1049,7 @@ int nphm_identity_train_forward(const void* packed, const void* packed_bwd, cons
 int nphm_identity_train_backward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                  int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                  const float* grad_member_sdf, const float* grad_member_grad,
-                                 float* grad_xyz, void* saved, void* edge, int operands_bf16, void* stream) {
+                                 float* grad_xyz, void* saved, void* edge, int operands, const float* operand_scales, void* stream) {
   nphm::train::TrainArgs a;
   if (train_common(a, packed, packed_bwd, latent_state, xyz, n_points, tiles, n_tiles, point_list,
                    "nphm_identity_train_backward: null pointer or bad sizes")) return 1;
@@ -1000,11 +1060,17 @@ int nphm_identity_train_backward(const void* packed, const void* packed_bwd, con
   a.edge = static_cast<float*>(edge);
   a.g_sdf = grad_member_sdf; a.g_grad = grad_member_grad;
   a.gxyz = grad_xyz;
-  if (operands_bf16)
-    hipLaunchKernelGGL((nphm::train::train_kernel<true, true>), dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+  a.op_scale = operand_scales;
+  if (operands < 0 || operands > 2 || (operands == 2 && !operand_scales))
+    return nphm_fail_msg("nphm_identity_train_backward: operands = 0 (fp32), 1 (bf16) or 2 (binary16 + operand_scales)");
+  if (operands == 2)
+    hipLaunchKernelGGL((nphm::train::train_kernel<true, 2>), dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else if (operands == 1)
+    hipLaunchKernelGGL((nphm::train::train_kernel<true, 1>), dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
                        static_cast<hipStream_t>(stream), a);
   else
-    hipLaunchKernelGGL((nphm::train::train_kernel<true, false>), dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
+    hipLaunchKernelGGL((nphm::train::train_kernel<true, 0>), dim3(n_tiles), dim3(64 * nphm::bwd::WAVES), 0,
                        static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_train_backward launch", e);
@@ -1061,18 +1127,34 @@ int nphm_identity_train_tables(const long long* counts, int n_rows, const int* m
 
 size_t nphm_identity_train_wpart_bytes(int n_chunks) { return n_chunks <= 0 ? 0 : size_t(n_chunks) * nphm::train::WPART_FLOATS * 4; }
 
-int nphm_identity_train_weight_grads(const void* saved, int operands_bf16, const int* chunks, int n_chunks, void* wpart,
+int nphm_identity_train_operand_scales(const float* grad_member_sdf, int64_t n_sdf, const float* grad_member_grad, int64_t n_grad,
+                                       void* work, float* operand_scales, void* stream) {
+  if (!grad_member_sdf || !work || !operand_scales || n_sdf <= 0) return nphm_fail_msg("nphm_identity_train_operand_scales: null pointer");
+  hipLaunchKernelGGL(nphm::train::operand_scales_kernel, dim3(512), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     grad_member_sdf, n_sdf, grad_member_grad, grad_member_grad ? n_grad : 0, static_cast<unsigned*>(work), operand_scales);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nphm_fail("nphm_identity_train_operand_scales launch", e);
+  return 0;
+}
+
+int nphm_identity_train_weight_grads(const void* saved, int operands, const float* operand_scales, const int* chunks, int n_chunks, void* wpart,
                                      void* stream) {
   if (!saved || !chunks || !wpart) return nphm_fail_msg("nphm_identity_train_weight_grads: null pointer");
   if (n_chunks < 0) return nphm_fail_msg("nphm_identity_train_weight_grads: bad sizes");
   if (n_chunks == 0) return 0;
   nphm::train::WgradArgs a;
   a.saved = static_cast<const float*>(saved); a.chunks = chunks; a.part = static_cast<float*>(wpart);
-  if (operands_bf16)
-    hipLaunchKernelGGL(nphm::train::wgrad_kernel<true>, dim3(n_chunks, 3), dim3(64 * nphm::bwd::WAVES), 0,
+  a.op_scale = operand_scales;
+  if (operands < 0 || operands > 2 || (operands == 2 && !operand_scales))
+    return nphm_fail_msg("nphm_identity_train_weight_grads: operands = 0 (fp32), 1 (bf16) or 2 (binary16 + operand_scales)");
+  if (operands == 2)
+    hipLaunchKernelGGL(nphm::train::wgrad_kernel<2>, dim3(n_chunks, 3), dim3(64 * nphm::bwd::WAVES), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else if (operands == 1)
+    hipLaunchKernelGGL(nphm::train::wgrad_kernel<1>, dim3(n_chunks, 3), dim3(64 * nphm::bwd::WAVES), 0,
                        static_cast<hipStream_t>(stream), a);
   else
-    hipLaunchKernelGGL(nphm::train::wgrad_kernel<false>, dim3(n_chunks, 3), dim3(64 * nphm::bwd::WAVES), 0,
+    hipLaunchKernelGGL(nphm::train::wgrad_kernel<0>, dim3(n_chunks, 3), dim3(64 * nphm::bwd::WAVES), 0,
                        static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_train_weight_grads launch", e);

@@ -548,7 +548,18 @@ class _MemberFieldFn(torch.autograd.Function):
         if T and (gS is not None or gG is not None):
             gS_c = torch.zeros(B, N, A, dtype=torch.float32, device=dev) if gS is None else gS.detach().contiguous().float()
             gG_c = None if gG is None else gG.detach().contiguous().float()
-            o16 = {"f32": 0, "bf16": 1}[module.train_operands]
+            mode = module.train_operands
+            if mode == "auto":            # binary16 storage where its rounding averages out (>= TRAIN_F16_MIN_POINTS points)
+                mode = "f16" if B * N >= module.TRAIN_F16_MIN_POINTS else "f32"
+            o16 = {"f32": 0, "bf16": 1, "f16": 2}[mode]
+            scales = None
+            if o16 == 2:
+                # per-stream power-of-two scales of the binary16 operand storage, from the seeds of THIS step (one launch)
+                sw = torch.zeros(8, dtype=torch.float32, device=dev)            # [4] scales | [3] work words
+                _lib.check(lib.nphm_identity_train_operand_scales(
+                    gS_c.data_ptr(), gS_c.numel(), None if gG_c is None else gG_c.data_ptr(), 0 if gG_c is None else gG_c.numel(),
+                    sw.data_ptr() + 16, sw.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "nphm_identity_train_operand_scales")
+                scales = sw
             saved = torch.empty(lib.nphm_identity_train_saved_bytes(max(n for _, n, _, _ in ctx.pieces), o16),
                                 dtype=torch.uint8, device=dev)
             # per tile: its share of the lin0 / lin4 gradients, summed over the tile's columns in the reverse kernel
@@ -570,10 +581,14 @@ class _MemberFieldFn(torch.autograd.Function):
                     packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N,
                     tiles.data_ptr() + 16 * t0, nt, plist.data_ptr(), gS_c.data_ptr(),
                     None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), saved.data_ptr(),
-                    edge.data_ptr() + edge_tile * t0, o16, stream), "nphm_identity_train_backward")
+                    edge.data_ptr() + edge_tile * t0, o16, None if scales is None else scales.data_ptr(), stream),
+                    "nphm_identity_train_backward")
                 _lib.check(lib.nphm_identity_train_weight_grads(
-                    saved.data_ptr(), o16, chunks.data_ptr() + 16 * c0, nc, wpart.data_ptr() + wpart_chunk * c0, stream),
-                    "nphm_identity_train_weight_grads")
+                    saved.data_ptr(), o16, None if scales is None else scales.data_ptr(), chunks.data_ptr() + 16 * c0, nc,
+                    wpart.data_ptr() + wpart_chunk * c0, stream), "nphm_identity_train_weight_grads")
+            if getattr(module, "_keep_train_operands", False):          # (tools/train_operand_stats.py: the last piece's stored operands)
+                module._last_train_operands = saved
+                module._last_train_seeds = (float(gS_c.abs().max()), 0.0 if gG_c is None else float(gG_c.abs().max()))
             scratch = torch.empty(C * edge_tile, dtype=torch.uint8, device=dev)
             _lib.check(lib.nphm_identity_train_reduce_grads(
                 edge.data_ptr(), T, wpart.data_ptr(), chunks.data_ptr(), C, ring, edge_tabs.data_ptr(),
@@ -717,10 +732,15 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         # pairs: 16.6 per point at 1e-7 on near-surface training samples
         self.train_prune_tol = (float(os.environ["NPHM_AMD_TRAIN_PRUNE_TOL"])
                                 if "NPHM_AMD_TRAIN_PRUNE_TOL" in os.environ else None)
-        # storage of the weight-gradient operands between the reverse and the weight-gradient kernel: "f32" (default,
-        # fp32-equivalent products end to end) | "bf16" (half the traffic that bounds both kernels; the weight gradients
-        # are then sums of bf16 x bf16 products: ~1e-3 of their largest entry, everything else unchanged)
-        self.train_operands = os.environ.get("NPHM_AMD_TRAIN_OPERANDS", "f32")
+        # storage of the weight-gradient operands between the reverse and the weight-gradient kernel: "f16" (round 5:
+        # binary16 with per-stream power-of-two scales derived from the step's seeds - half the traffic that bounds both
+        # kernels, one-pass contraction) | "f32" (rounds 2-4: fp32-equivalent products end to end; 17 % slower) | "bf16"
+        # (round 2: 8-bit mantissas) | "auto" (default): "f16" for batches of >= TRAIN_F16_MIN_POINTS points, "f32" below.
+        # The storage rounding is random and averages over the columns of a weight set: parameter gradients against the
+        # composite tier (largest entry per tensor) 5.2e-5 at 4 x 1000 points, ~1.5e-5 at the nphm.yaml batch (32 x 1693),
+        # but 3e-4 on a 2 x 400-point batch, where fp32 storage gives 5e-6 .. 2e-5 and the traffic does not matter.
+        # Values, spatial gradients and the lin0 / lin4 / bias gradients are the same bits in all modes.
+        self.train_operands = os.environ.get("NPHM_AMD_TRAIN_OPERANDS", "auto")
 
     # ------------------------------------------------------------------------------------------
     def invalidate_pack(self):
@@ -912,6 +932,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     AUTO_MIN_POINTS = 1 << 16
     _EXACT_KNOBS = (-1.0, "f16x3")
     CHURN_USES = 3          # large evaluations a calibration must have served for the next weight version to be calibrated at once
+    TRAIN_F16_MIN_POINTS = 4000     # train_operands = "auto": batches of at least this many points store binary16 operands
 
     def _pinned_is_approximate(self):
         return self._prune_tol >= 0 or self._precision in ("bf16x3a", "bf16x3a2", "f16x3a2")

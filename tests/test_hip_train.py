@@ -56,10 +56,15 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("prune_tol,tol", [(-1.0, 2e-4), (1e-7, 1e-3)])
-def test_training_tier_matches_composite_double_backward(dev, prune_tol, tol):
+@pytest.mark.parametrize("prune_tol,tol,operands", [(-1.0, 1e-4, "auto"), (1e-7, 2e-4, "auto"), (-1.0, 2e-5, "f32"), (1e-7, 2e-5, "f32")])
+def test_training_tier_matches_composite_double_backward(dev, prune_tol, tol, operands):
+    """Every parameter and latent gradient of a double-backward step against the composite tier (PyTorch autograd), in units
+    of the tensor's largest entry.  Measured on MI355X: 5.2e-5 with the binary16 operand storage of the weight gradients
+    that the default ("auto") takes at this batch size (lin1 .. lin3; everything else 5e-6), 5.3e-6 with fp32 operands - with all members and with the default pruning
+    budget alike (rounds 2-4 asserted 2e-4 / 1e-3 here)."""
     net = U.build_identity(device=dev).train()
     net.prune_tol = prune_tol
+    net.train_operands = operands
     lat, xyz, nrm = _batch(dev, B=4, N=1000)
     used = {}
     orig = net._train_members
@@ -204,21 +209,39 @@ def test_training_tier_ragged_shapes(dev, B, N, far):
         assert all(v < 1e-3 for v in worst.values()), (mode, worst)
 
 
-def test_bf16_operand_storage_is_opt_in_and_close(dev):
-    """train_operands = "bf16": the weight-gradient operands cross HBM as bf16 (half the traffic of the two kernels that
-    it bounds).  Values and spatial gradients are untouched; parameter / latent gradients stay within 5e-3 of the
-    default's largest entry per tensor (observed ~5e-4: rounding errors average out over ~10^4 columns)."""
+def test_16_bit_operand_storage_against_fp32_operands(dev):
+    """train_operands: the weight-gradient operands cross HBM as binary16 with per-stream scales ("f16", the default) or as
+    bf16 (round 2's opt-in) - half the traffic of the two kernels it bounds - against fp32 storage ("f32").  Values and
+    spatial gradients are the same bits; parameter / latent gradients stay within 1e-4 (f16; 5e-5 measured) / 5e-3 (bf16;
+    4e-4) of the fp32 storage's largest entry per tensor; and the f16 scales hold when the seeds are 1000 x larger or
+    smaller (they are derived from the seeds of the step)."""
     net = U.build_identity(device=dev).train()
-    net.train_prune_tol = 1e-7                           # pinned: both runs keep the same member set (bitwise comparison below)
-    assert net.train_operands == "f32"
+    net.train_prune_tol = 1e-7                           # pinned: all runs keep the same member set (bitwise comparison below)
+    assert net.train_operands == "auto" and 4 * 1000 >= net.TRAIN_F16_MIN_POINTS      # (this batch: binary16 by default)
     lat, xyz, nrm = _batch(dev, B=4, N=1000, seed=21)
+    net.train_operands = "f32"
     ref = _run(net, "hip", lat, xyz, nrm)
-    net.train_operands = "bf16"
-    out = _run(net, "hip", lat, xyz, nrm)
-    assert torch.equal(out["pred"], ref["pred"]) and torch.equal(out["grad"], ref["grad"])
-    worst = {k: _rel(out[k], ref[k]) for k in ref if k not in ("pred", "grad", "loss")}
-    assert all(v < 5e-3 for v in worst.values()), worst
-    assert max(worst.values()) > 0            # the option does something
+    for ops, tol in (("f16", 1e-4), ("bf16", 5e-3)):
+        net.train_operands = ops
+        out = _run(net, "hip", lat, xyz, nrm)
+        assert torch.equal(out["pred"], ref["pred"]) and torch.equal(out["grad"], ref["grad"])
+        worst = {k: _rel(out[k], ref[k]) for k in ref if k not in ("pred", "grad", "loss")}
+        print(ops, "against fp32 operands:", max(worst.values()))
+        assert all(v < tol for v in worst.values()), (ops, worst)
+        assert max(worst.values()) > 0            # the option does something
+    # seeds scaled by 1e3 / 1e-3 (another loss weighting, another batch size): same relative accuracy
+    for factor in (1e3, 1e-3):
+        res = {}
+        for ops in ("f32", "f16"):
+            net.train_operands = ops
+            net.zero_grad(set_to_none=True)
+            l = lat.clone().requires_grad_()
+            loss, _, _ = _loss_terms(net, l, xyz, nrm)
+            (loss * factor).backward()
+            res[ops] = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        worst = max(_rel(res["f16"][k], res["f32"][k]) for k in res["f32"])
+        print(f"seeds x {factor:g}: f16 against fp32 operands {worst:.2e}")
+        assert worst < 1e-4 and all(bool(torch.isfinite(v).all()) for v in res["f16"].values())
 
 
 def test_validate_training_numerics(dev):
