@@ -800,3 +800,37 @@ def test_k_loops_with_partial_last_round(dev, hidden, monkeypatch):
     two = net.forward_hip(big, cond[:1])
     err = float((two - ref).abs().max())
     assert 0 < err < 2e-4 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("hidden,nlayers,lat,out", [(64, 2, 5, 1), (96, 4, 29, 3), (400, 6, 40, 4), (512, 3, 8, 2), (1024, 4, 64, 1), (640, 5, 16, 3)])
+def test_tiers_and_fp32_last_layer_across_architectures(dev, hidden, nlayers, lat, out):
+    """Every architecture family the kernel covers (hidden <= 512: 64 / 128 points per workgroup, hidden <= 1024: 32 / 64;
+    2 .. 6 layers, 1 .. 4 outputs, partial tiles and partial K rounds) in every tier - three-term, two-term, single-term on all
+    hidden layers (the variant without the lo plane) and a mixed mask - against the composite tier in fp32 autograd
+    arithmetic, points launch with a ragged tail and lattice launch (bitwise the points launch)."""
+    torch.manual_seed(hidden + nlayers)
+    net = nphm_amd.DeepSDF(lat_dim=lat, hidden_dim=hidden, nlayers=nlayers, geometric_init=False, out_dim=out).to(dev).eval()
+    if not net.hip_supported():
+        pytest.skip("architecture outside the kernel's plan")
+    g = torch.Generator().manual_seed(7)
+    x = ((torch.rand(1, 1000 + 77, 3, generator=g) - 0.5) * 0.9).to(dev)
+    cond = (torch.randn(1, lat, generator=g) * 0.3).to(dev)
+    net.backend = "composite"
+    with torch.no_grad():
+        ref, _ = net(x, cond[:, None, :].expand(1, x.shape[1], lat))
+    net.backend = "hip"
+    hid = net._hidden_mask()
+    mixed_one = hid & 0b101010
+    scale = max(1.0, float(ref.abs().max()))
+    net.numerics = "fixed"
+    axes = R.grid_axes(U.MINI, U.MAXI, 12)
+    pts = torch.from_numpy(np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)).to(dev)
+    for name, two, one, tol in (("three", 0, 0, 2e-6), ("two", hid, 0, 5e-5), ("single", 0, hid, 2e-4), ("mixed", hid, mixed_one, 2e-4)):
+        net.two_pass_mask, net.single_mask = two, one
+        with torch.no_grad():
+            outp = net.forward_hip(x, cond)
+            err = float((outp - ref).abs().max()) / scale
+            vol = R.evaluate_grid_mlp(net, cond, axes)
+            assert torch.equal(vol.reshape(-1, out), net.forward_hip(pts, cond).reshape(-1, out)), name
+        print(f"hidden {hidden} x {nlayers} layers, out {out}, {name}: {err:.2e} of the output scale against fp32 autograd")
+        assert err < tol, (name, err)
