@@ -4,19 +4,20 @@
 // src/NPHM/models/reconstruction.py:28-88).  One latent per batch row (mlp_layout.h).
 //
 // Structure (numbers in DESIGN.md):
-//   * one workgroup = 8 wavefronts = M points (64 at hidden <= 512, 32 at hidden <= 1024) for the
-//     WHOLE network; activations live in LDS as split-bf16 (hi | lo) K chunks, 128 KiB;
+//   * one workgroup = 8 wavefronts = M points (64 at hidden <= 512, 32 at hidden <= 1024; twice that in the variant
+//     without a lo plane, ONE) for the WHOLE network; activations live in LDS as split 16-bit (hi | lo) K chunks, 128 KiB;
 //   * a layer is an output-stationary GEMM: wavefront w owns the 32-row output tiles w, w+8, ...
 //     for all M points (accumulators in registers), its A fragments (weights) stream L2 -> VGPR
 //     with no reuse inside the workgroup (every weight byte is fetched once per M points), B
 //     fragments (activations) come from LDS with conflict-free 16-byte reads;
-//   * x*w ~= xh*wh + xl*wh + xh*wl on v_mfma_f32_32x32x16_bf16 (fp32 accumulate);
+//   * x*w ~= xh*wh + xl*wh + xh*wl on v_mfma_f32_32x32x16_{f16,bf16} (fp32 accumulate), per layer also xh*wh + xl*wh or
+//     xh*wh alone (calibrated per checkpoint by the host module);
 //   * the accumulators are initialised by one extra "coordinate K-step" per tile that carries the
 //     bias, the folded latent and - for lin0 and the skip layer - the xyz columns;
-//   * epilogue: base-2 softplus, re-split to bf16 hi/lo in registers; the LDS tile is overwritten
+//   * epilogue: base-2 softplus, re-split to hi/lo INTO the accumulators' registers; the LDS tile is overwritten
 //     in place between two workgroup barriers;
-//   * the last layer (out <= 4) splits K over the 8 wavefronts and combines the partial sums in a
-//     fixed order (bitwise reproducible).
+//   * the last linear layer (out <= 4) is applied in fp32 by the epilogue of the last hidden layer, from registers;
+//     the wavefronts' sums meet in LDS and are added in wavefront order (bitwise reproducible).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
