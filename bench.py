@@ -471,6 +471,18 @@ def npm_record(args, dev, steps, warmup, cpu):
            "roofline": {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
                         "traffic": measured_traffic(kname, n), "algorithmic_bytes": 4 * n, "kernel": kname,
                         "kernel_ms": float(np.mean(k_ms)), "executed_flops_per_point": flops}}
+    # the same lattice with the tier target relaxed to 1e-5 (opt-in: npm.numerics_target; still a decade inside the 1e-4 bar):
+    # every hidden layer single-term -> the 64-points-per-workgroup variant, half the weight bytes per point.  Reported BESIDE
+    # the default, never instead of it
+    keep_target, keep_cache = npm.numerics_target, npm._two_pass_cache
+    try:
+        npm.numerics_target, npm._two_pass_cache = 1e-5, None
+        dt2, k2 = _timed(lambda: R.evaluate_grid_mlp(npm, lat, axes_dev), steps, warmup)
+        num2, flops2 = _mlp_numerics_report(npm)
+        out["relaxed_target_1e-5"] = {"value": n * steps / dt2 / 1e6, "unit": "Mpoints/s", "kernel_ms": float(np.mean(k2)), "numerics": num2,
+                                      "frac": flops2 * n / (np.mean(k2) * 1e-3) / 1e12 / 2500.0, "kernel": _mlp_kernel_name(npm, "1,4", num2)}
+    finally:
+        npm.numerics_target, npm._two_pass_cache = keep_target, keep_cache
     if cpu:
         # the whole config on the host cores, the way the reference runs it: chunked get_logits, fp32 PyTorch-CPU - the
         # reference's own DeepSDF + get_logits when oracle/_ref holds their bytecode (oracle/build_ref.py), else the restatement
