@@ -401,6 +401,9 @@ def _mlp_kernel_name(mlp, shape, num):
     if hidden and all(p == 1 for p in hidden):
         shape = {"2,2": "4,2", "1,4": "2,4"}[shape]          # single-term everywhere: twice the points per workgroup
         return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,false,true>"
+    if len(hidden) >= 2 and all(p == 1 for p in hidden[:-1]) and hidden[-1] == 2:
+        shape = {"2,2": "4,2", "1,4": "2,4"}[shape]          # ... but the last hidden layer, two-term in two point halves
+        return f"nphm::mlp::mlp_eval_kernel<{shape},1,5,true,false,true>"
     no_wl = bool(hidden) and all(p <= 2 for p in hidden)     # no three-term layer: the variant without wl registers
     return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,{'true' if no_wl else 'false'},false>"
 
@@ -411,7 +414,7 @@ def _mlp_numerics_report(mlp):
     single_mask = int(r.get("single_mask", 0))
     flops, passes = _mlp_exec_flops(mlp, mask, single_mask)
     return {"precision": mlp.precision, "numerics": mlp.numerics, "single_mask": single_mask, "two_pass_mask": mask,
-            "passes_per_layer": passes, "points_per_workgroup": (2 if r.get("single_term") else 1) * (64 if mlp.hidden_dim <= 512 else 32),
+            "passes_per_layer": passes, "points_per_workgroup": (2 if (r.get("single_term") or r.get("tail_two_term")) else 1) * (64 if mlp.hidden_dim <= 512 else 32),
             "target": r.get("target"), "sample_err": r.get("err"), "verified_err": r.get("verified_err"),
             "all_single_err": r.get("all_single_err")}, flops
 

@@ -405,7 +405,8 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
  *   NPHM_MLP_ONE_PASS(mask) (ABI 9; NPHM_MLP_F16X3, nphm_mlp_eval_points / nphm_mlp_eval_grid only): bit l = hidden GEMM
  *   layer l runs the SINGLE-term product rn(x) wh - one MFMA per tile and K-step, no read of the activations' lo plane; all
  *   hidden layers: a variant without the lo plane that holds twice the points per workgroup (128 at hidden_dim <= 512), i.e.
- *   half the weight bytes per point.  Error ~2^-12 relative per product on both operands, random in the activations: again
+ *   half the weight bytes per point (all but the LAST hidden layer, that one in NPHM_MLP_TWO_PASS: the same workgroup shape, the
+ *   last hidden layer in two point halves).  Error ~2^-12 relative per product on both operands, random in the activations: again
  *   measured per checkpoint against the three-term product before it is used (nphm_amd/deepsdf.py, calibrate_numerics).
  * The value+Jacobian, Broyden and saving entry points below take format and two-pass mask (hidden_dim <= 512: both formats;
  * the 1024-wide variant runs them on bf16 halves only).

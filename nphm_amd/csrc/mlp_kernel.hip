@@ -376,10 +376,18 @@ __device__ __forceinline__ frag_t unit_operand(int c) {
 // (Round 5 also built a phase-shifted schedule - wavefronts 0..3 half a layer ahead of 4..7, LDS flags instead of the second
 // barrier, so that one wavefront of a SIMD runs its epilogue while the other owns the matrix pipe: correct, and 3-5 % SLOWER
 // on all three tiers; the kernel sits at the board's power limit, a denser MFMA stream is a lower clock.  profiles/NOTES.md.)
+// TAIL2 (with ONE): the LAST hidden layer two-term, every other one single-term (what NPM's calibration asks for: the input of
+// its last hidden layer needs the lo half).  There is no room for a lo plane beside the hi plane of 2 x the points - so the
+// last hidden layer runs in two point halves: the operands of the first half (hi | lo) take the whole plane while the second
+// half's wait in the registers of the D tiles they came from (they ARE those registers, see activate), then the other way
+// round.  The layer's weights are streamed twice, every other layer's once per 2 x the points.
+template <int N> using IC = std::integral_constant<int, N>;
 template <int MT, int NTW, int MODE, int KIND, bool F16 = false, bool ALL2 = false, bool ONE = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   constexpr bool JVP = KIND == 1 || KIND == 4, BROY = KIND == 2, SAVE = KIND == 3 || KIND == 4;   // 4: value+Jacobian, sigma' saved
-  static_assert(!ONE || (F16 && KIND == 0), "the single-term product serves the plain split-f16 evaluation");
+  constexpr bool TAIL2 = KIND == 5;         // plain evaluation (like 0), the last hidden layer in two point halves
+  static_assert(!ONE || (F16 && (KIND == 0 || KIND == 5)), "the single-term product serves the plain split-f16 evaluation");
+  static_assert(!TAIL2 || (ONE && MT % 2 == 0), "two point halves of the variant without a lo plane");
   constexpr int M = 32 * MT;               // columns per workgroup
   constexpr int PTS = JVP ? M / 4 : M;     // points per workgroup
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
@@ -477,7 +485,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   // `last`, the last hidden layer - this wavefront's share of the last linear layer in fp32, straight from the registers
   // (rounds 1-4 stored the tile and ran the out_dim <= 4 rows as a K-split MFMA layer on split operands: one more store,
   // barrier and operand rounding; the single-term variant has no lo plane to run it on)
-  auto activate = [&](int ni, int layer, bool last) __attribute__((always_inline)) {
+  // (point tiles T0 .. T1 - 1; PACK: 0 = the hi operand alone, 1 = hi | lo, 2 = none - the tile feeds the last linear layer only)
+  auto activate = [&](int ni, int layer, bool last, auto t0c, auto t1c, auto packc) __attribute__((always_inline)) {
+    constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, PACK = decltype(packc)::value;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           for (int r = 0; r < 16; ++r) sgv[r] = sigmoid2(acc[i][0][r]);
         }
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
+        for (int t = T0; t < T1; ++t) {
           if constexpr (SAVE && !JVP) {
             static_assert(!(SAVE && !JVP) || M == 64, "the saving forward runs 64-point workgroups (mlp_bwd_kernel's layout)");
             float* so = p.sig_out + ((((size_t(row) * size_t((n_pts + 63) >> 6) + size_t(base >> 6)) * p.sig_tiles + p.sig_base[layer] + wave + WAVES * i) * MT + t) * 64 + lane) * 16;
@@ -553,7 +563,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           // (__uint_as_float, NOT __builtin_bit_cast: the builtin applied to an ext-vector ELEMENT reads element 0.)
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
-            if constexpr (ONE) {
+            if constexpr (PACK == 2) {
+            } else if constexpr (PACK == 0) {
               const frag_t o = pack8_rn(v + 8 * half);
 #pragma unroll
               for (int q = 0; q < 4; ++q) acc[i][t][8 * half + q] = __uint_as_float(o[q]);
@@ -571,16 +582,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     }
   };
   // D tile (n, t): registers 8*half .. 8*half+7 of lane (h, j) are K chunk 4n + 2*half + h of point 32t + j
-  auto store_tiles = [&](int ni) __attribute__((always_inline)) {
+  // (point tiles T0 .. T1 - 1.  HALF, TAIL2's last hidden layer: these tiles alone, hi | lo, in a plane of T1 - T0 tiles each)
+  auto store_tiles = [&](int ni, auto t0c, auto t1c, auto halfc) __attribute__((always_inline)) {
+    constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+    constexpr bool HALF = decltype(halfc)::value != 0;
+    constexpr int MX = HALF ? 32 * (T1 - T0) : M;
+    char* dst_lo = HALF ? act_hi + PART_BYTES / 2 : act_lo;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
         const int n = wave + WAVES * i;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
+        for (int t = T0; t < T1; ++t) {
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
-            const int off = ((4 * n + 2 * half + h) * M + 32 * t + j) * 16;
+            const int off = ((4 * n + 2 * half + h) * MX + 32 * (HALF ? t - T0 : t) + j) * 16;
             frag_t fh, fl;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -588,7 +604,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
               fl[q] = __float_as_uint(acc[i][t][8 * half + 4 + q]);
             }
             *reinterpret_cast<frag_t*>(act_hi + off) = fh;
-            if constexpr (!ONE) *reinterpret_cast<frag_t*>(act_lo + off) = fl;
+            if constexpr (!ONE || HALF) *reinterpret_cast<frag_t*>(dst_lo + off) = fl;
           }
         }
       }
@@ -603,28 +619,30 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     for (int i = 0; i < NTW; ++i)
       if (i < ni) cfrag[i] = C[(wave + WAVES * i) * 64];
   };
-  auto coord_mma = [&](int ni) __attribute__((always_inline)) {
+  auto coord_mma = [&](int ni, auto t0c, auto t1c) __attribute__((always_inline)) {
+    constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (i < ni) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int t = T0; t < T1; ++t)
           acc[i][t] = mfma16<F16>(cfrag[i], bv[t], zero16);
       }
     }
   };
   auto coord_step = [&](const LayerDev& L, int ni) __attribute__((always_inline)) {
     coord_load(L, ni);
-    coord_mma(ni);
+    coord_mma(ni, IC<0>{}, IC<MT>{});
   };
+  constexpr int PACK_DEF = ONE ? 0 : 1;
 
   // ---- layer 0: coordinates only ---------------------------------------------------------------
   {
     const LayerDev& L = p.layer[0];
     const int ni = tiles_of(L.n_tiles);
     coord_step(L, ni);
-    activate(ni, 0, false);
-    store_tiles(ni);
+    activate(ni, 0, false, IC<0>{}, IC<MT>{}, IC<PACK_DEF>{});
+    store_tiles(ni, IC<0>{}, IC<MT>{}, IC<0>{});
   }
 
   // ---- hidden layers ---------------------------------------------------------------------------
@@ -770,11 +788,86 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     // (the last hidden layer feeds the last linear layer from its registers: nothing to store.  Its operands are still packed
     // like the others' - a second epilogue body here costs hipcc's register allocation far more than the dead converts)
     const bool last = l == p.n_linear - 2;
-    activate(ni, l, last);
+    if constexpr (TAIL2) { if (l == p.n_linear - 3) break; }          // (its epilogue: below, hi | lo)
+    activate(ni, l, last, IC<0>{}, IC<MT>{}, IC<PACK_DEF>{});
     if (!last) {
       __syncthreads();                                // every wavefront has read the old tile
-      store_tiles(ni);
+      store_tiles(ni, IC<0>{}, IC<MT>{}, IC<0>{});
     }
+  }
+
+  // ---- TAIL2: the last hidden layer, two-term, in two point halves --------------------------------------------------------
+  if constexpr (TAIL2) {
+    constexpr int MH = MT / 2, MX = 32 * MH;
+    const int lp = p.n_linear - 3, ll = p.n_linear - 2;
+    const int ni_p = tiles_of(p.layer[lp].n_tiles);
+    const LayerDev& L = p.layer[ll];
+    const int ni = tiles_of(L.n_tiles);
+    const int ks = L.k_steps;
+    // (the ring holds the layer's first K-steps: requested behind the last MFMAs of layer lp)
+    activate(ni_p, lp, false, IC<0>{}, IC<MT>{}, IC<1>{});             // hi | lo of BOTH halves, in the registers of their D tiles
+    __syncthreads();                                                  // every wavefront has read the old tile
+    store_tiles(ni_p, IC<0>{}, IC<MH>{}, IC<1>{});                     // first half: hi | lo planes of MH point tiles
+    auto tail_pass = [&](auto t0c) __attribute__((always_inline)) {
+      constexpr int T0 = decltype(t0c)::value;
+      if (ni > 0) {
+        const frag_t* Bh = reinterpret_cast<const frag_t*>(act_hi) + h * MX + j;
+        const frag_t* Bl = reinterpret_cast<const frag_t*>(act_hi + PART_BYTES / 2) + h * MX + j;
+        frag_t bh[2][MH], bl[2][MH];
+        auto load_b = [&](int slot, int s) __attribute__((always_inline)) {
+#pragma unroll
+          for (int t = 0; t < MH; ++t) {
+            bh[slot][t] = Bh[2 * s * MX + 32 * t];
+            bl[slot][t] = Bl[2 * s * MX + 32 * t];
+          }
+        };
+        auto mma = [&](int sa, int sb) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (i < ni) {
+#pragma unroll
+              for (int t = 0; t < MH; ++t) acc[i][T0 + t] = mfma16<F16>(ah[sa][i], bh[sb][t], acc[i][T0 + t]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (i < ni) {
+#pragma unroll
+              for (int t = 0; t < MH; ++t) acc[i][T0 + t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][T0 + t]);
+            }
+          }
+        };
+        load_b(0, 0);
+#pragma unroll 1
+        for (int s = 0; s < ks; s += NS) {
+#pragma unroll
+          for (int u = 0; u < NS; ++u) {
+            if (u < 2 || s + u < ks) {
+              if (s + u + 1 < ks) load_b((u + 1) & 1, s + u + 1);
+              __builtin_amdgcn_sched_barrier(0);
+              mma(u, u & 1);
+              __builtin_amdgcn_sched_barrier(0);
+              if (s + u + NS < ks) load_a(L, ni, u, s + u + NS, w_lane);
+            }
+          }
+        }
+      }
+    };
+    coord_load(L, ni);
+    coord_mma(ni, IC<0>{}, IC<MH>{});
+    __syncthreads();                                                  // the first half's operands are complete
+    tail_pass(IC<0>{});
+#pragma unroll
+    for (int u = 0; u < NS; ++u) if (u < 2 || u < ks) load_a(L, ni, u, u, w_lane);       // the layer's weights, second time
+    __builtin_amdgcn_sched_barrier(0);
+    activate(ni, ll, true, IC<0>{}, IC<MH>{}, IC<2>{});
+    __syncthreads();                                                  // every wavefront has read the first half
+    store_tiles(ni_p, IC<MH>{}, IC<MT>{}, IC<1>{});
+    coord_load(L, ni);
+    coord_mma(ni, IC<MH>{}, IC<MT>{});
+    __syncthreads();
+    tail_pass(IC<MH>{});
+    activate(ni, ll, true, IC<MH>{}, IC<MT>{}, IC<2>{});
   }
 
   // ---- last linear layer: the wavefronts' shares (activate, `last`) meet in LDS and are added in wavefront order ----------------
@@ -967,8 +1060,15 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
                    && false
 #endif
       ;
+  // every hidden GEMM layer single-term but the LAST, which is two-term: the same variant with that layer in two point halves (TAIL2)
+  const unsigned last_bit = 1u << (plan.n_linear - 2);
+  const bool tail2 = KIND == 0 && f16 && !one && plan.n_linear >= 4 && a.one_pass_mask == (hidden_mask & ~last_bit) && (a.two_pass_mask & last_bit)
+#if defined(NPHM_MLP_NO_ONE) || defined(NPHM_MLP_NO_TAIL2)
+                     && false
+#endif
+      ;
   // no hidden GEMM layer three-term (split-f16 only): the variant without wl fragments (mlp_eval_kernel, ALL2)
-  const bool all2 = f16 && !one && plan.n_linear > 2 && (a.two_pass_mask | a.one_pass_mask) == hidden_mask && (KIND == 0 || plan.variant == 0)
+  const bool all2 = f16 && !one && !tail2 && plan.n_linear > 2 && (a.two_pass_mask | a.one_pass_mask) == hidden_mask && (KIND == 0 || plan.variant == 0)
 #ifdef NPHM_MLP_NO_ALL2
                     && false
 #endif
@@ -983,7 +1083,7 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
                      && false
 #endif
       ;
-  const int M = (small ? 32 : plan.variant == 0 ? 64 : 32) * (one ? 2 : 1) / ((KIND == 1 || KIND == 4) ? 4 : 1);      // points per workgroup
+  const int M = (small ? 32 : plan.variant == 0 ? 64 : 32) * (one || tail2 ? 2 : 1) / ((KIND == 1 || KIND == 4) ? 4 : 1);      // points per workgroup
   const int64_t tiles = (n_pts + M - 1) / M;
   if (tiles > 0x7fffffffLL) return nphm_fail_msg("nphm_mlp_eval: too many points for one launch");
   const dim3 grid((unsigned)tiles, n_rows), block(64 * WAVES);
@@ -1003,6 +1103,11 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
     if constexpr (KIND == 0) {
       if (plan.variant == 0 ? go(mlp_eval_kernel<4, 2, MODE, 0, true, false, true>, lds_bytes<4, 2, true>())
                             : go(mlp_eval_kernel<2, 4, MODE, 0, true, false, true>, lds_bytes<2, 4, true>())) return -2;
+    }
+  } else if (tail2) {
+    if constexpr (KIND == 0) {
+      if (plan.variant == 0 ? go(mlp_eval_kernel<4, 2, MODE, 5, true, false, true>, lds_bytes<4, 2, true>())
+                            : go(mlp_eval_kernel<2, 4, MODE, 5, true, false, true>, lds_bytes<2, 4, true>())) return -2;
     }
   } else if (plan.variant == 0) {
     if (all2 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true, true>, lds_bytes<2, 2>())

@@ -378,7 +378,8 @@ class DeepSDF(nn.Module):
     def calibrate_numerics(self, packed, state, sample_xyz):
         """The cheapest per-layer tiers of the plain evaluation that stay within ``numerics_target`` of the three-term product
         on ``sample_xyz``: -> (numerics code, report).  Order: the single-term product rn(x) wh in EVERY hidden layer (half
-        the MFMAs of the two-term tier and, with twice the points per workgroup, half its weight bytes per point); else the
+        the MFMAs of the two-term tier and, with twice the points per workgroup, half its weight bytes per point); that with the
+        last hidden layer two-term (same workgroup shape); else the
         two-term layers of ``calibrate_two_pass`` and, of those, single-term layers added in the order of their individual
         errors while the measured error of the whole setting stays inside."""
         fmt = self._format_code()
@@ -393,6 +394,15 @@ class DeepSDF(nn.Module):
         if e_all <= self.numerics_target:
             return self._code(0, hid), {"target": self.numerics_target, "single_term": True, "single_mask": hid, "mask": 0,
                                         "err": e_all, "sample_points": int(sample_xyz.shape[1])}
+        if self.nlayers >= 3:
+            # ... but the LAST hidden layer two-term: still twice the points per workgroup (mlp_kernel.hip, TAIL2 - that layer runs
+            # in two point halves, its weights are streamed twice, every other layer's once)
+            tail = 1 << (self.nlayers - 1)
+            e_tail = err_of(tail, hid & ~tail)
+            if e_tail <= self.numerics_target:
+                return self._code(tail, hid & ~tail), {"target": self.numerics_target, "single_term": False, "tail_two_term": True,
+                                                       "single_mask": hid & ~tail, "mask": tail, "err": e_tail, "all_single_err": e_all,
+                                                       "sample_points": int(sample_xyz.shape[1])}
         mask, report = self.calibrate_two_pass(packed, state, sample_xyz)
         report["all_single_err"] = e_all
         layers = [l for l in range(1, self.nlayers) if (mask >> l) & 1]

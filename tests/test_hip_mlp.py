@@ -609,7 +609,9 @@ def test_single_term_layers_fixed_and_auto(dev):
         mlp.numerics, mlp.two_pass_mask, mlp.single_mask = "fixed", 0, 0
         ref = mlp.forward_hip(xyz, cond)
         errs = {}
-        for name, two, one in (("all", 0, hid), ("layers 1,3 single / rest two-term", hid, 0b1010), ("layer 2 single / rest three-term", 0, 0b100)):
+        tail = 1 << (mlp.nlayers - 1)                        # the last hidden layer
+        for name, two, one in (("all", 0, hid), ("all but the last, two-term", tail, hid & ~tail), ("layers 1,3 single / rest two-term", hid, 0b1010),
+                               ("layer 2 single / rest three-term", 0, 0b100)):
             mlp.two_pass_mask, mlp.single_mask = two, one
             out = mlp.forward_hip(xyz, cond)
             errs[name] = float((out - ref).abs().max())
@@ -618,6 +620,8 @@ def test_single_term_layers_fixed_and_auto(dev):
             assert torch.equal(a, out[:, :1077])
         print("single-term tiers against the three-term product:", errs, "outputs up to", float(ref.abs().max()))
         assert 0.0 < errs["layer 2 single / rest three-term"] < errs["all"] < 5e-5
+        # (the 128-point variant with the last hidden layer in two point halves: the layer that lost most with its lo half)
+        assert 0.0 < errs["all but the last, two-term"] < errs["all"]
         # lattice launch = points launch, bit for bit, in the 128-point variant too
         axes = R.grid_axes(U.MINI, U.MAXI, 20)
         pts = torch.from_numpy(np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)).to(dev)
@@ -806,7 +810,7 @@ def test_k_loops_with_partial_last_round(dev, hidden, monkeypatch):
 def test_tiers_and_fp32_last_layer_across_architectures(dev, hidden, nlayers, lat, out):
     """Every architecture family the kernel covers (hidden <= 512: 64 / 128 points per workgroup, hidden <= 1024: 32 / 64;
     2 .. 6 layers, 1 .. 4 outputs, partial tiles and partial K rounds) in every tier - three-term, two-term, single-term on all
-    hidden layers (the variant without the lo plane) and a mixed mask - against the composite tier in fp32 autograd
+    hidden layers (the variant without the lo plane), that with the last hidden layer two-term, and a mixed mask - against the composite tier in fp32 autograd
     arithmetic, points launch with a ragged tail and lattice launch (bitwise the points launch)."""
     torch.manual_seed(hidden + nlayers)
     net = nphm_amd.DeepSDF(lat_dim=lat, hidden_dim=hidden, nlayers=nlayers, geometric_init=False, out_dim=out).to(dev).eval()
@@ -825,7 +829,9 @@ def test_tiers_and_fp32_last_layer_across_architectures(dev, hidden, nlayers, la
     net.numerics = "fixed"
     axes = R.grid_axes(U.MINI, U.MAXI, 12)
     pts = torch.from_numpy(np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)).to(dev)
-    for name, two, one, tol in (("three", 0, 0, 2e-6), ("two", hid, 0, 5e-5), ("single", 0, hid, 2e-4), ("mixed", hid, mixed_one, 2e-4)):
+    tail = 1 << (nlayers - 1)                                # the last hidden layer (two point halves in the variant without a lo plane)
+    for name, two, one, tol in (("three", 0, 0, 2e-6), ("two", hid, 0, 5e-5), ("single", 0, hid, 2e-4), ("mixed", hid, mixed_one, 2e-4),
+                                ("single, last two-term", tail, hid & ~tail, 2e-4)):
         net.two_pass_mask, net.single_mask = two, one
         with torch.no_grad():
             outp = net.forward_hip(x, cond)
