@@ -19,9 +19,10 @@ python - "$OUT" "$ROOT/gpurun_out/traffic.json" <<'PY'
 import collections, csv, glob, json, os, sys, time
 out, dst = sys.argv[1], sys.argv[2]
 pts = {"nphm::eval_kernel<2,2>": 256 ** 3, "nphm::eval_kernel<2,1>": 256 ** 3,
-       # dense MLP lattice launches (bench.py: _mlp_kernel_name): <MT,NTW,MODE,KIND,F16,no wl fragments,single-term everywhere>
+       # dense MLP lattice launches (bench.py: _mlp_kernel_name): <MT,NTW,MODE,KIND (5: last hidden layer two-term in two point halves),F16,no wl fragments,single-term>
        "nphm::mlp::mlp_eval_kernel<4,2,1,0,true,false,true>": 256 ** 3, "nphm::mlp::mlp_eval_kernel<2,2,1,0,true,true,false>": 256 ** 3,
        "nphm::mlp::mlp_eval_kernel<2,2,1,0,true,false,false>": 256 ** 3, "nphm::mlp::mlp_eval_kernel<2,4,1,0,true,false,true>": 64 ** 3,
+       "nphm::mlp::mlp_eval_kernel<2,4,1,5,true,false,true>": 64 ** 3, "nphm::mlp::mlp_eval_kernel<4,2,1,5,true,false,true>": 256 ** 3,
        "nphm::mlp::mlp_eval_kernel<1,4,1,0,true,true,false>": 64 ** 3, "nphm::mlp::mlp_eval_kernel<1,4,1,0,true,false,false>": 64 ** 3}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(out + "/*/**/*counter_collection.csv", recursive=True)):
