@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 9
+#define NPHM_AMD_ABI_VERSION 10
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -323,13 +323,43 @@ int nphm_head_forward(const float* const weight[3], const float* const bias[3], 
                       int x_stride, const float* y_add, int n_rows, float* y, float* hidden, void* stream);
 int nphm_head_backward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* hidden,
                        const float* g_y, int n_rows, float* g_x, int x_stride, void* stream);
+/* (ABI 10) The conditioning rows of the forward-deformation field in 'compress' mode when ONE identity code serves every row
+ * (deepSDF.py:212-223 with the latent of the fitting loops, fitting.py:83-85): cond [n_rows, out_dim + expr_dim] =
+ * [compressor([code | anchors]) on every row | z_ex[b]] in one launch - the input row is read from its two parts (no cat), the
+ * compressor runs once (the reference runs it per batch row on identical inputs).  Backward: g_code [code_dim], g_anchors
+ * [anchors_dim] from the first out_dim columns of g_cond summed over the rows in row order; the gradient of z_ex is the remaining
+ * columns of g_cond as they are. */
+int nphm_compress_condition(const float* weight, const float* bias, const float* code, int code_dim, const float* anchors, int anchors_dim,
+                            int out_dim, const float* z_ex, int n_rows, int expr_dim, float* cond, void* stream);
+int nphm_compress_condition_backward(const float* weight, const float* bias, int code_dim, int anchors_dim, int out_dim, const float* g_cond,
+                                     int n_rows, int expr_dim, float* g_code, float* g_anchors, void* stream);
 int nphm_fit_loss(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
                   const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
                   float* row, void* stream);
 int nphm_fit_loss_backward(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
                            const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
                            const float* g_out, float* g_sdf, float* g_shape, float* g_expr, void* stream);
+/* (ABI 10) forward and backward of the loss in ONE launch, for the step that seeds loss.backward() right behind the forward
+ * (fitting.py:168-169): row as nphm_fit_loss, the gradients as nphm_fit_loss_backward with the seed *g_out (NULL = 1). */
+int nphm_fit_loss_with_gradients(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                                 const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                                 const float* g_out, float* row, float* g_sdf, float* g_shape, float* g_expr, void* stream);
 int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g_posed, int64_t n, void* stream);
+/* (ABI 10) The inputs of one fitting step from its draw (fitting.py:61-85) in one launch: drawn = [n_rows observation indices |
+ * n_rows x n_points point indices] (int64); obs [n_rows, n_points, cloud_width] = clouds[o_b][p_br] (clouds [n_obs, cloud_points,
+ * cloud_width], padded); z_ex [n_rows, expr_dim] = z_expr_table[o_b]; glob_cond [n_rows, shape_dim + expr_dim] = [z_shape | z_ex[b]].
+ * nphm_fit_inputs_backward: g_z_expr_table [n_obs, expr_dim] = g_table_use (the gradient of another use of the table, e.g. the
+ * regulariser's; may be NULL) + per row the sum over its draws, in draw order, of g_z_ex[b] (rows z_ex_row_stride floats apart; may
+ * be NULL) + the expression columns of g_glob_cond[b] (may be NULL); g_z_shape [shape_dim] (NULL: not wanted) = the sum of
+ * g_shape_uses[0..3] ([shape_dim] each, NULL entries skipped: the gradients of the identity code's other uses in the step - anchor
+ * head, field, regularisers, compressor - added here in this order instead of by one add launch each) + the sum over b of the
+ * identity columns of g_glob_cond. */
+int nphm_fit_inputs(const int64_t* drawn, int n_rows, int n_points, const float* clouds, int n_obs, int cloud_points, int cloud_width,
+                    const float* z_shape, int shape_dim, const float* z_expr_table, int expr_dim, float* obs, float* z_ex,
+                    float* glob_cond, void* stream);
+int nphm_fit_inputs_backward(const float* g_z_ex, int64_t z_ex_row_stride, const float* g_glob_cond, const int64_t* obs_idx, int n_rows,
+                             int n_obs, int shape_dim, int expr_dim, const float* const g_shape_uses[4], const float* g_table_use,
+                             float* g_z_expr_table, float* g_z_shape, void* stream);
 /* sdf [n_points] = sum over the kept members of blend_weights * member_values (both [n_points, 40]; weights exactly 0 where
  * the pruning rule dropped the member - nphm_identity_build_lists - and member_values is not read there: the output of
  * nphm_identity_member_forward needs no zero-fill).  The blend of EnsembledDeepSDF.py:129-150 on the autograd tier (ABI 6). */
@@ -343,6 +373,11 @@ int nphm_gather_rows_backward(const float* g_out, const int64_t* idx, int n_draw
  * latent codes in fitting.py:47-48 / :196 (ABI 6). */
 int nphm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,
                    float step_size, float bias_correction2_sqrt, float eps, void* stream);
+/* (ABI 10) The same update of up to two tensors (n[q] = 0: absent) in one launch with the scalars in DEVICE memory: scalars [2][6] =
+ * {1 - beta1, beta2, 1 - beta2, step_size, bias_correction2_sqrt, eps} per tensor - the optimizer steps of the two codes inside
+ * the replayed graph of a fitting step (the values change every step and travel with the step's draw). */
+int nphm_adam_step_pair(float* const param[2], const float* const grad[2], float* const exp_avg[2], float* const exp_avg_sq[2],
+                        const int64_t n[2], const float* scalars, void* stream);
 int nphm_identity_blend_members(const float* blend_weights, const float* member_values, int64_t n_points, float* sdf, void* stream);
 /* (ABI 7: `scratch` of nphm_identity_latent_grad_scratch_bytes(n_rows) bytes holds the members' shares of the 64 global columns;
  * they are summed in member order - every element of g_lat is written once, bitwise reproducible, nothing to zero beforehand) */

@@ -36,11 +36,19 @@ SYMBOLS = {
     "nphm_identity_prepare_latent_anchors": (c_int, [_PtrArr5, _PtrArr5, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nphm_head_forward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_head_backward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "nphm_compress_condition": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "nphm_compress_condition_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_fit_loss": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_void_p, c_void_p]),
     "nphm_fit_loss_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_fit_loss_with_gradients": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                             c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_fit_root_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "nphm_fit_inputs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    "nphm_fit_inputs_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_void_p * 4, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
     "nphm_identity_latent_grad_scratch_bytes": (c_size_t, [c_int]),
     "nphm_identity_latent_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_set_member_bounds": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
@@ -112,6 +120,7 @@ SYMBOLS = {
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_train_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_adam_step_pair": (c_int, [c_void_p * 2, c_void_p * 2, c_void_p * 2, c_void_p * 2, c_int64 * 2, c_void_p, c_void_p]),
     "nphm_gather_rows_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nphm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                c_void_p]),
@@ -153,7 +162,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 9:
+    if lib.nphm_abi_version() != 10:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

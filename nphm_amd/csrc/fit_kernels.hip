@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "capi_common.h"
 #include "layout.h"
 
@@ -47,9 +49,11 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return t;
 }
 
-// one workgroup.  BWD = false: the loss terms (row).  BWD = true: the gradients of the weighted total.
-template <bool BWD>
+// one workgroup.  MODE 0: the loss terms (row).  1: the gradients of the weighted total.  2: both (the step that calls
+// loss.backward(seed) right behind the forward hands the seed over with it: one launch instead of two, same arithmetic).
+template <int MODE>
 __global__ __launch_bounds__(1024) void fit_loss_kernel(LossArgs a) {
+  constexpr bool BWD = MODE != 0;
   __shared__ float sh[16];
   __shared__ float pair_norm[N_SYMM];
   const int t = threadIdx.x;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(1024) void fit_loss_kernel(LossArgs a) {
     }
   e2 = block_sum(e2, sh) / float(max(a.B, 1));
   const float terms[N_TERMS] = {surface, e2, g2, u2, l2, symm};
-  if (!BWD) {
+  if (MODE != 1) {
     if (t == 0) {
       float total = 0.f;
       for (int i = 0; i < N_TERMS; ++i) {
@@ -118,8 +122,8 @@ __global__ __launch_bounds__(1024) void fit_loss_kernel(LossArgs a) {
       a.row[N_TERMS + 1] = nv;
       a.row[N_TERMS + 2] = total;       // a second copy: the caller's differentiable scalar next to the report row
     }
-    return;
   }
+  if (!BWD) return;
   const float go = a.g_out ? *a.g_out : 1.f;
   // d surface / d sdf_i = sign(sdf_i) keep_i / count
   const float ws = go * a.lam[0] / c;
@@ -210,6 +214,38 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   p[i] = p[i] + (-step_size) * (mi / denom);
 }
 
+// The same update for up to two code tensors in one launch, the six scalars of each read from DEVICE memory
+// (scalars [2][6] = 1 - b1, b2, 1 - b2, step_size, bc2_sqrt, eps: they change with the step count and the schedule, and
+// travel with the step's draw) - so that the optimizer steps of a fitting step sit INSIDE its replayed graph (eager launches
+// behind every replay: two launches and the gap in front of them).
+struct AdamPairArgs {
+  float* p[2];
+  const float* g[2];
+  float* m[2];
+  float* v[2];
+  int64_t n[2];
+  const float* scalars;
+};
+__global__ __launch_bounds__(256) void adam_pair_kernel(AdamPairArgs a) {
+#pragma clang fp contract(off)
+  int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int which = i < a.n[0] ? 0 : 1;
+  if (which) i -= a.n[0];
+  if (i >= a.n[which]) return;
+  const float* sc = a.scalars + 6 * which;
+  const float one_minus_b1 = sc[0], b2 = sc[1], one_minus_b2 = sc[2], step_size = sc[3], bc2_sqrt = sc[4], eps = sc[5];
+  float* p = a.p[which];
+  float* m = a.m[which];
+  float* v = a.v[which];
+  const float gi = a.g[which][i];
+  const float mi = m[i] + one_minus_b1 * (gi - m[i]);
+  const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] + (-step_size) * (mi / denom);
+}
+
 // backward of out[b] = table[idx[b]] (the expression codes of the drawn observations, fitting.py:83): g_table[r] = sum of
 // g_out[b] over the draws b of row r, in draw order - one launch where the index_put(accumulate) of autograd sorts the
 // indices first (eight launches for five rows)
@@ -222,6 +258,81 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
   for (int b = 0; b < n_draws; ++b)
     if (idx[b] == r) acc += g[size_t(b) * width + c];
   out[e] = acc;
+}
+
+// The inputs of one fitting step from the draw (fitting.py:61-85), one launch: the sampled points obs[b][r] =
+// clouds[o_b][p_br] of the drawn observations, their expression codes z_ex[b] = table[o_b] and the conditioning rows
+// glob_cond[b] = [z_shape | z_ex[b]] - an advanced-indexing gather, an index_select and a cat in the PyTorch formulation
+// (four launches).  drawn = [B observation indices | B x n point indices] (int64, _ObservationSampler.draw).
+struct InputsArgs {
+  const int64_t* drawn;
+  const float* clouds;      // [n_obs][P][C]
+  const float* z_shape;     // [L]
+  const float* table;       // [n_obs][E]
+  int B, n, P, C, L, E;
+  float* obs;               // [B][n][C]
+  float* z_ex;              // [B][E]
+  float* glob_cond;         // [B][L + E]
+};
+__global__ __launch_bounds__(256) void fit_inputs_kernel(InputsArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < a.B * a.n * a.C) {
+    const int c = e % a.C, br = e / a.C, b = br / a.n;
+    const int64_t o = a.drawn[b], pi = a.drawn[a.B + br];
+    a.obs[e] = a.clouds[(o * a.P + pi) * a.C + c];
+  }
+  const int W = a.L + a.E;
+  if (e < a.B * W) {
+    const int b = e / W, i = e % W;
+    if (i < a.L) {
+      a.glob_cond[e] = a.z_shape[i];
+    } else {
+      const float v = a.table[a.drawn[b] * a.E + (i - a.L)];
+      a.glob_cond[e] = v;
+      a.z_ex[b * a.E + (i - a.L)] = v;
+    }
+  }
+}
+// its backward: g_table[r] = sum over the draws b of row r, in draw order, of g_z_ex[b] (+ the expression columns of
+// g_glob_cond[b]); g_shape = sum over b of the identity columns of g_glob_cond[b].  Either gradient may be absent (null);
+// g_z_ex rows are `zex_stride` floats apart (a column slice of the conditioning's gradient: no contiguous copy first).
+// The step's uses of the two codes get ALIASES of them from the forward (fitting.py: the identity code feeds the anchor
+// head, the identity field, the regularisers and the compressor; the expression codes the regulariser and the gather): their
+// gradients (shape_parts [4] / table_part, each null when that use produced none) are summed here, in this fixed order,
+// instead of by one elementwise add launch per extra use.
+struct InputsBwdArgs {
+  const float* g_z_ex;
+  int64_t zex_stride;
+  const float* g_glob;
+  const int64_t* idx;
+  int B, n_obs, L, E;
+  const float* shape_parts[4];
+  const float* table_part;
+  float* g_table;
+  float* g_shape;
+};
+__global__ __launch_bounds__(256) void fit_inputs_bwd_kernel(InputsBwdArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = a.L + a.E;
+  if (e < a.n_obs * a.E) {
+    const int r = e / a.E, c = e % a.E;
+    float acc = a.table_part ? a.table_part[e] : 0.f;
+    for (int b = 0; b < a.B; ++b)
+      if (a.idx[b] == r) {
+        if (a.g_z_ex) acc += a.g_z_ex[int64_t(b) * a.zex_stride + c];
+        if (a.g_glob) acc += a.g_glob[size_t(b) * W + a.L + c];
+      }
+    a.g_table[e] = acc;
+  }
+  if (a.g_shape && e < a.L) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (a.shape_parts[q]) acc += a.shape_parts[q][e];
+    if (a.g_glob)
+      for (int b = 0; b < a.B; ++b) acc += a.g_glob[size_t(b) * W + e];
+    a.g_shape[e] = acc;
+  }
 }
 
 // batched 3x3 inverse (adjugate) of matrices addressed by strides - element (i, j) of matrix p at
@@ -353,6 +464,17 @@ struct HeadArgs {
   float* hidden;               // [rows, dims[1] + dims[2]] post-ReLU activations (saved for the backward pass)
   const float* g_y;            // backward: [rows, out]
   float* g_x;                  // backward: [rows, x_stride] - columns beyond dims[0] are written as zeros
+  // the compressor inside a conditioning row (nphm_compress_condition): the input row is [x[0 .. x_split) | x2[0 .. dims[0] - x_split)]
+  // (identity code | anchors: no cat launch), the ONE output row goes to the first `out` columns of y_rep rows of y (y_stride apart),
+  // tail [y_rep][tail_w] behind it; backward: g_y = the sum over g_rows rows (g_stride apart) of their first `out` columns, g_x / g_x2
+  // receive the two parts of the input's gradient.  (All zero / null: the plain head.)
+  const float* x2;
+  int x_split;
+  int y_rep, y_stride;
+  const float* tail;
+  int tail_w;
+  int g_rows, g_stride;
+  float* g_x2;
 };
 constexpr int HEAD_MAX = 1536;   // widest layer input / output held in LDS
 
@@ -367,8 +489,12 @@ constexpr int HEAD_PART = 8192;   // floats of partial sums: ceil(din / 256) * d
 __global__ __launch_bounds__(1024) void head_fwd_kernel(HeadArgs a) {
   __shared__ float cur[HEAD_MAX], part[HEAD_PART];
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
-  for (int i = t; i < a.dims[0]; i += blockDim.x) cur[i] = a.x[size_t(row) * a.x_stride + i];
+  for (int i = t; i < a.dims[0]; i += blockDim.x)
+    cur[i] = (a.x2 && i >= a.x_split) ? a.x2[i - a.x_split] : a.x[size_t(row) * a.x_stride + i];
   __syncthreads();
+  if (a.y_rep)                                        // the rest of the conditioning rows: the expression codes
+    for (int e = t; e < a.y_rep * a.tail_w; e += blockDim.x)
+      a.y[size_t(e / a.tail_w) * a.y_stride + a.dims[a.n_layers] + e % a.tail_w] = a.tail[e];
   int hoff = 0;
   const int hstride = a.dims[1] + (a.n_layers > 2 ? a.dims[2] : 0);
   for (int l = 0; l < a.n_layers; ++l) {
@@ -410,8 +536,13 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(HeadArgs a) {
       if (!last) v = fmaxf(v, 0.f);
       else if (a.y_add) v += a.y_add[i];
       cur[i] = v;
-      if (last) a.y[size_t(row) * dout + i] = v;
-      else if (a.hidden) a.hidden[size_t(row) * hstride + hoff + i] = v;
+      if (last && a.y_rep) {
+        for (int b = 0; b < a.y_rep; ++b) a.y[size_t(b) * a.y_stride + i] = v;
+      } else if (last) {
+        a.y[size_t(row) * dout + i] = v;
+      } else if (a.hidden) {
+        a.hidden[size_t(row) * hstride + hoff + i] = v;
+      }
     }
     if (!last) hoff += dout;
     __syncthreads();
@@ -425,7 +556,15 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadArgs a) {
   __shared__ float cur[HEAD_MAX], part[HEAD_PART];
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
   const int dout_last = a.dims[a.n_layers];
-  for (int i = t; i < dout_last; i += blockDim.x) cur[i] = a.g_y[size_t(row) * dout_last + i];
+  for (int i = t; i < dout_last; i += blockDim.x) {
+    if (a.g_rows) {
+      float v = 0.f;
+      for (int b = 0; b < a.g_rows; ++b) v += a.g_y[size_t(b) * a.g_stride + i];       // (row order: deterministic)
+      cur[i] = v;
+    } else {
+      cur[i] = a.g_y[size_t(row) * dout_last + i];
+    }
+  }
   __syncthreads();
   const int hstride = a.dims[1] + (a.n_layers > 2 ? a.dims[2] : 0);
   for (int l = a.n_layers - 1; l >= 0; --l) {
@@ -458,11 +597,14 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadArgs a) {
       if (i < din) {
         for (int oc = 0; oc < n_oc; ++oc) v += part[oc * din + i];
         if (l > 0) v = a.hidden[size_t(row) * hstride + hoff + i] > 0.f ? v : 0.f;       // ReLU of the previous layer
-        if (l == 0) a.g_x[size_t(row) * a.x_stride + i] = v;
+        if (l == 0) {
+          if (a.g_x2 && i >= a.x_split) a.g_x2[i - a.x_split] = v;
+          else a.g_x[size_t(row) * a.x_stride + i] = v;
+        }
       }
       keep[q] = v;
     }
-    if (l == 0)
+    if (l == 0 && !a.g_x2)
       for (int i = din + t; i < a.x_stride; i += blockDim.x) a.g_x[size_t(row) * a.x_stride + i] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -485,7 +627,7 @@ int nphm_fit_loss(const float* sdf, const unsigned char* valid, int64_t n_points
   if (z_expr && (!obs_idx || n_rows <= 0 || n_obs <= 0 || expr_dim <= 0)) return nphm_fail_msg("nphm_fit_loss: bad expression-code arguments");
   nphm::fit::LossArgs a{sdf, valid, thr, lam, z_shape, z_expr, obs_idx, int(n_points), n_rows, n_obs, expr_dim, nullptr, row,
                         nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(nphm::fit::fit_loss_kernel<false>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(nphm::fit::fit_loss_kernel<0>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_fit_loss launch", e);
 }
@@ -498,9 +640,22 @@ int nphm_fit_loss_backward(const float* sdf, const unsigned char* valid, int64_t
     return nphm_fail_msg("nphm_fit_loss_backward: bad expression-code arguments");
   nphm::fit::LossArgs a{sdf, valid, thr, lam, z_shape, z_expr, obs_idx, int(n_points), n_rows, n_obs, expr_dim, g_out, nullptr,
                         g_sdf, g_shape, g_expr};
-  hipLaunchKernelGGL(nphm::fit::fit_loss_kernel<true>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(nphm::fit::fit_loss_kernel<1>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_fit_loss_backward launch", e);
+}
+
+int nphm_fit_loss_with_gradients(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                                 const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                                 const float* g_out, float* row, float* g_sdf, float* g_shape, float* g_expr, void* stream) {
+  if (!sdf || !thr || !lam || !z_shape || !row || !g_sdf || !g_shape || n_points <= 0) return nphm_fail_msg("nphm_fit_loss_with_gradients: bad arguments");
+  if (z_expr && (!obs_idx || !g_expr || n_rows <= 0 || n_obs <= 0 || expr_dim <= 0))
+    return nphm_fail_msg("nphm_fit_loss_with_gradients: bad expression-code arguments");
+  nphm::fit::LossArgs a{sdf, valid, thr, lam, z_shape, z_expr, obs_idx, int(n_points), n_rows, n_obs, expr_dim, g_out, row,
+                        g_sdf, g_shape, g_expr};
+  hipLaunchKernelGGL(nphm::fit::fit_loss_kernel<2>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_fit_loss_with_gradients launch", e);
 }
 
 int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g_posed, int64_t n, void* stream) {
@@ -551,6 +706,38 @@ int nphm_head_backward(const float* const weight[3], const float* const bias[3],
   return e == hipSuccess ? 0 : nphm_fail("nphm_head_backward launch", e);
 }
 
+int nphm_compress_condition(const float* weight, const float* bias, const float* code, int code_dim, const float* anchors, int anchors_dim,
+                            int out_dim, const float* z_ex, int n_rows, int expr_dim, float* cond, void* stream) {
+  nphm::fit::HeadArgs a{};
+  if (!weight || !bias || !code || !anchors || !z_ex || !cond || n_rows <= 0 || expr_dim <= 0 || code_dim <= 0 || anchors_dim <= 0)
+    return nphm_fail_msg("nphm_compress_condition: bad arguments");
+  const float* w[3] = {weight, nullptr, nullptr};
+  const float* b[3] = {bias, nullptr, nullptr};
+  const int dims[4] = {code_dim + anchors_dim, out_dim, 0, 0};
+  if (head_args(a, w, b, dims, 1, "nphm_compress_condition: unsupported widths (<= 1536)")) return -2;
+  a.x = code; a.x_stride = code_dim; a.x2 = anchors; a.x_split = code_dim;
+  a.y = cond; a.y_rep = n_rows; a.y_stride = out_dim + expr_dim; a.tail = z_ex; a.tail_w = expr_dim;
+  hipLaunchKernelGGL(nphm::fit::head_fwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_compress_condition launch", e);
+}
+
+int nphm_compress_condition_backward(const float* weight, const float* bias, int code_dim, int anchors_dim, int out_dim, const float* g_cond,
+                                     int n_rows, int expr_dim, float* g_code, float* g_anchors, void* stream) {
+  nphm::fit::HeadArgs a{};
+  if (!weight || !bias || !g_cond || !g_code || !g_anchors || n_rows <= 0 || expr_dim <= 0 || code_dim <= 0 || anchors_dim <= 0)
+    return nphm_fail_msg("nphm_compress_condition_backward: bad arguments");
+  const float* w[3] = {weight, nullptr, nullptr};
+  const float* b[3] = {bias, nullptr, nullptr};
+  const int dims[4] = {code_dim + anchors_dim, out_dim, 0, 0};
+  if (head_args(a, w, b, dims, 1, "nphm_compress_condition_backward: unsupported widths (<= 1536)")) return -2;
+  a.g_y = g_cond; a.g_rows = n_rows; a.g_stride = out_dim + expr_dim;
+  a.g_x = g_code; a.x_stride = code_dim; a.g_x2 = g_anchors; a.x_split = code_dim;
+  hipLaunchKernelGGL(nphm::fit::head_bwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_compress_condition_backward launch", e);
+}
+
 size_t nphm_identity_latent_grad_scratch_bytes(int n_rows) {
   return n_rows > 0 ? size_t(n_rows) * nphm::N_MEMBERS * nphm::LAT_GLOB * sizeof(float) : 0;
 }
@@ -589,6 +776,34 @@ int nphm_gather_rows_backward(const float* g_out, const int64_t* idx, int n_draw
   return e == hipSuccess ? 0 : nphm_fail("nphm_gather_rows_backward launch", e);
 }
 
+int nphm_fit_inputs(const int64_t* drawn, int n_rows, int n_points, const float* clouds, int n_obs, int cloud_points, int cloud_width,
+                    const float* z_shape, int shape_dim, const float* z_expr_table, int expr_dim, float* obs, float* z_ex,
+                    float* glob_cond, void* stream) {
+  if (!drawn || !clouds || !z_shape || !z_expr_table || !obs || !z_ex || !glob_cond) return nphm_fail_msg("nphm_fit_inputs: null pointer");
+  if (n_rows <= 0 || n_points <= 0 || n_obs <= 0 || cloud_points <= 0 || cloud_width <= 0 || shape_dim <= 0 || expr_dim <= 0)
+    return nphm_fail_msg("nphm_fit_inputs: bad sizes");
+  const int64_t total = std::max(int64_t(n_rows) * n_points * cloud_width, int64_t(n_rows) * (shape_dim + expr_dim));
+  if (total > 0x7fffffffLL) return nphm_fail_msg("nphm_fit_inputs: too many elements");
+  nphm::fit::InputsArgs a{drawn, clouds, z_shape, z_expr_table, n_rows, n_points, cloud_points, cloud_width, shape_dim, expr_dim, obs, z_ex, glob_cond};
+  hipLaunchKernelGGL(nphm::fit::fit_inputs_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_fit_inputs launch", e);
+}
+
+int nphm_fit_inputs_backward(const float* g_z_ex, int64_t z_ex_row_stride, const float* g_glob_cond, const int64_t* obs_idx, int n_rows,
+                             int n_obs, int shape_dim, int expr_dim, const float* const g_shape_uses[4], const float* g_table_use,
+                             float* g_z_expr_table, float* g_z_shape, void* stream) {
+  if (!obs_idx || !g_z_expr_table) return nphm_fail_msg("nphm_fit_inputs_backward: null pointer");
+  if (n_rows <= 0 || n_obs <= 0 || shape_dim <= 0 || expr_dim <= 0) return nphm_fail_msg("nphm_fit_inputs_backward: bad sizes");
+  const int total = std::max(n_obs * expr_dim, g_z_shape ? shape_dim : 0);
+  nphm::fit::InputsBwdArgs a{g_z_ex, z_ex_row_stride, g_glob_cond, obs_idx, n_rows, n_obs, shape_dim, expr_dim, {nullptr, nullptr, nullptr, nullptr},
+                             g_table_use, g_z_expr_table, g_z_shape};
+  for (int q = 0; q < 4; ++q) a.shape_parts[q] = g_shape_uses ? g_shape_uses[q] : nullptr;
+  hipLaunchKernelGGL(nphm::fit::fit_inputs_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_fit_inputs_backward launch", e);
+}
+
 int nphm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,
                    float step_size, float bias_correction2_sqrt, float eps, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq) return nphm_fail_msg("nphm_adam_step: null pointer");
@@ -597,6 +812,22 @@ int nphm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                      param, grad, exp_avg, exp_avg_sq, n, 1.f - beta1, beta2, 1.f - beta2, step_size, bias_correction2_sqrt, eps);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_adam_step launch", e);
+}
+
+int nphm_adam_step_pair(float* const param[2], const float* const grad[2], float* const exp_avg[2], float* const exp_avg_sq[2],
+                        const int64_t n[2], const float* scalars, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !n || !scalars) return nphm_fail_msg("nphm_adam_step_pair: null pointer");
+  nphm::fit::AdamPairArgs a{};
+  for (int q = 0; q < 2; ++q) {
+    if (n[q] < 0 || (n[q] > 0 && (!param[q] || !grad[q] || !exp_avg[q] || !exp_avg_sq[q]))) return nphm_fail_msg("nphm_adam_step_pair: bad tensor");
+    a.p[q] = param[q]; a.g[q] = grad[q]; a.m[q] = exp_avg[q]; a.v[q] = exp_avg_sq[q]; a.n[q] = n[q];
+  }
+  a.scalars = scalars;
+  const int64_t total = n[0] + n[1];
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(nphm::fit::adam_pair_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_adam_step_pair launch", e);
 }
 
 int nphm_inverse3x3_strided(const float* matrices, int64_t matrix_stride, int64_t row_stride, int64_t col_stride,

@@ -672,6 +672,40 @@ class DeepSDF(nn.Module):
         return self.evaluate(self._embed(xyz), lat_rep), None
 
 
+class _CompressCondFn(torch.autograd.Function):
+    """cond [B,1,32+e] = [compressor([z_id | anchors]) on every row | z_ex[b]] (deepSDF.py:212-223 for ONE identity on every
+    row: the fitting loops) in one launch, and one launch back (``nphm_compress_condition`` / ``_backward``) - a cat, a fused
+    head launch and a cat forward, a sum over the rows and the head's backward launch in the composite formulation.  The
+    gradient of z_ex is a column slice of the incoming gradient (a view)."""
+
+    @staticmethod
+    def forward(ctx, z_id, anchors1, z_ex, weight, bias):
+        lib = _lib.load()
+        B, E, O = z_ex.shape[0], z_ex.shape[-1], weight.shape[0]
+        cond = torch.empty(B, 1, O + E, dtype=torch.float32, device=z_ex.device)
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        _lib.check(lib.nphm_compress_condition(w.data_ptr(), b.data_ptr(), z_id.detach().data_ptr(), z_id.numel(), anchors1.detach().data_ptr(),
+                                               anchors1.numel(), O, z_ex.detach().data_ptr(), B, E, cond.data_ptr(),
+                                               torch.cuda.current_stream(z_ex.device).cuda_stream), "nphm_compress_condition")
+        ctx.save_for_backward(w, b)
+        ctx.meta = (z_id.shape, anchors1.shape, B, E, O)
+        return cond
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_cond):
+        lib = _lib.load()
+        w, b = ctx.saved_tensors
+        s_id, s_anc, B, E, O = ctx.meta
+        g = g_cond.contiguous().float()
+        g_id = torch.empty(s_id, dtype=torch.float32, device=g.device)
+        g_anc = torch.empty(s_anc, dtype=torch.float32, device=g.device)
+        _lib.check(lib.nphm_compress_condition_backward(w.data_ptr(), b.data_ptr(), g_id.numel(), g_anc.numel(), O, g.data_ptr(), B, E,
+                                                        g_id.data_ptr(), g_anc.data_ptr(), torch.cuda.current_stream(g.device).cuda_stream),
+                   "nphm_compress_condition_backward")
+        return g_id, g_anc, g[..., O:], None, None
+
+
 class DeformationNetwork(nn.Module):
     """Forward deformation field F_ex (deepSDF.py:118-239).  Conditioning modes: 'glob_only',
     'expr_only', 'interpolate', 'compress' (the NPHM one: identity code + anchors are projected to
@@ -763,9 +797,16 @@ class DeformationNetwork(nn.Module):
             return
         z_id, z_ex, anchors1 = parts
         from .ensembled_deepsdf import frozen_head
-        packed = torch.cat([z_id.reshape(1, -1), anchors1.reshape(1, -1)], dim=-1)
-        comp = frozen_head(self.compressor, packed, False)                       # [1,32]
-        cond = torch.cat([comp.unsqueeze(1).expand(z_ex.shape[0], 1, -1), z_ex], dim=-1)
+        lin = self.compressor[0]
+        if (len(self.compressor) == 1 and z_id.is_cuda and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", "")
+                and not any(p.requires_grad for p in lin.parameters()) and lin.bias is not None and lin.in_features <= 1536
+                and all(t.dtype == torch.float32 and t.is_contiguous() for t in (z_id, z_ex, anchors1))
+                and z_id.numel() + anchors1.numel() == lin.in_features and z_ex.dim() == 3 and z_ex.shape[1] == 1):
+            cond = _CompressCondFn.apply(z_id, anchors1, z_ex, lin.weight, lin.bias)     # [B,1,32+e]: one launch each way
+        else:
+            packed = torch.cat([z_id.reshape(1, -1), anchors1.reshape(1, -1)], dim=-1)
+            comp = frozen_head(self.compressor, packed, False)                       # [1,32]
+            cond = torch.cat([comp.unsqueeze(1).expand(z_ex.shape[0], 1, -1), z_ex], dim=-1)
         key = (lat_rep.data_ptr(), lat_rep._version, tuple(lat_rep.shape), tuple(lat_rep.stride()),
                anchors.data_ptr(), anchors._version, tuple(anchors.shape), tuple(anchors.stride()))
         self._cond_scope[key] = (cond, lat_rep, anchors, cond.requires_grad)

@@ -70,14 +70,24 @@ class _CodeAdam(optim.Adam):
     step is bound by the GPU's launch rate, and the two optimizers' sixteen launches were 3 % of it.  Same update rule
     (exp_avg.lerp_, exp_avg_sq.mul_.addcmul_, addcdiv_ with host-side bias corrections); other tensors: the parent's step."""
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        fast = closure is None and all(
+    def _fast_ok(self):
+        return all(
             p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and (p.grad is None or (p.grad.is_contiguous() and not p.grad.is_sparse))
             for g in self.param_groups for p in g["params"]) and all(
             not g["amsgrad"] and g["weight_decay"] == 0 and not g["maximize"] and not g.get("capturable") and not g.get("differentiable")
             for g in self.param_groups)
-        if not fast:
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0, dtype=torch.float32)          # a host tensor, as the parent keeps it
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not (closure is None and self._fast_ok()):
             return super().step(closure)
         import math
         from . import _lib
@@ -87,11 +97,7 @@ class _CodeAdam(optim.Adam):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)          # a host tensor, as the parent keeps it
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st = self._state_of(p)
                 st["step"] += 1
                 t = float(st["step"])
                 lr = float(group["lr"])
@@ -106,6 +112,61 @@ class _CodeAdam(optim.Adam):
 
 def _adam(code, lr):
     return _CodeAdam(params=[code], lr=lr) if code.is_cuda else optim.Adam(params=[code], lr=lr)
+
+
+class _PairAdam:
+    """``opt.step(); opt_expr.step()`` of the joint loop (fitting.py:170-171) as ONE launch INSIDE the step - and so inside its
+    replayed hipGraph (``nphm_adam_step_pair``).  What changes from step to step - the bias corrections and the scheduled
+    learning rate - is computed on the host as before (``host_scalars``: advances the optimizers' step counts, same float32
+    values ``nphm_adam_step`` receives) and travels to the device with the step's draw, in the same pinned upload; the kernel
+    reads it from there.  Same state entries, same update rule, same bits as two ``_CodeAdam.step()`` calls."""
+
+    SLOTS = 6                        # int64 slots behind the draw = 2 x 6 float32
+
+    def __init__(self, optimizers):
+        import os
+        self.opts = list(optimizers)
+        self.ok = (len(self.opts) == 2 and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", "")
+                   and all(isinstance(o, _CodeAdam) and o._fast_ok() and len(o.param_groups) == 1 and len(o.param_groups[0]["params"]) == 1
+                           for o in self.opts))
+
+    def params(self):
+        return [o.param_groups[0]["params"][0] for o in self.opts]
+
+    @torch.no_grad()
+    def host_scalars(self):
+        import math
+        import numpy as np
+        vals = []
+        for o in self.opts:
+            group = o.param_groups[0]
+            st = o._state_of(group["params"][0])
+            st["step"] += 1
+            t = float(st["step"])
+            b1, b2 = group["betas"]
+            f = np.float32
+            vals += [f(1) - f(b1), f(b2), f(1) - f(b2), f(float(group["lr"]) / (1.0 - b1 ** t)), f(math.sqrt(1.0 - b2 ** t)), f(group["eps"])]
+        return torch.from_numpy(np.asarray(vals, dtype=np.float32).view(np.int64).copy())
+
+    @torch.no_grad()
+    def launch(self, scalars_i64):
+        """the update itself (inside the step, behind loss.backward()); ``scalars_i64``: the tail of the uploaded draw"""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        ps = self.params()
+        sts = [o.state[p] for o, p in zip(self.opts, ps)]
+        arr = lambda ts: (ctypes.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in ts])
+        n = (ctypes.c_int64 * 2)(*[0 if p.grad is None else p.numel() for p in ps])
+        _lib.check(lib.nphm_adam_step_pair(arr(ps), arr([p.grad for p in ps]), arr([st["exp_avg"] for st in sts]),
+                                           arr([st["exp_avg_sq"] for st in sts]), n, scalars_i64.data_ptr(),
+                                           torch.cuda.current_stream(ps[0].device).cuda_stream), "nphm_adam_step_pair")
+
+    def bump(self):
+        """after a step (replayed or eager): the kernel wrote through raw pointers - tell autograd and every cache keyed on the
+        codes' version counters"""
+        for p in self.params():
+            torch.autograd.graph.increment_version(p)
 
 
 class _ObservationSampler:
@@ -123,6 +184,7 @@ class _ObservationSampler:
         for i, c in enumerate(all_obs):
             self.clouds[i, : c.shape[0]] = c
         self.on_gpu = self.device.type == "cuda"
+        self.extra = 0           # int64 slots behind the indices of an uploaded draw (_PairAdam's scalars)
 
     def draw(self):
         """host side: (obs_idx [n_batch], point indices [n_batch, n]) as ONE flat int64 tensor [n_batch | n_batch * n]
@@ -139,7 +201,7 @@ class _ObservationSampler:
 
     def draw_like(self):
         """an index tensor of the shape ``draw`` returns, WITHOUT touching the RNG (allocation of the static input)"""
-        return torch.zeros(self.n_batch * (1 + min(self.n_points, min(self.sizes))), dtype=torch.int64)
+        return torch.zeros(self.n_batch * (1 + min(self.n_points, min(self.sizes))) + self.extra, dtype=torch.int64)
 
     def upload(self, drawn, out=None):
         if self.on_gpu:
@@ -152,7 +214,7 @@ class _ObservationSampler:
     def gather(self, drawn_dev):
         """device side: (obs_idx [n_batch] long, points [n_batch, n, 3])"""
         obs_idx = drawn_dev[: self.n_batch]
-        return obs_idx, self.clouds[obs_idx[:, None], drawn_dev[self.n_batch:].view(self.n_batch, -1)]
+        return obs_idx, self.clouds[obs_idx[:, None], drawn_dev[self.n_batch: drawn_dev.numel() - self.extra].view(self.n_batch, -1)]
 
 
 def _shape_regularisers(decoder, lat_rep_shape, loss_dict):
@@ -274,7 +336,10 @@ class _FitLossFn(torch.autograd.Function):
     ``_LOSS_SLOTS`` order, the total, the number of valid correspondences)."""
 
     @staticmethod
-    def forward(ctx, sdf, valid, z_shape, z_expr, obs_idx, thr, lam6):
+    def forward(ctx, sdf, valid, z_shape, z_expr, obs_idx, thr, lam6, seed=None):
+        """``seed``: the device scalar the caller will pass to ``loss.backward(gradient=seed)`` right behind this call - the
+        gradients are then computed by THIS launch (nphm_fit_loss_with_gradients) and ``backward`` hands them over when it
+        receives that very tensor (one launch per step instead of two; anything else: the backward kernel as before)."""
         from . import _lib
         lib = _lib.load()
         dev = sdf.device
@@ -287,10 +352,21 @@ class _FitLossFn(torch.autograd.Function):
         row = buf[:8]
         stream = torch.cuda.current_stream(dev).cuda_stream
         n_obs, expr_dim = (ze.shape[0], ze.shape[-1]) if ze is not None else (0, 0)
-        _lib.check(lib.nphm_fit_loss(sdf_c.data_ptr(), None if valid_c is None else valid_c.data_ptr(), sdf_c.numel(), thr.data_ptr(),
-                                     lam6.data_ptr(), zs.data_ptr(), None if ze is None else ze.data_ptr(),
-                                     None if ze is None else obs_idx.data_ptr(), 0 if ze is None else obs_idx.numel(), n_obs, expr_dim,
-                                     row.data_ptr(), stream), "nphm_fit_loss")
+        ctx.seeded = None
+        if seed is not None and seed.is_cuda and seed.dtype == torch.float32 and seed.numel() == 1:
+            g_sdf, g_shape = torch.empty_like(sdf_c), torch.empty_like(zs)
+            g_expr = None if ze is None else torch.empty_like(ze)
+            _lib.check(lib.nphm_fit_loss_with_gradients(
+                sdf_c.data_ptr(), None if valid_c is None else valid_c.data_ptr(), sdf_c.numel(), thr.data_ptr(), lam6.data_ptr(),
+                zs.data_ptr(), None if ze is None else ze.data_ptr(), None if ze is None else obs_idx.data_ptr(),
+                0 if ze is None else obs_idx.numel(), n_obs, expr_dim, seed.data_ptr(), row.data_ptr(), g_sdf.data_ptr(),
+                g_shape.data_ptr(), None if g_expr is None else g_expr.data_ptr(), stream), "nphm_fit_loss_with_gradients")
+            ctx.seeded = (seed.data_ptr(), seed._version, g_sdf, g_shape, g_expr)
+        else:
+            _lib.check(lib.nphm_fit_loss(sdf_c.data_ptr(), None if valid_c is None else valid_c.data_ptr(), sdf_c.numel(), thr.data_ptr(),
+                                         lam6.data_ptr(), zs.data_ptr(), None if ze is None else ze.data_ptr(),
+                                         None if ze is None else obs_idx.data_ptr(), 0 if ze is None else obs_idx.numel(), n_obs, expr_dim,
+                                         row.data_ptr(), stream), "nphm_fit_loss")
         ctx.save_for_backward(sdf_c, valid_c, zs, ze, obs_idx, thr, lam6)
         ctx.shapes = (sdf.shape, z_shape.shape, None if z_expr is None else z_expr.shape)
         ctx.mark_non_differentiable(row)
@@ -301,7 +377,11 @@ class _FitLossFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_total, _g_row):
         if g_total is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
+        s_sdf, s_shape, s_expr = ctx.shapes
+        if ctx.seeded is not None and g_total.data_ptr() == ctx.seeded[0] and g_total._version == ctx.seeded[1]:
+            _, _, g_sdf, g_shape, g_expr = ctx.seeded          # the announced seed: the forward launch computed these
+            return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None, None)
         from . import _lib
         lib = _lib.load()
         sdf_c, valid_c, zs, ze, obs_idx, thr, lam6 = ctx.saved_tensors
@@ -317,8 +397,7 @@ class _FitLossFn(torch.autograd.Function):
                                               None if ze is None else obs_idx.data_ptr(), 0 if ze is None else obs_idx.numel(), n_obs,
                                               expr_dim, go.data_ptr(), g_sdf.data_ptr(), g_shape.data_ptr(),
                                               None if g_expr is None else g_expr.data_ptr(), stream), "nphm_fit_loss_backward")
-        s_sdf, s_shape, s_expr = ctx.shapes
-        return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None)
+        return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None, None)
 
 
 class _GatherRowsFn(torch.autograd.Function):
@@ -344,6 +423,96 @@ class _GatherRowsFn(torch.autograd.Function):
         _lib.check(lib.nphm_gather_rows_backward(g.data_ptr(), idx.data_ptr(), idx.numel(), out.shape[0], width, out.data_ptr(),
                                                  torch.cuda.current_stream(g.device).cuda_stream), "nphm_gather_rows_backward")
         return out, None
+
+
+class _FitInputsFn(torch.autograd.Function):
+    """(obs [B,n,C], z_ex [B,1,E], glob_cond [B,1,L+E]) of a step from its draw - the sampled points of the drawn observations,
+    their expression codes ``lat_rep[obs_idx]`` and the conditioning rows ``cat([lat_rep_shape on every row, z_ex])``
+    (fitting.py:61-85) - in ONE launch (``nphm_fit_inputs``: an advanced-indexing gather, an index_select and a cat in the
+    PyTorch formulation), and one launch back (``nphm_fit_inputs_backward``: per code the sum over its draws in draw order,
+    straight from a column slice of the conditioning's gradient)."""
+
+    @staticmethod
+    def forward(ctx, z_shape, table, drawn, clouds, n_batch, extra=0):
+        from . import _lib
+        lib = _lib.load()
+        dev = table.device
+        n_obs, P, C = clouds.shape
+        n = (drawn.numel() - n_batch - extra) // n_batch
+        L, E = z_shape.shape[-1], table.shape[-1]
+        obs = torch.empty(n_batch, n, C, dtype=torch.float32, device=dev)
+        z_ex = torch.empty(n_batch, 1, E, dtype=torch.float32, device=dev)
+        glob = torch.empty(n_batch, 1, L + E, dtype=torch.float32, device=dev)
+        _lib.check(lib.nphm_fit_inputs(drawn.data_ptr(), n_batch, n, clouds.data_ptr(), n_obs, P, C, z_shape.detach().data_ptr(), L,
+                                       table.detach().data_ptr(), E, obs.data_ptr(), z_ex.data_ptr(), glob.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream), "nphm_fit_inputs")
+        ctx.save_for_backward(drawn)
+        ctx.meta = (n_batch, n_obs, L, E, z_shape.shape, table.shape)
+        ctx.mark_non_differentiable(obs)
+        ctx.set_materialize_grads(False)
+        # one alias of the identity code per use in the step (anchor head, identity field, regularisers, compressor) and one of
+        # the expression codes (regulariser): same storage and version counter - every cache keyed on them sees ONE tensor -
+        # but separate autograd edges, whose gradients the backward launch adds in a fixed order (autograd would run one
+        # elementwise add per extra use of a tensor: four launches per step)
+        return (obs, z_ex, glob) + tuple(z_shape.detach() for _ in range(4)) + (table.detach(),)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, _g_obs, g_z_ex, g_glob, *g_uses):
+        from . import _lib
+        lib = _lib.load()
+        (drawn,) = ctx.saved_tensors
+        B, n_obs, L, E, s_shape, s_table = ctx.meta
+        g_uses = [None if g is None else g.contiguous().float() for g in g_uses]
+        g_shape_uses, g_table_use = g_uses[:4], g_uses[4]
+        if g_z_ex is None and g_glob is None and all(g is None for g in g_uses):
+            return None, None, None, None, None, None
+        dev = drawn.device
+        stride = 0
+        if g_z_ex is not None:
+            g_z_ex = g_z_ex.float()
+            if g_z_ex.stride(-1) != 1 or (g_z_ex.dim() == 3 and g_z_ex.shape[1] != 1):
+                g_z_ex = g_z_ex.contiguous()
+            stride = g_z_ex.stride(0)
+        if g_glob is not None:
+            g_glob = g_glob.contiguous().float()
+        for g in g_shape_uses:
+            assert g is None or g.numel() == L, "gradient of an identity-code alias"
+        assert g_table_use is None or g_table_use.numel() == n_obs * E, "gradient of the expression-code alias"
+        g_table = torch.empty(s_table, dtype=torch.float32, device=dev)
+        want_shape = g_glob is not None or any(g is not None for g in g_shape_uses)
+        g_shape = torch.empty(s_shape, dtype=torch.float32, device=dev) if want_shape else None
+        import ctypes
+        uses = (ctypes.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in g_shape_uses])
+        _lib.check(lib.nphm_fit_inputs_backward(None if g_z_ex is None else g_z_ex.data_ptr(), stride,
+                                                None if g_glob is None else g_glob.data_ptr(), drawn.data_ptr(), B, n_obs, L, E,
+                                                uses, None if g_table_use is None else g_table_use.data_ptr(),
+                                                g_table.data_ptr(), None if g_shape is None else g_shape.data_ptr(),
+                                                torch.cuda.current_stream(dev).cuda_stream), "nphm_fit_inputs_backward")
+        return g_shape, g_table, None, None, None, None
+
+
+class _StepCodes:
+    """the two codes as the step's uses see them: the leaves themselves, or (fused inputs) one alias per use"""
+
+    def __init__(self, lat_rep_shape, lat_rep, shape_uses=None, table_use=None):
+        self.anchors, self.field, self.loss, self.compressor = shape_uses if shape_uses is not None else (lat_rep_shape,) * 4
+        self.expr_loss = lat_rep if table_use is None else table_use
+
+
+def _step_inputs(sampler, drawn_dev, lat_rep_shape, lat_rep, n_batch):
+    """(obs_idx [B], obs [B,n,C], z_ex [B,1,E], glob_cond [B,1,L+E], _StepCodes) of a joint-fit step (fitting.py:61-85)"""
+    import os
+    obs_idx = drawn_dev[:n_batch]
+    if (sampler.on_gpu and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", "") and sampler.clouds.dtype == torch.float32
+            and lat_rep.dtype == torch.float32 and lat_rep.is_contiguous() and lat_rep_shape.is_contiguous()
+            and lat_rep.dim() == 3 and lat_rep.shape[1] == 1 and lat_rep_shape.shape[:2] == (1, 1) and drawn_dev.is_contiguous()):
+        obs, z_ex, glob_cond, *uses = _FitInputsFn.apply(lat_rep_shape, lat_rep, drawn_dev, sampler.clouds, n_batch, sampler.extra)
+        return obs_idx, obs, z_ex, glob_cond, _StepCodes(lat_rep_shape, lat_rep, uses[:4], uses[4])
+    obs_idx, obs = sampler.gather(drawn_dev)
+    z_ex = _rows_of(lat_rep, obs_idx)
+    glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), z_ex], dim=-1)
+    return obs_idx, obs, z_ex, glob_cond, _StepCodes(lat_rep_shape, lat_rep)
 
 
 def _rows_of(table, idx):
@@ -475,12 +644,14 @@ class _GraphedStep:
         return self.out
 
 
-def _run_step(step, sampler, drawn_static, drawn_cur):
+def _run_step(step, sampler, drawn_static, drawn_cur, pair=None):
     """Draw this step's sample (host RNG, reference order) and run the step on it.  The graph reads the static index
     tensor; observations of different sizes below n_points can yield a draw of another length (every row of a draw
     has the length of ITS observation, fitting.py:64-70, and the reference needs them equal within a step only): such
-    a step runs eagerly on its own index tensor."""
+    a step runs eagerly on its own index tensor.  ``pair``: the step's optimizer scalars ride behind the indices."""
     drawn = sampler.draw()
+    if pair is not None:
+        drawn = torch.cat([drawn, pair.host_scalars()])
     if drawn.shape == drawn_static.shape:
         sampler.upload(drawn, out=drawn_static)
         drawn_cur[0] = drawn_static
@@ -555,13 +726,18 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
     n_iter = int(n_steps * step_scale)
     hist = _History(history, lambdas.keys(), n_iter, device, extra=("n_valid",))
     ctl = _StepControls(lambdas, device)
-    drawn_static = sampler.upload(sampler.draw_like())       # static input of the step: the sampled indices
-    drawn_cur = [drawn_static]                               # what the step reads (another tensor for odd-shaped draws)
     fused = _fused_losses_ok(decoder, lambdas, device) and "reg_expr" in lambdas
     if fused:
         hist.perm = ctl.fused_perm(extra=("n_valid",))
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder, decoder_expr) and not compute_unused_sdf_grad
+    pair = _PairAdam((opt, opt_expr)) if fused else None       # both optimizer steps as one launch inside the step
+    if pair is not None and not pair.ok:
+        pair = None
+    if pair is not None:
+        sampler.extra = pair.SLOTS
+    drawn_static = sampler.upload(sampler.draw_like())       # static input of the step: the sampled indices (+ the optimizers' scalars)
+    drawn_cur = [drawn_static]                               # what the step reads (another tensor for odd-shaped draws)
 
     def body():
         with (decoder_expr.condition_scope() if hasattr(decoder_expr, "condition_scope") else nullcontext()), \
@@ -569,16 +745,14 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             return body_in_scope()
 
     def body_in_scope():
+        obs_idx, obs, z_ex, glob_cond, codes = _step_inputs(sampler, drawn_cur[0], lat_rep_shape, lat_rep, n_batch)     # glob_cond [B,1,L]
         # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
-        anchors = _anchors_of(decoder, lat_rep_shape, device)
-        obs_idx, obs = sampler.gather(drawn_cur[0])
-        z_ex = _rows_of(lat_rep, obs_idx)
-        glob_cond = torch.cat([lat_rep_shape.expand(n_batch, -1, -1), z_ex], dim=-1)                     # [B,1,L]
+        anchors = _anchors_of(decoder, codes.anchors, device)
         anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
 
         if hasattr(decoder_expr, "prime_condition"):
             # one conditioning per step, shared by the calls below; its identity half from ONE row
-            decoder_expr.prime_condition(glob_cond, anchors_b, parts=(lat_rep_shape, z_ex, anchors) if anchors_b is not None else None)
+            decoder_expr.prime_condition(glob_cond, anchors_b, parts=(codes.compressor, z_ex, anchors) if anchors_b is not None else None)
         # canonical correspondences by Broyden root finding (no gradient flows through it)
         p_corresp, search_result = search(obs, glob_cond, decoder_expr,
                                           None if anchors_b is None else anchors_b.detach(), multi_corresp=False)
@@ -603,19 +777,21 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             correction = -(grad_inv.detach() * correction.unsqueeze(-2)).sum(dim=-1)
             xc = p_corresp + correction
 
-        shape_cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, xc.shape[1], 1)
-        sdf = _field_of_one_code(decoder, xc, lat_rep_shape, shape_cond, local)
+        shape_cond = codes.field.expand(n_batch, -1, -1) if local else codes.field.repeat(n_batch, xc.shape[1], 1)
+        sdf = _field_of_one_code(decoder, xc, codes.field, shape_cond, local)
         if compute_unused_sdf_grad:
             _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
 
         if fused:                          # every loss term, the total and (backward) their gradients: two launches
-            loss, row8 = _FitLossFn.apply(sdf, valid, lat_rep_shape, lat_rep, obs_idx, ctl.thr, ctl.lam6)
-            loss.backward(gradient=ctl.one)       # (a preallocated seed: no ones_like launch per step)
+            loss, row8 = _FitLossFn.apply(sdf, valid, codes.loss, codes.expr_loss, obs_idx, ctl.thr, ctl.lam6, ctl.one)
+            loss.backward(gradient=ctl.one)       # (a preallocated seed, announced to the loss: its launch computes the gradients too)
             row = row8                     # raw: hist.perm orders it on the host
+            if pair is not None:
+                pair.launch(drawn_cur[0][drawn_cur[0].numel() - pair.SLOTS:])
         else:
             loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr, valid),
-                         "reg_expr": (torch.norm(lat_rep[obs_idx, :, :], dim=-1) ** 2).mean()}
-            _shape_regularisers(decoder, lat_rep_shape, loss_dict)
+                         "reg_expr": (torch.norm(codes.expr_loss[obs_idx, :, :], dim=-1) ** 2).mean()}
+            _shape_regularisers(decoder, codes.loss, loss_dict)
             loss = ctl.total(loss_dict)
             loss.backward(gradient=ctl.one)
             row = hist.row(loss_dict, loss, n_valid=valid.sum())
@@ -635,11 +811,14 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             ctl.refresh(lambdas, j, step_scale)
             step.zero_grad()
             ev = _step_events(timing, step)
-            row, anchors = _run_step(step, sampler, drawn_static, drawn_cur)
+            row, anchors = _run_step(step, sampler, drawn_static, drawn_cur, pair)
             if ev is not None:
                 ev[1].record()
-            opt.step()
-            opt_expr.step()
+            if pair is None:
+                opt.step()
+                opt_expr.step()
+            else:
+                pair.bump()
             hist.record(j, row)
             done = j + 1
             if verbose:

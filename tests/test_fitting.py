@@ -334,6 +334,87 @@ def test_fused_step_pieces_match_the_pytorch_formulation():
     ra.backward(seed3)
     rb.backward(seed3)
     assert float((ta.grad - tb.grad).abs().max()) < 1e-6 and float(ta.grad[1].abs().max()) > 0
+    # the loss with its seed announced: one launch computes the gradients too - same bits as the two-launch form
+    c = [t.clone().requires_grad_() for t in (sdf0, zs0, ze0)]
+    loss_s, row_s = F._FitLossFn.apply(c[0], valid, c[1], c[2], obs_idx, ctl.thr, ctl.lam6, ctl.one)
+    loss_s.backward(gradient=ctl.one)
+    assert torch.equal(loss_s, loss_f) and torch.equal(row_s, row)
+    for y, z in zip(b, c):
+        assert torch.equal(y.grad, z.grad)
+    c2 = [t.clone().requires_grad_() for t in (sdf0, zs0, ze0)]           # ... and another seed than the announced one: the backward launch
+    loss_o, _ = F._FitLossFn.apply(c2[0], valid, c2[1], c2[2], obs_idx, ctl.thr, ctl.lam6, ctl.one)
+    loss_o.backward(gradient=torch.full((), 2.0, device=dev))
+    for y, z in zip(b, c2):
+        assert float((2.0 * y.grad - z.grad).abs().max()) <= 1e-6 * float(y.grad.abs().max())
+    # the step's inputs from its draw, one launch each way: sampled points, drawn expression codes, conditioning rows, and the
+    # aliases of the two codes whose gradients the backward launch sums
+    sizes = [700, 650, 800]
+    clouds = [torch.randn(n_pts, 3, generator=g).to(dev) for n_pts in sizes]
+    sampler = F._ObservationSampler(clouds, B, 100)
+    sampler.extra = 6
+    torch.manual_seed(5)
+    drawn = torch.cat([sampler.draw(), torch.arange(6)])
+    drawn_dev = sampler.upload(drawn)
+    za, zb = zs0.clone().requires_grad_(), zs0.clone().requires_grad_()
+    ta2, tb2 = ze0.clone().requires_grad_(), ze0.clone().requires_grad_()
+    oi, obs_f, zex_f, glob_f, codes = F._step_inputs(sampler, drawn_dev, za, ta2, B)
+    oi_r, obs_r = sampler.gather(drawn_dev)
+    zex_r = tb2[oi_r]
+    glob_r = torch.cat([zb.expand(B, -1, -1), zex_r], dim=-1)
+    assert torch.equal(oi, oi_r) and torch.equal(obs_f, obs_r) and torch.equal(zex_f, zex_r) and torch.equal(glob_f, glob_r)
+    assert codes.anchors.data_ptr() == za.data_ptr() and codes.anchors._version == za._version and codes.anchors is not codes.field
+    sg, sz = torch.randn(B, 1, 1344 + 200, generator=g).to(dev), torch.randn(B, 1, 232, generator=g).to(dev)
+    su = [torch.randn(1, 1, 1344, generator=g).to(dev) for _ in range(4)]
+    st = torch.randn(n_obs, 1, 200, generator=g).to(dev)
+    # (z_ex's gradient arrives as a column slice of the conditioning's gradient: rows 232 floats apart)
+    total_f = (glob_f * sg).sum() + (zex_f * sz[..., 32:]).sum() + sum((u * w).sum() for u, w in zip((codes.anchors, codes.field, codes.loss, codes.compressor), su)) \
+        + (codes.expr_loss * st).sum()
+    total_r = (glob_r * sg).sum() + (zex_r * sz[..., 32:]).sum() + sum((zb * w).sum() for w in su) + (tb2 * st).sum()
+    total_f.backward()
+    total_r.backward()
+    assert float((za.grad - zb.grad).abs().max()) < 1e-5 * float(zb.grad.abs().max())
+    assert float((ta2.grad - tb2.grad).abs().max()) < 1e-5 * float(tb2.grad.abs().max())
+    # the compressor inside the conditioning rows: [compressor([z_id | anchors]) on every row | z_ex[b]]
+    dnet = U.build_deformation(device=dev).eval()
+    for prm in dnet.parameters():
+        prm.requires_grad_(False)
+    anc = (torch.randn(1, 39, 3, generator=g) * 0.1).to(dev)
+    zex = (torch.randn(B, 1, 200, generator=g) * 0.05).to(dev)
+    ins_f = [t.clone().requires_grad_() for t in (zs0, anc, zex)]
+    ins_r = [t.clone().requires_grad_() for t in (zs0, anc, zex)]
+    from nphm_amd.deepsdf import _CompressCondFn
+    lin = dnet.compressor[0]
+    cond_f = _CompressCondFn.apply(ins_f[0], ins_f[1], ins_f[2], lin.weight, lin.bias)
+    comp_r = lin(torch.cat([ins_r[0].reshape(1, -1), ins_r[1].reshape(1, -1)], dim=-1))
+    cond_r = torch.cat([comp_r.unsqueeze(1).expand(B, 1, -1), ins_r[2]], dim=-1)
+    assert float((cond_f - cond_r).abs().max()) < 1e-5
+    cond_f.backward(sz)
+    cond_r.backward(sz)
+    for x, y, name in zip(ins_f, ins_r, ("identity code", "anchors", "expression codes")):
+        assert float((x.grad - y.grad).abs().max()) < 1e-5 * max(1e-3, float(y.grad.abs().max())), name
+    # both optimizer steps as one launch with the scalars in device memory: the bits of two _CodeAdam.step() calls
+    pa = [(torch.randn(1, 1, 1344, generator=g) * 0.05).to(dev).requires_grad_(), (torch.randn(n_obs, 1, 200, generator=g) * 0.05).to(dev).requires_grad_()]
+    pb = [t.detach().clone().requires_grad_() for t in pa]
+    oa, ob = [F._adam(t, 0.01) for t in pa], [F._adam(t, 0.01) for t in pb]
+    pair = F._PairAdam(ob)
+    assert pair.ok
+    for it in range(4):
+        grads = [torch.randn(t.shape, generator=g).to(dev) * 0.3 for t in pa]
+        if it == 2:
+            for o in oa + ob:
+                o.param_groups[0]["lr"] /= 5                            # a schedule step
+        for t, u, gr in zip(pa, pb, grads):
+            t.grad, u.grad = gr.clone(), gr.clone()
+        for o in oa:
+            o.step()
+        v0 = pb[0]._version
+        pair.launch(pair.host_scalars().to(dev))
+        pair.bump()
+        assert pb[0]._version > v0
+        for t, u in zip(pa, pb):
+            assert torch.equal(t, u), it
+        for o, q in zip(oa, ob):
+            assert float(o.state[o.param_groups[0]["params"][0]]["step"]) == float(q.state[q.param_groups[0]["params"][0]]["step"]) == it + 1
     # conditioning gradient of the deformation backbone from the two bias gradients
     H, lat, d, k_act = 512, 232, 3, 277
     W0 = torch.randn(H, d + lat, generator=g).to(dev) * 0.1
@@ -532,7 +613,7 @@ def test_code_gradients_match_the_reference_autograd_on_trained_weights(fit_nume
     scale = float(g["step_scale"])
     n_steps = int(np.ceil(1 / scale))
     assert int(n_steps * scale) == 1
-    step0 = F._CodeAdam.step
+    step0, launch0 = F._CodeAdam.step, F._PairAdam.launch
 
     def one_step(codes=None):
         grads = []
@@ -541,7 +622,13 @@ def test_code_gradients_match_the_reference_autograd_on_trained_weights(fit_nume
             if len(grads) < 2:
                 grads.append([p.grad.detach().clone() for grp in self.param_groups for p in grp["params"]][0])
             return step0(self, *a, **k)
+
+        def recording_launch(self, *a, **k):             # (the fused step: both optimizer steps in one launch inside the step)
+            if not grads:
+                grads.extend(p.grad.detach().clone() for p in self.params())
+            return launch0(self, *a, **k)
         monkeypatch.setattr(F._CodeAdam, "step", recording_step)
+        monkeypatch.setattr(F._PairAdam, "launch", recording_launch)
         torch.manual_seed(0)
         run = lambda: F.inference_iterative_root_finding_joint(shape_net, expr_net, obs, dict(LAMBDAS), n_steps,
                                                                {k: dict(v) for k, v in LONG_SCHEDULE.items()}, step_scale=scale,
@@ -552,6 +639,7 @@ def test_code_gradients_match_the_reference_autograd_on_trained_weights(fit_nume
             with U.start_codes(*codes):
                 run()
         monkeypatch.setattr(F._CodeAdam, "step", step0)
+        monkeypatch.setattr(F._PairAdam, "launch", launch0)
         assert len(grads) == 2
         return grads
 
