@@ -318,11 +318,12 @@ int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
  * 1..3 layers, widths <= 1536; hidden [n_rows, dims[1] + dims[2]] receives the post-ReLU activations the backward needs.
  * ABI 6: the input is the first dims[0] columns of rows x_stride floats apart (the global part of a latent row, no slice copy), g_x
  * has the same row stride and is written in full (zeros beyond dims[0]); y_add [out] or NULL is added to every output row (the mean
- * anchors). */
+ * anchors).  ABI 10: g_y_other [n_rows, out] or NULL is a second gradient of y (another use of the same output - the anchors feed
+ * the identity field AND the deformation field's compressor), added while loading instead of by an add launch. */
 int nphm_head_forward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* x,
                       int x_stride, const float* y_add, int n_rows, float* y, float* hidden, void* stream);
 int nphm_head_backward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* hidden,
-                       const float* g_y, int n_rows, float* g_x, int x_stride, void* stream);
+                       const float* g_y, const float* g_y_other, int n_rows, float* g_x, int x_stride, void* stream);
 /* (ABI 10) The conditioning rows of the forward-deformation field in 'compress' mode when ONE identity code serves every row
  * (deepSDF.py:212-223 with the latent of the fitting loops, fitting.py:83-85): cond [n_rows, out_dim + expr_dim] =
  * [compressor([code | anchors]) on every row | z_ex[b]] in one launch - the input row is read from its two parts (no cat), the
@@ -468,11 +469,14 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
  * out[:,:,0,:] = x + F(x), out[:,:,1+c,:] = d (x + F) / d x_c — the analytic form of
  * jac(decoder_expr, xc, ...) (src/NPHM/models/diff_operators.py:26-54: 1 forward + 3 autograd VJPs),
  * used twice per fitting step (iterative_root_finding.py:123, fitting.py:101).
- * out [n_rows, n_points, 4, out_dim]. */
+ * out [n_rows, n_points, 4, out_dim].  (ABI 10) jac_inverse [n_rows, n_points, 3, 3] or NULL: the inverse of the matrix
+ * M[i][c] = out[.., 1 + c, i] (i, c < 3; out_dim >= 3) - the `.inverse()` both callers apply to the Jacobian - written by the same
+ * launch (the adjugate formula of nphm_inverse3x3 on the values written to `out`). */
 int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                              const void* packed, const void* latent_state,
                              const float* xyz, int n_rows, int64_t n_points, int add_input,
-                             float* out, int numerics, int64_t point_base, int64_t point_count, int columns, void* stream);
+                             float* out, int numerics, int64_t point_base, int64_t point_count, int columns, float* jac_inverse,
+                             void* stream);
 
 /* Correspondence search of the fitting loop in ONE launch: Broyden root finding of
  * x + F(x) = obs per point (src/NPHM/models/iterative_root_finding.py:5-71 broyden as called by
@@ -517,11 +521,12 @@ int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int ou
                                 float* out, void* saved, int numerics, void* stream);
 /* nphm_mlp_eval_points_jvp that also leaves sigma' of the VALUE stream in `saved` (same layout and size as
  * nphm_mlp_eval_points_saving): posed points, their Jacobian and the state of the backward in one launch - what the
- * fitting step needs at the canonical correspondences (fitting.py:99-103). */
+ * fitting step needs at the canonical correspondences (fitting.py:99-103).  (ABI 10) jac_inverse: as nphm_mlp_eval_points_jvp. */
 int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                                     const void* packed, const void* latent_state,
                                     const float* xyz, int n_rows, int64_t n_points, int add_input,
-                                    float* out, void* saved, int numerics, int64_t point_base, int64_t point_count, int columns, void* stream);
+                                    float* out, void* saved, int numerics, int64_t point_base, int64_t point_count, int columns,
+                                    float* jac_inverse, void* stream);
 size_t nphm_mlp_bwd_packed_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim);
 int nphm_mlp_pack_bwd(int lat_dim, int hidden_dim, int nlayers, int out_dim, const float* const* lin_weight,
                       void* packed_bwd, void* stream);

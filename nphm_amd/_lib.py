@@ -35,7 +35,7 @@ SYMBOLS = {
                                              c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_prepare_latent_anchors": (c_int, [_PtrArr5, _PtrArr5, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nphm_head_forward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "nphm_head_backward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "nphm_head_backward": (c_int, [_PtrArr3, _PtrArr3, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "nphm_compress_condition": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nphm_compress_condition_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nphm_fit_loss": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -100,7 +100,7 @@ SYMBOLS = {
     "nphm_mlp_eval_points": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
                                                     c_void_p, c_void_p]),
     "nphm_mlp_eval_points_jvp": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
-                                                        c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
+                                                        c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "nphm_mlp_broyden": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                                 c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nphm_mlp_broyden_from": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -109,7 +109,7 @@ SYMBOLS = {
     "nphm_mlp_eval_points_saving": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                                            c_void_p, c_void_p, c_int, c_void_p]),
     "nphm_mlp_eval_points_jvp_saving": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
-                                                               c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
+                                                               c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "nphm_mlp_bwd_packed_bytes": (c_size_t, [c_int] * 4),
     "nphm_mlp_pack_bwd": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     "nphm_mlp_bwd_partial_bytes": (c_size_t, [c_int, c_int, c_int64]),

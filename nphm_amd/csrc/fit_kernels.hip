@@ -463,6 +463,7 @@ struct HeadArgs {
   float* y;                    // [rows, dims[n_layers]]
   float* hidden;               // [rows, dims[1] + dims[2]] post-ReLU activations (saved for the backward pass)
   const float* g_y;            // backward: [rows, out]
+  const float* g_y2;           // or null: a second gradient of the same output (another use of it), added while loading
   float* g_x;                  // backward: [rows, x_stride] - columns beyond dims[0] are written as zeros
   // the compressor inside a conditioning row (nphm_compress_condition): the input row is [x[0 .. x_split) | x2[0 .. dims[0] - x_split)]
   // (identity code | anchors: no cat launch), the ONE output row goes to the first `out` columns of y_rep rows of y (y_stride apart),
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadArgs a) {
       for (int b = 0; b < a.g_rows; ++b) v += a.g_y[size_t(b) * a.g_stride + i];       // (row order: deterministic)
       cur[i] = v;
     } else {
-      cur[i] = a.g_y[size_t(row) * dout_last + i];
+      cur[i] = a.g_y2 ? a.g_y[size_t(row) * dout_last + i] + a.g_y2[size_t(row) * dout_last + i] : a.g_y[size_t(row) * dout_last + i];
     }
   }
   __syncthreads();
@@ -695,12 +696,12 @@ int nphm_head_forward(const float* const weight[3], const float* const bias[3], 
 }
 
 int nphm_head_backward(const float* const weight[3], const float* const bias[3], const int dims[4], int n_layers, const float* hidden,
-                       const float* g_y, int n_rows, float* g_x, int x_stride, void* stream) {
+                       const float* g_y, const float* g_y_other, int n_rows, float* g_x, int x_stride, void* stream) {
   nphm::fit::HeadArgs a{};
   if (!g_y || !g_x || n_rows <= 0 || (n_layers > 1 && !hidden)) return nphm_fail_msg("nphm_head_backward: bad arguments");
   if (head_args(a, weight, bias, dims, n_layers, "nphm_head_backward: unsupported head (1..3 layers, widths <= 1536)")) return -2;
   if (x_stride < dims[0]) return nphm_fail_msg("nphm_head_backward: x_stride < input width");
-  a.hidden = const_cast<float*>(hidden); a.g_y = g_y; a.g_x = g_x; a.x_stride = x_stride;
+  a.hidden = const_cast<float*>(hidden); a.g_y = g_y; a.g_y2 = g_y_other; a.g_x = g_x; a.x_stride = x_stride;
   hipLaunchKernelGGL(nphm::fit::head_bwd_kernel, dim3(n_rows), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_head_backward launch", e);

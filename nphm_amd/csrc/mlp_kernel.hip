@@ -204,6 +204,7 @@ struct EvalArgs {
   const char* state;
   size_t state_row_bytes;
   float* out;             // [n_rows, n_points, out_dim]
+  float* jinv_out;        // value + Jacobian launches, or null: [n_rows, n_points, 3, 3] inverse of d (x + F)_i / d x_c (row i, column c)
   int out_dim;
   int add_input;          // out[..., c] += xyz[..., c] (c < 3): canonical / posed points
   int n_linear;
@@ -908,6 +909,36 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
           else p.out[(int64_t(row) * n_pts + i) * p.out_dim + c] = v;
         }
       }
+      if constexpr (JVP) {
+        // the inverse Jacobian of the posed points with it (iterative_root_finding.py:118, fitting.py:102 `.inverse()`): one thread
+        // per point, the adjugate formula of inverse3x3_kernel on the values written above - a launch of its own before
+        if (p.jinv_out) {
+          for (int m = threadIdx.x; m < PTS; m += blockDim.x) {
+            const int64_t i = base + m;
+            if (i < n_end) {
+              float a[9];
+#pragma unroll
+              for (int o = 0; o < 3; ++o)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                  float v = 0.f;
+#pragma unroll
+                  for (int w = 0; w < WAVES; ++w) v += partial[(w * M + (c + 1) * PTS + m) * 4 + o];
+                  v *= 1.f / SP_SCALE;
+                  if (p.add_input && o == c) v += 1.f;
+                  a[3 * o + c] = v;
+                }
+              const float c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+              const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+              const float r = 1.f / det;
+              float* q = p.jinv_out + (int64_t(row) * n_pts + i) * 9;
+              q[0] = c00 * r; q[1] = (a[2] * a[7] - a[1] * a[8]) * r; q[2] = (a[1] * a[5] - a[2] * a[4]) * r;
+              q[3] = c01 * r; q[4] = (a[0] * a[8] - a[2] * a[6]) * r; q[5] = (a[2] * a[3] - a[0] * a[5]) * r;
+              q[6] = c02 * r; q[7] = (a[1] * a[6] - a[0] * a[7]) * r; q[8] = (a[0] * a[4] - a[1] * a[3]) * r;
+            }
+          }
+        }
+      }
     }
   }
   }  // evaluation (skipped when the start residual is given)
@@ -1250,7 +1281,8 @@ int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int ou
 int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                                     const void* packed, const void* latent_state,
                                     const float* xyz, int n_rows, int64_t n_points, int add_input,
-                                    float* out, void* saved, int numerics, int64_t point_base, int64_t point_count, int columns, void* stream) {
+                                    float* out, void* saved, int numerics, int64_t point_base, int64_t point_count, int columns,
+                                    float* jac_inverse, void* stream) {
   Plan plan;
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: unsupported architecture");
   if (!packed || !latent_state || !xyz || !out || !saved) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: null pointer");
@@ -1265,6 +1297,8 @@ int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, in
   a.xyz = xyz;
   a.n_points = n_points;
   a.sig_out = static_cast<float*>(saved);
+  if (jac_inverse && out_dim < 3) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: the inverse Jacobian needs out_dim >= 3");
+  a.jinv_out = jac_inverse;
   if (!mlp_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_points_jvp_saving: unknown numerics format");
   a.point_base = point_base;
   a.point_end = point_count > 0 ? point_base + point_count : (point_base == 0 ? 0 : n_points);
@@ -1274,7 +1308,8 @@ int nphm_mlp_eval_points_jvp_saving(int lat_dim, int hidden_dim, int nlayers, in
 int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                              const void* packed, const void* latent_state,
                              const float* xyz, int n_rows, int64_t n_points, int add_input,
-                             float* out, int numerics, int64_t point_base, int64_t point_count, int columns, void* stream) {
+                             float* out, int numerics, int64_t point_base, int64_t point_count, int columns, float* jac_inverse,
+                             void* stream) {
   Plan plan;
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points_jvp: unsupported architecture");
   if (!packed || !latent_state || !xyz || !out) return nphm_fail_msg("nphm_mlp_eval_points_jvp: null pointer");
@@ -1288,6 +1323,8 @@ int nphm_mlp_eval_points_jvp(int lat_dim, int hidden_dim, int nlayers, int out_d
   a.add_input = add_input;
   a.xyz = xyz;
   a.n_points = n_points;
+  if (jac_inverse && out_dim < 3) return nphm_fail_msg("nphm_mlp_eval_points_jvp: the inverse Jacobian needs out_dim >= 3");
+  a.jinv_out = jac_inverse;
   if (!mlp_numerics_ok(numerics)) return nphm_fail_msg("nphm_mlp_eval_points_jvp: unknown numerics format");
   a.point_base = point_base;
   a.point_end = point_count > 0 ? point_base + point_count : (point_base == 0 ? 0 : n_points);

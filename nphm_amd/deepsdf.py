@@ -40,9 +40,10 @@ class _MlpCondFn(torch.autograd.Function):
     the skip layer, which the two latent blocks of those layers map onto the conditioning vector."""
 
     @staticmethod
-    def forward(ctx, module, xyz, cond_rows, add_input, with_jacobian=False):
+    def forward(ctx, module, xyz, cond_rows, add_input, with_jacobian=False, with_inverse=False):
         """-> [R,n,out] or, ``with_jacobian``, (value [R,n,out], [R,n,3,out] = d/dx | d/dy | d/dz as forward_hip_jvp; only
-        the value is differentiable)"""
+        the value is differentiable) - and, ``with_inverse``, the inverse [R,n,3,3] of the Jacobian of the first three
+        outputs (rows = outputs, columns = x, y, z) from the same launch"""
         lib = _lib.load()
         R, n, _ = xyz.shape
         dev = xyz.device
@@ -51,12 +52,16 @@ class _MlpCondFn(torch.autograd.Function):
         saved = torch.empty(lib.nphm_mlp_saved_bytes(*module._arch(), R, n), dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         code = module._fit_code(packed, state, xyz_c)
+        jinv = None
         if with_jacobian:
             out = torch.empty(R, n, 4, module.n_out, dtype=torch.float32, device=dev)
+            if with_inverse:
+                jinv = torch.empty(R, n, 3, 3, dtype=torch.float32, device=dev)
             for p0, cnt, cols in module._jvp_split(R, n, dev, 64):
                 _lib.check(lib.nphm_mlp_eval_points_jvp_saving(*module._arch(), packed.data_ptr(), state.data_ptr(),
                                                                xyz_c.data_ptr(), R, n, int(bool(add_input)), out.data_ptr(),
-                                                               saved.data_ptr(), code, p0, cnt, cols, stream),
+                                                               saved.data_ptr(), code, p0, cnt, cols,
+                                                               None if jinv is None else jinv.data_ptr(), stream),
                            "nphm_mlp_eval_points_jvp_saving")
         else:
             out = torch.empty(R, n, module.n_out, dtype=torch.float32, device=dev)
@@ -71,15 +76,18 @@ class _MlpCondFn(torch.autograd.Function):
         # as its own tensor - a single output would receive zeros [R,n,4,out] + a slice copy from autograd, and the
         # backward below would copy the slice out again
         jac = out[:, :, 1:]
-        ctx.mark_non_differentiable(jac)
         ctx.set_materialize_grads(False)       # (no zeros [R,n,3,out] + fill launch for the Jacobian's absent gradient)
+        if jinv is not None:
+            ctx.mark_non_differentiable(jac, jinv)
+            return out[:, :, 0], jac, jinv
+        ctx.mark_non_differentiable(jac)
         return out[:, :, 0], jac
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_out, _grad_jac=None):
+    def backward(ctx, grad_out, _grad_jac=None, _grad_jinv=None):
         if grad_out is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         lib = _lib.load()
         module = ctx.module
         (saved,) = ctx.saved_tensors
@@ -107,7 +115,7 @@ class _MlpCondFn(torch.autograd.Function):
         else:
             gb0, gbs = parts.view(R, -1, 2, H).sum(dim=1).unbind(1)
             grad_cond = gb0 @ W0[:, d:] + (gbs @ Ws[:, k_act + d:]) / _SQRT2
-        return None, None, grad_cond, None, None
+        return None, None, grad_cond, None, None, None
 
 
 class DeepSDF(nn.Module):
@@ -477,7 +485,7 @@ class DeepSDF(nn.Module):
         out = torch.empty(B, N, 4, self.n_out, dtype=torch.float32, device=xyz.device)
         stream = torch.cuda.current_stream(xyz.device).cuda_stream
         _lib.check(lib.nphm_mlp_eval_points_jvp(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(), B, N, 0,
-                                                out.data_ptr(), int(code), 0, 0, 64, stream), "nphm_mlp_eval_points_jvp")
+                                                out.data_ptr(), int(code), 0, 0, 64, None, stream), "nphm_mlp_eval_points_jvp")
         return out
 
     def _fit_err(self, packed, state, sample):
@@ -565,22 +573,25 @@ class DeepSDF(nn.Module):
         code = self._numerics_code(packed, state, B * N, sample) if B == 1 else self._format_code()
         return self._eval_points_raw(packed, state, xyz, add_input, code)
 
-    def forward_hip_jvp(self, xyz, cond_rows, add_input=False):
+    def forward_hip_jvp(self, xyz, cond_rows, add_input=False, inverse=False):
         """Value and spatial Jacobian in one fused launch (forward-mode tangents carried through the
         same GEMMs): xyz [B,N,3], cond_rows [B,lat_dim] -> [B,N,4,out_dim] with [:,:,0] = f(x)
-        (+ x if ``add_input``) and [:,:,1+c,i] = d f_i / d x_c (+ identity if ``add_input``)."""
+        (+ x if ``add_input``) and [:,:,1+c,i] = d f_i / d x_c (+ identity if ``add_input``).  ``inverse``: -> (that, the
+        inverse [B,N,3,3] of the Jacobian of the first three outputs - rows = outputs, columns = x, y, z) from the same launch."""
         lib = _lib.load()
         B, N, _ = xyz.shape
         packed, state = self.prepare_latent(cond_rows)
         xyz = xyz.contiguous().float()
         out = torch.empty(B, N, 4, self.n_out, dtype=torch.float32, device=xyz.device)
+        jinv = torch.empty(B, N, 3, 3, dtype=torch.float32, device=xyz.device) if inverse else None
         stream = torch.cuda.current_stream(xyz.device).cuda_stream
         code = self._fit_code(packed, state, xyz)
         for p0, cnt, cols in self._jvp_split(B, N, xyz.device, 16):
             _lib.check(lib.nphm_mlp_eval_points_jvp(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(),
-                                                    B, N, int(bool(add_input)), out.data_ptr(), code, p0, cnt, cols, stream),
-                   "nphm_mlp_eval_points_jvp")
-        return out
+                                                    B, N, int(bool(add_input)), out.data_ptr(), code, p0, cnt, cols,
+                                                    None if jinv is None else jinv.data_ptr(), stream),
+                       "nphm_mlp_eval_points_jvp")
+        return (out, jinv) if inverse else out
 
     def broyden_hip(self, obs, x_init, jinv_init, cond_rows, max_steps, cvg_thresh, dvg_thresh, eps=1e-6, posed_init=None):
         """Roots of x + f(x) = obs by Broyden's method, fused around the network in one launch
@@ -870,7 +881,7 @@ class DeformationNetwork(nn.Module):
     def backend(self, value):
         self.defDeepSDF.backend = value
 
-    def jacobian(self, xyz, lat_rep, anchors):
+    def jacobian(self, xyz, lat_rep, anchors, inverse=False):
         """Posed points x + F_ex(x) [B,N,3] and the Jacobian d (x + F_ex) / d x [B,N,3,3]
         ([..., i, c] = d posed_i / d x_c — the layout of diff_operators.jac) in ONE fused launch
         instead of one forward + three autograd VJPs.  Detached results; returns None when the HIP
@@ -886,10 +897,17 @@ class DeformationNetwork(nn.Module):
             plan = self.defDeepSDF._hip_rows(x, cond)
             if plan is None:
                 return None
-            out = self.defDeepSDF.forward_hip_jvp(*plan, add_input=True).reshape(x.shape[0], x.shape[1], 4, -1)
+            out = self.defDeepSDF.forward_hip_jvp(*plan, add_input=True, inverse=inverse)
+            jinv = None
+            if inverse:
+                out, jinv = out
+                jinv = jinv.reshape(x.shape[0], x.shape[1], 3, 3)
+            out = out.reshape(x.shape[0], x.shape[1], 4, -1)
+        if inverse:                        # (the inverse of the returned Jacobian, from the same launch)
+            return out[:, :, 0, :3], out[:, :, 1:, :3].transpose(-1, -2), jinv
         return out[:, :, 0, :3], out[:, :, 1:, :3].transpose(-1, -2)
 
-    def posed_and_jacobian(self, xyz, lat_rep, anchors):
+    def posed_and_jacobian(self, xyz, lat_rep, anchors, inverse=False):
         """(x + F_ex(x) [B,N,3] differentiable w.r.t. the conditioning, d (x + F_ex) / d x [B,N,3,3] detached) in ONE
         launch - ``forward`` + ``jacobian`` at the same points, as the fitting step needs them at the canonical
         correspondences (fitting.py:99-103).  None when the HIP autograd tier cannot serve the call (see ``forward``)."""
@@ -903,11 +921,18 @@ class DeformationNetwork(nn.Module):
         plan = self.defDeepSDF._hip_rows(xyz, cond, cond_grad_ok=True)
         if plan is None:
             return None
-        val, jac = _MlpCondFn.apply(self.defDeepSDF, plan[0], plan[1], True, True)
         B, N = xyz.shape[0], xyz.shape[1]
+        jinv = None
+        if inverse:
+            val, jac, jinv = _MlpCondFn.apply(self.defDeepSDF, plan[0], plan[1], True, True, True)
+            jinv = jinv.reshape(B, N, 3, 3)
+        else:
+            val, jac = _MlpCondFn.apply(self.defDeepSDF, plan[0], plan[1], True, True)
         val, jac = val.reshape(B, N, -1), jac.reshape(B, N, 3, -1)
         if val.shape[-1] != 3:             # (a full-range slice would still cost a zero-fill + copy in the backward pass)
             val, jac = val[..., :3], jac[..., :3]
+        if inverse:                        # (+ the inverse of that Jacobian, from the same launch)
+            return val, jac.transpose(-1, -2).detach(), jinv
         return val, jac.transpose(-1, -2).detach()
 
     def broyden(self, obs, x_init, jinv_init, lat_rep, anchors, max_steps=15, cvg_thresh=1e-6, dvg_thresh=0.2,

@@ -297,9 +297,11 @@ class _FrozenHeadFn(torch.autograd.Function):
     (``nphm_head_forward / _backward``) - the PyTorch formulation is a GEMM + bias + ReLU launch per layer and direction."""
 
     @staticmethod
-    def forward(ctx, x, n_layers, y_add, *wb):
+    def forward(ctx, x, n_layers, y_add, twice, *wb):
         """x [rows, >= in_features]: the head reads the first in_features columns of every row (a latent row goes in whole -
-        no slice, whose backward would be a zero-fill plus a copy); y_add [out] or None is added to every output row"""
+        no slice, whose backward would be a zero-fill plus a copy); y_add [out] or None is added to every output row.
+        ``twice``: -> (y, an alias of y) for an output with two uses - their gradients meet in the backward launch instead of
+        in an add launch of autograd's"""
         lib = _lib.load()
         ws, bs = list(wb[0::2]), list(wb[1::2])
         rows = x.shape[0]
@@ -316,25 +318,33 @@ class _FrozenHeadFn(torch.autograd.Function):
                    "nphm_head_forward")
         ctx.save_for_backward(hidden, *[t.detach() for t in wb])
         ctx.meta = (n_layers, dims, xc.shape[1])
+        if twice:
+            ctx.set_materialize_grads(False)
+            return y, y.detach()
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_y):
+    def backward(ctx, g_y, g_y2=None):
         lib = _lib.load()
         hidden, *wb = ctx.saved_tensors
         n_layers, dims, width = ctx.meta
         ws, bs = list(wb[0::2]), list(wb[1::2])
+        if g_y is None:
+            g_y, g_y2 = g_y2, None
+        if g_y is None:
+            return (None,) * (4 + len(wb))
         g = g_y.contiguous().float()
+        g2 = None if g_y2 is None else g_y2.contiguous().float()
         rows = g.shape[0]
         g_x = torch.empty(rows, width, dtype=torch.float32, device=g.device)        # written in full: zeros beyond the input columns
         import ctypes
         cdims = (ctypes.c_int * 4)(*(dims + [0] * (4 - len(dims))))
         pad = lambda ts: _lib.ptr_array3(list(ts) + [ts[0]] * (3 - len(ts)))
         stream = torch.cuda.current_stream(g.device).cuda_stream
-        _lib.check(lib.nphm_head_backward(pad(ws), pad(bs), cdims, n_layers, hidden.data_ptr(), g.data_ptr(), rows, g_x.data_ptr(), width,
-                                          stream), "nphm_head_backward")
-        return (g_x, None, None) + (None,) * len(wb)
+        _lib.check(lib.nphm_head_backward(pad(ws), pad(bs), cdims, n_layers, hidden.data_ptr(), g.data_ptr(),
+                                          None if g2 is None else g2.data_ptr(), rows, g_x.data_ptr(), width, stream), "nphm_head_backward")
+        return (g_x, None, None, None) + (None,) * len(wb)
 
 
 def _row0(lat_rep):
@@ -343,10 +353,11 @@ def _row0(lat_rep):
     return lat_rep.reshape(lat_rep.shape[0], lat_rep.shape[2]) if lat_rep.shape[1] == 1 else lat_rep[:, 0, :]
 
 
-def frozen_head(seq, x, frozen: bool, add=None):
+def frozen_head(seq, x, frozen: bool, add=None, twice=False):
     """``seq(x[:, :in_features]) (+ add)`` for an nn.Sequential of Linear (+ ReLU between) layers; on a ROCm device, with
     parameters that do not require grad (or ``frozen``), fp32 rows and <= 3 linear layers of width <= 1536 through the fused
-    kernels.  ``x`` may be wider than the head's input (a whole latent row); ``add`` [out_features] is a constant."""
+    kernels.  ``x`` may be wider than the head's input (a whole latent row); ``add`` [out_features] is a constant.
+    ``twice``: -> (y, y2) with y2 an alias of y for its second use (fused path; else the same tensor twice)."""
     lins = [m for m in seq if isinstance(m, nn.Linear)]
     others = [m for m in seq if not isinstance(m, nn.Linear)]
     ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= len(lins) <= 3 and len(others) == len(lins) - 1
@@ -357,11 +368,12 @@ def frozen_head(seq, x, frozen: bool, add=None):
           and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", ""))
     if not ok:
         y = seq(x[:, :lins[0].in_features] if x.shape[1] != lins[0].in_features else x)
-        return y if add is None else y + add.reshape(1, -1).to(y)
+        y = y if add is None else y + add.reshape(1, -1).to(y)
+        return (y, y) if twice else y
     wb = [t for l in lins for t in (l.weight, l.bias)]
     if add is not None:
         add = add.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
-    return _FrozenHeadFn.apply(x, len(lins), add, *wb)
+    return _FrozenHeadFn.apply(x, len(lins), add, bool(twice), *wb)
 
 
 class _IdentityFieldFn(torch.autograd.Function):
@@ -1225,14 +1237,18 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             key = (lat_rows.data_ptr(), lat_rows._version, lat_rows.shape[1], str(lat_rows.device))
             hit = scope.get(key)
             if hit is not None and (hit[0].shape[0] == B or (hit[0].shape[0] == 1 and (B == 1 or lat_rows.stride(0) == 0))):
-                return hit[0] if hit[0].shape[0] == B else hit[0].expand(B, -1, -1)
+                a2 = hit[2]                                  # the alias for the later uses (their gradients meet in the head's backward launch)
+                return a2 if a2.shape[0] == B else a2.expand(B, -1, -1)
             if B > 1 and lat_rows.stride(0) == 0:
                 lat_rows = lat_rows[:1]                      # identical rows (an expanded code): evaluate one
         frozen = self.assume_frozen_parameters
         # the head reads the global part of the whole row and adds the mean anchors itself (no slice / add launches)
-        a = frozen_head(self.mlp_pos, lat_rows, frozen, add=self.anchors).view(lat_rows.shape[0], self.num_kps, 3)
         if key is not None:
-            scope[key] = (a, lat_rows)
+            a, a2 = frozen_head(self.mlp_pos, lat_rows, frozen, add=self.anchors, twice=True)
+            a, a2 = a.view(lat_rows.shape[0], self.num_kps, 3), a2.view(lat_rows.shape[0], self.num_kps, 3)
+            scope[key] = (a, lat_rows, a2)
+        else:
+            a = frozen_head(self.mlp_pos, lat_rows, frozen, add=self.anchors).view(lat_rows.shape[0], self.num_kps, 3)
         return a if a.shape[0] == B else a.expand(B, -1, -1)
 
     from contextlib import contextmanager as _cm

@@ -760,14 +760,14 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         valid = search_result["valid_ids"]
 
         # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
-        pj = decoder_expr.posed_and_jacobian(p_corresp, glob_cond, anchors_b) if hasattr(decoder_expr, "posed_and_jacobian") else None
-        if pj is not None:                 # posed points, Jacobian and the state of the backward in one launch
-            preds_posed, jac_posed = pj
+        pj = decoder_expr.posed_and_jacobian(p_corresp, glob_cond, anchors_b, inverse=True) if hasattr(decoder_expr, "posed_and_jacobian") else None
+        if pj is not None:                 # posed points, Jacobian, its inverse and the state of the backward in one launch
+            preds_posed, jac_posed, grad_inv = pj
         else:
             preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
             preds_posed = preds_posed + p_corresp
             jac_posed = jac(decoder_expr, p_corresp, glob_cond, anchors_b)
-        grad_inv = _inverse3x3(jac_posed.detach())
+            grad_inv = _inverse3x3(jac_posed.detach())
         if pj is not None:
             xc = _ImplicitRootFn.apply(p_corresp, preds_posed, grad_inv)
         else:

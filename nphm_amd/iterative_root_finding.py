@@ -85,12 +85,13 @@ def search(obs, cond, decoder_expr, anchors, multi_corresp=True):
     # the reference: jac(...) then `.inverse()` (:118).  The fused value+Jacobian launch also yields x_init + F(x_init),
     # i.e. the residual of the solver's iteration 0: handed to the fused solver, which then skips that evaluation
     posed_init = None
-    fused = decoder_expr.jacobian(xc_init, cond, anchors) if hasattr(decoder_expr, "jacobian") else None
+    fused = decoder_expr.jacobian(xc_init, cond, anchors, inverse=True) if hasattr(decoder_expr, "jacobian") else None
     if fused is not None:
-        posed_init, J0 = fused
+        posed_init, J0, J_inv_init = fused               # (the inverse from the same launch)
+        J_inv_init = J_inv_init.flatten(0, 1)
     else:
         J0 = jac(decoder_expr, xc_init, cond, anchors).detach()
-    J_inv_init = inverse3x3(J0.detach()).flatten(0, 1)
+        J_inv_init = inverse3x3(J0.detach()).flatten(0, 1)
     x0 = xc_init.reshape(-1, 3, 1)
     # conditioning may come as one row per batch entry (cond [B,1,L], anchors [B,K,3]: what the mirrored fitting
     # loop passes); the python solver below wants the reference's per-point tensors

@@ -452,6 +452,16 @@ def test_frozen_heads_match_the_linear_layers():
         seed = torch.randn(yb.shape, generator=g).to(dev)
         (ga,), (gb,) = torch.autograd.grad(ya, a, seed), torch.autograd.grad(yb, b, seed)
         assert float((ga - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
+        # an output with two uses: two aliases, whose gradients meet in the backward launch
+        c = x0.clone().requires_grad_()
+        y1, y2 = frozen_head(seq, c, False, twice=True)
+        assert y1.data_ptr() == y2.data_ptr() and torch.equal(y1, ya)
+        seed2 = torch.randn(yb.shape, generator=g).to(dev)
+        (gc,) = torch.autograd.grad((y1 * seed).sum() + (y2 * seed2).sum(), c)
+        (gd,) = torch.autograd.grad(seq(b), b, seed + seed2)
+        assert float((gc - gd).abs().max()) < 1e-5 * max(1.0, float(gd.abs().max()))
+        (ge,) = torch.autograd.grad((frozen_head(seq, c, False, twice=True)[1] * seed).sum(), c)       # only the alias used
+        assert float((ge - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
     lat = torch.zeros(1, 1, 1344, device=dev, requires_grad=True)
     with net.anchor_scope():
         a1 = net.predict_anchors(lat)

@@ -292,6 +292,12 @@ def test_fused_jacobian_matches_autograd(dnet, npm, dev):
     x = _t(xyz, dev)
     posed, J = dnet.jacobian(x, _t(lat, dev), _t(anc, dev))
     assert posed.shape == (S, n, 3) and J.shape == (S, n, 3, 3) and not J.requires_grad
+    # the inverse from the same launch (ABI 10): the separate inverse3x3 launch on that Jacobian, up to the contraction of
+    # the adjugate's products into FMAs
+    posed_i, J_i, J_inv = dnet.jacobian(x, _t(lat, dev), _t(anc, dev), inverse=True)
+    assert torch.equal(posed_i, posed) and torch.equal(J_i, J) and J_inv.shape == (S, n, 3, 3)
+    assert float((J_inv - D.inverse3x3(J)).abs().max()) < 1e-6
+    assert float((J_inv @ J - torch.eye(3, device=dev)).abs().max()) < 1e-5
     with torch.no_grad():
         off, _ = dnet(x, _t(lat, dev), _t(anc, dev))
     assert U.maxdiff((x + off).cpu().numpy(), posed.cpu().numpy()) < 1e-6
