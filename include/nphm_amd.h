@@ -513,7 +513,9 @@ int nphm_mlp_broyden_from(int lat_dim, int hidden_dim, int nlayers, int out_dim,
  *     layer as per-slot sums bias_partials [n_rows][ceil(n_points / 32)][2][hidden_dim] (nphm_mlp_bwd_partial_bytes; ABI 8:
  *     every slot is WRITTEN - no zero fill, no atomics); their sums over the slots of a row, g0 and gs, map onto the
  *     conditioning as d L / d cond = g0 W0[:, 3:] + gs W_skip[:, K+3:] / sqrt(2) (nphm_mlp_cond_grad adds the slots in
- *     order: bitwise reproducible). */
+ *     order: bitwise reproducible).  (ABI 10) root_jac_inverse [n_rows, n_points, 3, 3] or NULL: grad_out is then the gradient of
+ *     the implicit root x_c = root - J^-1 (F(root) - F(root).detach()) (fitting.py:99-106) and the kernel applies -J^-T to it while
+ *     loading (out_dim = 3) - nphm_fit_root_backward's launch, folded in. */
 size_t nphm_mlp_saved_bytes(int lat_dim, int hidden_dim, int nlayers, int out_dim, int n_rows, int64_t n_points);
 int nphm_mlp_eval_points_saving(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                                 const void* packed, const void* latent_state,
@@ -532,7 +534,7 @@ int nphm_mlp_pack_bwd(int lat_dim, int hidden_dim, int nlayers, int out_dim, con
                       void* packed_bwd, void* stream);
 size_t nphm_mlp_bwd_partial_bytes(int hidden_dim, int n_rows, int64_t n_points);
 int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim, const void* packed_bwd,
-                           const void* saved, const float* grad_out, int n_rows, int64_t n_points,
+                           const void* saved, const float* grad_out, const float* root_jac_inverse, int n_rows, int64_t n_points,
                            void* bias_partials, void* stream);
 
 /* Batched inverse of n row-major 3x3 matrices (adjugate formula, one thread each): the `.inverse()` calls on

@@ -113,7 +113,7 @@ SYMBOLS = {
     "nphm_mlp_bwd_packed_bytes": (c_size_t, [c_int] * 4),
     "nphm_mlp_pack_bwd": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     "nphm_mlp_bwd_partial_bytes": (c_size_t, [c_int, c_int, c_int64]),
-    "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "nphm_mlp_backward_cond": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "nphm_inverse3x3": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nphm_train_loss_blocks": (c_int, []),
     "nphm_train_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,

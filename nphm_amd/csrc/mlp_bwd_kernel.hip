@@ -125,6 +125,8 @@ struct Args {
   const char* packed_bwd;
   const float* saved;          // sigma' dumps of the forward (EvalArgs::sig_out)
   const float* gout;           // [n_rows, n_points, out_dim]  d L / d output
+  const float* jinv;           // or null: [n_rows, n_points, 3, 3] - gout is the gradient of the implicit root x_c = root - J^-1 (F - F.detach())
+                               // (fitting.py:99-106), d L / d output = -J^-T gout (out_dim = 3): applied while loading (a launch of its own before)
   int out_dim;
   int64_t n_points;
   int n_stage;
@@ -273,6 +275,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_bwd_kernel(Args p) {
         const float* q = p.gout + (int64_t(row) * p.n_points + i) * p.out_dim;
 #pragma unroll
         for (int c = 0; c < 3; ++c) g[c] = c < p.out_dim ? q[c] : 0.f;
+        if (p.jinv) {
+          const float* J = p.jinv + (int64_t(row) * p.n_points + i) * 9;
+          const float gx = g[0], gy = g[1], gz = g[2];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) g[c] = -(J[c] * gx + J[3 + c] * gy + J[6 + c] * gz);
+        }
       }
       bv[t] = grad_operand(g[0], g[1], g[2], h);
     }
@@ -412,7 +420,7 @@ size_t nphm_mlp_bwd_partial_bytes(int hidden_dim, int n_rows, int64_t n_points) 
 }
 
 int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim, const void* packed_bwd,
-                           const void* saved, const float* grad_out, int n_rows, int64_t n_points,
+                           const void* saved, const float* grad_out, const float* root_jac_inverse, int n_rows, int64_t n_points,
                            void* bias_partials, void* stream) {
   Plan plan;
   nphm::mlp::bwd::BwdPlan b;
@@ -425,6 +433,8 @@ int nphm_mlp_backward_cond(int lat_dim, int hidden_dim, int nlayers, int out_dim
   a.packed_bwd = static_cast<const char*>(packed_bwd);
   a.saved = static_cast<const float*>(saved);
   a.gout = grad_out;
+  if (root_jac_inverse && out_dim != 3) return nphm_fail_msg("nphm_mlp_backward_cond: the implicit-root gradient needs out_dim = 3");
+  a.jinv = root_jac_inverse;
   a.out_dim = out_dim;
   a.n_points = n_points;
   a.n_stage = b.n_stage;

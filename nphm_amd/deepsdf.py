@@ -40,10 +40,13 @@ class _MlpCondFn(torch.autograd.Function):
     the skip layer, which the two latent blocks of those layers map onto the conditioning vector."""
 
     @staticmethod
-    def forward(ctx, module, xyz, cond_rows, add_input, with_jacobian=False, with_inverse=False):
+    def forward(ctx, module, xyz, cond_rows, add_input, with_jacobian=False, with_inverse=False, implicit_root=False):
         """-> [R,n,out] or, ``with_jacobian``, (value [R,n,out], [R,n,3,out] = d/dx | d/dy | d/dz as forward_hip_jvp; only
         the value is differentiable) - and, ``with_inverse``, the inverse [R,n,3,3] of the Jacobian of the first three
-        outputs (rows = outputs, columns = x, y, z) from the same launch"""
+        outputs (rows = outputs, columns = x, y, z) from the same launch.
+        ``implicit_root`` (with ``add_input``, jacobian and inverse; out_dim 3): ``xyz`` are roots of x + F(x; cond) = obs and
+        the FIRST output is  x_c = xyz - J^-1 (F - F.detach())  (fitting.py:99-106): the roots themselves, whose gradient
+        reaches the conditioning through -J^-T - applied by the backward kernel while it loads the gradient"""
         lib = _lib.load()
         R, n, _ = xyz.shape
         dev = xyz.device
@@ -69,6 +72,15 @@ class _MlpCondFn(torch.autograd.Function):
                                                        R, n, int(bool(add_input)), out.data_ptr(), saved.data_ptr(), code, stream),
                        "nphm_mlp_eval_points_saving")
         ctx.module, ctx.shape, ctx.with_jacobian = module, (R, n), bool(with_jacobian)
+        ctx.root = bool(implicit_root)
+        if ctx.root:
+            assert jinv is not None and add_input and module.n_out == 3, "implicit root: value + Jacobian + inverse of a 3-vector field"
+            ctx.save_for_backward(saved, jinv)
+            ctx.set_materialize_grads(False)
+            jac = out[:, :, 1:]
+            root = xyz_c.view(R, n, 3).detach()
+            ctx.mark_non_differentiable(jac, jinv)
+            return root, jac, jinv
         ctx.save_for_backward(saved)
         if not with_jacobian:
             return out
@@ -87,10 +99,11 @@ class _MlpCondFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out, _grad_jac=None, _grad_jinv=None):
         if grad_out is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         lib = _lib.load()
         module = ctx.module
-        (saved,) = ctx.saved_tensors
+        saved, *rest = ctx.saved_tensors
+        root_jinv = rest[0] if ctx.root else None
         R, n = ctx.shape
         dev = grad_out.device
         H = module.hidden_dim
@@ -99,7 +112,8 @@ class _MlpCondFn(torch.autograd.Function):
         g = grad_out.detach().contiguous().float()
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.nphm_mlp_backward_cond(*module._arch(), module._packed_bwd(dev).data_ptr(), saved.data_ptr(),
-                                              g.data_ptr(), R, n, parts.data_ptr(), stream), "nphm_mlp_backward_cond")
+                                              g.data_ptr(), None if root_jinv is None else root_jinv.data_ptr(), R, n, parts.data_ptr(), stream),
+                   "nphm_mlp_backward_cond")
         d = module.input_dim
         skip = module.skip_in[0]
         W0 = module.lin0.weight                                   # [H, d + lat]
@@ -115,7 +129,7 @@ class _MlpCondFn(torch.autograd.Function):
         else:
             gb0, gbs = parts.view(R, -1, 2, H).sum(dim=1).unbind(1)
             grad_cond = gb0 @ W0[:, d:] + (gbs @ Ws[:, k_act + d:]) / _SQRT2
-        return None, None, grad_cond, None, None, None
+        return None, None, grad_cond, None, None, None, None
 
 
 class DeepSDF(nn.Module):
@@ -934,6 +948,24 @@ class DeformationNetwork(nn.Module):
         if inverse:                        # (+ the inverse of that Jacobian, from the same launch)
             return val, jac.transpose(-1, -2).detach(), jinv
         return val, jac.transpose(-1, -2).detach()
+
+    def implicit_root(self, roots, lat_rep, anchors):
+        """x_c = roots - J^-1 (F(roots) - F(roots).detach()) with F = x + F_ex(x; z) (fitting.py:99-106): the detached roots
+        of the correspondence search, made differentiable w.r.t. the conditioning by the implicit function theorem - value,
+        Jacobian, its inverse and the state of the backward in ONE launch, and the -J^-T of the gradient inside the backward
+        kernel.  [B,N,3], or None when the HIP autograd tier cannot serve the call (see ``posed_and_jacobian``)."""
+        if roots.dim() < 3:
+            roots = roots.unsqueeze(0)
+        if self.backend == "composite" or not roots.is_cuda or self.defDeepSDF.n_out != 3 or roots.requires_grad:
+            return None
+        cond = self._condition(roots, lat_rep, anchors)
+        if not (torch.is_grad_enabled() and cond.requires_grad) or any(p.requires_grad for p in self.parameters()):
+            return None
+        plan = self.defDeepSDF._hip_rows(roots, cond, cond_grad_ok=True)
+        if plan is None:
+            return None
+        xc, _, _ = _MlpCondFn.apply(self.defDeepSDF, plan[0], plan[1], True, True, True, True)
+        return xc.reshape(roots.shape)
 
     def broyden(self, obs, x_init, jinv_init, lat_rep, anchors, max_steps=15, cvg_thresh=1e-6, dvg_thresh=0.2,
                 eps=1e-6, posed_init=None):

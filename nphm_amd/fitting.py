@@ -760,17 +760,20 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         valid = search_result["valid_ids"]
 
         # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
-        pj = decoder_expr.posed_and_jacobian(p_corresp, glob_cond, anchors_b, inverse=True) if hasattr(decoder_expr, "posed_and_jacobian") else None
-        if pj is not None:                 # posed points, Jacobian, its inverse and the state of the backward in one launch
+        xc = decoder_expr.implicit_root(p_corresp, glob_cond, anchors_b) if hasattr(decoder_expr, "implicit_root") else None
+        pj = None
+        if xc is None and hasattr(decoder_expr, "posed_and_jacobian"):
+            pj = decoder_expr.posed_and_jacobian(p_corresp, glob_cond, anchors_b, inverse=True)
+        if xc is not None:                 # posed points, Jacobian, its inverse, the state of the backward: one launch; -J^-T in the backward launch
+            pass
+        elif pj is not None:               # (the same with the implicit function's backward as a launch of its own)
             preds_posed, jac_posed, grad_inv = pj
+            xc = _ImplicitRootFn.apply(p_corresp, preds_posed, grad_inv)
         else:
             preds_posed, _ = decoder_expr(p_corresp, glob_cond, anchors_b)
             preds_posed = preds_posed + p_corresp
             jac_posed = jac(decoder_expr, p_corresp, glob_cond, anchors_b)
             grad_inv = _inverse3x3(jac_posed.detach())
-        if pj is not None:
-            xc = _ImplicitRootFn.apply(p_corresp, preds_posed, grad_inv)
-        else:
             correction = preds_posed - preds_posed.detach()
             # 3x3 matrix-vector products per point, elementwise: as an einsum this is a rocBLAS batched GEMM of 5000 3x3
             # problems (69 us forward + 40 us backward per step)

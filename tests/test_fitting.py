@@ -189,10 +189,13 @@ def test_long_horizon_hip_tier_against_the_reference_arithmetic_on_this_gpu():
     print("HIP tier vs reference CPU trace:", hip)
     # (measured on MI355X, composite / HIP: surface_rel_max 1.9e-2 / 2.0e-2, first 50 steps 2.2e-4 / 1.2e-3 - the two-term
     # layers of the expression decoder's launches, 2.8e-4 with fit_numerics "f16x3" - end of fit 3.1e-3 / 2.1e-3, fitted
-    # identity code max 1.8e-3 / 2.0e-3, median 1.9e-5 / 4.2e-5, expression codes 4.5e-4 / 8.6e-4)
+    # identity code max 1.8e-3 / 2.0e-3, median 1.9e-5 / 4.2e-5, expression codes 4.5e-4 / 8.6e-4.  After the 28-launch step
+    # of round 5 - other summation orders of the code gradients on BOTH tiers, nothing else: 1.9e-2 / 1.4e-2, first 50 steps
+    # 2.3e-4 / 1.0e-4, end of fit 2.9e-3 / 8.5e-4, identity code max 2.5e-3 / 1.8e-3, expression codes 3.6e-4 / 9.3e-4: the
+    # largest of 600 expression-code components moves by 1e-4 when a sum is reassociated - that measure's resolution is 5e-4)
     floor = {"valid_mismatch_steps": 0, "surface_rel_max": 2e-3, "surface_rel_first50": 1e-3, "surface_abs_max": 5e-6,
              "final_surface_rel": 1e-3, "lat_shape_median": 2e-5, "lat_shape_q90": 2e-4, "lat_shape_max": 1e-3,
-             "lat_expr_max": 2e-4, "anchors_max": 5e-5}
+             "lat_expr_max": 5e-4, "anchors_max": 5e-5}
     for k, v in hip.items():
         assert v <= 2.0 * comp[k] + floor[k], (k, v, comp[k])
 

@@ -534,6 +534,16 @@ def test_posed_and_jacobian_in_one_launch(dev, n):
     net.backend = "hip"
     scale = float(lat_c.grad.abs().max())
     assert float((lat.grad - lat_c.grad).abs().max()) < 2e-5 * scale + 1e-9
+    # the implicit root x_c = x - J^-1 (F - F.detach()) in the same launch, -J^-T inside the backward launch (ABI 10): the values
+    # are the points, the conditioning gradient is that of the two-piece form (posed_and_jacobian + the root's own backward)
+    from nphm_amd import fitting as F
+    lat_a, lat_b = lat0.clone().requires_grad_(True), lat0.clone().requires_grad_(True)
+    xc = net.implicit_root(xyz, lat_a, anc)
+    assert xc is not None and torch.equal(xc.detach(), xyz) and xc.requires_grad
+    (xc * cot).sum().backward()
+    posed_b, _, jinv_b = net.posed_and_jacobian(xyz, lat_b, anc, inverse=True)
+    (F._ImplicitRootFn.apply(xyz, posed_b, jinv_b) * cot).sum().backward()
+    assert float((lat_a.grad - lat_b.grad).abs().max()) < 1e-6 * float(lat_b.grad.abs().max()) + 1e-12
 
 
 # ---- round 4: operand format and two-term layers of the plain evaluation (include/nphm_amd.h NPHM_MLP_*) ------------------
