@@ -257,6 +257,12 @@ size_t nphm_identity_train_edge_bytes(int n_tiles);
  * [n_sets + 1], pair_first [pairs + 1]; sizes[4] = forward tiles, backward tiles, chunks, tiles per piece. */
 int nphm_identity_train_tables(const long long* counts, int n_rows, const int* member_set, int n_sets, int ring_tiles, int chunk_tiles,
                                int* tiles_fwd, int* tiles_bwd, int* chunks, int* set_chunk_first, int* pair_first, int* sizes);
+/* (ABI 10) The counts and the point list themselves, on the device, from blend_weights [n_rows, n_points, 40] (a pair lists the
+ * points whose weight is > 0, nphm_identity_build_lists with NULL lists): counts [40 * n_rows] device ints, pair = member * n_rows +
+ * row - the one array the host waits for; point_list (capacity n_rows * n_points * 40 ints; used: sum(counts)) ordered by (member,
+ * row, point), which runs while the host builds the tables.  Two launches for torch.nonzero + bincount (~25 launches, two syncs). */
+int nphm_identity_train_pair_counts(const float* blend_weights, int n_rows, int64_t n_points, int* counts, void* stream);
+int nphm_identity_train_point_list(const float* blend_weights, int n_rows, int64_t n_points, const int* counts, int* point_list, void* stream);
 int nphm_identity_train_forward(const void* packed, const void* packed_bwd, const void* latent_state, const float* xyz,
                                 int64_t n_points, const int* tiles, int n_tiles, const int* point_list,
                                 float* member_sdf, float* member_grad, void* stream);

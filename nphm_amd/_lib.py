@@ -76,6 +76,8 @@ SYMBOLS = {
     "nphm_identity_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
     "nphm_identity_train_edge_bytes": (c_size_t, [c_int]),
+    "nphm_identity_train_pair_counts": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "nphm_identity_train_point_list": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "nphm_identity_train_tables": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p]),
     "nphm_identity_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,

@@ -1003,6 +1003,56 @@ __global__ __launch_bounds__(256) void operand_scales_kernel(const float* gs, in
   }
 }
 
+// ---- the training tier's point list on the device ------------------------------------------------------------------------
+// The list is ordered by (member, row, point) and as long as the batch keeps pairs: its tile tables are built on the host from the
+// pairs' counts (nphm_identity_train_tables - they size five launches).  Two launches, one workgroup per pair = member * n_rows +
+// row, replace torch.nonzero + bincount on the [B,N,40] mask (~25 launches and a host synchronisation of their own):
+//   pair_counts_kernel: counts[pair] = listed points of the pair (blend weight > 0) - the ONE array the host waits for;
+//   pair_list_kernel  : list[offset(pair) + rank] = point, ranks in point order (offset = sum of the counts in front, which every
+//                       workgroup adds up itself) - runs while the host builds the tile tables from the counts.
+__global__ __launch_bounds__(256) void pair_counts_kernel(const float* __restrict__ what, int n_rows, int64_t n_points, int* __restrict__ counts) {
+  __shared__ int wsum[4];
+  const int pair = blockIdx.x, member = pair / n_rows, row = pair % n_rows;
+  const float* w = what + int64_t(row) * n_points * N_MEMBERS + member;
+  int c = 0;
+  for (int64_t n = threadIdx.x; n < n_points; n += blockDim.x) c += w[n * N_MEMBERS] > 0.f ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[pair] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void pair_list_kernel(const float* __restrict__ what, int n_rows, int64_t n_points, const int* __restrict__ counts,
+                                                         int* __restrict__ list) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int pair = blockIdx.x, member = pair / n_rows, row = pair % n_rows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int off = 0;
+  for (int q = threadIdx.x; q < pair; q += blockDim.x) off += counts[q];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o);
+  if (lane == 0) wsum[wave] = off;
+  __syncthreads();
+  if (threadIdx.x == 0) base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  const float* w = what + int64_t(row) * n_points * N_MEMBERS + member;
+  for (int64_t n0 = 0; n0 < n_points; n0 += blockDim.x) {
+    const int64_t n = n0 + threadIdx.x;
+    const bool keep = n < n_points && w[n * N_MEMBERS] > 0.f;
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) wsum[wave] = __popcll(b);
+    __syncthreads();
+    int at = base;
+    for (int q = 0; q < wave; ++q) at += wsum[q];
+    if (keep) list[at + __popcll(b & ((1ull << lane) - 1ull))] = int(n);
+    __syncthreads();
+    if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+
 }  // namespace train
 }  // namespace nphm
 
@@ -1075,6 +1125,22 @@ int nphm_identity_train_backward(const void* packed, const void* packed_bwd, con
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_train_backward launch", e);
   return 0;
+}
+
+int nphm_identity_train_pair_counts(const float* blend_weights, int n_rows, int64_t n_points, int* counts, void* stream) {
+  if (!blend_weights || !counts || n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_identity_train_pair_counts: bad arguments");
+  hipLaunchKernelGGL(nphm::train::pair_counts_kernel, dim3(nphm::N_MEMBERS * n_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     blend_weights, n_rows, n_points, counts);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_identity_train_pair_counts launch", e);
+}
+
+int nphm_identity_train_point_list(const float* blend_weights, int n_rows, int64_t n_points, const int* counts, int* point_list, void* stream) {
+  if (!blend_weights || !counts || !point_list || n_rows <= 0 || n_points <= 0) return nphm_fail_msg("nphm_identity_train_point_list: bad arguments");
+  hipLaunchKernelGGL(nphm::train::pair_list_kernel, dim3(nphm::N_MEMBERS * n_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     blend_weights, n_rows, n_points, counts, point_list);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_identity_train_point_list launch", e);
 }
 
 // Host side of the training tier's work lists (no device work): from the number of listed points of every (member, row) pair,

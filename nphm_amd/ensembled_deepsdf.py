@@ -198,9 +198,12 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
     return what * mask, torch.from_numpy(tiles).to(xyz.device), idx[:, 2].to(torch.int32).contiguous()
 
 
+_PINNED_COUNTS = {}
+
+
 def _train_member_lists(mask, sets):
     """Point lists of the training kernels (ident_train_kernel.hip) from ``mask`` [B,N,A] (the members the pruning
-    rule keeps per point): tiles ordered by (member, row), so the tiles of one weight set are contiguous (``sets``
+    rule keeps per point: a bool mask, or the blend weights, > 0 where kept): tiles ordered by (member, row), so the tiles of one weight set are contiguous (``sets``
     [A] = member -> set, non-decreasing).  Returns the forward
     kernel's tile table (64-point tiles), the backward kernel's int32 [T,4] = (row, member, offset, count <= 32)
     over the same point list, the point list int32 and the work list of the backward pass:
@@ -211,9 +214,31 @@ def _train_member_lists(mask, sets):
     nphm_identity_train_reduce_grads: int32 [sets + 1 | A * B + 1] = first chunk of every weight set (the chunk table is ordered
     by tile, hence by set) | first backward tile of every (member, row) pair, and the tiles per piece.  One host sync."""
     B, N, A = mask.shape
-    with torch.no_grad():
-        idx = mask.permute(2, 0, 1).nonzero()                  # sorted by (member, row, point)
-        counts = torch.bincount(idx[:, 0] * B + idx[:, 1], minlength=A * B).cpu().numpy().astype(np.int64)   # the one sync
+    lib = _lib.load() if mask.is_cuda else None
+    plist = None
+    if mask.is_cuda and mask.dtype == torch.float32 and mask.is_contiguous() and A == 40:
+        # ``mask`` = the blend weights themselves (> 0 where listed): counts and point list by two launches of our own - the host
+        # waits for the 40 B counts only, the list is written while it builds the tables (torch.nonzero + bincount: ~25
+        # launches and two synchronisations)
+        dev = mask.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        counts_dev = torch.empty(A * B, dtype=torch.int32, device=dev)
+        _lib.check(lib.nphm_identity_train_pair_counts(mask.data_ptr(), B, N, counts_dev.data_ptr(), stream), "nphm_identity_train_pair_counts")
+        counts_host = _PINNED_COUNTS.get(A * B)
+        if counts_host is None:                                # (pinning is a driver call: once per size)
+            counts_host = _PINNED_COUNTS[A * B] = torch.empty(A * B, dtype=torch.int32).pin_memory()
+        counts_host.copy_(counts_dev, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        plist = torch.empty(B * N * A, dtype=torch.int32, device=dev)
+        _lib.check(lib.nphm_identity_train_point_list(mask.data_ptr(), B, N, counts_dev.data_ptr(), plist.data_ptr(), stream),
+                   "nphm_identity_train_point_list")
+        ready.synchronize()                                    # the one sync: the counts size five launches
+        counts = counts_host.numpy().astype(np.int64)
+    else:
+        with torch.no_grad():
+            idx = (mask if mask.dtype == torch.bool else mask > 0).permute(2, 0, 1).nonzero()        # sorted by (member, row, point)
+            counts = torch.bincount(idx[:, 0] * B + idx[:, 1], minlength=A * B).cpu().numpy().astype(np.int64)   # the one sync
     sets_np = _sets_on_host(sets)
     n_sets = int(sets_np.max()) + 1
     # the tables on the host in C (nphm_identity_train_tables; numpy took 0.5 ms per step with the GPU idle), in ONE buffer
@@ -224,7 +249,17 @@ def _train_member_lists(mask, sets):
     o_fwd, o_bwd, o_ch = 0, 4 * cap64, 4 * cap64 + 4 * cap32
     o_set = o_ch + 4 * cap32
     o_pair = o_set + n_sets + 1
-    buf = np.empty(o_pair + A * B + 1, np.int32)
+    need = o_pair + A * B + 1
+    pinned = None
+    if mask.is_cuda:
+        # (a pinned staging buffer, kept: the tables travel by an asynchronous copy - a pageable source is a blocking, staged one.
+        # Its previous contents were consumed by a copy that this step's wait for the counts has long passed.)
+        pinned = _PINNED_COUNTS.get("tables")
+        if pinned is None or pinned.numel() < need:
+            pinned = _PINNED_COUNTS["tables"] = torch.empty(max(need, 1 << 16) * 2, dtype=torch.int32).pin_memory()
+        buf = pinned.numpy()[:need]
+    else:
+        buf = np.empty(need, np.int32)
     sizes = np.zeros(4, np.int32)
     base = buf.ctypes.data
     _lib.check(lib.nphm_identity_train_tables(counts.ctypes.data, B, sets_np.ctypes.data, n_sets, int(_TRAIN_RING_TILES), int(_WGRAD_CHUNK),
@@ -238,12 +273,18 @@ def _train_member_lists(mask, sets):
         c_count = np.diff(np.r_[c_first, C])
         pieces = [(int(pi * ring), int(min(ring, T - pi * ring)), int(c0), int(nc)) for pi, (c0, nc) in enumerate(zip(c_first, c_count))]
     dev = mask.device
-    d = torch.from_numpy(buf).to(dev)
+    if pinned is not None:
+        d = torch.empty(need, dtype=torch.int32, device=dev)
+        d.copy_(pinned[:need], non_blocking=True)
+    else:
+        d = torch.from_numpy(buf).to(dev)
     tiles_fwd = d[o_fwd:o_fwd + 4 * t64].view(t64, 4)
     tiles = d[o_bwd:o_bwd + 4 * T].view(T, 4)
     chunks = d[o_ch:o_ch + 4 * C].view(C, 4)
     edge_tabs = d[o_set:]                                      # [n_sets + 1 | A * B + 1], contiguous
-    return tiles_fwd, tiles, idx[:, 2].to(torch.int32).contiguous(), chunks, pieces, (edge_tabs, n_sets, ring)
+    if plist is None:
+        plist = idx[:, 2].to(torch.int32).contiguous()
+    return tiles_fwd, tiles, plist, chunks, pieces, (edge_tabs, n_sets, ring)
 
 
 _SETS_HOST = {}
@@ -485,9 +526,10 @@ class _MemberFieldFn(torch.autograd.Function):
         # members the pruning rule keeps per point: the list kernel's normalised blend weights (0 where pruned)
         tol = module._train_tol()
         what = _blend_weights_device(state, xyz_c, tol, A, stream)
-        tiles_fwd, tiles, plist, chunks, pieces, (edge_tabs, n_sets, ring) = _train_member_lists(what > 0, module.ensembled_deep_sdf.lin0._sets)
+        # (the zero fills in front of the list building: its wait for the counts then has them queued behind it)
         S = torch.zeros(B, N, A, dtype=torch.float32, device=dev)
         G = torch.zeros(B, N, A, 3, dtype=torch.float32, device=dev)
+        tiles_fwd, tiles, plist, chunks, pieces, (edge_tabs, n_sets, ring) = _train_member_lists(what, module.ensembled_deep_sdf.lin0._sets)
         _lib.check(lib.nphm_identity_train_forward(
             packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz_c.data_ptr(), N, tiles_fwd.data_ptr(),
             tiles_fwd.shape[0], plist.data_ptr(), S.data_ptr(), G.data_ptr(), stream), "nphm_identity_train_forward")

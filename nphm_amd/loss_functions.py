@@ -104,6 +104,29 @@ def _fused_terms(decoder, pred, grad, normals, glob_cond, anchors, anchors_gt, s
     return out
 
 
+_LAMBDA_VECTORS = {}
+
+
+def weighted_total(loss_dict, lambdas):
+    """``sum(lambdas[k] * loss_dict[k] for k in loss_dict)`` - the line of the trainers that turns the loss terms into the
+    scalar they call ``backward()`` on (training.py:118-122: ``loss += loss_dict[k] * lambdas[k]`` over the terms) - as a stack
+    and a dot product against a cached device vector of the weights: 3 launches forward and 3 backward where the Python sum over
+    eight 0-dim tensors is 16 + 16 (a training step is ~150 launches around three large kernels).  Terms that are None or carry
+    no weight entry are skipped, like a trainer that only weights what it lists."""
+    keys = [k for k, v in loss_dict.items() if v is not None and k in lambdas]
+    terms = [loss_dict[k] for k in keys]
+    if not terms:
+        raise ValueError("weighted_total: no weighted loss term")
+    dev = terms[0].device
+    key = (str(dev), tuple(float(lambdas[k]) for k in keys))
+    lam = _LAMBDA_VECTORS.get(key)
+    if lam is None:
+        if len(_LAMBDA_VECTORS) > 64:
+            _LAMBDA_VECTORS.clear()
+        lam = _LAMBDA_VECTORS[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+    return torch.dot(torch.stack([t.reshape(()).float() for t in terms]), lam)
+
+
 def compute_loss(batch, decoder, latent_codes, device):
     """loss_functions.py:7-18: move the batch to ``device``, look the latent codes up, evaluate the loss terms."""
     return actual_compute_loss(_to_device(batch, device), decoder, latent_codes(batch["idx"].to(device)))

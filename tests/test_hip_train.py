@@ -355,3 +355,23 @@ def _run_fused(net, backend, lat0, xyz, nrm):
     for name, p in net.named_parameters():
         out[name] = p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
     return out
+
+
+@pytest.mark.parametrize("B,N,tol", [(3, 777, 1e-7), (2, 64, -1.0), (32, 1693, 1e-7)])
+def test_device_built_point_list_matches_nonzero(dev, B, N, tol):
+    """(ABI 10) the training tier's counts and point list from two launches of its own (`nphm_identity_train_pair_counts` /
+    `_point_list`) = what torch.nonzero + bincount on the same mask give: same tables, same list."""
+    import nphm_amd.ensembled_deepsdf as E
+    net = U.build_identity(device=dev).train()
+    lat, xyz, _ = _batch(dev, B, N, seed=3)
+    _, state, _ = net.prepare_latent(lat[:, 0, :])
+    what = E._blend_weights_device(state, xyz.contiguous(), tol, 40, torch.cuda.current_stream(dev).cuda_stream)
+    sets = net.ensembled_deep_sdf.lin0._sets
+    a = E._train_member_lists(what, sets)                       # device counts + list
+    b = E._train_member_lists(what > 0, sets)                   # nonzero + bincount
+    torch.cuda.synchronize()
+    total = int((what > 0).sum())
+    assert b[2].numel() == total and torch.equal(a[2][:total], b[2])
+    for x, y in zip((a[0], a[1], a[3], a[5][0]), (b[0], b[1], b[3], b[5][0])):
+        assert torch.equal(x, y)
+    assert a[4] == b[4] and a[5][1:] == b[5][1:]

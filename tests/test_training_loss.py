@@ -243,3 +243,24 @@ def test_deformation_stage_losses_match_reference_hip():
     """loss_joint differentiates the identity field w.r.t. POSED points through the deformation network: the training
     tier's second-order gradient w.r.t. its (non-leaf) query points chains into the deformation network's graph."""
     _run_def_losses(torch.device("cuda:0"), 2e-5, 1e-3)
+
+
+def test_weighted_total_is_the_trainers_sum_cpu():
+    """nphm_amd.loss_functions.weighted_total = the trainers' ``sum(lambdas[k] * loss_dict[k])`` (training.py:118-122): same
+    value, same gradients of the terms; None terms and unweighted terms skipped."""
+    from nphm_amd.loss_functions import weighted_total
+    g = torch.Generator().manual_seed(0)
+    vals = torch.rand(8, generator=g)
+    a = [v.clone().requires_grad_() for v in vals]
+    b = [v.clone().requires_grad_() for v in vals]
+    keys = list(LAMBDAS)
+    da, db = dict(zip(keys, a)), dict(zip(keys, b))
+    da["extra_unweighted"], db["extra_unweighted"] = torch.tensor(3.0), torch.tensor(3.0)
+    da["absent"], db["absent"] = None, None
+    ref = sum(LAMBDAS[k] * da[k] for k in keys)
+    got = weighted_total(db, dict(LAMBDAS, absent=1.0))
+    assert abs(float(ref) - float(got)) < 1e-6
+    ref.backward()
+    got.backward()
+    for x, y in zip(a, b):
+        assert abs(float(x.grad) - float(y.grad)) < 1e-7
