@@ -176,6 +176,28 @@ def long_deviation(g, keys, table, lat_e, lat_s, anc):
 
 
 @pytest.mark.gpu
+def test_fused_glue_of_the_step_gives_the_steps_of_the_pytorch_formulation_gpu(monkeypatch):
+    """NPHM_AMD_FIT_FUSED=0 runs the step's glue - inputs from the draw, loss terms, compressor, code gradients' sums, Adam -
+    as the PyTorch ops of rounds 1-2 around the same field kernels: the first 12 steps of the 250-step loop agree with the
+    fused step (one launch each, aliases of the codes, optimizer inside the step) to round-off, and both with the fixture."""
+    dev = torch.device("cuda:0")
+    fused = _run_long(dev, None, n_steps=48, use_graph=False)
+    monkeypatch.setenv("NPHM_AMD_FIT_FUSED", "0")
+    plain = _run_long(dev, None, n_steps=48, use_graph=False)
+    monkeypatch.delenv("NPHM_AMD_FIT_FUSED")
+    g, keys, ta, ea, sa, aa = fused
+    _, _, tb, eb, sb, ab = plain
+    assert ta.shape == tb.shape == (12, len(keys) + 1) and np.array_equal(ta[:, -1], tb[:, -1])
+    i = keys.index("surface")
+    assert np.abs(ta[:, i] / tb[:, i] - 1).max() < 2e-4 and np.abs(ta[:, i] / g["history"][:12, i] - 1).max() < 1e-3
+    # (Adam normalises components whose gradient is round-off to +-lr steps: the codes agree to a few lr = 1e-2 * 0.01 after 12 steps
+    # only in the components that matter - compared through what they produce, and bounded)
+    d = np.abs(sa - sb)
+    print(f"fused vs PyTorch glue after 12 steps: identity code max {d.max():.2e} median {np.median(d):.2e}, anchors {np.abs(aa - ab).max():.2e}")
+    assert d.max() < 1e-2 and np.median(d) < 2e-5 and np.abs(aa - ab).max() < 1e-4
+
+
+@pytest.mark.gpu
 def test_long_horizon_hip_tier_against_the_reference_arithmetic_on_this_gpu():
     """The yardstick of the 250-step bounds: the SAME loop in the reference's own arithmetic (composite tier: PyTorch ops,
     autograd double backward) on PyTorch-ROCm is itself a second fp32 implementation of the CPU trace the fixture holds - a
