@@ -125,8 +125,8 @@ class _PairAdam:
 
     def __init__(self, optimizers):
         import os
-        self.opts = list(optimizers)
-        self.ok = (len(self.opts) == 2 and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", "")
+        self.opts = list(optimizers)                 # (one or two: the identity-only loop has one code)
+        self.ok = (len(self.opts) in (1, 2) and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", "")
                    and all(isinstance(o, _CodeAdam) and o._fast_ok() and len(o.param_groups) == 1 and len(o.param_groups[0]["params"]) == 1
                            for o in self.opts))
 
@@ -146,6 +146,7 @@ class _PairAdam:
             b1, b2 = group["betas"]
             f = np.float32
             vals += [f(1) - f(b1), f(b2), f(1) - f(b2), f(float(group["lr"]) / (1.0 - b1 ** t)), f(math.sqrt(1.0 - b2 ** t)), f(group["eps"])]
+        vals += [np.float32(0)] * (12 - len(vals))
         return torch.from_numpy(np.asarray(vals, dtype=np.float32).view(np.int64).copy())
 
     @torch.no_grad()
@@ -156,8 +157,9 @@ class _PairAdam:
         lib = _lib.load()
         ps = self.params()
         sts = [o.state[p] for o, p in zip(self.opts, ps)]
-        arr = lambda ts: (ctypes.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in ts])
-        n = (ctypes.c_int64 * 2)(*[0 if p.grad is None else p.numel() for p in ps])
+        pad = lambda ts: list(ts) + [None] * (2 - len(ts))
+        arr = lambda ts: (ctypes.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in pad(ts)])
+        n = (ctypes.c_int64 * 2)(*[0 if (p is None or p.grad is None) else p.numel() for p in pad(ps)])
         _lib.check(lib.nphm_adam_step_pair(arr(ps), arr([p.grad for p in ps]), arr([st["exp_avg"] for st in sts]),
                                            arr([st["exp_avg_sq"] for st in sts]), n, scalars_i64.data_ptr(),
                                            torch.cuda.current_stream(ps[0].device).cuda_stream), "nphm_adam_step_pair")
@@ -850,13 +852,18 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
     n_iter = int(n_steps * step_scale)
     hist = _History(history, lambdas.keys(), n_iter, device)
     ctl = _StepControls(lambdas, device)
-    drawn_static = sampler.upload(sampler.draw_like())
-    drawn_cur = [drawn_static]
     fused = _fused_losses_ok(decoder, lambdas, device) and "reg_expr" not in lambdas
     if fused:
         hist.perm = ctl.fused_perm()
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder)
+    pair = _PairAdam((opt,)) if fused else None             # the optimizer step as a launch inside the step (see the joint loop)
+    if pair is not None and not pair.ok:
+        pair = None
+    if pair is not None:
+        sampler.extra = pair.SLOTS
+    drawn_static = sampler.upload(sampler.draw_like())
+    drawn_cur = [drawn_static]
 
     def body():
         anchors = _anchors_of(decoder, lat_rep_shape, device)
@@ -864,8 +871,10 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
         cond = lat_rep_shape.expand(n_batch, -1, -1) if local else lat_rep_shape.repeat(n_batch, obs.shape[1], 1)
         sdf = _field_of_one_code(decoder, obs, lat_rep_shape, cond, local)
         if fused:
-            loss, row8 = _FitLossFn.apply(sdf, None, lat_rep_shape, None, None, ctl.thr, ctl.lam6)
-            loss.backward(gradient=ctl.one)
+            loss, row8 = _FitLossFn.apply(sdf, None, lat_rep_shape, None, None, ctl.thr, ctl.lam6, ctl.one)
+            loss.backward(gradient=ctl.one)       # (the announced seed: the loss launch wrote the gradients too)
+            if pair is not None:
+                pair.launch(drawn_cur[0][drawn_cur[0].numel() - pair.SLOTS:])
             return row8, anchors.detach()
         loss_dict = {"surface": _masked_surface_loss(sdf, ctl.thr)}
         _shape_regularisers(decoder, lat_rep_shape, loss_dict)
@@ -881,8 +890,11 @@ def inference_identity_space(decoder, all_obs: List[torch.Tensor], lambdas, n_st
             _apply_schedule(j, step_scale, schedule_cfg, lambdas, (opt,), False)
             ctl.refresh(lambdas, j, step_scale)
             step.zero_grad()
-            row, anchors = _run_step(step, sampler, drawn_static, drawn_cur)
-            opt.step()
+            row, anchors = _run_step(step, sampler, drawn_static, drawn_cur, pair)
+            if pair is None:
+                opt.step()
+            else:
+                pair.bump()
             hist.record(j, row)
             done = j + 1
             if verbose:
