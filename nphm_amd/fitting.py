@@ -733,6 +733,10 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         hist.perm = ctl.fused_perm(extra=("n_valid",))
     if use_graph is None:
         use_graph = _graph_default(device, verbose, decoder, decoder_expr) and not compute_unused_sdf_grad
+    import os
+    side = None                                              # a second stream for the step's independent branch (see body_in_scope)
+    if fused and device.type == "cuda" and os.environ.get("NPHM_AMD_FIT_OVERLAP", "1") not in ("0", ""):
+        side = torch.cuda.Stream(device)
     pair = _PairAdam((opt, opt_expr)) if fused else None       # both optimizer steps as one launch inside the step
     if pair is not None and not pair.ok:
         pair = None
@@ -762,7 +766,20 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         valid = search_result["valid_ids"]
 
         # implicit differentiation of the root: d x_c = -J^-1 d F(x_c; z) attached to the detached root
-        xc = decoder_expr.implicit_root(p_corresp, glob_cond, anchors_b) if hasattr(decoder_expr, "implicit_root") else None
+        xc = None
+        if hasattr(decoder_expr, "implicit_root"):
+            if side is not None:
+                # The launch pair behind this call (value + Jacobian + inverse + the backward's state at the roots) feeds nothing
+                # before the conditioning's backward - x_c's VALUE is the root itself.  On a second stream it runs beside the
+                # identity field's forward and backward (neither fills the chip: 313 / 157 / 380 workgroups on 256 CUs);
+                # autograd runs its backward on that stream too and orders the two (inside a capture: parallel branches of the graph).
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    xc = decoder_expr.implicit_root(p_corresp, glob_cond, anchors_b)
+                if xc is None:
+                    torch.cuda.current_stream(device).wait_stream(side)
+            else:
+                xc = decoder_expr.implicit_root(p_corresp, glob_cond, anchors_b)
         pj = None
         if xc is None and hasattr(decoder_expr, "posed_and_jacobian"):
             pj = decoder_expr.posed_and_jacobian(p_corresp, glob_cond, anchors_b, inverse=True)
