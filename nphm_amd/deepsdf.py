@@ -491,6 +491,10 @@ class DeepSDF(nn.Module):
         n_a = ((cus // R) * 16) // align * align
         if n_a <= 0 or n_a >= n:
             return [(0, 0, 64)]
+        # (the SHORT round first: whatever runs beside these launches on another stream - the fitting step's identity field - finds
+        # free CUs at once and has left them again when the chip-filling round arrives; same result either way)
+        if os.environ.get("NPHM_AMD_JVP_SMALL_FIRST", "1") not in ("0", ""):
+            return [(n_a, n - n_a, 32), (0, n_a, 64)]
         return [(0, n_a, 64), (n_a, n - n_a, 32)]
 
     def _eval_jvp_raw(self, packed, state, xyz, code):

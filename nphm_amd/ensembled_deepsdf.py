@@ -887,6 +887,12 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         the caller has evaluated ``mlp_pos`` already (the autograd tier's differentiable head) - the prologue then skips it."""
         lib = _lib.load()
         device = lat_rows.device
+        scope = getattr(self, "_anchor_scope", None)
+        if scope is not None and anchors is not None and not inference and isinstance(bounds, str):
+            hit = scope.get(self._state_key(lat_rows, anchors))
+            if hit is not None:                 # run ahead on another stream (prefetch_state): this stream waits for it
+                torch.cuda.current_stream(device).wait_event(hit[1])
+                return hit[0]
         if getattr(self, "_needs_validation", False):
             from .numerics import validate_numerics
             self._needs_validation = False
@@ -934,6 +940,32 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
         if knobs is not None:
             state.nphm_knobs = knobs          # (prune_tol, precision code) the inference kernels run this state with
         return packed, state, anchors
+
+    @staticmethod
+    def _state_key(lat_rows, anchors):
+        return ("state", lat_rows.data_ptr(), lat_rows._version, tuple(lat_rows.shape), anchors.data_ptr(), anchors._version, tuple(anchors.shape))
+
+    def prefetch_state(self, lat_rep, anchors, stream):
+        """Inside an ``anchor_scope``: the field's prologue for (row 0 of ``lat_rep`` [1,1,L], ``anchors`` [1,K,3]) launched NOW
+        on ``stream``; the next ``prepare_latent`` call of the autograd tier with these tensors takes the result after making
+        ITS stream wait.  The fitting step knows code and anchors four launches before it needs the field: the prologue then
+        runs beside the correspondence search instead of in front of the member lists.  No-op outside a scope / on the CPU."""
+        scope = getattr(self, "_anchor_scope", None)
+        if scope is None or not lat_rep.is_cuda or anchors is None or lat_rep.shape[0] != 1:
+            return
+        rows = _row0(lat_rep).detach()
+        anchors = anchors.detach()
+        cur = torch.cuda.current_stream(rows.device)
+        stream.wait_stream(cur)
+        with torch.cuda.stream(stream):
+            res = self.prepare_latent(rows, anchors=anchors)
+            done = torch.cuda.Event()
+            done.record(stream)
+        if not torch.cuda.is_current_stream_capturing():
+            for t in res:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)                 # (allocated under `stream`, read by the caller's)
+        scope[self._state_key(rows, anchors)] = (res, done, rows, anchors)
 
     def _weights_key(self, device):
         ws, bs = self._lin_params()

@@ -761,8 +761,9 @@ def test_value_jacobian_launch_cut_in_16_and_8_point_workgroups_is_bitwise_the_s
     for split in ("1", "0"):
         monkeypatch.setenv("NPHM_AMD_JVP_SPLIT", split)
         cuts = mlp._jvp_split(R, n, dev, 64)
-        assert (len(cuts) == 2 and cuts[0][2] == 64 and cuts[1][2] == 32 and cuts[0][1] + cuts[1][1] == n
-                and cuts[0][1] % 64 == 0) if split == "1" else cuts == [(0, 0, 64)]
+        # (the short round of 8-point workgroups is launched FIRST: a launch on another stream then finds free CUs at once)
+        assert (len(cuts) == 2 and cuts[0][2] == 32 and cuts[1][2] == 64 and cuts[0][1] + cuts[1][1] == n and cuts[1][0] == 0
+                and cuts[0][0] == cuts[1][1] and cuts[1][1] % 64 == 0) if split == "1" else cuts == [(0, 0, 64)]
         lat = lat0.clone().requires_grad_(True)
         # the saved-state buffer comes from the caching allocator unwritten past each row's end: hand it NaNs
         from nphm_amd import _lib
