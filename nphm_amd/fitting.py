@@ -755,7 +755,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         # anchors of the current identity code (the reference runs an N = 1 forward and drops its SDF)
         anchors = _anchors_of(decoder, codes.anchors, device)
         anchors_b = anchors.expand(n_batch, -1, -1) if (local and anchors is not None) else None        # [B,39,3]
-        if side is not None and local and hasattr(decoder, "prefetch_state") and getattr(decoder, "training", False):
+        if (side is not None and local and hasattr(decoder, "prefetch_state") and getattr(decoder, "training", False)
+                and os.environ.get("NPHM_AMD_FIT_PREFETCH", "1") not in ("0", "")):
             decoder.prefetch_state(codes.field, anchors, side)     # the identity field's prologue, beside the correspondence search
 
         if hasattr(decoder_expr, "prime_condition"):
