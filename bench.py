@@ -161,21 +161,29 @@ class IdentityBench:
         self.collective_events = []      # (start, all-gather done, reorder done) on the side stream, timed steps only
         self.rank_report = None
         self.calibration_ms = 0.0
+        self.shared = None               # N > 1: rank 0's ((prune_tol, precision code), member bounds) for this lattice
 
     def set_precision(self, precision):
         """'auto' = calibrated knobs (the module's default); anything else pins the mode at prune_tol 1e-7 / --prune-tol"""
         net = self.net
         if precision == "auto":
             net.numerics = "auto"
-            # calibrate (and verify on this latent) outside the timed region; every rank does this on its own and must arrive
-            # at the same knobs (the shards are slices of one volume): its wall time and a hash of the result go into `ranks`
+            # calibrate (and verify on this latent) outside the timed region.  N > 1: rank 0 alone does it and every rank runs
+            # ITS knobs and member bounds (R.shared_numerics: one broadcast, cached - the shards are slices of one volume);
+            # the wall time and a hash of what each rank runs go into `ranks`
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            net.kernel_knobs(self.dev, self.lat[None], self.rx * self.ry * self.rz)
+            if self.distributed:
+                self.shared = self.R.shared_numerics(net, self.lat[None], self.rx * self.ry * self.rz)[0]
+            else:
+                net.kernel_knobs(self.dev, self.lat[None], self.rx * self.ry * self.rz)
             torch.cuda.synchronize()
             self.calibration_ms = (time.perf_counter() - t0) * 1e3
+            if self.distributed:
+                return net._MODE_NAMES[self.shared[0][1] & 0xff]
             c = net.calibration
             return c["precision"]
+        self.shared = None
         net.precision = precision                              # pins the numerics
         net.light_tol, net.mid_tol, net.refine_band = None, None, None
         net.prune_tol = self.args.prune_tol if self.args.prune_tol is not None else 1e-7
@@ -183,7 +191,10 @@ class IdentityBench:
 
     def step(self, precision, binned, stats=None, ev=None):
         net, R = self.net, self.R
-        packed, state, _ = net.prepare_latent(self.lat[None], inference=True, n_points=self.rx * self.ry * self.rz)
+        if self.distributed and net.numerics == "auto":      # rank 0's decision (cached: a steady-state step sends nothing)
+            self.shared = R.shared_numerics(net, self.lat[None], self.rx * self.ry * self.rz)[0]
+        packed, state, _ = R._identity_state(net, self.lat[None], self.rx * self.ry * self.rz,
+                                             self.shared if self.distributed else None)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         ws = R.grid_workspace(self.dev, self.n_planes, self.ry, self.rz) if binned and self.n_planes else None
         i = self.k & 1
@@ -250,18 +261,20 @@ class IdentityBench:
             self.collective_events = []
             # per-rank figures of the timed region: what makes an N > 1 line diagnosable (load balance, how much of the
             # all-gather + reorder stays exposed behind the next step's kernel)
-            c = self.net.calibration if self.net.numerics == "auto" else None
             knob_hash = 0.0
-            if c is not None:                                 # a float64 carries 52 bits of the digest: enough to see a disagreement
+            if self.shared is not None:                       # a float64 carries 52 bits of the digest: enough to see a disagreement
                 import hashlib
-                blob = repr((c["precision"], c["light_tol"], c["mid_tol"], c["prune_tol"], c.get("refine_band"))).encode() + \
-                    (b"" if c.get("bounds") is None else c["bounds"].cpu().numpy().tobytes())
+                (tol, code), bnd = self.shared
+                blob = repr((float(tol), int(code))).encode() + (b"" if bnd is None else bnd.cpu().numpy().tobytes())
                 knob_hash = float(int(hashlib.sha1(blob).hexdigest()[:13], 16))
             mine = torch.tensor([dt, k_ms, float(np.mean(ag)) if ag else 0.0, float(np.mean(ro)) if ro else 0.0,
                                  float(self.n_planes), self.calibration_ms, knob_hash], dtype=torch.float64, device=self.dev)
             allr = [torch.zeros_like(mine) for _ in range(self.world)]
             dist.all_gather(allr, mine)
             allr = torch.stack(allr).cpu().numpy()
+            if len(set(allr[:, 6].tolist())) != 1:
+                raise RuntimeError("ranks ran different numerics (knob / member-bound digests %r): the gathered volume is not the "
+                                   "single-GPU volume" % (allr[:, 6].tolist(),))
             dt = float(allr[:, 0].max())
             self.rank_report = {"step_ms": [round(v / steps * 1e3, 3) for v in allr[:, 0]], "kernel_ms": [round(v, 3) for v in allr[:, 1]],
                                 "allgather_ms": [round(v, 3) for v in allr[:, 2]], "reorder_ms": [round(v, 3) for v in allr[:, 3]],

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 10
+#define NPHM_AMD_ABI_VERSION 11
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -246,7 +246,11 @@ int nphm_identity_backward(const void* packed, const void* packed_bwd, const voi
  *     n_chunks * nphm_identity_train_edge_bytes(1) bytes. */
 size_t nphm_identity_train_saved_bytes(int n_tiles, int operands);
 /* ABI 9: operand_scales [4 floats, device] of `operands` = 2 from grad_member_sdf [n_sdf] and grad_member_grad [n_grad] (NULL:
- * none) in ONE launch; work = 16 bytes of device memory, zero before the first call (the kernel leaves them zero). */
+ * none) in ONE launch; work = 16 bytes of device memory, zero before the first call (the kernel leaves them zero).
+ * ABI 11: `operand_scales` is an array of 8 words; word [7], read as unsigned, is IN/OUT of nphm_identity_train_backward with
+ * `operands` = 2: += the number of wavefronts that clamped a stored operand to the binary16 range (the scales come from the
+ * seeds' maxima through ratios measured on two weight sets; a step that clamps has biased lin1..lin3 gradients).  Zero it, run
+ * the step's pieces, read it: not zero -> repeat the backward with `operands` = 0 (what the host module does). */
 int nphm_identity_train_operand_scales(const float* grad_member_sdf, int64_t n_sdf, const float* grad_member_grad, int64_t n_grad,
                                        void* work, float* operand_scales, void* stream);
 size_t nphm_identity_train_edge_bytes(int n_tiles);

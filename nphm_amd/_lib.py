@@ -164,7 +164,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 10:
+    if lib.nphm_abi_version() != 11:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -79,7 +79,10 @@ struct EvalArgs {
 #endif
 // timing ablations (results are garbage): 1 = no weight streaming, 2 = no workgroup barrier, 4 = no epilogue arithmetic,
 // 16 = no wait for the weight DMA, 32 = every member streams weight set 0 / member 0's state (L2-resident stream),
-// 64 = no softplus arithmetic for single-pass members only
+// 64 = no softplus arithmetic for single-pass members only, 128 = the A fragments of a chunk are read from LDS once (K-step 0) and
+// reused for every K-step (no repeated ds_read_b128: what the LDS read bandwidth costs), 256 = accumulators start from zero
+// instead of the chunk's tail in LDS, 512 = no A fragment is read at all (a lane constant stands in), 1024 = no member is evaluated
+// at all (what a workgroup costs before and after its member loop: launch, tile state, masks, the store)
 #ifndef NPHM_ABLATE
 #define NPHM_ABLATE 0
 #endif
@@ -108,6 +111,16 @@ struct EvalArgs {
 #ifndef NPHM_RUNK_LIGHT
 #define NPHM_RUNK_LIGHT 0
 #endif
+// epilogue units (accumulator registers) of the previous chunk placed in front of a chunk's first MFMA, per tier (gemm_fused_bf16: HEAD)
+#ifndef NPHM_HEAD_HEAVY
+#define NPHM_HEAD_HEAVY 0
+#endif
+#ifndef NPHM_HEAD_MID
+#define NPHM_HEAD_MID 0
+#endif
+#ifndef NPHM_HEAD_LIGHT
+#define NPHM_HEAD_LIGHT 0
+#endif
 #ifndef NPHM_STACK_TAILS
 #define NPHM_STACK_TAILS 1    // split-f16 path: the last 32-row block of a layer holds 8 real rows - its A fragment carries wh in rows
 #endif                        // 0..7 and wl in rows 8..15 (prep_kernels.hip), two MFMAs per K-step instead of three, half the DMA bytes
@@ -115,9 +128,9 @@ struct EvalArgs {
 #define NPHM_LDS_STASH 1      // per-lane (qx, qy, qz, denom) parked in LDS across the member loop instead of in VGPRs
 #endif
 #ifndef NPHM_PROF
-#define NPHM_PROF 0  // 1: per-phase s_memtime accounting into stats[2..8] (timing builds only)
-#endif
-#if NPHM_PROF
+#define NPHM_PROF 0  // timing builds only.  1: per-phase s_memtime accounting into stats[2..8] (two stamps + a drain per chunk: the
+#endif               // launch takes ~3x as long) and the per-tier table; 2: the per-tier table with member totals alone (two stamps per member)
+#if NPHM_PROF == 1
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
 #else
@@ -533,7 +546,7 @@ struct Streamer {
     // CI + 1, at least groups / NW of them, and VMEM completes in order: waiting until at most that many
     // operations are outstanding retires every load of chunk CI.
     constexpr int T = CI + 1;
-#if NPHM_PROF
+#if NPHM_PROF == 1
     const long long ta = clock64();
 #endif
     if constexpr ((NPHM_ABLATE & 16) != 0) {
@@ -544,17 +557,17 @@ struct Streamer {
     } else {
       if (k_nxt >= 0) wait_vm<Stream<PREC>::groups(0) / NW>(); else wait_vm<0>();
     }
-#if NPHM_PROF
+#if NPHM_PROF == 1
     const long long tb = clock64();
 #endif
     if constexpr (!(NPHM_ABLATE & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-#if NPHM_PROF
+#if NPHM_PROF == 1
     const long long tc = clock64();
 #endif
     if constexpr (!NPHM_DMA_INSTREAM) prefetch<CI>();
-#if NPHM_PROF
+#if NPHM_PROF == 1
     const long long td = clock64();
     sprof[0] += tb - ta; sprof[1] += tc - tb; sprof[2] += td - tc;
 #endif
@@ -606,7 +619,10 @@ __host__ __device__ constexpr bool epilogue_exposed(int P) {
 // in the shadow of that MFMA (32 cycles of matrix pipe, 4 of issue) - measured in
 // tools/micro/overlap.hip: MFMA + softplus interleaved in one wavefront cost max(...) + ~15 %, not the sum.
 // sched_barrier(0) after every slot keeps hipcc from regrouping the stream.
-template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, bool F16, int RUNK, int AS, class Epi, class Pre, class Slot>
+// HEAD: epilogue units of the previous chunk that run BEFORE this chunk's first MFMA, behind the LDS reads of its first A
+// fragments and accumulator init - the VALU work covers that latency (the reads cannot be issued earlier: a barrier, or
+// the previous chunk's own MFMAs, are in front of them), the remaining units ride behind the MFMAs as before
+template <int NKS16, int FULL, int NIN, int NPASS, int PF, int NU, bool F16, int RUNK, int AS, int HEAD, class Epi, class Pre, class Slot>
 __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc, const ActB (&in)[NIN],
                                                   int lane, Epi&& epi, Pre&& pre, Slot&& slot_hook) {
   static_assert(AS == 2 || (AS == 1 && NPASS <= 2), "AS = 1: stacked tail fragments (one fragment per K-step, no separate lo fragment)");
@@ -658,14 +674,31 @@ __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc,
   }
 #pragma unroll
   for (int ks = 0; ks < PF && ks < NKS16; ++ks) {
+    if ((NPHM_ABLATE & 128) && ks > 0) { wh[ks] = wh[0]; if (NPASS == 3) wl[ks] = wl[0]; continue; }
+    if (NPHM_ABLATE & 512) {
+      u32x4 fake = {unsigned(lane), 0x3c003c00u, unsigned(lane), 0x3c003c00u};
+      asm volatile("" : "+v"(fake));
+      wh[ks] = fake; if (NPASS == 3) wl[ks] = fake;
+      continue;
+    }
     wh[ks] = A[(AS * ks) * 64];
     if (NPASS == 3) wl[ks] = A[(AS * ks + 1) * 64];
+  }
+  if constexpr (HEAD > 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    static_range<0, HEAD>(epi);
+    __builtin_amdgcn_sched_barrier(0);
   }
   static_for<NKS16>([&](auto kk) __attribute__((always_inline)) {
     constexpr int ks = decltype(kk)::value;
     if constexpr (ks + PF < NKS16) {
-      wh[ks + PF] = A[(AS * (ks + PF)) * 64];
-      if (NPASS == 3) wl[ks + PF] = A[(AS * (ks + PF) + 1) * 64];
+      if constexpr ((NPHM_ABLATE & 128) != 0) {
+        wh[ks + PF] = wh[0];
+        if (NPASS == 3) wl[ks + PF] = wl[0];
+      } else {
+        wh[ks + PF] = A[(AS * (ks + PF)) * 64];
+        if (NPASS == 3) wl[ks + PF] = A[(AS * (ks + PF) + 1) * 64];
+      }
     }
     pre(kk);                               // one piece of the weight prefetch (LDS-DMA issue) per K-step
     __builtin_amdgcn_sched_barrier(0);     // the reads above are issued HERE, ahead of the MFMAs
@@ -677,7 +710,7 @@ __device__ __forceinline__ f32x16 gemm_fused_bf16(const char* afrag, f32x16 acc,
       else if constexpr (m == 1) acc = mfma16<F16>(wh[ks], in[b].lo[sb], acc);
       else acc = mfma16<F16>(wl[ks], in[b].hi[sb], acc);
       constexpr int slot = ks * NM + m;
-      static_range<unit_begin(slot, NS, NU), unit_begin(slot + 1, NS, NU)>(epi);
+      static_range<HEAD + unit_begin(slot, NS, NU - HEAD), HEAD + unit_begin(slot + 1, NS, NU - HEAD)>(epi);
       slot_hook(kk, mm);                   // work with its own placement (the L0 epilogues inside lin1's first chunk)
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -918,6 +951,15 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   // MODE 0 / 1: (output index | valid << 62 | hack << 63) of the lane's point, parked the same way (MODE 2 recomputes them from
   // the tile id): as VGPRs that live across the member loop they were 3 spilled registers of the brick / point-set variants
   __shared__ unsigned long long lane_w[MODE == 2 ? 1 : 64 * NW];
+#if NPHM_PROF
+  // per-tier phase profile (timing builds): cycles of every (wavefront, member) visit by the wavefront's own tier t and the
+  // heaviest tier T any wavefront of the workgroup runs that member at (0 = not needed, 1 = single-term, 2 = two-term,
+  // 3 = three-term): [t][T][visits, total, vmcnt wait, barrier wait, GEMM + epilogue] -> stats[16 + (4 t + T) 5 + i]
+  __shared__ unsigned long long tier_prof[4 * 4 * 5];
+  __shared__ unsigned int wg_tier[N_MEMBERS];
+  __shared__ long long tier_t0[NW];      // start stamp of the current member visit, per wavefront (not kept in registers)
+  __shared__ unsigned char my_tier[NW][N_MEMBERS];
+#endif
 
   const int lane_inv = threadIdx.x & 63;
   const int lane = lane_inv;
@@ -1011,12 +1053,11 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   }
 #endif
   const unsigned long long nv = __popcll(__ballot(valid)) >> 1;   // both half-waves hold the same points
-  if (p.stats && lane == 0) {
-    atomicAdd(p.stats, nv * __popcll(wmask));
-    atomicAdd(p.stats + 1, nv);
-    atomicAdd(p.stats + 15, nv * __popcll(wmask & ~hmask));      // single-pass ("light") pairs
-    atomicAdd(p.stats + 14, nv * __popcll(wmask & hmask & ~fmask));   // two-pass pairs
-  }
+  // counters: summed over the workgroup in LDS, then ONE global atomic per counter and workgroup.  (Rounds 1-5: four global
+  // atomics per wavefront, 2.1 M per 256^3 launch on four addresses of one cache line - alone they take 12.5 ms, beside the
+  // member loop 3.3 % of a launch in the calibrated mode and 12 % with every member single-term: tools/identity_variants.py.)
+  __shared__ unsigned long long wg_stats[4];
+  if (p.stats && threadIdx.x < 4) wg_stats[threadIdx.x] = 0ull;
 
   float acc = 0.f;
   // Two passes at most.  Pass 0 is the evaluation proper.  Pass 1 (refine_band > 0, rare) is the sign-safe refinement:
@@ -1032,15 +1073,42 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   if (lane == 0) {
     atomicOr(&wg_mask[0], (unsigned int)(wmask & 0xffffffffull));
     atomicOr(&wg_mask[1], (unsigned int)(wmask >> 32));
+    if (p.stats && pass == 0) {
+      atomicAdd(&wg_stats[0], nv * __popcll(wmask));
+      atomicAdd(&wg_stats[1], nv);
+      atomicAdd(&wg_stats[2], nv * __popcll(wmask & hmask & ~fmask));   // two-pass pairs
+      atomicAdd(&wg_stats[3], nv * __popcll(wmask & ~hmask));           // single-pass ("light") pairs
+    }
   }
   __syncthreads();
+  if (p.stats && pass == 0 && threadIdx.x < 4) {
+    const unsigned long long v = wg_stats[threadIdx.x];
+    if (v) atomicAdd(p.stats + (threadIdx.x < 2 ? threadIdx.x : 12 + threadIdx.x), v);   // slots 0, 1, 14, 15
+  }
   const uint64_t gmask = (uint64_t(wg_mask[1]) << 32) | wg_mask[0];
-  const int n_active = __popcll(gmask);
+  const int n_active = (NPHM_ABLATE & 1024) ? 0 : __popcll(gmask);
   if (threadIdx.x < N_MEMBERS) {
     if ((gmask >> threadIdx.x) & 1ull)
       wg_list[__popcll(gmask & ((1ull << threadIdx.x) - 1))] = (unsigned char)threadIdx.x;
   }
   __syncthreads();
+#if NPHM_PROF
+  auto tier_of = [&](int k) __attribute__((always_inline)) -> int {
+    if (!((wmask >> k) & 1ull)) return 0;
+    if (PREC == 0) return 3;
+    if (!((hmask >> k) & 1ull)) return 1;
+    return ((fmask >> k) & 1ull) ? 3 : 2;
+  };
+  if (threadIdx.x < 80) tier_prof[threadIdx.x] = 0ull;
+  if (threadIdx.x < N_MEMBERS) wg_tier[threadIdx.x] = 0u;
+  __syncthreads();
+  if (lane == 0) for (int i = 0; i < n_active; ++i) {
+    const int t = tier_of(wg_list[i]);
+    my_tier[wave][i] = (unsigned char)t;
+    atomicMax(&wg_tier[i], (unsigned)t);
+  }
+  __syncthreads();
+#endif
 #if NPHM_SETPRIO
   if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);    // the younger wavefront of each SIMD loses every issue arbitration otherwise
 #endif
@@ -1049,7 +1117,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   ws.issue(false, 0);
   ws.issue(false, 1);
 
-#if NPHM_PROF
+#if NPHM_PROF == 1
   long long prof[6] = {0, 0, 0, 0, 0, 0};   // L0 gemm, sync, gemm, epilogue, member total, kernel total
   const long long t_kernel = clock64();
 #endif
@@ -1057,6 +1125,25 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
 #pragma unroll 1
   for (int mi = 0; mi < n_active; ++mi) {
     const int k = wg_list[mi];
+#if NPHM_PROF
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) tier_t0[wave] = clock64();
+#if NPHM_PROF == 1
+    const long long tp_v0 = ws.sprof[0], tp_b0 = ws.sprof[1], tp_g0 = prof[0] + prof[2];
+#endif
+    auto tier_record = [&]() __attribute__((always_inline)) {
+      const long long t1 = clock64();
+      if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+        unsigned long long* q = tier_prof + (4 * int(my_tier[wave][mi]) + int(wg_tier[mi])) * 5;
+        atomicAdd(q, 1ull);
+        atomicAdd(q + 1, (unsigned long long)(t1 - tier_t0[wave]));
+#if NPHM_PROF == 1
+        atomicAdd(q + 2, (unsigned long long)(ws.sprof[0] - tp_v0));
+        atomicAdd(q + 3, (unsigned long long)(ws.sprof[1] - tp_b0));
+        atomicAdd(q + 4, (unsigned long long)(prof[0] + prof[2] - tp_g0));
+#endif
+      }
+    };
+#endif
     if (!((wmask >> k) & 1ull)) {
       // this wavefront's 32 points do not need member k: keep the ring moving only
       static_for<CHUNKS_PER_MEMBER>([&](auto cc) __attribute__((always_inline)) {
@@ -1064,6 +1151,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         if constexpr (NPHM_DMA_INSTREAM) ws.template prefetch<decltype(cc)::value>();
       });
       ws.next_member();
+#if NPHM_PROF
+      tier_record();
+#endif
       continue;
     }
     // lane-derived values are re-materialised per member (opaque to LICM): hoisting the dozens of
@@ -1315,7 +1405,8 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
             }
           }
         };
-        f32x16 d = load_frag16(WS::tail_of(buf) + h * 16);
+        f32x16 d = {};
+        if constexpr (!(NPHM_ABLATE & 256)) d = load_frag16(WS::tail_of(buf) + h * 16);
         if constexpr (PREC == 0) {
           if constexpr (g < L1_OB) d = gemm_fused_f32<L1_KS, 6, 7, NU>(buf, d, H, lane, epi, pre);
           else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_f32<L2_KS, 3, 4, NU>(buf, d, G, lane, epi, pre);
@@ -1331,9 +1422,11 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           // rows 8..15 xh wl + xl wl (added to rows 0..7 by a three-term member's epilogue, ignored by the other tiers)
           constexpr bool STACK = F16 && NPHM_STACK_TAILS && is_tail_chunk(c);
           constexpr int NP = (STACK && NPASS == 3) ? 2 : NPASS, AS = STACK ? 1 : 2;
-          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NP, PF, NU, F16, RUNK, AS>(buf, d, H, lane, epi, pre, slot_hook);
-          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NP, PF, NU, F16, RUNK, AS>(buf, d, G, lane, epi, pre, slot_hook);
-          else d = gemm_fused_bf16<L3_KS16, 6, 7, NP, PF, NU, F16, RUNK, AS>(buf, d, H, lane, epi, pre, slot_hook);
+          constexpr int HEAD_T = TIER == 1 ? NPHM_HEAD_LIGHT : TIER == 2 ? NPHM_HEAD_MID : NPHM_HEAD_HEAVY;
+          constexpr int HEAD = (RUNK > 0) ? 0 : (NU < HEAD_T ? NU : HEAD_T);
+          if constexpr (g < L1_OB) d = gemm_fused_bf16<L1_KS16, 6, 7, NP, PF, NU, F16, RUNK, AS, HEAD>(buf, d, H, lane, epi, pre, slot_hook);
+          else if constexpr (g < L1_OB + L2_OB) d = gemm_fused_bf16<L2_KS16, 3, 4, NP, PF, NU, F16, RUNK, AS, HEAD>(buf, d, G, lane, epi, pre, slot_hook);
+          else d = gemm_fused_bf16<L3_KS16, 6, 7, NP, PF, NU, F16, RUNK, AS, HEAD>(buf, d, H, lane, epi, pre, slot_hook);
         }
         accs[c & 1] = d;
         if constexpr (epilogue_exposed(c)) {
@@ -1353,7 +1446,7 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         PROF_T(t_s1);
         PROF_ADD(1, t_s0, t_s1);
         step(cc, LL);
-#if NPHM_PROF
+#if NPHM_PROF == 1
         asm volatile("" : "+v"(accs[c & 1][0]));
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // let the last MFMA retire before the stamp
 #endif
@@ -1376,14 +1469,24 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
     ws.next_member();
     PROF_T(t_m2);
     PROF_ADD(4, t_m0, t_m2);
-  }
 #if NPHM_PROF
+    tier_record();
+#endif
+  }
+#if NPHM_PROF == 1
   prof[5] = clock64() - t_kernel;
+#endif
+#if NPHM_PROF
+  __syncthreads();
+  // (only for a caller that announces a 96-slot table: stats[12] = "tierprof")
+  if (p.stats && p.stats[12] == 0x7469657270726f66ull && threadIdx.x < 80 && tier_prof[threadIdx.x]) atomicAdd(p.stats + 16 + threadIdx.x, tier_prof[threadIdx.x]);
+#if NPHM_PROF == 1
   if (p.stats && lane == 0 && n_active > 0) {
     for (int i = 0; i < 6; ++i) atomicAdd(p.stats + 2 + i, (unsigned long long)prof[i]);
     for (int i = 0; i < 3; ++i) atomicAdd(p.stats + 8 + i, (unsigned long long)ws.sprof[i]);
     atomicAdd(p.stats + 11, 1ull);
   }
+#endif
 #endif
     if (pass == 1 || !(p.refine_band > 0.f)) break;
     // ---- does any wavefront of the workgroup sit on the zero level set? -------------------------------------------

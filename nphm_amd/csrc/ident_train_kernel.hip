@@ -96,7 +96,8 @@ struct TrainArgs {
   float* save;                    // backward: [n_tiles][SV_ROWS][64]
   float* edge;                    // backward: [n_tiles][EDGE_FLOATS]
   const float* op_scale;          // operands == 2: [4] = scale of the adjoints' value columns (S_d), of the inputs' tangent
-                                  // columns (S_u), of the adjoints' tangent columns (S_t = S_d / S_u), 1 / S_d
+                                  // columns (S_u), of the adjoints' tangent columns (S_t = S_d / S_u), 1 / S_d; word [7] (unsigned,
+                                  // in/out): += wavefronts of this launch that clamped a stored operand to the binary16 range
 };
 
 // coord_operand without the constant slots: the B operand of the tangent stream at lin0 (no bias)
@@ -168,8 +169,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   const float* st = p.state + size_t(row) * LS_ROW_STRIDE;
   const float sign_x = (k < 2 * N_SYMM && (k & 1)) ? -1.f : 1.f;
   char* const save = SECOND ? reinterpret_cast<char*>(p.save) + size_t(tile_index) * SV_ROWS * 64 * ES : nullptr;
+  // OM == 2: wavefront-wide mask of "a stored operand left the binary16 range" (kept in SGPRs; v_cmp + s_or per value): the
+  // clamp below is silent, the count of such wavefronts goes to op_scale[7] (read as unsigned) - the host re-runs the step
+  // with fp32 storage when it is not zero (advisor, round 5: scales derived from seed maxima through measured ratios)
+  unsigned long long sat = 0ull;
   auto put = [&](char* at, float v) __attribute__((always_inline)) {
-    if constexpr (OM == 2) *reinterpret_cast<_Float16*>(at) = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    if constexpr (OM == 2) {
+      sat |= __ballot(fabsf(v) > 65504.f);
+      *reinterpret_cast<_Float16*>(at) = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    }
     else if constexpr (OM == 1) *reinterpret_cast<__bf16*>(at) = (__bf16)v;
     else *reinterpret_cast<float*>(at) = v;
   };
@@ -200,14 +208,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
 
   // this lane's column of tile 0 and of tile 1: point j and (forward) point 32 + j / (backward) its tangent
   constexpr int J1 = SECOND ? 0 : 32;
-  const float cx = pt_c[j][0], cy = pt_c[j][1], cz = pt_c[j][2], valid = pt_c[j][3], seed = pt_v[j][3];
-  const float c1x = pt_c[J1 + j][0], c1y = pt_c[J1 + j][1], c1z = pt_c[J1 + j][2], seed1 = pt_v[J1 + j][3];
-  const float vx = pt_v[j][0], vy = pt_v[j][1], vz = pt_v[j][2];
-  // what tile 1 carries into the coordinate slots (lin0 operand, skip features 101..103)
-  const float e1x = SECOND ? vx : c1x, e1y = SECOND ? vy : c1y, e1z = SECOND ? vz : c1z;
+  // Per-lane point data (coordinates, direction, seeds) is READ FROM LDS WHERE IT IS USED (four sites), not held: the sweep
+  // keeps acc, val and sigma' / sigma'' of four layers (192 VGPRs) beside 64 of weight and activation fragments - ten more
+  // registers that merely live from here to stage C were 2 spilled VGPRs + 12 B of scratch in rounds 2-5.
+  auto pt4 = [&](const float (*tab)[4], int m) __attribute__((always_inline)) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(tab[m]);
+  };
   bf16x8 bv[NT];
-  bv[0] = coord_operand(cx, cy, cz, h);
-  bv[1] = SECOND ? tangent_operand(vx, vy, vz, h) : coord_operand(c1x, c1y, c1z, h);
+  {
+    const f32x4 c0 = pt4(pt_c, j), e1 = SECOND ? pt4(pt_v, j) : pt4(pt_c, J1 + j);
+    bv[0] = coord_operand(c0[0], c0[1], c0[2], h);
+    bv[1] = SECOND ? tangent_operand(e1[0], e1[1], e1[2], h) : coord_operand(e1[0], e1[1], e1[2], h);
+  }
 
   const uint16_t* fw = p.packed_bf16 + size_t(set) * BF_SET_STRIDE;
   const uint16_t* bw = p.packed_bwd + size_t(set) * BWD_SET_STRIDE;
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     if (j < 16 && f < limit) edge[off + f] = o;
   };
   if (SECOND && wave == 7 && h == 0) {             // lin4's bias gradient: the value seeds of the tile
-    const float sb = half_wave_sum(seed);
+    const float sb = half_wave_sum(pt_v[j][3]);
     if (j == 0) edge[EDGE_B4] = sb;
   }
 
@@ -392,8 +404,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     gemm_tile(acc, fw + BF_OFF_L1A, wave, std::integral_constant<int, L1_KS16>{});
     activate(acc, s1, q1, val);
     if (wave == L1_OB - 1) {
-      val[0][1] = h ? cx : val[0][1]; val[0][2] = h ? cy : val[0][2]; val[0][3] = h ? cz : val[0][3];
-      val[1][1] = h ? e1x : val[1][1]; val[1][2] = h ? e1y : val[1][2]; val[1][3] = h ? e1z : val[1][3];
+      // what the tiles carry into the skip features 101..103: coordinates | (backward) the direction / (forward) tile 1's coordinates
+      const f32x4 c0 = pt4(pt_c, j), e1 = SECOND ? pt4(pt_v, j) : pt4(pt_c, J1 + j);
+      val[0][1] = h ? c0[0] : val[0][1]; val[0][2] = h ? c0[1] : val[0][2]; val[0][3] = h ? c0[2] : val[0][3];
+      val[1][1] = h ? e1[0] : val[1][1]; val[1][2] = h ? e1[1] : val[1][2]; val[1][3] = h ? e1[2] : val[1][3];
     }
   }
   __syncthreads();                       // every wavefront has read a0
@@ -433,6 +447,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
       // lin4's weight gradient: dW4[f] = sum over the points of h3'[f] sbar + u3'[f] (valid): this lane holds point j.
       // The sum of register r is kept by lane j = r: one store of 16 lanes per half-wave instead of sixteen of one lane.
       float o4 = 0.f;
+      const float seed = pt_v[j][3], valid = pt_c[j][3];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float sum = half_wave_sum(fmaf(val[0][r], seed, val[1][r] * valid));
@@ -455,6 +470,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
   // backward: output seeds H3 = sbar w4/k, U3 = w4/k (valid columns) -> D3 = H3 s3 + U3 s3' tau3, T3 = U3 s3
   // forward : G3 = w4/k s3 for both point tiles (seed 1 on valid points)
   if (wave < 7) {
+    const float seed = pt_v[j][3], valid = pt_c[j][3], seed1 = pt_v[J1 + j][3];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (SECOND) {
@@ -513,6 +529,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
     if (SECOND) {
       // lin0: dW0[f][c] = sum over the points of D0[f] c_in[c] + T0[f] v[c]; folded bias: sum of D0[f]
       float ox = 0.f, oy = 0.f, oz = 0.f, ob = 0.f;          // (lane j = r keeps register r's sums, as for lin4)
+      const f32x4 c0 = pt4(pt_c, j), v0 = pt4(pt_v, j);
+      const float cx = c0[0], cy = c0[1], cz = c0[2], vx = v0[0], vy = v0[1], vz = v0[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float d = val[0][r], t = val[1][r];
@@ -565,6 +583,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void train_kernel(TrainArgs p) {
       // gradient reaches mlp_pos and the latent codes)
       if (m == 0) { edge[EDGE_GA] = -sx; edge[EDGE_GA + 1] = -sy; edge[EDGE_GA + 2] = -sz; }
     }
+  }
+  if constexpr (SECOND && OM == 2) {
+    if (sat != 0ull && lane == 0) atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(p.op_scale)) + 7, 1u);
   }
 }
 

@@ -458,6 +458,7 @@ class DeepSDF(nn.Module):
         if self._two_pass_cache is None or self._two_pass_cache[0] != key:
             code, report = self.calibrate_numerics(packed, state, sample)
             self._two_pass_cache = (key, code, report)
+            self._numerics_serial = getattr(self, "_numerics_serial", 0) + 1      # (reconstruction.shared_mlp_code)
             self.last_numerics = dict(report, precision=self.precision, verified_err=report.get("err", 0.0), calibrated_here=True)
             return code
         code = self._two_pass_cache[1]
@@ -472,6 +473,7 @@ class DeepSDF(nn.Module):
             # otherwise repeat verify -> fail -> recalibrate, ~2 nlayers launches and host syncs each)
             code, report = self.calibrate_numerics(packed, state, sample)
             self._two_pass_cache = (key, code, dict(report, tightened_for_conditioning=True))
+            self._numerics_serial = getattr(self, "_numerics_serial", 0) + 1
             self.last_numerics = dict(report, precision=self.precision, verified_err=report.get("err", 0.0), calibrated_here=True,
                                       recalibrated_for_conditioning=True)
         return code

@@ -36,6 +36,8 @@ import torch.nn as nn
 
 from . import _lib
 
+_CAL_SERIAL = __import__("itertools").count(1)      # numbers the calibrations of a process (inference_numerics)
+
 _SQRT2 = float(np.sqrt(2))
 
 
@@ -614,8 +616,6 @@ class _MemberFieldFn(torch.autograd.Function):
                     gS_c.data_ptr(), gS_c.numel(), None if gG_c is None else gG_c.data_ptr(), 0 if gG_c is None else gG_c.numel(),
                     sw.data_ptr() + 16, sw.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "nphm_identity_train_operand_scales")
                 scales = sw
-            saved = torch.empty(lib.nphm_identity_train_saved_bytes(max(n for _, n, _, _ in ctx.pieces), o16),
-                                dtype=torch.uint8, device=dev)
             # per tile: its share of the lin0 / lin4 gradients, summed over the tile's columns in the reverse kernel
             edge = torch.empty(lib.nphm_identity_train_edge_bytes(T), dtype=torch.uint8, device=dev)
             edge_tile = lib.nphm_identity_train_edge_bytes(1)
@@ -630,16 +630,43 @@ class _MemberFieldFn(torch.autograd.Function):
             # every chunk's share of lin1 .. lin3 (written by the weight-gradient kernel, summed per weight set afterwards)
             wpart = torch.empty(lib.nphm_identity_train_wpart_bytes(C), dtype=torch.uint8, device=dev)
             wpart_chunk = lib.nphm_identity_train_wpart_bytes(1)
-            for t0, nt, c0, nc in ctx.pieces:
-                _lib.check(lib.nphm_identity_train_backward(
-                    packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N,
-                    tiles.data_ptr() + 16 * t0, nt, plist.data_ptr(), gS_c.data_ptr(),
-                    None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), saved.data_ptr(),
-                    edge.data_ptr() + edge_tile * t0, o16, None if scales is None else scales.data_ptr(), stream),
-                    "nphm_identity_train_backward")
-                _lib.check(lib.nphm_identity_train_weight_grads(
-                    saved.data_ptr(), o16, None if scales is None else scales.data_ptr(), chunks.data_ptr() + 16 * c0, nc,
-                    wpart.data_ptr() + wpart_chunk * c0, stream), "nphm_identity_train_weight_grads")
+
+            def sweep(o16, scales):
+                saved = torch.empty(lib.nphm_identity_train_saved_bytes(max(n for _, n, _, _ in ctx.pieces), o16),
+                                    dtype=torch.uint8, device=dev)
+                for t0, nt, c0, nc in ctx.pieces:
+                    _lib.check(lib.nphm_identity_train_backward(
+                        packed.data_ptr(), packed_bwd.data_ptr(), state.data_ptr(), xyz.data_ptr(), N,
+                        tiles.data_ptr() + 16 * t0, nt, plist.data_ptr(), gS_c.data_ptr(),
+                        None if gG_c is None else gG_c.data_ptr(), gx.data_ptr(), saved.data_ptr(),
+                        edge.data_ptr() + edge_tile * t0, o16, None if scales is None else scales.data_ptr(), stream),
+                        "nphm_identity_train_backward")
+                    _lib.check(lib.nphm_identity_train_weight_grads(
+                        saved.data_ptr(), o16, None if scales is None else scales.data_ptr(), chunks.data_ptr() + 16 * c0, nc,
+                        wpart.data_ptr() + wpart_chunk * c0, stream), "nphm_identity_train_weight_grads")
+                return saved
+
+            saved = sweep(o16, scales)
+            if o16 == 2:
+                # Did a stored operand leave the binary16 range?  The scales follow the seeds' maxima through ratios measured on
+                # two weight sets (operand_scales_kernel, 30 x margin); the kernel clamps silently and counts (ABI 11).  The
+                # count is read - one synchronisation - on the first two binary16 steps of a module and on every
+                # TRAIN_SAT_CHECK_EVERY-th after them: a step that clamped is REPEATED with fp32 storage and the module stays
+                # there (train_operands = "f32"), with a warning.
+                n16 = module.__dict__.get("_train_f16_steps", 0)
+                module.__dict__["_train_f16_steps"] = n16 + 1
+                if n16 < 2 or n16 % module.TRAIN_SAT_CHECK_EVERY == 0:
+                    clamped = int(scales[7:8].view(torch.int32).item())
+                    if clamped:
+                        import warnings
+                        warnings.warn(f"nphm_amd: {clamped} wavefronts of the training step's reverse sweep clamped a weight-gradient "
+                                      "operand to the binary16 range (seed / adjoint ratios outside the measured ones): the step is "
+                                      "repeated with fp32 operand storage and train_operands is set to 'f32' for this module")
+                        module.train_operands = "f32"
+                        module.__dict__["train_clamped_steps"] = module.__dict__.get("train_clamped_steps", 0) + 1
+                        gx.zero_()                                   # (the only output the first sweep ACCUMULATED into)
+                        o16, scales = 0, None
+                        saved = sweep(0, None)
             if getattr(module, "_keep_train_operands", False):          # (tools/train_operand_stats.py: the last piece's stored operands)
                 module._last_train_operands = saved
                 module._last_train_seeds = (float(gS_c.abs().max()), 0.0 if gG_c is None else float(gG_c.abs().max()))
@@ -985,6 +1012,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     _MODES = {"f32": _lib.NPHM_PREC_F32, "bf16x3": _lib.NPHM_PREC_BF16X3, "bf16x3a": _lib.NPHM_PREC_BF16X3_ADAPTIVE,
               "bf16x3a2": _lib.NPHM_PREC_BF16X3_ADAPTIVE2, "f16x3": _lib.NPHM_PREC_F16X3,
               "f16x3a2": _lib.NPHM_PREC_F16X3_ADAPTIVE2}
+    _MODE_NAMES = {v: k for k, v in _MODES.items()}
 
     @staticmethod
     def _tier_code(tol):
@@ -1019,6 +1047,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
     _EXACT_KNOBS = (-1.0, "f16x3")
     CHURN_USES = 3          # large evaluations a calibration must have served for the next weight version to be calibrated at once
     TRAIN_F16_MIN_POINTS = 4000     # train_operands = "auto": batches of at least this many points store binary16 operands
+    TRAIN_SAT_CHECK_EVERY = 25      # ... and every this many binary16 steps the kernel's clamp counter is read (one synchronisation)
 
     def _pinned_is_approximate(self):
         return self._prune_tol >= 0 or self._precision in ("bf16x3a", "bf16x3a2", "f16x3a2")
@@ -1093,7 +1122,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             hist["uses"], hist["pending"] = 1, None
             from .numerics import calibrate_numerics
             lat = None if lat_rows is None else lat_rows.detach().reshape(-1, self.lat_dim)[:2]
-            object.__setattr__(self, "_calibration", (key, calibrate_numerics(self, lat, device=device)))
+            object.__setattr__(self, "_calibration", (key, dict(calibrate_numerics(self, lat, device=device), serial=next(_CAL_SERIAL))))
             object.__setattr__(self, "_verified_latents", {})
             if lat is not None:
                 self._verified_latents[self._latent_digest(lat)] = self._calibration[1]["error"]
@@ -1107,6 +1136,15 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
                 self._verify_latent(lat, dig, device)
         c = self._calibration[1]
         return float(c["prune_tol"]), self.precision_code(c["precision"], c["light_tol"], c["mid_tol"], c.get("refine_band"))
+
+    def inference_numerics(self, device, lat_rows, n_points):
+        """((prune_tol, precision code), member bounds [40,4] or None) this rank would run an inference call with, and a
+        serial number of the calibration behind them (0: none; it changes whenever the calibration is replaced) - what
+        ``reconstruction.shared_identity_numerics`` sends from one rank to the others of a sharded evaluation."""
+        knobs = self.kernel_knobs(device, lat_rows, n_points)
+        c = self._calibration
+        have = self.numerics == "auto" and c is not None and c[0] == self._weights_key(device)
+        return knobs, (c[1].get("bounds") if have else None), (int(c[1].get("serial", 0)) if have else 0)
 
     def _latent_digest(self, lat):
         """Content digest of the latent rows (a device -> host copy of a few KiB = one synchronisation), memoised per
@@ -1140,6 +1178,7 @@ class FastEnsembleDeepSDFMirrored(nn.Module):
             union = torch.cat([c["latents"].to(lat), worst])[-4:]
             new = calibrate_numerics(self, union, device=device)
             new["recalibrated_for"] = {"digest": dig, "error_before": err}
+            new["serial"] = next(_CAL_SERIAL)
             object.__setattr__(self, "_calibration", (self._calibration[0], new))
             self._verified_latents.clear()               # measured with the old knobs
             err = new["error"]

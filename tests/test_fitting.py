@@ -558,6 +558,40 @@ def test_joint_fit_is_bitwise_reproducible_gpu(use_graph):
         assert torch.equal(a, b)
 
 
+@pytest.mark.gpu
+def test_second_stream_changes_no_bit_of_the_fit_gpu(monkeypatch):
+    """The step's second stream (NPHM_AMD_FIT_OVERLAP, default on: the identity field's prologue and the launch pair at the
+    roots run beside the main branch, inside the replayed graph as parallel branches) only changes WHEN launches run.  Every
+    tensor that crosses the two streams is ordered by an event or a stream wait and kept alive by its scope; a missing edge
+    would show as a fit that differs from the single-stream one, or from itself.  Four runs with the second stream and two
+    without, 60 replayed steps each (advisor, round 5: one box had shown 2 deviating runs of 16)."""
+    g = U.golden("fitting_trained")
+    dev = torch.device("cuda:0")
+    shape_net, _ = U.build_trained_identity(device=dev)
+    shape_net.train()
+    expr_net, _, _ = U.build_trained_deformation(device=dev)
+    obs = [torch.from_numpy(g[f"obs{i}"]).to(dev) for i in range(3)]
+    import hashlib
+
+    def run():
+        hist = []
+        torch.manual_seed(0)
+        lat_e, lat_s, anc = F.inference_iterative_root_finding_joint(
+            shape_net, expr_net, obs, dict(LAMBDAS), 60, {k: dict(v) for k, v in LONG_SCHEDULE.items()},
+            step_scale=float(g["step_scale"]), verbose=False, history=hist, use_graph=True)
+        keys = sorted(hist[0])
+        h = hashlib.sha1(np.array([[r[k] for k in keys] for r in hist]).tobytes())
+        for t in (lat_e, lat_s, anc):
+            h.update(t.detach().cpu().numpy().tobytes())
+        return h.hexdigest()
+
+    digests = []
+    for overlap in ("1", "0", "1", "1", "0", "1"):
+        monkeypatch.setenv("NPHM_AMD_FIT_OVERLAP", overlap)
+        digests.append((overlap, run()))
+    assert len({d for _, d in digests}) == 1, digests
+
+
 def _run_trained_pair(dev, backend, **kw):
     g = U.golden("fitting_trained")
     shape_net, _ = U.build_trained_identity(device=dev)

@@ -100,3 +100,90 @@ def test_partitions_cover_without_overlap():
             assert all(np.all(np.diff(s) > 0) for s in sets if len(s) > 1)
             if rx % (8 * world) == 0:
                 assert len({len(s) for s in sets}) == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# numerics of a sharded evaluation: rank 0 decides, the others take its decision (shared_numerics)
+# ---------------------------------------------------------------------------------------------
+class _StubDecoder:
+    """the four members shared_numerics uses; ``decide`` counts the calls of this rank's own decision"""
+    numerics = "auto"
+    lat_dim = 4
+
+    def __init__(self, rank):
+        self.rank, self.decided, self.serial, self.tol = rank, 0, 7, 2e-7
+
+    def _weights_key(self, device):
+        return ("w", 0)
+
+    def _latent_digest(self, lat):
+        return tuple(lat.reshape(-1).tolist())
+
+    def inference_numerics(self, device, lat, n_points):
+        assert self.rank == 0, "only the deciding rank may calibrate"
+        self.decided += 1
+        bounds = torch.arange(160, dtype=torch.float32).reshape(40, 4) * 0.5 + 1.0
+        return (self.tol, 0x2a0b0c06), bounds, self.serial
+
+
+def _shared_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dec = _StubDecoder(rank)
+        sent = [0]
+        orig = R._broadcast_from
+
+        def counting(*a, **k):
+            sent[0] += 1
+            return orig(*a, **k)
+
+        R._broadcast_from = counting
+        lat_a, lat_b = torch.zeros(1, 4), torch.ones(1, 4)
+        (knobs, bounds), code = R.shared_numerics(dec, lat_a, 1 << 20)
+        first = (knobs, bounds.reshape(-1).tolist(), code, sent[0])
+        R.shared_numerics(dec, lat_a, 1 << 20)                      # same call: served from the cache, nothing is sent
+        after_repeat = sent[0]
+        R.shared_numerics(dec, lat_b, 1 << 20)                      # another latent: rank 0 decides again
+        R.shared_numerics(dec, lat_a, 1 << 20)                      # the first one is still cached
+        after_b = sent[0]
+        dec.serial, dec.tol = 8, 1e-7                               # rank 0 re-calibrated while serving latent c:
+        lat_c = torch.full((1, 4), 2.0)
+        R.shared_numerics(dec, lat_c, 1 << 20)                      # ... the new serial voids every cached decision
+        (knobs_a2, _), _ = R.shared_numerics(dec, lat_a, 1 << 20)
+        # the dense MLP's tier code rides in the same broadcast; its callable runs on rank 0 only
+        mlp = type("M", (), {"precision": "f16x3", "numerics_target": 5e-6, "_lin_params": lambda self: ([], [])})()
+        called = [0]
+
+        def code_fn():
+            called[0] += 1
+            return 0x00f00001
+
+        (_, _), mcode = R.shared_numerics(dec, lat_a, 1 << 21, mlp=mlp, mlp_key=("expr",), mlp_code_fn=code_fn)
+        q.put((rank, first, after_repeat, after_b, sent[0], knobs_a2, dec.decided, mcode, called[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_zero_decides_the_numerics_of_a_sharded_evaluation():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shared_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = res
+    # the same decision on both ranks, bounds bit for bit; rank 1 never decided anything
+    assert r0[1] == r1[1] and r0[1][0] == (2e-7, 0x2a0b0c06) and r0[1][2] is None and r0[1][3] == 1
+    assert r0[1][1] == [1.0 + 0.5 * i for i in range(160)]
+    assert r0[2] == r1[2] == 1                    # the repeated call sent nothing
+    assert r0[3] == r1[3] == 2                    # latent b: one more broadcast; latent a again: cached
+    assert r0[4] == r1[4] == 5                    # latent c, latent a after the new serial, the two-stage call
+    assert r0[5] == r1[5] == (1e-7, 0x2a0b0c06)
+    assert r0[6] == 5 and r1[6] == 0
+    assert r0[7] == r1[7] == 0x00f00001 and r0[8] == 1 and r1[8] == 0
