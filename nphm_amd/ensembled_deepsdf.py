@@ -616,6 +616,10 @@ class _MemberFieldFn(torch.autograd.Function):
                     gS_c.data_ptr(), gS_c.numel(), None if gG_c is None else gG_c.data_ptr(), 0 if gG_c is None else gG_c.numel(),
                     sw.data_ptr() + 16, sw.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "nphm_identity_train_operand_scales")
                 scales = sw
+                shift = float(getattr(module, "train_scale_shift", 0.0))
+                if shift:                 # extra octaves on S_d (and S_t = S_d / S_u): shrinks the margin - what the tests of the clamp detector use
+                    f = 2.0 ** shift
+                    sw[0:4].mul_(torch.tensor([f, 1.0, f, 1.0 / f], device=dev))
             # per tile: its share of the lin0 / lin4 gradients, summed over the tile's columns in the reverse kernel
             edge = torch.empty(lib.nphm_identity_train_edge_bytes(T), dtype=torch.uint8, device=dev)
             edge_tile = lib.nphm_identity_train_edge_bytes(1)
