@@ -124,6 +124,18 @@ struct EvalArgs {
 #ifndef NPHM_STACK_TAILS
 #define NPHM_STACK_TAILS 1    // split-f16 path: the last 32-row block of a layer holds 8 real rows - its A fragment carries wh in rows
 #endif                        // 0..7 and wl in rows 8..15 (prep_kernels.hip), two MFMAs per K-step instead of three, half the DMA bytes
+#ifndef NPHM_M0_SAVE
+#define NPHM_M0_SAVE 0        // 1: the LDS-DMA statements save and restore M0 around their use of it (rounds 1-5)
+#endif
+#ifndef NPHM_EPI_PAIRS
+#define NPHM_EPI_PAIRS 1      // split formats, two- and three-term members: the epilogue works on register PAIRS (softplus2_pair) at the odd register
+#endif
+#ifndef NPHM_HOIST_BASES
+#define NPHM_HOIST_BASES 1    // the two members' weight-set / tail byte offsets live in SGPRs across the member (Streamer::member_bases)
+#endif
+#ifndef NPHM_HI_ONLY
+#define NPHM_HI_ONLY 0        // (measured +-0 twice: round 2 and round 6, tools/identity_variants.py - the stream's cost is not its bytes) split formats: a member that NO wavefront of the workgroup runs three-term is streamed without its wl
+#endif                        // fragments (single- and two-term products read wh alone): half the bytes of those chunks, L2 -> LDS
 #ifndef NPHM_LDS_STASH
 #define NPHM_LDS_STASH 1      // per-lane (qx, qy, qz, denom) parked in LDS across the member loop instead of in VGPRs
 #endif
@@ -157,6 +169,25 @@ __device__ __forceinline__ float softplus2(float d) {
   // v_max(x, x) is put in front; inline asm is not an option - it would read MFMA results without
   // the hazard wait states the compiler inserts for its own instructions)
   return fmaxf(d, 0.f) + __builtin_amdgcn_logf(1.f + t);             // raw v_log_f32, arg in [1,2]
+#endif
+}
+
+// Two values at once, the four instructions of each interleaved in program order: a transcendental's result must not be read by
+// the very next VALU instruction (gfx950: one wait state - hipcc puts an s_nop between v_log_f32 and the v_med3_f32 of a lone
+// softplus2, 470 issue slots of the kernel); with two values in flight every consumer is two instructions behind its producer.
+__device__ __forceinline__ void softplus2_pair(float d0, float d1, float& x0, float& x1) {
+  if (NPHM_ABLATE & 4) { x0 = d0; x1 = d1; return; }
+#if NPHM_SOFTPLUS4
+  float e0 = __builtin_amdgcn_exp2f(d0);
+  float e1 = __builtin_amdgcn_exp2f(d1);
+  e0 = 1.f + e0;
+  e1 = 1.f + e1;
+  e0 = __builtin_amdgcn_logf(e0);
+  e1 = __builtin_amdgcn_logf(e1);
+  x0 = __builtin_amdgcn_fmed3f(d0, e0, 127.f);
+  x1 = __builtin_amdgcn_fmed3f(d1, e1, 127.f);
+#else
+  x0 = softplus2(d0); x1 = softplus2(d1);
 #endif
 }
 
@@ -439,32 +470,64 @@ struct Streamer {
   // M0 is a reserved register for hipcc: it is saved and restored inside the statement
   template <int N> __device__ static __forceinline__ void dma16(const v4i& rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
     static_assert(N >= 1 && N <= 4, "instruction offsets 0 .. 3072");
+#if NPHM_M0_SAVE
     unsigned keep;
 #define NPHM_DMA_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-#define NPHM_DMA_MORE(off) "buffer_load_dwordx4 %1, %2, %4 offen offset:" #off " lds\n\t"
+#define NPHM_DMA_TAIL "s_mov_b32 m0, %0"
 #define NPHM_DMA_ARGS : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory"
-    if constexpr (N == 1) asm volatile(NPHM_DMA_HEAD "s_mov_b32 m0, %0" NPHM_DMA_ARGS);
-    else if constexpr (N == 2) asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) "s_mov_b32 m0, %0" NPHM_DMA_ARGS);
-    else if constexpr (N == 3) asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) NPHM_DMA_MORE(2048) "s_mov_b32 m0, %0" NPHM_DMA_ARGS);
-    else asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) NPHM_DMA_MORE(2048) NPHM_DMA_MORE(3072) "s_mov_b32 m0, %0" NPHM_DMA_ARGS);
+#else
+    // M0 is written and left: nothing else in these kernels reads it (LDS instructions of gfx9+ do not; checked in the ISA:
+    // every m0 of eval_kernel sits inside these statements) - two SALU per piece less than saving and restoring it
+#define NPHM_DMA_HEAD "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds\n\t"
+#define NPHM_DMA_TAIL ""
+#define NPHM_DMA_ARGS : : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory"
+#endif
+#if NPHM_M0_SAVE
+#define NPHM_DMA_MORE(off) "buffer_load_dwordx4 %1, %2, %4 offen offset:" #off " lds\n\t"
+#else
+#define NPHM_DMA_MORE(off) "buffer_load_dwordx4 %0, %1, %3 offen offset:" #off " lds\n\t"
+#endif
+    if constexpr (N == 1) asm volatile(NPHM_DMA_HEAD NPHM_DMA_TAIL NPHM_DMA_ARGS);
+    else if constexpr (N == 2) asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) NPHM_DMA_TAIL NPHM_DMA_ARGS);
+    else if constexpr (N == 3) asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) NPHM_DMA_MORE(2048) NPHM_DMA_TAIL NPHM_DMA_ARGS);
+    else asm volatile(NPHM_DMA_HEAD NPHM_DMA_MORE(1024) NPHM_DMA_MORE(2048) NPHM_DMA_MORE(3072) NPHM_DMA_TAIL NPHM_DMA_ARGS);
 #undef NPHM_DMA_HEAD
 #undef NPHM_DMA_MORE
+#undef NPHM_DMA_TAIL
 #undef NPHM_DMA_ARGS
   }
   __device__ static __forceinline__ void dma4(const v4i& rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+#if NPHM_M0_SAVE
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+#else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %3 offen lds"
+                 : : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+#endif
   }
   __device__ static __forceinline__ unsigned lds_addr(const char* q) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)q;
   }
 
   int k_cur, k_nxt;            // ids of the member being consumed and of the next one (-1: none)
+  uint64_t lo_mask = ~0ull;    // members whose wl fragments some wavefront of the workgroup reads (three-term members)
+  // byte offsets of the two members' weight set / chunk tails inside their buffers: computed ONCE per member (next_member) and
+  // kept in four SGPRs.  Rounds 4-5 recomputed member -> set -> offset at every one of the ~150 DMA sites (10 SALU each, a
+  // quarter of a single-term member's instruction stream) to keep hipcc from hoisting per-SITE values out of the member loop;
+  // the per-site values are still derived inside the loop - from these four, laundered at the site
+  unsigned mb_cur = 0, mb_nxt = 0, tb_cur = 0, tb_nxt = 0;
+  __device__ __forceinline__ void member_bases(int k, unsigned& mb, unsigned& tb) const {
+    const int kc = k < 0 ? 0 : ((NPHM_ABLATE & 32) ? 0 : k);
+    mb = unsigned(member_set(kc)) * Stream<PREC>::SET_BYTES;
+    tb = unsigned(LS_OFF_TAIL + kc * GEMM_CHUNKS * TAIL_FLOATS) * 4u;
+  }
 
   __device__ __forceinline__ void load_ids() {
     k_cur = mi < n_active ? __builtin_amdgcn_readfirstlane(int(list[mi])) : -1;
     k_nxt = mi + 1 < n_active ? __builtin_amdgcn_readfirstlane(int(list[mi + 1])) : -1;
+    member_bases(k_cur, mb_cur, tb_cur);
+    member_bases(k_nxt, mb_nxt, tb_nxt);
   }
   // Fetch of chunk `ci` of the current (next = false) or the next member into its ring slot, in pieces.
   // A chunk of ng 1 KiB groups: piece 0 = Q = ng / NW consecutive groups per wavefront (one M0),
@@ -487,9 +550,30 @@ struct Streamer {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(ring + (ci % RING) * SLOT_BYTES));
     const int ng = Stream<PREC>::groups(ci);
     const int q = ng / NW, rem = ng - q * NW;
+#if NPHM_HOIST_BASES
+    unsigned mb = next ? mb_nxt : mb_cur;
+    asm volatile("" : "+s"(mb));
+    const unsigned base = ci == 0 ? unsigned(Stream<PREC>::LS_OFF_L0 + k * L0_BLOCK_FLOATS) * 4u
+                                  : mb + unsigned(Stream<PREC>::offset(ci - 1));
+#else
     const unsigned base = ci == 0 ? unsigned(Stream<PREC>::LS_OFF_L0 + k * L0_BLOCK_FLOATS) * 4u
                                   : unsigned(member_set(k)) * Stream<PREC>::SET_BYTES + unsigned(Stream<PREC>::offset(ci - 1));
+#endif
     const v4i& rs = ci == 0 ? rs_s : rs_w;
+    if constexpr (NPHM_HI_ONLY && PREC >= 1 && PERIOD == 2) {
+      // [ks][hi | lo] fragments of 1 KiB: only the even groups, group 2 s from wavefront s % NW (LDS layout unchanged - the lo
+      // slots keep stale bytes nobody reads).  Not for chunk 0 (the L0 block) and the stacked tail blocks (one fragment per K-step).
+      if (ci > 0 && Stream<PREC>::groups(ci) == Stream<1>::groups(ci) && !((lo_mask >> k) & 1ull)) {
+        if (i < 2) {
+          const int sidx = wave + NW * i;
+          if (sidx < ng / 2) {
+            const unsigned g = unsigned(sidx) * 2048u;
+            dma16<1>(rs, l * 16, __builtin_amdgcn_readfirstlane(base + g), __builtin_amdgcn_readfirstlane(dst + g));
+          }
+          return;
+        }
+      }
+    }
     if (i == 0) {
       if (q == 0) return;                   // (a stacked lin2 tail: 7 groups, all of them "left-over" pieces)
       const unsigned g = unsigned(q * wave) * 1024u;
@@ -504,7 +588,13 @@ struct Streamer {
         dma16<1>(rs, l * 16, __builtin_amdgcn_readfirstlane(base + g), __builtin_amdgcn_readfirstlane(dst + g));
       }
     } else if (ci > 0 && wave == (ci & (NW - 1))) {
+#if NPHM_HOIST_BASES
+      unsigned tb = next ? tb_nxt : tb_cur;
+      asm volatile("" : "+s"(tb));
+      const unsigned soff = tb + unsigned((ci - 1) * TAIL_FLOATS) * 4u;
+#else
       const unsigned soff = unsigned(LS_OFF_TAIL + (k * GEMM_CHUNKS + ci - 1) * TAIL_FLOATS) * 4u;
+#endif
       dma4(rs_s, l * 4, __builtin_amdgcn_readfirstlane(soff), dst + Stream<PREC>::MAIN_BYTES);
     }
   }
@@ -580,7 +670,10 @@ struct Streamer {
     ++mi;
     k_cur = k_nxt;
     k_nxt = mi + 1 < n_active ? __builtin_amdgcn_readfirstlane(int(list[mi + 1])) : -1;
+    mb_cur = mb_nxt; tb_cur = tb_nxt;
+    member_bases(k_nxt, mb_nxt, tb_nxt);
     asm volatile("" : "+s"(k_cur), "+s"(k_nxt));   // opaque: nothing per-site hoisted out of the loop
+    asm volatile("" : "+s"(mb_cur), "+s"(mb_nxt), "+s"(tb_cur), "+s"(tb_nxt));
   }
   __device__ static __forceinline__ const float* tail_of(const char* buf) {
     return reinterpret_cast<const float*>(buf + Stream<PREC>::MAIN_BYTES);
@@ -940,7 +1033,7 @@ template <int MODE, int PREC>
 __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   using WS = Streamer<PREC>;
   __shared__ __attribute__((aligned(16))) char ring[RING * WS::SLOT_BYTES];
-  __shared__ unsigned int wg_mask[2];
+  __shared__ unsigned int wg_mask[4];        // [0..1] members some wavefront evaluates, [2..3] ... runs three-term
   __shared__ unsigned char wg_list[N_MEMBERS];
   // per-lane query point and blend normaliser, parked in LDS across the member loop: the loop body holds 7 + 4 activation
   // blocks, 2-3 accumulators and the A fragments in 256 VGPRs - every VGPR that merely LIVES across it ends up as a scratch
@@ -1068,11 +1161,16 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
   // ---- union over the workgroup: the members whose weights get streamed ----------------------
-  if (threadIdx.x < 2) wg_mask[threadIdx.x] = 0u;
+  if (threadIdx.x < 4) wg_mask[threadIdx.x] = 0u;
   __syncthreads();
   if (lane == 0) {
     atomicOr(&wg_mask[0], (unsigned int)(wmask & 0xffffffffull));
     atomicOr(&wg_mask[1], (unsigned int)(wmask >> 32));
+    if (NPHM_HI_ONLY && PREC >= 1) {                     // members this wavefront runs three-term: their wl fragments are needed
+      const uint64_t three = wmask & hmask & fmask;
+      atomicOr(&wg_mask[2], (unsigned int)(three & 0xffffffffull));
+      atomicOr(&wg_mask[3], (unsigned int)(three >> 32));
+    }
     if (p.stats && pass == 0) {
       atomicAdd(&wg_stats[0], nv * __popcll(wmask));
       atomicAdd(&wg_stats[1], nv);
@@ -1113,6 +1211,9 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);    // the younger wavefront of each SIMD loses every issue arbitration otherwise
 #endif
   WS ws{p, st, ring, wg_list, n_active, 0, wave, lane, WS::make_rsrc(Stream<PREC>::set_base(p, 0)), WS::make_rsrc(st)};
+  if (NPHM_HI_ONLY && PREC >= 1) {
+    ws.lo_mask = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(wg_mask[3])))) << 32) | uint32_t(__builtin_amdgcn_readfirstlane(int(wg_mask[2])));
+  }
   ws.load_ids();
   ws.issue(false, 0);
   ws.issue(false, 1);
@@ -1246,6 +1347,42 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         }
         return;
       }
+      if constexpr (PREC >= 1) { if constexpr (NPHM_EPI_PAIRS && !LIGHT) {
+        // pairs: everything for registers r - 1, r happens at the odd one
+        if constexpr (P >= 1 + L1_OB + L2_OB) {
+          if constexpr (r % 4 == 0) {
+            typedef __attribute__((address_space(3))) const f32x4* lds_v4;
+            const unsigned int w4a = WS::lds_addr(reinterpret_cast<const char*>(WS::tail_of(ws.slot(P)) + 32 + h * 16 + r));
+            w4q = *(lds_v4)(size_t)w4a;
+          }
+          if constexpr (r & 1) {
+            float x0, x1;
+            softplus2_pair(a[r - 1], a[r], x0, x1);
+            part = fmaf(x0, w4q[(r - 1) % 4], part);
+            part = fmaf(x1, w4q[r % 4], part);
+            asm volatile("" : "+v"(part));
+          }
+        } else if constexpr (r & 1) {
+          float x0, x1;
+          softplus2_pair(a[r - 1], a[r], x0, x1);
+          if constexpr (g == L1_OB - 1) {        // skip connection (see below): registers 1..3 of the upper half-wave
+            if constexpr (r - 1 >= 1 && r - 1 <= 3) x0 = h ? coords[r - 2] : x0;
+            if constexpr (r <= 3) x1 = h ? coords[r - 1] : x1;
+          }
+          Act& dst = g < L1_OB ? G[g < L1_OB ? g : 0] : H[g >= L1_OB ? g - L1_OB : 0];
+          constexpr int NR = (g == L1_OB - 1 || g == L1_OB + L2_OB - 1) ? LAST_BLOCK_REGS : 16;
+          a[r - 1] = x0;
+          a[r] = x1;
+          pack_pair<r - 1, LIGHT, PREC == 2>(a, dst);
+          if constexpr (r == NR - 1 && NR < 16) {
+#pragma unroll
+            for (int q = NR / 2; q < 4; ++q) { dst.hi[0][q] = 0u; dst.lo[0][q] = 0u; }
+            asm volatile("" : "+v"(dst.hi[0]));
+            asm volatile("" : "+v"(dst.lo[0]));
+          }
+        }
+        return;
+      } }
       float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
       if constexpr (P >= 1 + L1_OB + L2_OB) {
         // lin3 block: lin4 (200 -> 1) fused; its 16 weights sit in the chunk's ring-slot tail
@@ -1297,6 +1434,22 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
         if constexpr (r == NR - 1 && NR < 16) zero_pad_hi<NR>(H[B]);
         return;
       }
+      if constexpr (PREC >= 1) { if constexpr (NPHM_EPI_PAIRS && !LIGHT) {
+        if constexpr (r & 1) {
+          float x0, x1;
+          softplus2_pair(a[r - 1], a[r], x0, x1);
+          a[r - 1] = x0;
+          a[r] = x1;
+          pack_pair<r - 1, LIGHT, PREC == 2>(a, H[B]);
+          if constexpr (r == NR - 1 && NR < 16) {
+#pragma unroll
+            for (int q = NR / 2; q < 4; ++q) { H[B].hi[0][q] = 0u; H[B].lo[0][q] = 0u; }
+            asm volatile("" : "+v"(H[B].hi[0]));
+            asm volatile("" : "+v"(H[B].lo[0]));
+          }
+        }
+        return;
+      } }
       const float x = (LIGHT && NPHM_LIGHT_POLY) ? softplus2_light(a[r]) : softplus2(a[r]);
       if constexpr (PREC == 0) {
         H[B][r] = x;
