@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3", "bf16x3a", "bf16x3a2", "f16x3", "f16x3a2"],
                     help="auto (default) = the module's default: knobs calibrated for the checkpoint (numerics = 'auto')")
     ap.add_argument("--chunk", type=int, default=25000, help="get_logits chunk whose last voxel is overwritten (eval mode)")
-    ap.add_argument("--workload", default="all", choices=["all", "identity", "two_stage", "npm", "fitting", "training"],
+    ap.add_argument("--workload", default="all", choices=["all", "identity", "two_stage", "npm", "fitting", "training", "training_corresp"],
                     help="all (default) = the contract line for configs[1] with every other config / precision as "
                          "sub-records; identity = the contract line alone; the others = one of the remaining configs "
                          "as a line of its own (two_stage = configs[2], npm = configs[0], fitting = configs[4])")
@@ -718,6 +718,67 @@ def training_record(args, dev, with_composite=True, steps=8):
     return out
 
 
+def training_corresp_record(args, dev, steps=8):
+    """SURVEY 8 f4, widened: one step of the reference's SECOND training stage (training_corresp.py: compute_loss_corresp_forward,
+    loss_functions.py:282-326, backward w.r.t. every weight of the deformation network, both code tables and the identity decoder's
+    anchor head, Adam) at nphm_def.yaml's sizes - batch 32 x 1000 correspondences + 100 free samples per subject - with the
+    dense backbone on the training kernels (csrc/dense_train_kernels.hip) next to the SAME step on the composite PyTorch tier
+    (nn.Linear / Softplus under autograd: library GEMMs).  Synthetic points, seeded random-init weights."""
+    import _util as U
+    from nphm_amd.loss_functions import compute_loss_corresp_forward
+    B, n = 32, 1000
+    g = torch.Generator().manual_seed(17)
+    neutral = (torch.rand(B, n, 3, generator=g) - 0.5) * torch.tensor([0.5, 0.6, 0.5])
+    batch = {"points_neutral": neutral, "points_posed": torch.cat([neutral + 0.01 * torch.randn(B, n, 3, generator=g),
+                                                                    torch.randn(B, n, 3, generator=g)], -1),
+             "gt_anchors": torch.from_numpy(U.anchors_mean()).reshape(1, 39, 3).repeat(B, 1, 1),
+             "subj_ind": torch.arange(B).reshape(B, 1) % 24, "idx": torch.arange(B).reshape(B, 1)}
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    lam = {"corresp": 100.0, "lat_reg": 0.01, "loss_reg_zero": 5.0}
+
+    def run(backend):
+        torch.manual_seed(3)
+        shape_net = U.build_identity(device=dev).train()
+        expr_net = U.build_deformation(device=dev).train()
+        expr_net.defDeepSDF.train_backend = backend
+        lat_shape, lat_expr = torch.nn.Embedding(24, 1344).to(dev), torch.nn.Embedding(B, 200).to(dev)
+        with torch.no_grad():
+            lat_shape.weight.copy_(torch.stack([U.sample_latent(40 + i) for i in range(24)]).to(dev))
+            lat_expr.weight.mul_(0.1)
+        params = list(expr_net.parameters()) + list(shape_net.mlp_pos.parameters()) + list(lat_shape.parameters()) + list(lat_expr.parameters())
+        opt = torch.optim.Adam(params, lr=5e-4)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            losses = compute_loss_corresp_forward(batch, expr_net, shape_net, lat_expr, lat_shape, dev, epoch=3)
+            total = sum(lam[k] * losses[k] for k in lam)
+            total.backward()
+            opt.step()
+            return total.detach()
+
+        losses = [float(step()) for _ in range(3)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = [step() for _ in range(steps)][-1]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {"ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "first_loss": losses[0], "last_loss": float(last)}
+
+    ours, ref = run("hip"), run("composite")
+    pts = B * (n + 100)
+    flops = 3 * 2 * pts * (235 * 512 + 512 * 512 + 512 * 277 + 512 * 512 + 2 * 512 * 512 + 512 * 3)     # forward + two backward products per layer
+    return {"metric": "deformation-network training steps/s (compute_loss_corresp_forward + backward + Adam)", "value": ours["steps_per_s"],
+            "unit": "steps/s", "ms_per_step": ours["ms_per_step"], "steps": steps,
+            "dtype": "split-bf16 x3 MFMA (fp32 accumulate) for the six hidden layers and their data / weight gradients; fp32 PyTorch ops for the "
+                     "concatenations, the 3-row output layer, the compressor, losses and the optimizer",
+            "config": {"workload": f"train_corresp step, batch {B} x ({n} correspondences + 100 free samples), nphm_def.yaml sizes and lambdas, "
+                                   "'compress' deformation network (6 x 512), every weight + both code tables trainable (SURVEY 8 f4)"},
+            "first_loss": ours["first_loss"], "last_loss": ours["last_loss"],
+            "model_tflops_per_step": flops / 1e12, "model_tflops_per_s": flops / 1e12 / (ours["ms_per_step"] * 1e-3),
+            "composite_same_gpu": ref, "speedup_vs_composite": ref["ms_per_step"] / ours["ms_per_step"],
+            "last_loss_diff": abs(ours["last_loss"] - ref["last_loss"])}
+
+
 # ------------------------------------------------------------------------------------------------------
 # baselines
 # ------------------------------------------------------------------------------------------------------
@@ -895,6 +956,8 @@ def single_workload(args):
         rec = npm_record(args, dev, args.steps, args.warmup, not args.no_cpu_baseline)
     elif args.workload == "training":
         rec = training_record(args, dev, with_composite=not args.no_cpu_baseline, steps=max(args.steps, 5))
+    elif args.workload == "training_corresp":
+        rec = training_corresp_record(args, dev, steps=max(args.steps, 5))
     else:
         rec = fitting_record(args, dev, with_reference_loop=not args.no_cpu_baseline)
     rec.setdefault("cpu_baseline", None)
@@ -934,6 +997,10 @@ def summary_of(out):
         s["f4_training"] = {"steps_per_s": r3(t["value"]), "ms": r3(t["ms_per_step"]),
                             "composite_ms": r3((t.get("composite_same_gpu") or {}).get("ms_per_step")),
                             "hbm_frac": r3((t.get("roofline") or {}).get("frac"))}
+    if "training_corresp" in c:
+        t = c["training_corresp"]
+        s["f4_training_corresp"] = {"ms": r3(t["ms_per_step"]), "composite_ms": r3(t["composite_same_gpu"]["ms_per_step"]),
+                                    "model_tflops_per_s": r3(t["model_tflops_per_s"])}
     if "trained_checkpoint_256" in c:
         t = c["trained_checkpoint_256"]
         s["trained_ckpt"] = {"mpts": r3(t["value"]), "frac": r3(t["roofline"]["frac"]), "members": r3(t["roofline"]["mean_active_members"]),
@@ -1055,6 +1122,7 @@ def main():
                 "fitting": fitting_record(args, dev, with_reference_loop=not args.no_cpu_baseline),
                 "grid512_one_gpu": grid512_record(args, dev),
                 "training": training_record(args, dev, with_composite=not args.no_cpu_baseline),
+                "training_corresp": training_corresp_record(args, dev),
                 "trained_checkpoint_256": trained_record(args, dev),
             }
             ib.set_precision(args.precision)

@@ -596,6 +596,27 @@ int nphm_mc_device_count(const float* volume, int nx, int ny, int nz, double iso
 int nphm_mc_device_emit(const float* volume, int nx, int ny, int nz, double iso, int negate, void* workspace,
                         double* verts, int64_t* faces, void* stream);
 
+/* ---- dense skip-MLP with trainable parameters (ABI 11; csrc/dense_train_kernels.hip) ---------------------------------------
+ * Replaces, inside the reference's second training stage (scripts/training/train_corresp.py -> compute_loss_corresp_forward,
+ * src/NPHM/models/loss_functions.py:282-326), the nn.Linear + Softplus pairs of DeepSDF.forward (src/NPHM/models/deepSDF.py:
+ * 64-89) and what autograd derives from them: per hidden layer one launch forward, three backward.
+ *   nphm_dense_gemm_nt : C[M,N] = alpha A[M,K] B[N,K]^T (fp32 in HBM, rows lda / ldb / ldc floats apart; split-bf16 x3 on the
+ *     matrix pipe, fp32-equivalent), epilogue 0: nothing, 1: C = act(C + E[m / e_rows]), act = Softplus(beta) (beta <= 0: ReLU),
+ *     2: C = C + E[m / e_rows]; E [ceil(M / e_rows), N] contiguous.  k_splits > 1 (epilogue 0 only): the K range is cut into
+ *     k_splits pieces whose products are WRITTEN to C[z][M][ldc] - nphm_dense_reduce_splits adds them in order (weight
+ *     gradients: K = the point axis; no atomics).
+ *       forward y = gemm(x, W, e, epilogue 1);  dx = gemm(gp, W^T);  dW = reduce(gemm(gp^T, x^T, k_splits))
+ *   nphm_dense_gpre : gp[n][c] = g[n][c] act'(y[n][c]) with act' from the activation's output (Softplus: 1 - exp(-beta y)); y NULL:
+ *     gp = g.  Writes gp (NULL: not) and / or its transpose gp_t[c][n] (rows ld_t floats apart; NULL: not) - also the
+ *     transpose kernel of x and W - and (column_sums not NULL) the column sums of every 32-row tile, [ceil(n / 32), c].
+ *   nphm_dense_column_sums : out[c] = sum over the rows of x [rows, c] in a fixed order (bias gradients: the tiles' sums). */
+int nphm_dense_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                       const float* E, int e_rows, float alpha, float beta, int epilogue, int k_splits, void* stream);
+int nphm_dense_reduce_splits(const float* parts, int k_splits, int64_t count, float scale, float* out, void* stream);
+int nphm_dense_gpre(const float* g, const float* y, int n, int c, float beta, float* gp, float* gp_t, int ld_t, float* column_sums,
+                    void* stream);
+int nphm_dense_column_sums(const float* x, int rows, int c, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,11 @@ SYMBOLS = {
                                      ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_void_p]),
     "nphm_mc_device_emit": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    "nphm_dense_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_float,
+                                   c_int, c_int, c_void_p]),
+    "nphm_dense_reduce_splits": (c_int, [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p]),
+    "nphm_dense_gpre": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nphm_dense_column_sums": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -9,7 +9,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip", "mlp_bwd_kernel.hip", "ident_bwd_kernel.hip", "ident_train_kernel.hip", "fit_kernels.hip", "train_loss_kernels.hip", "mc_device.hip", "probe.hip", "marching_cubes.cpp"]
+SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip", "mlp_bwd_kernel.hip", "ident_bwd_kernel.hip", "ident_train_kernel.hip", "fit_kernels.hip", "train_loss_kernels.hip", "dense_train_kernels.hip", "mc_device.hip", "probe.hip", "marching_cubes.cpp"]
 OUT = os.path.join(HERE, "libnphm_amd.so")
 OBJ_CACHE = os.path.join(HERE, "..", ".build_cache")      # objects by content hash (git- and gpurun-ignored)
 

@@ -132,6 +132,71 @@ class _MlpCondFn(torch.autograd.Function):
         return None, None, grad_cond, None, None, None, None
 
 
+class _DenseLayerFn(torch.autograd.Function):
+    """y = act(alpha x W^T + b) of one nn.Linear (+ Softplus) of the backbone with TRAINABLE parameters, on the kernels of
+    csrc/dense_train_kernels.hip: one launch forward; backward: act' from y and the transposes (one launch + two small ones),
+    dx = alpha gp W (one launch), dW = alpha gp^T x with the point axis as K in splits added in order (two launches), db = column
+    sums of gp (per 32-row tile in the first launch, one more over the tiles).  First order only.  x [M,K], W [N,K], b [N]; beta None: no activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, beta):
+        lib = _lib.load()
+        x = x.contiguous()
+        W = weight.detach().contiguous()
+        M, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        b = bias.detach().contiguous()
+        _lib.check(lib.nphm_dense_gemm_nt(x.data_ptr(), K, W.data_ptr(), K, y.data_ptr(), N, M, N, K, b.data_ptr(), M,
+                                          float(alpha), 0.0 if beta is None else float(beta), 2 if beta is None else 1, 1, stream),
+                   "nphm_dense_gemm_nt")
+        ctx.save_for_backward(x, W, y)
+        ctx.alpha, ctx.beta = float(alpha), beta
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, W, y = ctx.saved_tensors
+        M, K = x.shape
+        N = W.shape[0]
+        dev = x.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        pad4 = lambda v: (v + 3) // 4 * 4
+        g = g.contiguous()
+        ldm = pad4(M)
+        gp = torch.empty(M, N, dtype=torch.float32, device=dev)
+        gp_t = torch.empty(N, ldm, dtype=torch.float32, device=dev)
+        tiles = torch.empty((M + 31) // 32, N, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        _lib.check(lib.nphm_dense_gpre(g.data_ptr(), None if ctx.beta is None else y.data_ptr(), M, N,
+                                       0.0 if ctx.beta is None else float(ctx.beta), gp.data_ptr(), gp_t.data_ptr(), ldm,
+                                       None if tiles is None else tiles.data_ptr(), stream), "nphm_dense_gpre")
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            ldn = pad4(N)
+            w_t = torch.empty(K, ldn, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_dense_gpre(W.data_ptr(), None, N, K, 0.0, None, w_t.data_ptr(), ldn, None, stream), "nphm_dense_gpre")
+            dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_dense_gemm_nt(gp.data_ptr(), N, w_t.data_ptr(), ldn, dx.data_ptr(), K, M, K, N, None, 1,
+                                              ctx.alpha, 0.0, 0, 1, stream), "nphm_dense_gemm_nt")
+        if ctx.needs_input_grad[1]:
+            x_t = torch.empty(K, ldm, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_dense_gpre(x.data_ptr(), None, M, K, 0.0, None, x_t.data_ptr(), ldm, None, stream), "nphm_dense_gpre")
+            splits = int(min(64, max(1, M // 512)))
+            parts = torch.empty(splits, N, K, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_dense_gemm_nt(gp_t.data_ptr(), ldm, x_t.data_ptr(), ldm, parts.data_ptr(), K, N, K, M, None, 1,
+                                              1.0, 0.0, 0, splits, stream), "nphm_dense_gemm_nt")
+            dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_dense_reduce_splits(parts.data_ptr(), splits, N * K, ctx.alpha, dW.data_ptr(), stream),
+                       "nphm_dense_reduce_splits")
+        if ctx.needs_input_grad[2]:
+            db = torch.empty(N, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_dense_column_sums(tiles.data_ptr(), tiles.shape[0], N, db.data_ptr(), stream), "nphm_dense_column_sums")
+        return dx, dW, db, None, None
+
+
 class DeepSDF(nn.Module):
     """Skip-MLP SDF / vector field (deepSDF.py:6-89).  dims = [d_in] + [hidden]*nlayers + [out];
     the input is re-injected (concatenated, divided by sqrt 2) before layer ``nlayers//2``;
@@ -150,6 +215,7 @@ class DeepSDF(nn.Module):
         self.n_out = out_dim
         self.beta = beta
         self.backend = "hip"            # "hip" | "composite"
+        self.train_backend = "hip"      # with trainable parameters: "hip" = the dense training tier (evaluate_train_hip) | "composite"
         self._pack_cache = None         # (key, packed tensor)
         self._pack_bwd_cache = None     # (key, transposed pack of the backward kernel)
         # Numerics of the plain HIP evaluation (forward_hip / lattice launches; include/nphm_amd.h NPHM_MLP_*):
@@ -239,6 +305,38 @@ class DeepSDF(nn.Module):
             if layer < last:
                 x = self.activation(x)
         return x
+
+    def train_tier_serves(self, xyz, lat):
+        """The dense training tier's conditions: trainable parameters, a recorded graph, ROCm fp32 tensors, and no gradient
+        asked w.r.t. the query points (its backward is first order: loss_joint's d sdf / d posed points through the offsets
+        needs the composite tier's double backward)."""
+        return (self.backend != "composite" and self.train_backend == "hip" and xyz.is_cuda and xyz.dtype == torch.float32
+                and lat.dtype == torch.float32 and torch.is_grad_enabled() and not xyz.requires_grad
+                and any(p.requires_grad for p in self.parameters())
+                and all(p.dtype == torch.float32 for p in self.parameters()))
+
+    def evaluate_train_hip(self, pos, lat):
+        """``evaluate`` with every hidden nn.Linear + activation as ONE launch of csrc/dense_train_kernels.hip and its
+        backward - data, weight and bias gradients - on the same kernels (``_DenseLayerFn``): the op sequence of the reference's
+        forward (deepSDF.py:64-89: cat, skip cat / sqrt 2, Linear, Softplus), the concatenations left to torch.  The last
+        linear layer (out_dim <= 4 rows) stays an nn.Linear call.  pos [B,N,d_spatial]; lat [B,Lr,lat_dim], Lr in {1,N}."""
+        B, N, _ = pos.shape
+        lat_full = lat if lat.shape[1] == N else lat.expand(B, N, lat.shape[-1])
+        inp = torch.cat([pos, lat_full], dim=-1).reshape(B * N, -1)
+        x = inp
+        last = self.num_layers - 2
+        beta = float(self.beta)
+        for layer in range(self.num_layers - 1):
+            lin = getattr(self, f"lin{layer}")
+            alpha = 1.0
+            if layer in self.skip_in:
+                x = torch.cat([x, inp], dim=-1)
+                alpha = 1.0 / _SQRT2
+            if layer < last:
+                x = _DenseLayerFn.apply(x, lin.weight, lin.bias, alpha, beta)
+            else:
+                x = torch.nn.functional.linear(x * alpha if alpha != 1.0 else x, lin.weight, lin.bias)
+        return x.reshape(B, N, -1)
 
     # ---- HIP tier ----------------------------------------------------------------------------
     def invalidate_pack(self):
@@ -700,6 +798,9 @@ class DeepSDF(nn.Module):
             fwd = self.forward_hip_cond_grad if (torch.is_grad_enabled() and lat_rep.requires_grad) else self.forward_hip
             out = fwd(*plan).reshape(x3.shape[0], x3.shape[1], self.n_out)
             return (out.squeeze(0) if squeeze else out), None
+        if lat_rep.dim() == 3 and self.train_tier_serves(x3, lat_rep):
+            out = self.evaluate_train_hip(self._embed(x3), lat_rep)
+            return (out.squeeze(0) if squeeze else out), None
         return self.evaluate(self._embed(xyz), lat_rep), None
 
 
@@ -889,6 +990,8 @@ class DeformationNetwork(nn.Module):
             fwd = (self.defDeepSDF.forward_hip_cond_grad if (torch.is_grad_enabled() and cond.requires_grad)
                    else self.defDeepSDF.forward_hip)
             pred = fwd(*plan).reshape(xyz.shape[0], xyz.shape[1], -1)
+        elif self.defDeepSDF.train_tier_serves(xyz, cond):
+            pred = self.defDeepSDF.evaluate_train_hip(self.defDeepSDF._embed(xyz), cond)     # trainable backbone: the dense training tier
         else:
             pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
         return pred[..., :3], pred[..., -1:]

@@ -233,7 +233,9 @@ def compute_loss_corresp_forward(batch, decoder, decoder_shape, latent_codes, la
         anchors = batch_cuda["gt_anchors"]
     cond = torch.cat([cond_shape, cond_pose], dim=-1)
 
-    neutral = batch_cuda["points_neutral"].clone().detach().requires_grad_()
+    # (the reference marks the neutral points as requiring a gradient, :301, and never reads it: without the mark the
+    # backbone's first-order training tier serves the call - same losses, same parameter / code gradients)
+    neutral = batch_cuda["points_neutral"].clone().detach()
     cond_rep = cond.repeat(1, neutral.shape[1], 1)
     delta, _ = decoder(neutral, cond_rep, anchors)
     posed = neutral + delta.squeeze()

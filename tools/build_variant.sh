@@ -8,7 +8,7 @@ NAME=$1; shift
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -fno-honor-nans -I include"
 mkdir -p gpurun_tmp/obj
 V=${VARIANT_SRC:-eval_kernel}
-ALL="prep_kernels eval_kernel mlp_kernel mlp_bwd_kernel ident_bwd_kernel ident_train_kernel fit_kernels train_loss_kernels mc_device probe"
+ALL="prep_kernels eval_kernel mlp_kernel mlp_bwd_kernel ident_bwd_kernel ident_train_kernel fit_kernels train_loss_kernels dense_train_kernels mc_device probe"
 for f in $ALL; do
   [ $f = $V ] && continue
   # (headers are dependencies too: layout.h / the public header changing must rebuild every object)
