@@ -13,11 +13,14 @@
 //             db = column sums of gp               gpre_kernel's per-tile sums + column_sums_kernel (fixed order)
 // One kernel computes all three products: C[M,N] = alpha A[M,K] B[N,K]^T, both operands K-contiguous fp32 in HBM, split into
 // bf16 hi / lo on their way into LDS, three MFMA passes per product (fp32-equivalent: hi hi + hi lo + lo hi), fp32 accumulate.
-// Workgroup = 8 wavefronts = a 128 x 256 tile of C (wavefront: 64 x 64 = four 32x32 accumulators), K in chunks of 64
-// through LDS as MFMA fragments ([k-step][k-group][row][8]: one conflict-free ds_read_b128 per fragment), the next chunk's
-// global loads in flight during the current chunk's MFMAs.
+// Workgroup = 8 wavefronts = a 128 x 256 tile of C (wavefront: 64 x 64 = four 32x32 accumulators), K in chunks of 32
+// through two LDS buffers of MFMA fragments ([k-step][k-group][row][8]: one conflict-free ds_read_b128 per fragment): a chunk's
+// 24 MFMAs per wavefront carry the split + LDS writes of the NEXT chunk between them, whose global loads were issued two
+// chunks ahead; one barrier per chunk.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "capi_common.h"
 
@@ -31,11 +34,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BN = 256, KC = 64, THREADS = 512;
+constexpr int BM = 128, BN = 256, KC = 32, THREADS = 512;
 constexpr int KS = KC / 16;            // MFMA K-steps per chunk
 // rows of one (k-step, k-group) block of fragments in LDS, padded so that consecutive blocks sit 64 bytes apart modulo the 128
 // bytes of a bank row: the loader's 8-byte writes of one wavefront (4 rows x 8 blocks x 2 halves) then cover every bank equally
-// (unpadded: the 8 blocks of a row hit ONE bank group - an 8-way conflict on every ds_write_b64, the first version's bottleneck)
+// (unpadded: the blocks of a row hit ONE bank group - a conflict on every ds_write_b64)
 constexpr int BMP = BM + 4, BNP = BN + 4;
 
 struct GemmArgs {
@@ -97,40 +100,44 @@ __device__ __forceinline__ float activation(float v, float beta) {
 
 template <bool VA, bool VB>
 __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char a_hi[KS * 2 * BMP * 16], a_lo[KS * 2 * BMP * 16];     // 98 KB in all: one workgroup per CU
-  __shared__ __attribute__((aligned(16))) char b_hi[KS * 2 * BNP * 16], b_lo[KS * 2 * BNP * 16];
+  // two LDS buffers of fragments: chunk c is multiplied out of buffer c & 1 while chunk c + 1 is split and written into the other
+  constexpr int A_PLANE = KS * 2 * BMP * 16, B_PLANE = KS * 2 * BNP * 16;
+  __shared__ __attribute__((aligned(16))) char a_hi[2][A_PLANE], a_lo[2][A_PLANE];     // 100 KB in all: one workgroup per CU
+  __shared__ __attribute__((aligned(16))) char b_hi[2][B_PLANE], b_lo[2][B_PLANE];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int k_begin = blockIdx.z * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   float* C = p.C + size_t(blockIdx.z) * size_t(p.M) * p.ldc;
-  // loader: thread -> (row t / 16 + 32 i, four k at 4 (t % 16))
+  // loader: thread -> (row t / 8 + 64 i, four k at 4 (t % 8))
   constexpr int LROWS = THREADS / (KC / 4), NA = BM / LROWS, NB = BN / LROWS;
+  static_assert(NA + NB == 6, "six 16-byte loads per thread and chunk: one behind each group of four MFMAs");
   const int lr = t / (KC / 4), lk = (t % (KC / 4)) * 4;
   const int frag_off = ((lk >> 4) * 2 + ((lk >> 3) & 1));        // (k-step, k-group) of this thread's four k
-  f32x4 ra[NA], rb[NB];
-  auto fetch = [&](int k0) __attribute__((always_inline)) {
+  // two register sets: chunk c + 2 is requested into set c & 1 at the top of iteration c (two iterations of MFMAs ahead of its use)
+  f32x4 regs[2][NA + NB];
+  auto fetch = [&](auto set, int k0) __attribute__((always_inline)) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = load4<VA>(p.A, p.lda, p.M, k_end, m0 + lr + LROWS * i, k0 + lk);
+    for (int i = 0; i < NA; ++i) regs[S][i] = load4<VA>(p.A, p.lda, p.M, k_end, m0 + lr + LROWS * i, k0 + lk);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = load4<VB>(p.B, p.ldb, p.N, k_end, n0 + lr + LROWS * i, k0 + lk);
+    for (int i = 0; i < NB; ++i) regs[S][NA + i] = load4<VB>(p.B, p.ldb, p.N, k_end, n0 + lr + LROWS * i, k0 + lk);
   };
-  auto stage = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      u32x2 hi, lo;
-      split4(mask4(ra[i], p.M, k_end, m0 + lr + LROWS * i, k0 + lk), hi, lo);
-      const int o = ((frag_off * BMP + lr + LROWS * i) * 8 + (lk & 7)) * 2;
-      *reinterpret_cast<u32x2*>(a_hi + o) = hi;
-      *reinterpret_cast<u32x2*>(a_lo + o) = lo;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      u32x2 hi, lo;
-      split4(mask4(rb[i], p.N, k_end, n0 + lr + LROWS * i, k0 + lk), hi, lo);
+  // unit u of the staging of the chunk at k0 held in register set S -> LDS buffer `buf`
+  auto stage_unit = [&](auto set, auto unit, int buf, int k0) __attribute__((always_inline)) {
+    constexpr int S = decltype(set)::value, u = decltype(unit)::value;
+    u32x2 hi, lo;
+    if constexpr (u < NA) {
+      split4(mask4(regs[S][u], p.M, k_end, m0 + lr + LROWS * u, k0 + lk), hi, lo);
+      const int o = ((frag_off * BMP + lr + LROWS * u) * 8 + (lk & 7)) * 2;
+      *reinterpret_cast<u32x2*>(a_hi[buf] + o) = hi;
+      *reinterpret_cast<u32x2*>(a_lo[buf] + o) = lo;
+    } else {
+      constexpr int i = u - NA;
+      split4(mask4(regs[S][u], p.N, k_end, n0 + lr + LROWS * i, k0 + lk), hi, lo);
       const int o = ((frag_off * BNP + lr + LROWS * i) * 8 + (lk & 7)) * 2;
-      *reinterpret_cast<u32x2*>(b_hi + o) = hi;
-      *reinterpret_cast<u32x2*>(b_lo + o) = lo;
+      *reinterpret_cast<u32x2*>(b_hi[buf] + o) = hi;
+      *reinterpret_cast<u32x2*>(b_lo[buf] + o) = lo;
     }
   };
   const int wm = wave >> 2, wn = wave & 3, j = lane & 31, kg = lane >> 5;
@@ -140,34 +147,60 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{};
 
-  fetch(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += KC) {
-    __syncthreads();                      // every wavefront has read the previous chunk's fragments
-    stage(k0);
-    __syncthreads();
-    fetch(k0 + KC < k_end ? k0 + KC : k_begin);   // in flight during the MFMAs below (unconditional: the last one is not used)
-    __builtin_amdgcn_sched_barrier(0);            // (hipcc otherwise sinks the loads below the MFMAs, to where their values are used)
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  const int n_chunks = (k_end - k_begin + KC - 1) / KC;
+  fetch(I0{}, k_begin);
+  fetch(I1{}, k_begin + KC);                                       // (beyond k_end: clamped addresses, masked to zero when staged)
+  stage_unit(I0{}, std::integral_constant<int, 0>{}, 0, k_begin); stage_unit(I0{}, std::integral_constant<int, 1>{}, 0, k_begin);
+  stage_unit(I0{}, std::integral_constant<int, 2>{}, 0, k_begin); stage_unit(I0{}, std::integral_constant<int, 3>{}, 0, k_begin);
+  stage_unit(I0{}, std::integral_constant<int, 4>{}, 0, k_begin); stage_unit(I0{}, std::integral_constant<int, 5>{}, 0, k_begin);
+  __syncthreads();
+
+  // one chunk: 24 MFMAs per wavefront (2 K-steps x 4 accumulators x 3 products, the four accumulators interleaved so that no
+  // MFMA waits for the one before it) with one sixth of the next chunk's staging behind every group of four
+  auto iteration = [&](auto parity, int c) __attribute__((always_inline)) {
+    constexpr int P = decltype(parity)::value;
+    const int k0 = k_begin + c * KC;
+    fetch(parity, k0 + 2 * KC);                                    // set P held chunk c: staged during the previous iteration
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int oa = (((ks * 2 + kg) * BMP) + wm * 64 + i * 32 + j) * 16;
-        ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + oa);
-        al[i] = *reinterpret_cast<const bf16x8*>(a_lo + oa);
+        ah[i] = *reinterpret_cast<const bf16x8*>(a_hi[P] + oa);
+        al[i] = *reinterpret_cast<const bf16x8*>(a_lo[P] + oa);
         const int ob = (((ks * 2 + kg) * BNP) + wn * 64 + i * 32 + j) * 16;
-        bh[i] = *reinterpret_cast<const bf16x8*>(b_hi + ob);
-        bl[i] = *reinterpret_cast<const bf16x8*>(b_lo + ob);
+        bh[i] = *reinterpret_cast<const bf16x8*>(b_hi[P] + ob);
+        bl[i] = *reinterpret_cast<const bf16x8*>(b_lo[P] + ob);
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int term = 0; term < 3; ++term) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 2 ? al[a] : ah[a], term == 1 ? bl[b] : bh[b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) {
+          if (term == 0) stage_unit(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, 0>{}, 1 - P, k0 + KC);
+          if (term == 1) stage_unit(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, 1>{}, 1 - P, k0 + KC);
+          if (term == 2) stage_unit(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, 2>{}, 1 - P, k0 + KC);
+        } else {
+          if (term == 0) stage_unit(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, 3>{}, 1 - P, k0 + KC);
+          if (term == 1) stage_unit(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, 4>{}, 1 - P, k0 + KC);
+          if (term == 2) stage_unit(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, 5>{}, 1 - P, k0 + KC);
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    __syncthreads();        // buffer 1 - P is complete, everybody has left buffer P
+  };
+  for (int c = 0; c < n_chunks; c += 2) {
+    iteration(I0{}, c);
+    iteration(I1{}, c + 1);                                        // (an odd count: one chunk of zeros)
   }
 
   // ---- epilogue: register q of lane (j, kg) = C[row 8 (q / 4) + 4 kg + q % 4][column j] of its 32 x 32 tile -------------
