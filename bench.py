@@ -1140,4 +1140,16 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # ONE JSON line on stdout: whatever the modules print while they are built (the mirrored constructors repeat the reference's
+    # "creating DeepSDF with ..." lines) goes to stderr; only json.dumps above writes to the real stdout
+    import contextlib
+    _real_stdout = sys.stdout
+    _json_print = print
+
+    def print(*a, **k):                                   # noqa: A001 - the three json.dumps prints of this module
+        k.setdefault("file", _real_stdout)
+        _json_print(*a, **k)
+        _real_stdout.flush()
+
+    with contextlib.redirect_stdout(sys.stderr):
+        main()

@@ -312,9 +312,12 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s1[t][r] = sigmoid2(acc[t][r]); val[t][r] = softplus2(acc[t][r]); }
       if (wave == L1_OB - 1) {
-        val[t][1] = h ? cx[t] : val[t][1];
-        val[t][2] = h ? cy[t] : val[t][2];
-        val[t][3] = h ? cz[t] : val[t][3];
+        // (the skip connection's coordinates come from LDS here: as registers that live from the prologue to this point they
+        // were the 3 spilled VGPRs / 16 B of scratch of the backward variant in rounds 4-5)
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(pt_c[32 * t + j]);
+        val[t][1] = h ? c4[0] : val[t][1];
+        val[t][2] = h ? c4[1] : val[t][2];
+        val[t][3] = h ? c4[2] : val[t][3];
       }
     }
   }
@@ -374,11 +377,15 @@ __device__ __forceinline__ void member_tile(const BwdArgs& p, const int tile_ind
   // ================================ backward =====================================================
   // G3 = df * (w4 / k) * s3   (gradient w.r.t. the SCALED pre-activation of lin3)
   if (wave < 7) {
+    // (lin4's weights are read again here rather than kept across the barrier above: 16 VGPRs that only live from L3 to this line)
+    const float* tl4 = tails + (L1_OB + L2_OB + wave) * TAIL_FLOATS;
+    asm volatile("" : "+s"(tl4));
+    const f32x16 w4r = load_frag16(tl4 + 32 + h * 16);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const float df = pt_g[32 * t + j][0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) val[t][r] = df * w4v[r] * s3[t][r];
+      for (int r = 0; r < 16; ++r) val[t][r] = df * w4r[r] * s3[t][r];
     }
     store_tile(wave, val);               // a2 is no longer needed (every wavefront passed the barriers above)
   }
