@@ -335,6 +335,10 @@ class IdentityBench:
         if requested != "auto":
             return {"mode": "fixed", "precision": net.precision, "prune_tol": net.prune_tol}
         c = net.calibration
+        if c is None:                                  # N > 1, rank != 0: this rank runs rank 0's decision and calibrated nothing
+            (tol, code), bnd = self.shared
+            return {"mode": "auto (rank 0's calibration, broadcast: reconstruction.shared_numerics)", "prune_tol": tol,
+                    "precision_code": code, "member_bounds": bnd is not None, "calibration_ms": round(self.calibration_ms, 1)}
         return {"mode": "auto (calibrated per checkpoint against the dense exact-fp32 kernel)", "precision": c["precision"],
                 "light_tol": c["light_tol"], "mid_tol": c["mid_tol"], "prune_tol": c["prune_tol"], "refine_band": c["refine_band"],
                 "member_bounds": c["bounds"] is not None,
@@ -1047,6 +1051,8 @@ def two_stage_sharded(args, world):
     allt = [float(x.item()) for x in allt]
     if rank == 0:
         n, dt = args.res ** 3, max(allt)
+        mlp = dnet.defDeepSDF
+        num, _ = _mlp_numerics_report(mlp)          # (rank 0 decided the tiers: reconstruction.shared_numerics)
         print(json.dumps({"metric": "SDF query throughput, deformation -> NPHM identity (two-stage), dense lattice", "value": n * args.steps / dt / 1e6,
                           "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
