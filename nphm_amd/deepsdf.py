@@ -464,6 +464,10 @@ class DeepSDF(nn.Module):
         if err_of is None:
             ref = self._eval_points_raw(packed, state, sample_xyz, False, fmt)
             err_of = lambda m: float((self._eval_points_raw(packed, state, sample_xyz, False, fmt | (m << 8)) - ref).abs().max())
+        raw_err = err_of
+        # a NaN / inf error (a non-finite sample point, an overflowing layer) must FAIL every comparison below: `nan > tgt` and
+        # `nan <= tgt` are both false, which used to accept the layer (advisor, round 5)
+        err_of = lambda m: (lambda e: e if math.isfinite(e) else float("inf"))(raw_err(m))
         tgt = self.numerics_target if target is None else float(target)
         full = self._hidden_mask()
         e_all = err_of(full)
@@ -509,7 +513,8 @@ class DeepSDF(nn.Module):
             report.update(single_mask=0, single_term=False)
             return self._code(mask), report
         ref = self._eval_points_raw(packed, state, sample_xyz, False, fmt)
-        err_of = lambda two, one: float((self._eval_points_raw(packed, state, sample_xyz, False, self._code(two, one)) - ref).abs().max())
+        _e = lambda two, one: float((self._eval_points_raw(packed, state, sample_xyz, False, self._code(two, one)) - ref).abs().max())
+        err_of = lambda two, one: (lambda e: e if math.isfinite(e) else float("inf"))(_e(two, one))     # (NaN fails every comparison below)
         e_all = err_of(0, hid)
         if e_all <= self.numerics_target:
             return self._code(0, hid), {"target": self.numerics_target, "single_term": True, "single_mask": hid, "mask": 0,
@@ -622,7 +627,11 @@ class DeepSDF(nn.Module):
     def _fit_sample(xyz):
         n = xyz.shape[1]
         per_row = max(256, 4096 // max(1, xyz.shape[0]))
-        return xyz[:, :: max(1, n // per_row)][:, :per_row].contiguous().float()
+        s = xyz[:, :: max(1, n // per_row)][:, :per_row].contiguous().float()
+        # (after a capture the points are the correspondence search's roots, diverged Broyden points included: a non-finite or
+        # far-out point says nothing about the tiers - it is replaced by the origin)
+        ok = torch.isfinite(s).all(dim=-1, keepdim=True) & (s.abs().amax(dim=-1, keepdim=True) < 10.0)
+        return torch.where(ok, s, torch.zeros_like(s))
 
     def _fit_code(self, packed, state, xyz):
         """`numerics` argument of the tangent / Broyden / saving launches (``fit_numerics``).  xyz [B,N,3]: this call's points.
@@ -669,13 +678,13 @@ class DeepSDF(nn.Module):
         err_of = self._fit_err(packed, state, sample)
         e = err_of(c[1])
         c[2]["reverified_err"] = e
-        if e <= 1.0:
+        if e <= 1.0:                              # (a NaN fails this test: the mask is measured again below)
             return False
         mask, report = self.calibrate_two_pass(packed, state, sample, err_of=err_of, target=1.0)
         mask &= c[1]
         report.update(value_target=self.fit_target, jacobian_target=self.fit_jacobian_target, tightened_from=c[1], mask=mask)
         self._fit_cache = (c[0], mask, report)
-        return True
+        return mask != c[1]                       # only a CHANGED mask makes a recorded step stale
 
     def forward_hip(self, xyz, cond_rows, add_input=False):
         """xyz [B,N,3] fp32 on a ROCm device, cond_rows [B, lat_dim] -> [B,N,out_dim]

@@ -200,7 +200,24 @@ def _member_point_lists(anchors, xyz, prune_tol, n_members):
     return what * mask, torch.from_numpy(tiles).to(xyz.device), idx[:, 2].to(torch.int32).contiguous()
 
 
-_PINNED_COUNTS = {}
+_PINNED_COUNTS = {}           # (kind, device index, stream id) -> [pinned int32 tensor, event recorded behind its last asynchronous use]
+
+
+def _pinned_staging(kind, dev, n):
+    """A pinned int32 staging buffer of >= n elements for (device, current stream), kept across calls (pinning is a driver
+    call).  The buffer may still be the source / target of the asynchronous copy of the previous call on this stream's key:
+    its event is waited for before the buffer is handed out again; another device, stream or thread gets another buffer
+    (advisor, round 5: one process-global buffer was safe only for one stream)."""
+    import threading
+    key = (kind, dev.index, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident())
+    slot = _PINNED_COUNTS.get(key)
+    if slot is None or slot[0].numel() < n:
+        if slot is not None and slot[1] is not None:
+            slot[1].synchronize()
+        slot = _PINNED_COUNTS[key] = [torch.empty(max(n, 1 << 10) * (2 if kind == "tables" else 1), dtype=torch.int32).pin_memory(), None]
+    elif slot[1] is not None:
+        slot[1].synchronize()
+    return slot
 
 
 def _train_member_lists(mask, sets):
@@ -226,12 +243,12 @@ def _train_member_lists(mask, sets):
         stream = torch.cuda.current_stream(dev).cuda_stream
         counts_dev = torch.empty(A * B, dtype=torch.int32, device=dev)
         _lib.check(lib.nphm_identity_train_pair_counts(mask.data_ptr(), B, N, counts_dev.data_ptr(), stream), "nphm_identity_train_pair_counts")
-        counts_host = _PINNED_COUNTS.get(A * B)
-        if counts_host is None:                                # (pinning is a driver call: once per size)
-            counts_host = _PINNED_COUNTS[A * B] = torch.empty(A * B, dtype=torch.int32).pin_memory()
+        c_slot = _pinned_staging("counts", dev, A * B)
+        counts_host = c_slot[0][:A * B]
         counts_host.copy_(counts_dev, non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
+        c_slot[1] = ready
         plist = torch.empty(B * N * A, dtype=torch.int32, device=dev)
         _lib.check(lib.nphm_identity_train_point_list(mask.data_ptr(), B, N, counts_dev.data_ptr(), plist.data_ptr(), stream),
                    "nphm_identity_train_point_list")
@@ -254,11 +271,10 @@ def _train_member_lists(mask, sets):
     need = o_pair + A * B + 1
     pinned = None
     if mask.is_cuda:
-        # (a pinned staging buffer, kept: the tables travel by an asynchronous copy - a pageable source is a blocking, staged one.
-        # Its previous contents were consumed by a copy that this step's wait for the counts has long passed.)
-        pinned = _PINNED_COUNTS.get("tables")
-        if pinned is None or pinned.numel() < need:
-            pinned = _PINNED_COUNTS["tables"] = torch.empty(max(need, 1 << 16) * 2, dtype=torch.int32).pin_memory()
+        # (a pinned staging buffer, kept per device / stream / thread: the tables travel by an asynchronous copy - a pageable
+        # source is a blocking, staged one; _pinned_staging waits for the previous copy out of it)
+        t_slot = _pinned_staging("tables", mask.device, max(need, 1 << 16))
+        pinned = t_slot[0]
         buf = pinned.numpy()[:need]
     else:
         buf = np.empty(need, np.int32)
@@ -278,6 +294,8 @@ def _train_member_lists(mask, sets):
     if pinned is not None:
         d = torch.empty(need, dtype=torch.int32, device=dev)
         d.copy_(pinned[:need], non_blocking=True)
+        t_slot[1] = torch.cuda.Event()
+        t_slot[1].record()                                     # the buffer is free again when this copy has been consumed
     else:
         d = torch.from_numpy(buf).to(dev)
     tiles_fwd = d[o_fwd:o_fwd + 4 * t64].view(t64, 4)
