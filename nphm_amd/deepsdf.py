@@ -197,6 +197,48 @@ class _DenseLayerFn(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
+class _GemmNTFn(torch.autograd.Function):
+    """C = alpha A B^T on nphm_dense_gemm_nt (split-bf16 x3 MFMA, fp32 accumulate), differentiable to ANY order: its backward
+    is made of the same product (dA = alpha G B = gemm(G, B^T), dB = alpha G^T A = gemm(G^T, A^T); the transposes are torch
+    copies) - what the second-order passes of loss_joint / the NPM trainer (``gradient(sdf, x, create_graph=True)``, then
+    ``backward()``) need, which the fused first-order ``_DenseLayerFn`` cannot serve.  A [M,K], B [N,K] fp32 on a ROCm device."""
+
+    @staticmethod
+    def forward(ctx, A, B, alpha):
+        lib = _lib.load()
+        if not (A.is_contiguous() and B.is_contiguous()):
+            raise ValueError("_GemmNTFn: contiguous operands (copy OUTSIDE the function: a saved copy made here is detached)")
+        M, K = A.shape
+        N = B.shape[0]
+        dev = A.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        C = torch.empty(M, N, dtype=torch.float32, device=dev)
+        splits = int(min(64, K // 1024)) if (K >= 4096 and (M + 127) // 128 * ((N + 255) // 256) < 128) else 1
+        if splits > 1:       # a long K over a small result (a weight gradient): ordered splits fill the chip
+            parts = torch.empty(splits, M, N, dtype=torch.float32, device=dev)
+            _lib.check(lib.nphm_dense_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, parts.data_ptr(), N, M, N, K, None, 1, 1.0, 0.0, 0, splits,
+                                              stream), "nphm_dense_gemm_nt")
+            _lib.check(lib.nphm_dense_reduce_splits(parts.data_ptr(), splits, M * N, float(alpha), C.data_ptr(), stream),
+                       "nphm_dense_reduce_splits")
+        else:
+            _lib.check(lib.nphm_dense_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, None, 1, float(alpha), 0.0, 0, 1,
+                                              stream), "nphm_dense_gemm_nt")
+        ctx.save_for_backward(A, B)
+        ctx.alpha = float(alpha)
+        return C
+
+    @staticmethod
+    def backward(ctx, G):
+        A, B = ctx.saved_tensors
+        dA = dB = None
+        G = G.contiguous()
+        if ctx.needs_input_grad[0]:
+            dA = _GemmNTFn.apply(G, B.t().contiguous(), ctx.alpha)
+        if ctx.needs_input_grad[1]:
+            dB = _GemmNTFn.apply(G.t().contiguous(), A.t().contiguous(), ctx.alpha)
+        return dA, dB, None
+
+
 class DeepSDF(nn.Module):
     """Skip-MLP SDF / vector field (deepSDF.py:6-89).  dims = [d_in] + [hidden]*nlayers + [out];
     the input is re-injected (concatenated, divided by sqrt 2) before layer ``nlayers//2``;
@@ -284,11 +326,16 @@ class DeepSDF(nn.Module):
     def two_pass_target(self, v):
         self.numerics_target = float(v)
 
-    def evaluate(self, pos, lat):
-        """pos [B,N,d_spatial]; lat [B,Lr,lat_dim], Lr in {1,N}."""
+    def evaluate(self, pos, lat, gemm_hip=False):
+        """pos [B,N,d_spatial]; lat [B,Lr,lat_dim], Lr in {1,N}.  ``gemm_hip``: the hidden x W^T products (M = B N rows) on
+        ``_GemmNTFn`` instead of a library GEMM - same op sequence, differentiable to any order."""
         D = pos.shape[-1]
         last = self.num_layers - 2
         x = None
+        # (operands made contiguous OUT HERE, by differentiable copies: a copy made inside the Function would be saved detached,
+        # and the second-order term that reaches a weight through d/dx = G W would be lost - the skip layer's column slice)
+        mm = (lambda a, w: _GemmNTFn.apply(a.reshape(-1, a.shape[-1]).contiguous(), w.contiguous(), 1.0).reshape(*a.shape[:-1], w.shape[0])) \
+            if gemm_hip else (lambda a, w: a @ w.t())
         for layer in range(self.num_layers - 1):
             lin = getattr(self, f"lin{layer}")
             W, b = lin.weight, lin.bias
@@ -298,8 +345,10 @@ class DeepSDF(nn.Module):
                 lat_term = (lat @ W[:, n_prev + D:].t()) * scale + b          # [B,Lr,out]
                 y = (pos @ W[:, n_prev:n_prev + D].t()) * scale
                 if layer != 0:
-                    y = y + (x @ W[:, :n_prev].t()) * scale
+                    y = y + mm(x, W[:, :n_prev]) * scale
                 x = y + lat_term
+            elif layer < last:
+                x = mm(x, W) + b
             else:
                 x = x @ W.t() + b
             if layer < last:
@@ -313,6 +362,15 @@ class DeepSDF(nn.Module):
         return (self.backend != "composite" and self.train_backend == "hip" and xyz.is_cuda and xyz.dtype == torch.float32
                 and lat.dtype == torch.float32 and torch.is_grad_enabled() and not xyz.requires_grad
                 and any(p.requires_grad for p in self.parameters())
+                and all(p.dtype == torch.float32 for p in self.parameters()))
+
+    def gemm_tier_serves(self, xyz, lat):
+        """The any-order tier: a recorded graph on ROCm fp32 tensors with enough rows to fill the chip (``evaluate`` with its
+        hidden products on ``_GemmNTFn``) - what serves a call the first-order training tier cannot (a gradient w.r.t. the
+        query points that is differentiated again)."""
+        return (self.backend != "composite" and self.train_backend == "hip" and xyz.is_cuda and xyz.dtype == torch.float32
+                and lat.dtype == torch.float32 and torch.is_grad_enabled() and xyz.shape[0] * xyz.shape[1] >= 2048
+                and (xyz.requires_grad or lat.requires_grad or any(p.requires_grad for p in self.parameters()))
                 and all(p.dtype == torch.float32 for p in self.parameters()))
 
     def evaluate_train_hip(self, pos, lat):
@@ -810,7 +868,7 @@ class DeepSDF(nn.Module):
         if lat_rep.dim() == 3 and self.train_tier_serves(x3, lat_rep):
             out = self.evaluate_train_hip(self._embed(x3), lat_rep)
             return (out.squeeze(0) if squeeze else out), None
-        return self.evaluate(self._embed(xyz), lat_rep), None
+        return self.evaluate(self._embed(xyz), lat_rep, gemm_hip=lat_rep.dim() == 3 and self.gemm_tier_serves(x3, lat_rep)), None
 
 
 class _CompressCondFn(torch.autograd.Function):
@@ -1002,7 +1060,7 @@ class DeformationNetwork(nn.Module):
         elif self.defDeepSDF.train_tier_serves(xyz, cond):
             pred = self.defDeepSDF.evaluate_train_hip(self.defDeepSDF._embed(xyz), cond)     # trainable backbone: the dense training tier
         else:
-            pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond)
+            pred = self.defDeepSDF.evaluate(self.defDeepSDF._embed(xyz), cond, gemm_hip=self.defDeepSDF.gemm_tier_serves(xyz, cond))
         return pred[..., :3], pred[..., -1:]
 
     @property

@@ -155,3 +155,60 @@ def test_compute_loss_corresp_forward_matches_the_reference_fixture_on_the_gpu(d
     print(f"compute_loss_corresp_forward on the GPU against the reference fixture: expression-code gradients {e_tab:.1e}, "
           f"parameter gradient norms {e_norm:.1e}")
     assert e_tab < 2e-4 and e_norm < 2e-4
+
+
+def test_gemm_function_is_differentiable_twice(dev):
+    """_GemmNTFn's backward is made of _GemmNTFn products: a loss on the gradient w.r.t. the input (the eikonal pattern of
+    loss_joint / the NPM trainer: gradient(sdf, x, create_graph=True), then backward()) against float64 autograd."""
+    from nphm_amd.deepsdf import _GemmNTFn
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 4100, 259, 400
+    x0 = (torch.randn(M, K, generator=g) * 0.3).to(dev)
+    W0 = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    V0 = (torch.randn(3, N, generator=g) / N ** 0.5).to(dev)
+
+    def run(x, W, V, mm):
+        h = torch.nn.functional.softplus(mm(x, W), beta=100.0)
+        out = h @ V.t()
+        (gx,) = torch.autograd.grad(out.sum(), x, create_graph=True)
+        loss = (gx.norm(dim=-1) - 1).abs().mean() + out.square().mean()
+        loss.backward()
+        return loss.detach(), x.grad, W.grad, V.grad
+
+    a = [t.clone().requires_grad_() for t in (x0, W0, V0)]
+    got = run(*a, lambda x, W: _GemmNTFn.apply(x, W, 1.0))
+    b = [t.double().clone().requires_grad_() for t in (x0, W0, V0)]
+    want = run(*b, lambda x, W: x @ W.t())
+    errs = [_rel(p, q) for p, q in zip(got, want)]
+    print("second-order pass through _GemmNTFn against float64: loss %.1e, dx %.1e, dW %.1e, dV %.1e" % tuple(errs))
+    assert max(errs) < 3e-4          # (dx carries sigma'' = 25 at beta 100 on top of the products' 16 bits: 1.1e-4 measured)
+
+
+def test_second_order_pass_through_the_backbone_uses_the_kernels(dev):
+    """A DeepSDF whose query points need a gradient that is differentiated again (first-order tier refuses): `evaluate` with
+    its hidden products on _GemmNTFn, against the composite tier - values, d/dx and every parameter gradient of an eikonal-style
+    loss."""
+    import nphm_amd
+    torch.manual_seed(0)
+    net = nphm_amd.DeepSDF(lat_dim=64, hidden_dim=400, nlayers=4, out_dim=3).to(dev).train()
+    g = torch.Generator().manual_seed(9)
+    xyz = ((torch.rand(3, 900, 3, generator=g) - 0.5)).to(dev)
+    lat = (torch.randn(3, 1, 64, generator=g) * 0.3).to(dev)
+
+    def run(backend):
+        net.train_backend = backend
+        net.zero_grad(set_to_none=True)
+        x = xyz.clone().requires_grad_()
+        l = lat.clone().requires_grad_()
+        calls = []
+        orig = nphm_amd.deepsdf._GemmNTFn.apply
+        out, _ = net(x, l.expand(3, 900, 64))
+        (gx,) = torch.autograd.grad(out[..., 0].sum(), x, create_graph=True)
+        ((gx.norm(dim=-1) - 1).abs().mean() + out.square().mean()).backward()
+        return [out.detach(), gx.detach(), l.grad] + [p.grad.clone() for p in net.parameters()]
+
+    ref = run("composite")
+    got = run("hip")
+    errs = [_rel(a, b) for a, b in zip(got, ref)]
+    print("second-order pass through DeepSDF, kernels against composite:", ["%.1e" % e for e in errs])
+    assert max(errs) < 2e-4 and max(errs) > 0          # (> 0: the kernel path did run - its products carry 16 bits)
