@@ -83,10 +83,10 @@ def measured_traffic(kernel, n_points):
         return None
 
 
-# single-GPU kernel times of the default numerics (driver-run BENCH_r04 / profiles/r05*: ms per launch of the whole lattice, and of
+# single-GPU kernel times of the default numerics (profiles/r06_bench.json: ms per launch of the whole lattice, and of
 # rank 0's cyclic share of an 8-rank partition of 512^3 measured on one GPU) - inputs of `ranks.expected` only
-ONE_GPU_KERNEL_MS = {256: 29.8, 512: 209.0}
-RANK0_OF_8_MS_512 = 27.4
+ONE_GPU_KERNEL_MS = {256: 26.5, 512: 192.5}
+RANK0_OF_8_MS_512 = 25.3
 
 
 def expected_budget(rx, ry, rz, world):
@@ -104,7 +104,7 @@ def expected_budget(rx, ry, rz, world):
     return {"kernel_ms_per_rank": None if kernel is None else round(kernel, 2), "allgather_ms": round(ag, 3), "reorder_ms": round(ro, 3),
             "step_ms_if_overlapped": None if kernel is None else round(max(kernel, ag + ro), 2),
             "mpoints_per_s": None if kernel is None else round(n / max(kernel, ag + ro) / 1e3, 0),
-            "basis": "one-GPU kernel times (BENCH_r04, profiles/), assumed 300 GB/s all-gather ingress; NOT measured on N GPUs"}
+            "basis": "one-GPU kernel times (profiles/r06_bench.json), assumed 300 GB/s all-gather ingress; NOT measured on N GPUs"}
 
 
 TRAFFIC_SOURCE = "profiles/traffic.json (committed rocprofv3 --pmc passes, tools/pmc_traffic.sh), not measured in this run"
