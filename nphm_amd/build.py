@@ -9,7 +9,11 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["prep_kernels.hip", "eval_kernel.hip", "mlp_kernel.hip", "mlp_bwd_kernel.hip", "ident_bwd_kernel.hip", "ident_train_kernel.hip", "fit_kernels.hip", "train_loss_kernels.hip", "dense_train_kernels.hip", "mc_device.hip", "probe.hip", "marching_cubes.cpp"]
+# (source, extra flags, object tag): eval_kernel.hip is compiled in four parts (its nine kernel instantiations are 3 of the 3.5
+# minutes a one-piece build takes): the C ABI + dispatch, and the kernels of each precision (csrc/eval_kernel.hip, NPHM_EVAL_PART)
+EVAL_PARTS = [("eval_kernel.hip", ["-DNPHM_EVAL_PART=1"], "eval_kernel_api"), ("eval_kernel.hip", ["-DNPHM_EVAL_PART=10"], "eval_kernel_f32"),
+              ("eval_kernel.hip", ["-DNPHM_EVAL_PART=11"], "eval_kernel_bf16"), ("eval_kernel.hip", ["-DNPHM_EVAL_PART=12"], "eval_kernel_f16")]
+SOURCES = ["prep_kernels.hip", "mlp_kernel.hip", "mlp_bwd_kernel.hip", "ident_bwd_kernel.hip", "ident_train_kernel.hip", "fit_kernels.hip", "train_loss_kernels.hip", "dense_train_kernels.hip", "mc_device.hip", "probe.hip", "marching_cubes.cpp"]
 OUT = os.path.join(HERE, "libnphm_amd.so")
 OBJ_CACHE = os.path.join(HERE, "..", ".build_cache")      # objects by content hash (git- and gpurun-ignored)
 
@@ -45,15 +49,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
             common.update(open(os.path.join(CSRC, f), "rb").read())
     common.update(open(os.path.join(HERE, "..", "include", "nphm_amd.h"), "rb").read())
     jobs, objs = [], []
-    for src in SOURCES:
+    units = EVAL_PARTS + [(src, [], os.path.splitext(src)[0]) for src in SOURCES]       # (the slowest first)
+    for src, extra, tag in units:
         h = common.copy()
+        h.update(" ".join(extra).encode())
         h.update(open(os.path.join(CSRC, src), "rb").read())
-        obj = os.path.join(OBJ_CACHE, f"{os.path.splitext(src)[0]}-{h.hexdigest()[:20]}.o")
+        obj = os.path.join(OBJ_CACHE, f"{tag}-{h.hexdigest()[:20]}.o")
         objs.append(obj)
         if os.path.exists(obj) and not force:
             continue
         tmp = f"{obj}.{os.getpid()}.tmp"                    # (two builds at once - ranks, xdist workers - never share a temp file)
-        cmd = [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, src), "-o", tmp]
+        cmd = [hipcc] + FLAGS + extra + inc + ["-c", os.path.join(CSRC, src), "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         jobs.append((cmd, obj, tmp, subprocess.Popen(cmd)))
@@ -69,7 +75,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.replace(out_tmp, OUT)
     # objects of older versions of OUR sources only (another build's in-flight temp files are not ours to delete)
     keep = {os.path.basename(o) for o in objs}
-    stems = {os.path.splitext(src)[0] for src in SOURCES}
+    stems = {tag for _, _, tag in units} | {"eval_kernel"}
     for f in os.listdir(OBJ_CACHE):
         if f.endswith(".o") and f not in keep and f.rsplit("-", 1)[0] in stems:
             os.remove(os.path.join(OBJ_CACHE, f))

@@ -994,7 +994,7 @@ __device__ __forceinline__ void tile_lane(const EvalArgs& p, unsigned t, int j, 
   iz = tz * TLZ + tile_dz(j);
 }
 
-__global__ __launch_bounds__(256) void tile_prepass_kernel(EvalArgs p) {
+static __global__ __launch_bounds__(256) void tile_prepass_kernel(EvalArgs p) {
   const int lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
   const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const unsigned t = wave_id * 2 + half;
@@ -1724,8 +1724,42 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
   if (valid && h == 0) p.out[out_idx] = acc;
 }
 
+// ---- launches ----------------------------------------------------------------------------------------------------------
+// The nine instantiations are what compiling this file costs (~20 s each).  nphm_amd/build.py compiles it FOUR times in
+// parallel: -DNPHM_EVAL_PART=1 = the C ABI, the tile pre-pass and the dispatch below; 10 / 11 / 12 = the three kernels of
+// precision 0 / 1 / 2 behind launch_prec<P>.  Undefined (0: tools/build_variant.sh, `hipcc -c` of this file): everything in one
+// translation unit, as in rounds 1-5.
+#ifndef NPHM_EVAL_PART
+#define NPHM_EVAL_PART 0
+#endif
+void launch_prec0(int mode, dim3 grid, dim3 block, hipStream_t st, const EvalArgs& a);
+void launch_prec1(int mode, dim3 grid, dim3 block, hipStream_t st, const EvalArgs& a);
+void launch_prec2(int mode, dim3 grid, dim3 block, hipStream_t st, const EvalArgs& a);
+#if NPHM_EVAL_PART == 0 || NPHM_EVAL_PART >= 10
+template <int PREC>
+static void launch_modes(int mode, dim3 grid, dim3 block, hipStream_t st, const EvalArgs& a) {
+#ifdef NPHM_DEV_ONLY22   // ISA-inspection / variant builds: one instantiation (20 s instead of 3 min); never for a library that runs
+  if constexpr (PREC == 2) { if (mode == 2) hipLaunchKernelGGL((eval_kernel<2, 2>), grid, block, 0, st, a); }
+#else
+  if (mode == 0) hipLaunchKernelGGL((eval_kernel<0, PREC>), grid, block, 0, st, a);
+  else if (mode == 1) hipLaunchKernelGGL((eval_kernel<1, PREC>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((eval_kernel<2, PREC>), grid, block, 0, st, a);
+#endif
+}
+#endif
+#if NPHM_EVAL_PART == 0 || NPHM_EVAL_PART == 10
+void launch_prec0(int mode, dim3 grid, dim3 block, hipStream_t st, const EvalArgs& a) { launch_modes<0>(mode, grid, block, st, a); }
+#endif
+#if NPHM_EVAL_PART == 0 || NPHM_EVAL_PART == 11
+void launch_prec1(int mode, dim3 grid, dim3 block, hipStream_t st, const EvalArgs& a) { launch_modes<1>(mode, grid, block, st, a); }
+#endif
+#if NPHM_EVAL_PART == 0 || NPHM_EVAL_PART == 12
+void launch_prec2(int mode, dim3 grid, dim3 block, hipStream_t st, const EvalArgs& a) { launch_modes<2>(mode, grid, block, st, a); }
+#endif
+
 }  // namespace nphm
 
+#if NPHM_EVAL_PART <= 1
 // ============================================================================================
 // C ABI (include/nphm_amd.h)
 // ============================================================================================
@@ -1781,6 +1815,12 @@ static void set_tiers(nphm::EvalArgs& a, int precision) {
   a.refine_band = rc ? exp2f(1.f - 0.5f * float(rc)) : 0.f;
   a.refine_prune_tol = a.prune_tol >= 0.f ? a.prune_tol * (1.f / 32.f) : -1.f;
   if (a.prune_tol < 0.f && !is_adaptive(precision)) a.refine_band = 0.f;     // nothing to refine: already the exact setting
+}
+
+static void launch_by_precision(int mode, int precision, dim3 grid, dim3 block, hipStream_t st, const nphm::EvalArgs& a) {
+  if (prec_mode(precision) == NPHM_PREC_F32) nphm::launch_prec0(mode, grid, block, st, a);
+  else if (is_f16(precision)) nphm::launch_prec2(mode, grid, block, st, a);
+  else nphm::launch_prec1(mode, grid, block, st, a);
 }
 
 static void fill_common(nphm::EvalArgs& a, const void* packed, const void* latent_state, float* out,
@@ -1858,13 +1898,7 @@ static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t
     const int64_t round = nphm::XCD_RUN > 1 ? 8 * int64_t(nphm::XCD_RUN) : 1;
     const int64_t groups = ((l.n_tiles + nphm::NW - 1) / nphm::NW + round - 1) / round * round;
     const dim3 grid((unsigned)groups), block(64 * nphm::NW);
-#ifdef NPHM_DEV_ONLY22   // ISA-inspection builds: one instantiation (20 s instead of 3 min); never for a library that runs
-    hipLaunchKernelGGL((nphm::eval_kernel<2, 2>), grid, block, 0, st, a);
-#else
-    if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<2, 0>), grid, block, 0, st, a);
-    else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<2, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((nphm::eval_kernel<2, 1>), grid, block, 0, st, a);
-#endif
+    launch_by_precision(2, precision, grid, block, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return nphm_fail(who, e);
     return 0;
@@ -1877,11 +1911,7 @@ static int launch_grid(nphm::EvalArgs& a, int precision, void* workspace, size_t
   const int64_t bricks = supers * (nphm::SBX * nphm::SBY * nphm::SBZ);
   if (bricks > 0x7fffffffLL) return nphm_fail_msg("slab too large for one launch");
   const dim3 grid((unsigned)bricks), block(64 * nphm::NW);
-#ifndef NPHM_DEV_ONLY22
-  if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<1, 0>), grid, block, 0, st, a);
-  else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<1, 2>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((nphm::eval_kernel<1, 1>), grid, block, 0, st, a);
-#endif
+  launch_by_precision(1, precision, grid, block, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail(who, e);
   return 0;
@@ -1906,11 +1936,7 @@ int nphm_identity_eval_points(const void* packed, const void* latent_state,
 #if NPHM_PROF
   if (const char* e = getenv("NPHM_PROF_LIGHT_TOL")) a.light_tol = float(atof(e));   // timing builds: force all-light / all-heavy
 #endif
-#ifndef NPHM_DEV_ONLY22
-  if (prec_mode(precision) == NPHM_PREC_F32) hipLaunchKernelGGL((nphm::eval_kernel<0, 0>), grid, block, 0, st, a);
-  else if (is_f16(precision)) hipLaunchKernelGGL((nphm::eval_kernel<0, 2>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((nphm::eval_kernel<0, 1>), grid, block, 0, st, a);
-#endif
+  launch_by_precision(0, precision, grid, block, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nphm_fail("nphm_identity_eval_points launch", e);
   return 0;
@@ -1974,3 +2000,4 @@ int nphm_identity_eval_grid_points(const void* packed, const void* latent_state,
 }
 
 }  // extern "C"
+#endif  // NPHM_EVAL_PART <= 1
