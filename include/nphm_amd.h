@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPHM_AMD_ABI_VERSION 11
+#define NPHM_AMD_ABI_VERSION 12
 
 /* ---- library ------------------------------------------------------------------------ */
 int nphm_abi_version(void);
@@ -355,6 +355,13 @@ int nphm_fit_loss_backward(const float* sdf, const unsigned char* valid, int64_t
 int nphm_fit_loss_with_gradients(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
                                  const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
                                  const float* g_out, float* row, float* g_sdf, float* g_shape, float* g_expr, void* stream);
+/* (ABI 12) the same for a step replayed from a hipGraph beside nphm_fit_inputs_ring: the row is also stored at
+ * row_log[log_control[0] - 1] ([log_rows][8]; log_control = the ring's control words, whose first counts the replays including
+ * this one) - the loss trace of a replayed loop without a copy launch between two replays. */
+int nphm_fit_loss_with_gradients_logged(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                                        const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                                        const float* g_out, float* row, float* g_sdf, float* g_shape, float* g_expr,
+                                        float* row_log, const unsigned* log_control, int log_rows, void* stream);
 int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g_posed, int64_t n, void* stream);
 /* (ABI 10) The inputs of one fitting step from its draw (fitting.py:61-85) in one launch: drawn = [n_rows observation indices |
  * n_rows x n_points point indices] (int64); obs [n_rows, n_points, cloud_width] = clouds[o_b][p_br] (clouds [n_obs, cloud_points,
@@ -368,6 +375,17 @@ int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g
 int nphm_fit_inputs(const int64_t* drawn, int n_rows, int n_points, const float* clouds, int n_obs, int cloud_points, int cloud_width,
                     const float* z_shape, int shape_dim, const float* z_expr_table, int expr_dim, float* obs, float* z_ex,
                     float* glob_cond, void* stream);
+/* (ABI 12) nphm_fit_inputs for a step that is REPLAYED from a hipGraph: the draw is read from a ring of draws in pinned host memory
+ * (host_ring: ring_slots slots, slot_stride int64 apart, n_total int64 each = the draw and whatever rides behind it, e.g. the
+ * optimizer scalars of nphm_adam_step_pair) instead of from a device buffer some stream-ordered upload filled - a copy-engine
+ * hand-over and two queue gaps per step (35 us of a 725 us step).  control: two zero-initialised uint32 in device memory;
+ * control[0] counts the ring launches that have completed, the launch reads slot control[0] % ring_slots and copies its
+ * n_total values to drawn_out (device) for the later launches of the step.  The host fills slot (launches issued so far) %
+ * ring_slots before it issues the launch and must not run more than ring_slots launches ahead of the device. */
+int nphm_fit_inputs_ring(const int64_t* host_ring, int ring_slots, int64_t slot_stride, int64_t n_total, unsigned* control, int64_t* drawn_out,
+                         int n_rows, int n_points, const float* clouds, int n_obs, int cloud_points, int cloud_width,
+                         const float* z_shape, int shape_dim, const float* z_expr_table, int expr_dim, float* obs, float* z_ex,
+                         float* glob_cond, void* stream);
 int nphm_fit_inputs_backward(const float* g_z_ex, int64_t z_ex_row_stride, const float* g_glob_cond, const int64_t* obs_idx, int n_rows,
                              int n_obs, int shape_dim, int expr_dim, const float* const g_shape_uses[4], const float* g_table_use,
                              float* g_z_expr_table, float* g_z_shape, void* stream);
@@ -474,6 +492,19 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                          const float* xyz, int n_rows, int64_t n_points, int add_input, int numerics,
                          float* out, void* stream);
 
+/* The two plain evaluation entry points with a workspace (ABI 12; nphm_mlp_eval_workspace_bytes() bytes of device memory,
+ * 16-byte aligned, owned by the launch's stream while it runs; contents are scratch, nothing persists between calls).  It serves
+ * ONE combination of `numerics`: every hidden layer in NPHM_MLP_ONE_PASS but the last, that one in NPHM_MLP_TWO_PASS (what the
+ * calibration finds for the NPM SDF, deepSDF.py:6-89 with scripts/configs/npm.yaml:1-4).  Without a workspace that layer runs in
+ * two point halves and streams its weights twice; with one it runs in two K halves - the second half of its operands (128 KiB
+ * per workgroup) waits in a slot of the workspace, which stays in the last-level caches - and streams them once.  Results are
+ * bitwise identical to workspace = NULL; every other `numerics` ignores the workspace. */
+size_t nphm_mlp_eval_workspace_bytes(void);
+int nphm_mlp_eval_points_ws(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                            const void* packed, const void* latent_state,
+                            const float* xyz, int n_rows, int64_t n_points, int add_input, int numerics,
+                            float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Value AND spatial Jacobian in one launch (forward-mode, tangents carried through the same GEMMs):
  * out[b,n,0,:] = f(x), out[b,n,1+c,i] = d f_i / d x_c.  With add_input the identity is added too:
  * out[:,:,0,:] = x + F(x), out[:,:,1+c,:] = d (x + F) / d x_c — the analytic form of
@@ -572,6 +603,11 @@ int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                        const float* axis_x, const float* axis_y, const float* axis_z,
                        int rx, int ry, int rz, int ix0, int ix1, int add_input, int numerics,
                        float* out, void* stream);
+int nphm_mlp_eval_grid_ws(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                          const void* packed, const void* latent_state,
+                          const float* axis_x, const float* axis_y, const float* axis_z,
+                          int rx, int ry, int rz, int ix0, int ix1, int add_input, int numerics,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- host side: iso-surface extraction for mesh_from_logits ------------------------------- */
 /* Marching cubes on a HOST fp32 volume [nx,ny,nz] ('ij' order) — the step the reference delegates to

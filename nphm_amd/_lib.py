@@ -44,9 +44,13 @@ SYMBOLS = {
                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_fit_loss_with_gradients": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nphm_fit_loss_with_gradients_logged": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                    c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nphm_fit_root_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "nphm_fit_inputs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
+    "nphm_fit_inputs_ring": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                     c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nphm_fit_inputs_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_void_p * 4, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
     "nphm_identity_latent_grad_scratch_bytes": (c_size_t, [c_int]),
@@ -101,6 +105,12 @@ SYMBOLS = {
     "nphm_mlp_prepare_latent": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nphm_mlp_eval_points": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
                                                     c_void_p, c_void_p]),
+    "nphm_mlp_eval_workspace_bytes": (c_size_t, []),
+    "nphm_mlp_eval_points_ws": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
+                                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nphm_mlp_eval_grid_ws": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                                     c_void_p]),
     "nphm_mlp_eval_points_jvp": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                                         c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "nphm_mlp_broyden": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
@@ -169,7 +179,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nphm_abi_version() != 11:
+    if lib.nphm_abi_version() != 12:
         raise NphmAmdError("libnphm_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -34,6 +34,12 @@ struct LossArgs {
   float* g_sdf;                // backward: [P]
   float* g_shape;              // backward: [1344]
   float* g_expr;               // backward: [n_obs, 200]
+  // replayed steps (nphm_fit_loss_with_gradients_logged): the row is ALSO stored at row_log[log_ctl[0] - 1][0 .. 7] - log_ctl[0] =
+  // the ring launches completed (nphm_fit_inputs_ring of the same replay has counted itself already) - so that the loss trace of
+  // a graph-replayed loop needs no copy launch between two replays
+  float* row_log;
+  const unsigned* log_ctl;
+  int log_rows;
 };
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
@@ -121,6 +127,15 @@ __global__ __launch_bounds__(1024) void fit_loss_kernel(LossArgs a) {
       a.row[N_TERMS] = total;
       a.row[N_TERMS + 1] = nv;
       a.row[N_TERMS + 2] = total;       // a second copy: the caller's differentiable scalar next to the report row
+      if (a.row_log) {
+        const unsigned at = __hip_atomic_load(a.log_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+        if (at < unsigned(a.log_rows)) {
+          float* q = a.row_log + size_t(at) * (N_TERMS + 2);
+          for (int i = 0; i < N_TERMS; ++i) q[i] = terms[i];
+          q[N_TERMS] = total;
+          q[N_TERMS + 1] = nv;
+        }
+      }
     }
   }
   if (!BWD) return;
@@ -273,12 +288,45 @@ struct InputsArgs {
   float* obs;               // [B][n][C]
   float* z_ex;              // [B][E]
   float* glob_cond;         // [B][L + E]
+  // ring mode (a step replayed from a hipGraph; nphm_fit_inputs_ring): the draw is read straight from a ring of draws in
+  // pinned HOST memory - slot ctl[0] % ring_slots, ctl[0] = the number of ring launches completed so far - and copied to
+  // `drawn_out` for the later launches of the step; the last workgroup to arrive counts the launch.  No copy engine, no
+  // stream-ordered upload in front of the replay: the host fills slots ahead of the device.
+  const int64_t* ring;
+  int ring_slots;
+  int64_t slot_stride, n_total;
+  int64_t* drawn_out;
+  unsigned* ctl;            // [0] launches completed, [1] workgroups of the current launch that have read [0]
 };
+constexpr int FIT_RING_MAX_ROWS = 32;
 __global__ __launch_bounds__(256) void fit_inputs_kernel(InputsArgs a) {
+  __shared__ int64_t staged[FIT_RING_MAX_ROWS + 256 + 2];   // ring mode: [B observation indices | the point indices this workgroup gathers]
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < a.B * a.n * a.C) {
+  const int n_br = a.B * a.n;
+  int br0 = 0;
+  unsigned seq = 0;
+  if (a.ring) {
+    // every value of the slot crosses the bus once per workgroup that needs it (a PCIe read per 64 bytes: ~700 for the draw;
+    // the first form, every thread reading its own two indices with system-scope loads, took 51 us for 45 000 of them), and is
+    // written through to drawn_out by the workgroup that staged it
+    seq = __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const volatile int64_t* src = a.ring + int64_t(seq % unsigned(a.ring_slots)) * a.slot_stride;
+    const int e0 = blockIdx.x * blockDim.x;
+    br0 = min(e0 / a.C, n_br);
+    const int br1 = min((e0 + int(blockDim.x) - 1) / a.C + 1, n_br);
+    for (int i = threadIdx.x; i < a.B + (br1 - br0); i += blockDim.x) {
+      const int64_t at = i < a.B ? i : a.B + br0 + (i - a.B);
+      const int64_t v = src[at];
+      staged[i] = v;
+      a.drawn_out[at] = v;
+    }
+    if (blockIdx.x == 0)
+      for (int64_t at = a.B + n_br + threadIdx.x; at < a.n_total; at += blockDim.x) a.drawn_out[at] = src[at];   // what rides behind the draw
+    __syncthreads();
+  }
+  if (e < n_br * a.C) {
     const int c = e % a.C, br = e / a.C, b = br / a.n;
-    const int64_t o = a.drawn[b], pi = a.drawn[a.B + br];
+    const int64_t o = a.ring ? staged[b] : a.drawn[b], pi = a.ring ? staged[a.B + br - br0] : a.drawn[a.B + br];
     a.obs[e] = a.clouds[(o * a.P + pi) * a.C + c];
   }
   const int W = a.L + a.E;
@@ -287,9 +335,18 @@ __global__ __launch_bounds__(256) void fit_inputs_kernel(InputsArgs a) {
     if (i < a.L) {
       a.glob_cond[e] = a.z_shape[i];
     } else {
-      const float v = a.table[a.drawn[b] * a.E + (i - a.L)];
+      const float v = a.table[(a.ring ? staged[b] : a.drawn[b]) * a.E + (i - a.L)];
       a.glob_cond[e] = v;
       a.z_ex[b * a.E + (i - a.L)] = v;
+    }
+  }
+  if (a.ring) {
+    if (threadIdx.x == 0) {
+      // (this workgroup's loads of the slot returned in front of the barrier above)
+      if (atomicAdd(a.ctl + 1, 1u) == gridDim.x - 1) {                   // the last one to have read ctl[0]
+        __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ctl, seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -646,17 +703,26 @@ int nphm_fit_loss_backward(const float* sdf, const unsigned char* valid, int64_t
   return e == hipSuccess ? 0 : nphm_fail("nphm_fit_loss_backward launch", e);
 }
 
-int nphm_fit_loss_with_gradients(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
-                                 const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
-                                 const float* g_out, float* row, float* g_sdf, float* g_shape, float* g_expr, void* stream) {
+int nphm_fit_loss_with_gradients_logged(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                                        const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                                        const float* g_out, float* row, float* g_sdf, float* g_shape, float* g_expr,
+                                        float* row_log, const unsigned* log_control, int log_rows, void* stream) {
   if (!sdf || !thr || !lam || !z_shape || !row || !g_sdf || !g_shape || n_points <= 0) return nphm_fail_msg("nphm_fit_loss_with_gradients: bad arguments");
   if (z_expr && (!obs_idx || !g_expr || n_rows <= 0 || n_obs <= 0 || expr_dim <= 0))
     return nphm_fail_msg("nphm_fit_loss_with_gradients: bad expression-code arguments");
+  if (row_log && (!log_control || log_rows <= 0)) return nphm_fail_msg("nphm_fit_loss_with_gradients_logged: bad log arguments");
   nphm::fit::LossArgs a{sdf, valid, thr, lam, z_shape, z_expr, obs_idx, int(n_points), n_rows, n_obs, expr_dim, g_out, row,
-                        g_sdf, g_shape, g_expr};
+                        g_sdf, g_shape, g_expr, row_log, log_control, log_rows};
   hipLaunchKernelGGL(nphm::fit::fit_loss_kernel<2>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_fit_loss_with_gradients launch", e);
+}
+
+int nphm_fit_loss_with_gradients(const float* sdf, const unsigned char* valid, int64_t n_points, const float* thr, const float* lam,
+                                 const float* z_shape, const float* z_expr, const int64_t* obs_idx, int n_rows, int n_obs, int expr_dim,
+                                 const float* g_out, float* row, float* g_sdf, float* g_shape, float* g_expr, void* stream) {
+  return nphm_fit_loss_with_gradients_logged(sdf, valid, n_points, thr, lam, z_shape, z_expr, obs_idx, n_rows, n_obs, expr_dim, g_out, row,
+                                             g_sdf, g_shape, g_expr, nullptr, nullptr, 0, stream);
 }
 
 int nphm_fit_root_backward(const float* jac_inverse, const float* g_xc, float* g_posed, int64_t n, void* stream) {
@@ -785,10 +851,30 @@ int nphm_fit_inputs(const int64_t* drawn, int n_rows, int n_points, const float*
     return nphm_fail_msg("nphm_fit_inputs: bad sizes");
   const int64_t total = std::max(int64_t(n_rows) * n_points * cloud_width, int64_t(n_rows) * (shape_dim + expr_dim));
   if (total > 0x7fffffffLL) return nphm_fail_msg("nphm_fit_inputs: too many elements");
-  nphm::fit::InputsArgs a{drawn, clouds, z_shape, z_expr_table, n_rows, n_points, cloud_points, cloud_width, shape_dim, expr_dim, obs, z_ex, glob_cond};
+  nphm::fit::InputsArgs a{drawn, clouds, z_shape, z_expr_table, n_rows, n_points, cloud_points, cloud_width, shape_dim, expr_dim, obs, z_ex, glob_cond,
+                          nullptr, 0, 0, 0, nullptr, nullptr};
   hipLaunchKernelGGL(nphm::fit::fit_inputs_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : nphm_fail("nphm_fit_inputs launch", e);
+}
+
+int nphm_fit_inputs_ring(const int64_t* host_ring, int ring_slots, int64_t slot_stride, int64_t n_total, unsigned* control, int64_t* drawn_out,
+                         int n_rows, int n_points, const float* clouds, int n_obs, int cloud_points, int cloud_width,
+                         const float* z_shape, int shape_dim, const float* z_expr_table, int expr_dim, float* obs, float* z_ex,
+                         float* glob_cond, void* stream) {
+  if (!host_ring || !control || !drawn_out || !clouds || !z_shape || !z_expr_table || !obs || !z_ex || !glob_cond)
+    return nphm_fail_msg("nphm_fit_inputs_ring: null pointer");
+  if (n_rows <= 0 || n_points <= 0 || n_obs <= 0 || cloud_points <= 0 || cloud_width <= 0 || shape_dim <= 0 || expr_dim <= 0)
+    return nphm_fail_msg("nphm_fit_inputs_ring: bad sizes");
+  if (ring_slots <= 0 || n_total < int64_t(n_rows) * (1 + n_points) || slot_stride < n_total || n_rows > nphm::fit::FIT_RING_MAX_ROWS)
+    return nphm_fail_msg("nphm_fit_inputs_ring: bad ring geometry");
+  const int64_t total = std::max(int64_t(n_rows) * n_points * cloud_width, int64_t(n_rows) * (shape_dim + expr_dim));
+  if (total > 0x7fffffffLL) return nphm_fail_msg("nphm_fit_inputs_ring: too many elements");
+  nphm::fit::InputsArgs a{nullptr, clouds, z_shape, z_expr_table, n_rows, n_points, cloud_points, cloud_width, shape_dim, expr_dim, obs, z_ex, glob_cond,
+                          host_ring, ring_slots, slot_stride, n_total, drawn_out, control};
+  hipLaunchKernelGGL(nphm::fit::fit_inputs_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : nphm_fail("nphm_fit_inputs_ring launch", e);
 }
 
 int nphm_fit_inputs_backward(const float* g_z_ex, int64_t z_ex_row_stride, const float* g_glob_cond, const int64_t* obs_idx, int n_rows,

@@ -231,7 +231,17 @@ struct EvalArgs {
   float* sig_out;         // [n_rows][n_workgroups][sig_tiles][MT][64 lanes][16]: register dumps of the owning wavefront
   int sig_tiles;          // tiles per workgroup = sum of n_tiles over the hidden layers
   int sig_base[MAX_LINEAR];   // first tile of layer l
+  // KIND 6 (the K-split form of TAIL2): slots of TAIL_SLOT_BYTES each where a workgroup parks the second K half of the last
+  // hidden layer's operands, and one busy word per slot (zeroed by the launcher; compare-and-swap to take, store to release)
+  char* tail_ws;
+  unsigned* tail_flags;
+  unsigned tail_slots;
 };
+
+// (a parked half = the workgroup's hi | lo planes = all of its activation LDS, whatever the variant)
+constexpr size_t TAIL_SLOT_BYTES = size_t(128) << 10;
+constexpr unsigned TAIL_SLOTS = 512;        // >= 2 x the workgroups resident at once (one per CU: the planes take 128 KiB of LDS)
+constexpr size_t TAIL_FLAG_BYTES = 4096;
 
 // k softplus(d / k) in base 2 (see mlp_layout.h); agrees with nn.Softplus(beta=100, threshold=20)
 // to < 1e-9 in unscaled units
@@ -386,14 +396,16 @@ template <int N> using IC = std::integral_constant<int, N>;
 template <int MT, int NTW, int MODE, int KIND, bool F16 = false, bool ALL2 = false, bool ONE = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   constexpr bool JVP = KIND == 1 || KIND == 4, BROY = KIND == 2, SAVE = KIND == 3 || KIND == 4;   // 4: value+Jacobian, sigma' saved
-  constexpr bool TAIL2 = KIND == 5;         // plain evaluation (like 0), the last hidden layer in two point halves
-  static_assert(!ONE || (F16 && (KIND == 0 || KIND == 5)), "the single-term product serves the plain split-f16 evaluation");
+  constexpr bool TAIL2 = KIND == 5 || KIND == 6;   // plain evaluation (like 0), the last hidden layer two-term: in two point halves (5) ...
+  constexpr bool TAILK = KIND == 6;         // ... or in two K halves, the second one parked in EvalArgs::tail_ws meanwhile
+  static_assert(!ONE || (F16 && (KIND == 0 || TAIL2)), "the single-term product serves the plain split-f16 evaluation");
   static_assert(!TAIL2 || (ONE && MT % 2 == 0), "two point halves of the variant without a lo plane");
   constexpr int M = 32 * MT;               // columns per workgroup
   constexpr int PTS = JVP ? M / 4 : M;     // points per workgroup
   constexpr int HMAX = 32 * WAVES * NTW;   // widest layer
   constexpr int NCH = HMAX / 8;            // 16-byte K chunks per point
   constexpr int PART_BYTES = NCH * M * 16;
+  static_assert(!TAILK || size_t(PART_BYTES) == TAIL_SLOT_BYTES, "a parked K half is the size of the activation plane");
   constexpr bool YREG = MT <= 2;           // the last layer's per-wavefront sums live in registers (else in LDS)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act_hi = smem;
@@ -427,6 +439,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
     const int n4 = p.last_tiles * 32 + 1;                             // float4 entries
     for (int e = threadIdx.x; e < n4; e += blockDim.x)
       reinterpret_cast<float4*>(wlast)[e] = reinterpret_cast<const float4*>(p.last_tab)[e];
+  }
+
+  // ---- KIND 6: a slot of the parking space (read behind the hidden layers' barriers) -------------------------------------
+  if constexpr (TAILK) {
+    if (threadIdx.x == 0) {
+      unsigned sl = (blockIdx.x + blockIdx.y * gridDim.x) % p.tail_slots;
+      while (atomicCAS(p.tail_flags + sl, 0u, 1u) != 0u) sl = sl + 1 == p.tail_slots ? 0u : sl + 1;
+      reinterpret_cast<unsigned*>(xs)[0] = sl;
+    }
   }
 
   // ---- KIND 2: solver state of point threadIdx.x (threads < M) -----------------------------------
@@ -798,7 +819,135 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_eval_kernel(EvalArgs p) {
   }
 
   // ---- TAIL2: the last hidden layer, two-term, in two point halves --------------------------------------------------------
-  if constexpr (TAIL2) {
+  if constexpr (TAILK) {
+    // The K-split form: K half A = the tiles i < NTW / 2 of every wavefront (layer lp's outputs 0 .. 32 NA - 1) goes to LDS as
+    // hi | lo half planes of ALL the points, K half B is written to the workgroup's slot of tail_ws as the image of the same
+    // half planes and comes back by LDS-DMA once half A has been consumed: the accumulators run through both halves, the
+    // layer's weights are streamed ONCE (the per-accumulator order of the products is that of KIND 5: same bits).
+    constexpr int IH = NTW / 2, NA = WAVES * IH;
+    static_assert(NTW % 2 == 0 && NS == 2, "K halves by tile parity of the wavefront's tile list; two-slot ring");
+    const int lp = p.n_linear - 3, ll = p.n_linear - 2;
+    const int ni_p = tiles_of(p.layer[lp].n_tiles);
+    const LayerDev& L = p.layer[ll];
+    const int ni = tiles_of(L.n_tiles);
+    const int ks = L.k_steps;
+    const int ks_a = ks < 2 * NA ? ks : 2 * NA;                        // K-steps of half A (two per 32-feature tile)
+    const unsigned slot = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(xs)[0]);
+    const unsigned ws_off = slot * unsigned(PART_BYTES);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(p.tail_ws, 0, 0x7fffffff, 0x00020000);
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i rs_d;                                                         // the same resource as four SGPRs, for the inline-asm loads
+    {
+      const uint64_t a64 = reinterpret_cast<uint64_t>(p.tail_ws);
+      rs_d[0] = __builtin_amdgcn_readfirstlane(int(uint32_t(a64)));
+      rs_d[1] = __builtin_amdgcn_readfirstlane(int(uint32_t(a64 >> 32) & 0xffffu));
+      rs_d[2] = 0x7fffffff;
+      rs_d[3] = 0x00020000;
+    }
+    activate(ni_p, lp, false, IC<0>{}, IC<MT>{}, IC<1>{});             // hi | lo of every tile, in the registers of their D tiles
+    __syncthreads();                                                  // every wavefront has read the old tile
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (i < ni_p) {
+        const int n = wave + WAVES * (i < IH ? i : i - IH);           // tile inside its K half
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            frag_t fh, fl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              fh[q] = __float_as_uint(acc[i][t][8 * half + q]);
+              fl[q] = __float_as_uint(acc[i][t][8 * half + 4 + q]);
+            }
+            if (i < IH) {
+              const int off = ((4 * n + 2 * half + h) * M + 32 * t + j) * 16;
+              *reinterpret_cast<frag_t*>(act_hi + off) = fh;
+              *reinterpret_cast<frag_t*>(act_hi + PART_BYTES / 2 + off) = fl;
+            } else {
+              const unsigned so = __builtin_amdgcn_readfirstlane(ws_off + unsigned(((4 * n + 2 * half) * M + 32 * t) * 16));
+              const unsigned vo = unsigned((h * M + j) * 16);
+              __builtin_amdgcn_raw_buffer_store_b128(fh, rs_t, vo, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(fl, rs_t, vo, so + unsigned(PART_BYTES / 2), 0);
+            }
+          }
+        }
+      }
+    }
+    auto k_pass = [&](int s0, int s1) __attribute__((always_inline)) {          // K-steps s0 .. s1 - 1: chunks from 0 of the planes in LDS
+      if (ni > 0) {
+        const frag_t* Bh = reinterpret_cast<const frag_t*>(act_hi) + h * M + j;
+        const frag_t* Bl = reinterpret_cast<const frag_t*>(act_hi + PART_BYTES / 2) + h * M + j;
+        frag_t bh[2][MT], bl[2][MT];
+        auto load_b = [&](int sb, int s) __attribute__((always_inline)) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            bh[sb][t] = Bh[2 * (s - s0) * M + 32 * t];
+            bl[sb][t] = Bl[2 * (s - s0) * M + 32 * t];
+          }
+        };
+        auto mma = [&](int sa, int sb) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (i < ni) {
+#pragma unroll
+              for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(ah[sa][i], bh[sb][t], acc[i][t]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (i < ni) {
+#pragma unroll
+              for (int t = 0; t < MT; ++t) acc[i][t] = mfma16<F16>(ah[sa][i], bl[sb][t], acc[i][t]);
+            }
+          }
+        };
+        load_b(0, s0);
+#pragma unroll 1
+        for (int s = s0; s < s1; s += 2) {                             // (s0, s1 even; the ring's slot u holds K-step s + u)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (s + u + 1 < s1) load_b((u + 1) & 1, s + u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(u, u & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + u + 2 < ks) load_a(L, ni, u, s + u + 2, w_lane);  // (runs on into the second half)
+          }
+        }
+      }
+    };
+    coord_step(L, ni);                                                // (behind the stores: they read the accumulators)
+    __syncthreads();                                                  // half A is complete
+    k_pass(0, ks_a);
+    if (ks > ks_a) {
+      __syncthreads();                                                // every wavefront has read half A
+      {
+        // this wavefront's sixteenth of the image: 16 pieces of 1 KiB, four per M0
+        const unsigned voff = lane * 16u;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          const unsigned piece = unsigned(wave * 16 + k) * 1024u;
+          const unsigned dst = __builtin_amdgcn_readfirstlane(unsigned(size_t((__attribute__((address_space(3))) const char*)act_hi)) + piece);
+          const unsigned so = __builtin_amdgcn_readfirstlane(ws_off + piece);
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                       "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+                       "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+                       "buffer_load_dwordx4 %1, %2, %4 offen offset:2048 lds\n\t"
+                       "buffer_load_dwordx4 %1, %2, %4 offen offset:3072 lds\n\t"
+                       "s_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(voff), "s"(rs_d), "s"(dst), "s"(so) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (hipcc does not see these loads)
+      }
+      __syncthreads();                                                // half B is in LDS, nobody reads the slot any more
+      if (threadIdx.x == 0) __hip_atomic_store(p.tail_flags + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      k_pass(ks_a, ks);
+    } else {
+      if (threadIdx.x == 0) __hip_atomic_store(p.tail_flags + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    activate(ni, ll, true, IC<0>{}, IC<MT>{}, IC<2>{});
+  } else if constexpr (TAIL2) {
     constexpr int MH = MT / 2, MX = 32 * MH;
     const int lp = p.n_linear - 3, ll = p.n_linear - 2;
     const int ni_p = tiles_of(p.layer[lp].n_tiles);
@@ -1137,8 +1286,14 @@ static int launch_eval(const Plan& plan, nphm::mlp::EvalArgs& a, int64_t n_pts, 
     }
   } else if (tail2) {
     if constexpr (KIND == 0) {
-      if (plan.variant == 0 ? go(mlp_eval_kernel<4, 2, MODE, 5, true, false, true>, lds_bytes<4, 2, true>())
-                            : go(mlp_eval_kernel<2, 4, MODE, 5, true, false, true>, lds_bytes<2, 4, true>())) return -2;
+      if (a.tail_ws) {
+        // the K-split form (KIND 6): the busy words of the parking slots start at zero
+        e = hipMemsetAsync(a.tail_flags, 0, TAIL_FLAG_BYTES, st);
+        if (e != hipSuccess) return nphm_fail("nphm_mlp_eval: workspace", e);
+        if (plan.variant == 0 ? go(mlp_eval_kernel<4, 2, MODE, 6, true, false, true>, lds_bytes<4, 2, true>())
+                              : go(mlp_eval_kernel<2, 4, MODE, 6, true, false, true>, lds_bytes<2, 4, true>())) return -2;
+      } else if (plan.variant == 0 ? go(mlp_eval_kernel<4, 2, MODE, 5, true, false, true>, lds_bytes<4, 2, true>())
+                                   : go(mlp_eval_kernel<2, 4, MODE, 5, true, false, true>, lds_bytes<2, 4, true>())) return -2;
     }
   } else if (plan.variant == 0) {
     if (all2 ? go(mlp_eval_kernel<2, 2, MODE, KIND, true, true>, lds_bytes<2, 2>())
@@ -1226,10 +1381,37 @@ int nphm_mlp_prepare_latent(int lat_dim, int hidden_dim, int nlayers, int out_di
   return 0;
 }
 
+size_t nphm_mlp_eval_workspace_bytes(void) {
+  return nphm::mlp::TAIL_FLAG_BYTES + size_t(nphm::mlp::TAIL_SLOTS) * nphm::mlp::TAIL_SLOT_BYTES;
+}
+
+// [busy words | slots]; NULL: no workspace (the two-point-halves form), < 0: refused
+static int set_workspace(nphm::mlp::EvalArgs& a, void* workspace, size_t workspace_bytes, const char* who) {
+  if (!workspace) return 0;
+  if (workspace_bytes < nphm_mlp_eval_workspace_bytes() || (reinterpret_cast<uintptr_t>(workspace) & 15)) return nphm_fail_msg(who);
+  a.tail_flags = static_cast<unsigned*>(workspace);
+  a.tail_ws = static_cast<char*>(workspace) + nphm::mlp::TAIL_FLAG_BYTES;
+  a.tail_slots = nphm::mlp::TAIL_SLOTS;
+  return 0;
+}
+
+int nphm_mlp_eval_points_ws(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                            const void* packed, const void* latent_state,
+                            const float* xyz, int n_rows, int64_t n_points, int add_input, int numerics,
+                            float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                          const void* packed, const void* latent_state,
                          const float* xyz, int n_rows, int64_t n_points, int add_input, int numerics,
                          float* out, void* stream) {
+  return nphm_mlp_eval_points_ws(lat_dim, hidden_dim, nlayers, out_dim, packed, latent_state, xyz, n_rows, n_points, add_input,
+                                 numerics, out, nullptr, 0, stream);
+}
+
+int nphm_mlp_eval_points_ws(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                            const void* packed, const void* latent_state,
+                            const float* xyz, int n_rows, int64_t n_points, int add_input, int numerics,
+                            float* out, void* workspace, size_t workspace_bytes, void* stream) {
   Plan plan;
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_points: unsupported architecture");
   if (!packed || !latent_state || !xyz || !out) return nphm_fail_msg("nphm_mlp_eval_points: null pointer");
@@ -1244,6 +1426,7 @@ int nphm_mlp_eval_points(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   a.add_input = add_input;
   a.xyz = xyz;
   a.n_points = n_points;
+  if (set_workspace(a, workspace, workspace_bytes, "nphm_mlp_eval_points: workspace too small or misaligned (nphm_mlp_eval_workspace_bytes)")) return -2;
   return launch_eval<0>(plan, a, n_points, n_rows, static_cast<hipStream_t>(stream), numerics);
 }
 
@@ -1402,11 +1585,26 @@ int nphm_inverse3x3(const float* matrices, float* inverses, int64_t n, void* str
   return 0;
 }
 
+int nphm_mlp_eval_grid_ws(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                          const void* packed, const void* latent_state,
+                          const float* axis_x, const float* axis_y, const float* axis_z,
+                          int rx, int ry, int rz, int ix0, int ix1, int add_input, int numerics,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
                        const void* packed, const void* latent_state,
                        const float* axis_x, const float* axis_y, const float* axis_z,
                        int rx, int ry, int rz, int ix0, int ix1, int add_input, int numerics,
                        float* out, void* stream) {
+  return nphm_mlp_eval_grid_ws(lat_dim, hidden_dim, nlayers, out_dim, packed, latent_state, axis_x, axis_y, axis_z, rx, ry, rz,
+                               ix0, ix1, add_input, numerics, out, nullptr, 0, stream);
+}
+
+int nphm_mlp_eval_grid_ws(int lat_dim, int hidden_dim, int nlayers, int out_dim,
+                          const void* packed, const void* latent_state,
+                          const float* axis_x, const float* axis_y, const float* axis_z,
+                          int rx, int ry, int rz, int ix0, int ix1, int add_input, int numerics,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream) {
   Plan plan;
   if (!plan_of(lat_dim, hidden_dim, nlayers, out_dim, plan)) return nphm_fail_msg("nphm_mlp_eval_grid: unsupported architecture");
   if (!packed || !latent_state || !axis_x || !axis_y || !axis_z || !out) return nphm_fail_msg("nphm_mlp_eval_grid: null pointer");
@@ -1422,6 +1620,7 @@ int nphm_mlp_eval_grid(int lat_dim, int hidden_dim, int nlayers, int out_dim,
   a.add_input = add_input;
   a.ax = axis_x; a.ay = axis_y; a.az = axis_z;
   a.rx = rx; a.ry = ry; a.rz = rz; a.ix0 = ix0; a.ix1 = ix1;
+  if (set_workspace(a, workspace, workspace_bytes, "nphm_mlp_eval_grid: workspace too small or misaligned (nphm_mlp_eval_workspace_bytes)")) return -2;
   return launch_eval<1>(plan, a, int64_t(ix1 - ix0) * ry * rz, 1, static_cast<hipStream_t>(stream), numerics);
 }
 

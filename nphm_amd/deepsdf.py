@@ -276,6 +276,9 @@ class DeepSDF(nn.Module):
         # (0.7 - 1.3e-6 on the seeded and trained-like nets) and the single-term tier misses by a hair (2.1e-6)
         self.numerics_target = float(os.environ.get("NPHM_AMD_MLP_TARGET", "5e-6"))
         self.allow_single_term = os.environ.get("NPHM_AMD_MLP_SINGLE", "1") not in ("0", "")
+        # the tier set "single-term everywhere, last hidden layer two-term" with a workspace (eval_workspace): that layer's
+        # weights streamed once (two K halves) instead of twice (two point halves); same bits either way
+        self.tail_k_split = os.environ.get("NPHM_AMD_MLP_TAIL_KSPLIT", "1") not in ("0", "")
         self.two_pass_min_points = 1 << 18
         self._two_pass_cache = None     # (weight key, calibrated mask, report)
         # The value+Jacobian / Broyden / gradient-saving launches (the correspondence search and the implicit differentiation
@@ -500,13 +503,27 @@ class DeepSDF(nn.Module):
         """Bits of the linear layers that are hidden GEMM layers (1 .. nlayers - 1): the ones a two-term product may serve."""
         return ((1 << self.nlayers) - 1) & ~1
 
+    def eval_workspace(self, code: int, device) -> Optional[torch.Tensor]:
+        """Scratch of a plain evaluation launch with the tiers ``code`` (``nphm_mlp_eval_*_ws``), or None where the kernel has
+        no use for one.  It serves one tier set: every hidden layer single-term but the last, that one two-term (NPM's) -
+        the last hidden layer then streams its weights once, the second K half of its operands waiting in the workspace.
+        From torch's caching allocator, per call: stream-ordered like every other temporary, nothing kept alive here."""
+        hidden = self._hidden_mask()
+        last = 1 << (self.nlayers - 1)
+        one, two = (int(code) >> 20) & hidden, (int(code) >> 8) & hidden
+        if (int(code) & 0xff) != 1 or self.nlayers < 3 or one != (hidden & ~last) or not (two & last) or not self.tail_k_split:
+            return None
+        return torch.empty(int(_lib.load().nphm_mlp_eval_workspace_bytes()), dtype=torch.uint8, device=device)
+
     def _eval_points_raw(self, packed, state, xyz, add_input, code):
         lib = _lib.load()
         B, N, _ = xyz.shape
         out = torch.empty(B, N, self.n_out, dtype=torch.float32, device=xyz.device)
         stream = torch.cuda.current_stream(xyz.device).cuda_stream
-        _lib.check(lib.nphm_mlp_eval_points(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(),
-                                            B, N, int(bool(add_input)), int(code), out.data_ptr(), stream),
+        ws = self.eval_workspace(code, xyz.device)
+        _lib.check(lib.nphm_mlp_eval_points_ws(*self._arch(), packed.data_ptr(), state.data_ptr(), xyz.data_ptr(),
+                                               B, N, int(bool(add_input)), int(code), out.data_ptr(),
+                                               ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, stream),
                    "nphm_mlp_eval_points")
         return out
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 from contextlib import contextmanager, nullcontext
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 from torch import optim
 
@@ -187,6 +188,45 @@ class _ObservationSampler:
             self.clouds[i, : c.shape[0]] = c
         self.on_gpu = self.device.type == "cuda"
         self.extra = 0           # int64 slots behind the indices of an uploaded draw (_PairAdam's scalars)
+        self.ring = None         # replayed steps: the draws travel through a ring in pinned host memory (enable_ring)
+        self.ring_recorded = self.rows_logged = False
+        self.last_seq = None
+
+    RING_SLOTS = 8
+
+    def enable_ring(self, like, log_rows=0):
+        """A replayed step reads its draw straight from pinned host memory (``nphm_fit_inputs_ring``) instead of from a device
+        buffer that a stream-ordered upload filled in front of the replay: ``RING_SLOTS`` draws of the shape of ``like``, a
+        device counter of the replays done (which slot the next replay reads), one event per slot (the host fills slots
+        ahead of the device, never the one a replay in flight may still read)."""
+        import os
+        if not self.on_gpu or os.environ.get("NPHM_AMD_FIT_RING", "1") in ("0", ""):
+            return
+        self.ring = torch.empty(self.RING_SLOTS, like.numel(), dtype=torch.int64).pin_memory()
+        self.ring_ctl = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.ring_seq = 0                                  # replays issued so far = the value of ring_ctl[0] once they have run
+        self.ring_recorded = False                         # the current recording of the step reads the ring
+        # the loss rows of the replays, by replay number (nphm_fit_loss_with_gradients_logged), when a trace is kept
+        self.row_log = torch.zeros(log_rows, 8, dtype=torch.float32, device=self.device) if log_rows > 0 else None
+        self.rows_logged = False                           # the current recording stores them
+        self.last_seq = None                               # replay number of the step just run (None: it ran eagerly)
+        self.ring_events = [None] * self.RING_SLOTS
+
+    def ring_write(self, drawn):
+        slot = self.ring_seq % self.RING_SLOTS
+        ev = self.ring_events[slot]
+        if ev is not None:
+            ev.synchronize()                               # the replay that read this slot RING_SLOTS steps ago has finished
+        self.ring[slot].copy_(drawn)
+
+    def ring_commit(self):
+        """behind a replay that consumed the slot written last"""
+        slot = self.ring_seq % self.RING_SLOTS
+        if self.ring_events[slot] is None:
+            self.ring_events[slot] = torch.cuda.Event()
+        self.ring_events[slot].record()
+        self.last_seq = self.ring_seq
+        self.ring_seq += 1
 
     def draw(self):
         """host side: (obs_idx [n_batch], point indices [n_batch, n]) as ONE flat int64 tensor [n_batch | n_batch * n]
@@ -263,6 +303,13 @@ class _History:
         return torch.stack(vals)
 
     perm = None          # fused steps hand over the loss kernel's raw row [8]; this is its order in the history's columns
+    log = None           # rows of replayed steps, by replay number (written by the step's loss launch: _ObservationSampler.row_log)
+
+    def note(self, j, seq):
+        """step j was replay number ``seq``: its row is in ``log`` (no copy launch behind the replay)"""
+        if self.buf is not None:
+            self._noted = getattr(self, "_noted", [])
+            self._noted.append((j, seq))
 
     def record(self, j, row):
         if self.buf is not None:
@@ -278,6 +325,13 @@ class _History:
         if self.buf is None:
             return
         rows = self.buf[:n_done].cpu().numpy()
+        noted = [(j, q) for j, q in getattr(self, "_noted", []) if j < n_done]
+        if noted:
+            log = self.log.cpu().numpy()
+            if rows.shape[1] != log.shape[1]:               # (every step was replayed: record() never widened the buffer)
+                rows = np.zeros((rows.shape[0], log.shape[1]), dtype=np.float32)
+            for j, q in noted:
+                rows[j] = log[q]
         if self.perm is not None:
             rows = rows[:, self.perm]
         for r in rows:
@@ -338,7 +392,7 @@ class _FitLossFn(torch.autograd.Function):
     ``_LOSS_SLOTS`` order, the total, the number of valid correspondences)."""
 
     @staticmethod
-    def forward(ctx, sdf, valid, z_shape, z_expr, obs_idx, thr, lam6, seed=None):
+    def forward(ctx, sdf, valid, z_shape, z_expr, obs_idx, thr, lam6, seed=None, log=None):
         """``seed``: the device scalar the caller will pass to ``loss.backward(gradient=seed)`` right behind this call - the
         gradients are then computed by THIS launch (nphm_fit_loss_with_gradients) and ``backward`` hands them over when it
         receives that very tensor (one launch per step instead of two; anything else: the backward kernel as before)."""
@@ -358,11 +412,18 @@ class _FitLossFn(torch.autograd.Function):
         if seed is not None and seed.is_cuda and seed.dtype == torch.float32 and seed.numel() == 1:
             g_sdf, g_shape = torch.empty_like(sdf_c), torch.empty_like(zs)
             g_expr = None if ze is None else torch.empty_like(ze)
-            _lib.check(lib.nphm_fit_loss_with_gradients(
+            # ``log`` (the sampler of a loop whose replays read the host ring): while the step is RECORDED the row is also
+            # stored in its replay-indexed log (no copy launch between two replays; _History reads it after the loop)
+            logged = log is not None and getattr(log, "row_log", None) is not None and torch.cuda.is_current_stream_capturing()
+            _lib.check(lib.nphm_fit_loss_with_gradients_logged(
                 sdf_c.data_ptr(), None if valid_c is None else valid_c.data_ptr(), sdf_c.numel(), thr.data_ptr(), lam6.data_ptr(),
                 zs.data_ptr(), None if ze is None else ze.data_ptr(), None if ze is None else obs_idx.data_ptr(),
                 0 if ze is None else obs_idx.numel(), n_obs, expr_dim, seed.data_ptr(), row.data_ptr(), g_sdf.data_ptr(),
-                g_shape.data_ptr(), None if g_expr is None else g_expr.data_ptr(), stream), "nphm_fit_loss_with_gradients")
+                g_shape.data_ptr(), None if g_expr is None else g_expr.data_ptr(),
+                log.row_log.data_ptr() if logged else None, log.ring_ctl.data_ptr() if logged else None,
+                log.row_log.shape[0] if logged else 0, stream), "nphm_fit_loss_with_gradients")
+            if logged:
+                log.rows_logged = True
             ctx.seeded = (seed.data_ptr(), seed._version, g_sdf, g_shape, g_expr)
         else:
             _lib.check(lib.nphm_fit_loss(sdf_c.data_ptr(), None if valid_c is None else valid_c.data_ptr(), sdf_c.numel(), thr.data_ptr(),
@@ -379,11 +440,11 @@ class _FitLossFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_total, _g_row):
         if g_total is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         s_sdf, s_shape, s_expr = ctx.shapes
         if ctx.seeded is not None and g_total.data_ptr() == ctx.seeded[0] and g_total._version == ctx.seeded[1]:
             _, _, g_sdf, g_shape, g_expr = ctx.seeded          # the announced seed: the forward launch computed these
-            return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None, None)
+            return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None, None, None)
         from . import _lib
         lib = _lib.load()
         sdf_c, valid_c, zs, ze, obs_idx, thr, lam6 = ctx.saved_tensors
@@ -399,7 +460,7 @@ class _FitLossFn(torch.autograd.Function):
                                               None if ze is None else obs_idx.data_ptr(), 0 if ze is None else obs_idx.numel(), n_obs,
                                               expr_dim, go.data_ptr(), g_sdf.data_ptr(), g_shape.data_ptr(),
                                               None if g_expr is None else g_expr.data_ptr(), stream), "nphm_fit_loss_backward")
-        return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None, None)
+        return (g_sdf.view(s_sdf), None, g_shape.view(s_shape), None if g_expr is None else g_expr.view(s_expr), None, None, None, None, None)
 
 
 class _GatherRowsFn(torch.autograd.Function):
@@ -435,7 +496,7 @@ class _FitInputsFn(torch.autograd.Function):
     straight from a column slice of the conditioning's gradient)."""
 
     @staticmethod
-    def forward(ctx, z_shape, table, drawn, clouds, n_batch, extra=0):
+    def forward(ctx, z_shape, table, drawn, clouds, n_batch, extra=0, sampler=None):
         from . import _lib
         lib = _lib.load()
         dev = table.device
@@ -445,9 +506,18 @@ class _FitInputsFn(torch.autograd.Function):
         obs = torch.empty(n_batch, n, C, dtype=torch.float32, device=dev)
         z_ex = torch.empty(n_batch, 1, E, dtype=torch.float32, device=dev)
         glob = torch.empty(n_batch, 1, L + E, dtype=torch.float32, device=dev)
-        _lib.check(lib.nphm_fit_inputs(drawn.data_ptr(), n_batch, n, clouds.data_ptr(), n_obs, P, C, z_shape.detach().data_ptr(), L,
-                                       table.detach().data_ptr(), E, obs.data_ptr(), z_ex.data_ptr(), glob.data_ptr(),
-                                       torch.cuda.current_stream(dev).cuda_stream), "nphm_fit_inputs")
+        ring = getattr(sampler, "ring", None)
+        if ring is not None and ring.shape[1] == drawn.numel() and torch.cuda.is_current_stream_capturing():
+            # the recording of a replayed step: the draw comes out of the host ring (and is mirrored into ``drawn``)
+            _lib.check(lib.nphm_fit_inputs_ring(ring.data_ptr(), ring.shape[0], ring.stride(0), drawn.numel(), sampler.ring_ctl.data_ptr(),
+                                                drawn.data_ptr(), n_batch, n, clouds.data_ptr(), n_obs, P, C, z_shape.detach().data_ptr(), L,
+                                                table.detach().data_ptr(), E, obs.data_ptr(), z_ex.data_ptr(), glob.data_ptr(),
+                                                torch.cuda.current_stream(dev).cuda_stream), "nphm_fit_inputs_ring")
+            sampler.ring_recorded = True
+        else:
+            _lib.check(lib.nphm_fit_inputs(drawn.data_ptr(), n_batch, n, clouds.data_ptr(), n_obs, P, C, z_shape.detach().data_ptr(), L,
+                                           table.detach().data_ptr(), E, obs.data_ptr(), z_ex.data_ptr(), glob.data_ptr(),
+                                           torch.cuda.current_stream(dev).cuda_stream), "nphm_fit_inputs")
         ctx.save_for_backward(drawn)
         ctx.meta = (n_batch, n_obs, L, E, z_shape.shape, table.shape)
         ctx.mark_non_differentiable(obs)
@@ -468,7 +538,7 @@ class _FitInputsFn(torch.autograd.Function):
         g_uses = [None if g is None else g.contiguous().float() for g in g_uses]
         g_shape_uses, g_table_use = g_uses[:4], g_uses[4]
         if g_z_ex is None and g_glob is None and all(g is None for g in g_uses):
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dev = drawn.device
         stride = 0
         if g_z_ex is not None:
@@ -491,7 +561,7 @@ class _FitInputsFn(torch.autograd.Function):
                                                 uses, None if g_table_use is None else g_table_use.data_ptr(),
                                                 g_table.data_ptr(), None if g_shape is None else g_shape.data_ptr(),
                                                 torch.cuda.current_stream(dev).cuda_stream), "nphm_fit_inputs_backward")
-        return g_shape, g_table, None, None, None, None
+        return g_shape, g_table, None, None, None, None, None
 
 
 class _StepCodes:
@@ -509,7 +579,7 @@ def _step_inputs(sampler, drawn_dev, lat_rep_shape, lat_rep, n_batch):
     if (sampler.on_gpu and os.environ.get("NPHM_AMD_FIT_FUSED", "1") not in ("0", "") and sampler.clouds.dtype == torch.float32
             and lat_rep.dtype == torch.float32 and lat_rep.is_contiguous() and lat_rep_shape.is_contiguous()
             and lat_rep.dim() == 3 and lat_rep.shape[1] == 1 and lat_rep_shape.shape[:2] == (1, 1) and drawn_dev.is_contiguous()):
-        obs, z_ex, glob_cond, *uses = _FitInputsFn.apply(lat_rep_shape, lat_rep, drawn_dev, sampler.clouds, n_batch, sampler.extra)
+        obs, z_ex, glob_cond, *uses = _FitInputsFn.apply(lat_rep_shape, lat_rep, drawn_dev, sampler.clouds, n_batch, sampler.extra, sampler)
         return obs_idx, obs, z_ex, glob_cond, _StepCodes(lat_rep_shape, lat_rep, uses[:4], uses[4])
     obs_idx, obs = sampler.gather(drawn_dev)
     z_ex = _rows_of(lat_rep, obs_idx)
@@ -655,9 +725,20 @@ def _run_step(step, sampler, drawn_static, drawn_cur, pair=None):
     if pair is not None:
         drawn = torch.cat([drawn, pair.host_scalars()])
     if drawn.shape == drawn_static.shape:
-        sampler.upload(drawn, out=drawn_static)
+        ring = sampler.ring is not None and getattr(step, "enabled", False)
+        if ring and (step.graph is None or step._stale):
+            sampler.ring_recorded = sampler.rows_logged = False      # this call may record the step: _FitInputsFn / _FitLossFn say how
+        sampler.last_seq = None
+        if ring:
+            sampler.ring_write(drawn)
+        if not (ring and step.graph is not None and not step._stale and sampler.ring_recorded):
+            sampler.upload(drawn, out=drawn_static)        # (a pure replay of a ring recording needs none: its first launch reads the ring)
         drawn_cur[0] = drawn_static
-        return step()
+        before = getattr(step, "replays", 0)
+        out = step()
+        if ring and step.replays != before and sampler.ring_recorded:
+            sampler.ring_commit()
+        return out
     drawn_cur[0] = sampler.upload(drawn)
     try:
         return step.eager()
@@ -744,6 +825,10 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
         sampler.extra = pair.SLOTS
     drawn_static = sampler.upload(sampler.draw_like())       # static input of the step: the sampled indices (+ the optimizers' scalars)
     drawn_cur = [drawn_static]                               # what the step reads (another tensor for odd-shaped draws)
+    if use_graph and fused:
+        # replayed steps read their draw from pinned host memory and leave their loss row in a replay-indexed log
+        sampler.enable_ring(drawn_static, log_rows=n_iter if hist.buf is not None else 0)
+        hist.log = getattr(sampler, "row_log", None)
 
     def body():
         with (decoder_expr.condition_scope() if hasattr(decoder_expr, "condition_scope") else nullcontext()), \
@@ -808,7 +893,8 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
             _, sdf_grad = nabla(decoder, p_corresp, shape_cond, None)    # dead value in the reference (:112)
 
         if fused:                          # every loss term, the total and (backward) their gradients: two launches
-            loss, row8 = _FitLossFn.apply(sdf, valid, codes.loss, codes.expr_loss, obs_idx, ctl.thr, ctl.lam6, ctl.one)
+            loss, row8 = _FitLossFn.apply(sdf, valid, codes.loss, codes.expr_loss, obs_idx, ctl.thr, ctl.lam6, ctl.one,
+                                          sampler if sampler.ring is not None else None)
             loss.backward(gradient=ctl.one)       # (a preallocated seed, announced to the loss: its launch computes the gradients too)
             row = row8                     # raw: hist.perm orders it on the host
             if pair is not None:
@@ -844,7 +930,10 @@ def inference_iterative_root_finding_joint(decoder, decoder_expr, all_obs: List[
                 opt_expr.step()
             else:
                 pair.bump()
-            hist.record(j, row)
+            if sampler.ring is not None and sampler.last_seq is not None and sampler.rows_logged and hist.log is not None:
+                hist.note(j, sampler.last_seq)                 # (the replay's loss launch stored the row itself)
+            else:
+                hist.record(j, row)
             done = j + 1
             if verbose:
                 r = hist.ordered(row.cpu().numpy())

@@ -320,9 +320,11 @@ def evaluate_grid_mlp(mlp: DeepSDF, cond_row: torch.Tensor, axes: Sequence, *, x
     stream = torch.cuda.current_stream(device).cuda_stream
     if code is None:
         code = _mlp_lattice_code(mlp, packed, state, ax, ay, az)
-    _lib.check(lib.nphm_mlp_eval_grid(*mlp._arch(), packed.data_ptr(), state.data_ptr(), ax.data_ptr(),
-                                      ay.data_ptr(), az.data_ptr(), rx, ry, rz, ix0, ix1, int(bool(add_input)), int(code),
-                                      out.data_ptr(), stream), "nphm_mlp_eval_grid")
+    ws = mlp.eval_workspace(int(code), device)
+    _lib.check(lib.nphm_mlp_eval_grid_ws(*mlp._arch(), packed.data_ptr(), state.data_ptr(), ax.data_ptr(),
+                                         ay.data_ptr(), az.data_ptr(), rx, ry, rz, ix0, ix1, int(bool(add_input)), int(code),
+                                         out.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                         ws.numel() if ws is not None else 0, stream), "nphm_mlp_eval_grid")
     return out
 
 

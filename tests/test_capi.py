@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_queries_without_gpu():
     lib = _lib.load()
-    assert lib.nphm_abi_version() == 11
+    assert lib.nphm_abi_version() == 12
     assert lib.nphm_identity_supported(64, 32, 39, 16, 200, 4, 1, 3) == 1
     assert lib.nphm_identity_supported(64, 32, 39, 16, 256, 4, 1, 3) == 0
     assert lib.nphm_identity_packed_bytes() > 24 * 81_000 * 4          # >= folded fp32 weights

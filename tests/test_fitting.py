@@ -577,8 +577,9 @@ def test_second_stream_changes_no_bit_of_the_fit_gpu(monkeypatch):
         hist = []
         torch.manual_seed(0)
         lat_e, lat_s, anc = F.inference_iterative_root_finding_joint(
-            shape_net, expr_net, obs, dict(LAMBDAS), 60, {k: dict(v) for k, v in LONG_SCHEDULE.items()},
-            step_scale=float(g["step_scale"]), verbose=False, history=hist, use_graph=True)
+            shape_net, expr_net, obs, dict(LAMBDAS), 1000, {k: dict(v) for k, v in LONG_SCHEDULE.items()},
+            step_scale=float(g["step_scale"]), verbose=False, history=hist, use_graph=True)      # (1000 x 0.06 = 60 steps)
+        assert len(hist) == 60
         keys = sorted(hist[0])
         h = hashlib.sha1(np.array([[r[k] for k in keys] for r in hist]).tobytes())
         for t in (lat_e, lat_s, anc):
@@ -590,6 +591,54 @@ def test_second_stream_changes_no_bit_of_the_fit_gpu(monkeypatch):
         monkeypatch.setenv("NPHM_AMD_FIT_OVERLAP", overlap)
         digests.append((overlap, run()))
     assert len({d for _, d in digests}) == 1, digests
+
+
+@pytest.mark.gpu
+def test_host_ring_of_draws_changes_no_bit_of_the_fit_or_of_its_trace_gpu(monkeypatch):
+    """Replayed steps read their draw from a ring in pinned host memory (NPHM_AMD_FIT_RING, default on: the step's first
+    launch fetches the slot a device counter names, the loss launch stores the step's row in a replay-indexed log) instead of
+    from a device buffer that an upload in front of every replay filled, and of a copy launch behind it.  Same draws, same
+    arithmetic: latents, anchors and the loss trace of a 60-step fit (3 eager steps, then 57 replays - more replays
+    than ring slots, so slots are reused behind their events) are bit for bit those of the upload path; the ring path must
+    actually have been taken (replays counted on the device)."""
+    g = U.golden("fitting_trained")
+    dev = torch.device("cuda:0")
+    shape_net, _ = U.build_trained_identity(device=dev)
+    shape_net.train()
+    expr_net, _, _ = U.build_trained_deformation(device=dev)
+    obs = [torch.from_numpy(g[f"obs{i}"]).to(dev) for i in range(3)]
+    seen = {}
+    orig = F._ObservationSampler.enable_ring
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        seen["sampler"] = self
+
+    monkeypatch.setattr(F._ObservationSampler, "enable_ring", spy)
+
+    def run():
+        hist = []
+        torch.manual_seed(0)
+        lat_e, lat_s, anc = F.inference_iterative_root_finding_joint(
+            shape_net, expr_net, obs, dict(LAMBDAS), 1000, {k: dict(v) for k, v in LONG_SCHEDULE.items()},
+            step_scale=float(g["step_scale"]), verbose=False, history=hist, use_graph=True)      # (1000 x 0.06 = 60 steps)
+        keys = sorted(hist[0])
+        return (np.array([[r[k] for k in keys] for r in hist]), [t.detach().cpu().numpy() for t in (lat_e, lat_s, anc)])
+
+    monkeypatch.setenv("NPHM_AMD_FIT_RING", "1")
+    trace_r, out_r = run()
+    smp = seen["sampler"]
+    n_steps = trace_r.shape[0]
+    assert n_steps == 60
+    assert smp.ring is not None and smp.ring_seq == n_steps - 3 and int(smp.ring_ctl[0]) == smp.ring_seq and int(smp.ring_ctl[1]) == 0
+    assert smp.ring_seq > smp.RING_SLOTS and smp.rows_logged
+    monkeypatch.setenv("NPHM_AMD_FIT_RING", "0")
+    trace_u, out_u = run()
+    assert seen["sampler"].ring is None
+    assert np.isfinite(trace_r).all() and np.abs(trace_r).max() > 0
+    assert np.array_equal(trace_r, trace_u)
+    for a, b in zip(out_r, out_u):
+        assert np.array_equal(a, b)
 
 
 def _run_trained_pair(dev, backend, **kw):

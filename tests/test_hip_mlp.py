@@ -857,3 +857,59 @@ def test_tiers_and_fp32_last_layer_across_architectures(dev, hidden, nlayers, la
             assert torch.equal(vol.reshape(-1, out), net.forward_hip(pts, cond).reshape(-1, out)), name
         print(f"hidden {hidden} x {nlayers} layers, out {out}, {name}: {err:.2e} of the output scale against fp32 autograd")
         assert err < tol, (name, err)
+
+
+@pytest.mark.parametrize("hidden,nlayers,lat,out", [(1024, 8, 64, 1), (640, 5, 16, 3), (512, 3, 8, 2), (400, 6, 40, 4), (96, 4, 29, 3)])
+def test_last_hidden_layer_in_k_halves_is_bitwise_the_two_point_halves_form(dev, hidden, nlayers, lat, out):
+    """The tier set "single-term everywhere, last hidden layer two-term" (NPM's): with a workspace the last hidden layer runs
+    in two K halves - the second half of its operands parked in a slot of the workspace, back by LDS-DMA - and streams its
+    weights once; without one, in two point halves.  Same products in the same order per accumulator: the same bits.  Sizes:
+    more workgroups than slots (the slots are taken and released), a ragged tail, two conditioning rows, partial K halves
+    (640: 20 tiles = 16 + 4; 400, 96: the second half is short or empty), and the lattice launch."""
+    torch.manual_seed(3 * hidden + nlayers)
+    net = nphm_amd.DeepSDF(lat_dim=lat, hidden_dim=hidden, nlayers=nlayers, geometric_init=False, out_dim=out).to(dev).eval()
+    assert net.hip_supported()
+    g = torch.Generator().manual_seed(11)
+    n = 64 * 1024 + 37 if hidden > 512 else 128 * 700 + 5
+    x = ((torch.rand(2, n, 3, generator=g) - 0.5) * 0.9).to(dev)
+    cond = (torch.randn(2, lat, generator=g) * 0.3).to(dev)
+    tail = 1 << (nlayers - 1)
+    net.numerics, net.two_pass_mask, net.single_mask = "fixed", tail, net._hidden_mask() & ~tail
+    lib = nphm_amd._lib.load()
+    code = int(net._format_code() | (tail << 8) | ((net._hidden_mask() & ~tail) << 20))
+    packed, state = net.prepare_latent(cond)
+    calls = {"ws": 0, "plain": 0}
+    orig = lib.nphm_mlp_eval_points_ws
+
+    def spy(*a):
+        calls["ws" if a[-3] else "plain"] += 1
+        return orig(*a)
+
+    lib.nphm_mlp_eval_points_ws = spy
+    try:
+        with torch.no_grad():
+            net.tail_k_split = True
+            a = net._eval_points_raw(packed, state, x, False, code)
+            a2 = net._eval_points_raw(packed, state, x, False, code)      # (again: the slots of the first launch were all released)
+            net.tail_k_split = False
+            b = net._eval_points_raw(packed, state, x, False, code)
+            one_row = net.forward_hip(x[:1], cond[:1])                    # the module's own route to the same tiers ("fixed")
+    finally:
+        lib.nphm_mlp_eval_points_ws = orig
+    assert torch.equal(one_row, a[:1])
+    assert calls == {"ws": 2, "plain": 2}
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+    assert torch.equal(a, b) and torch.equal(a, a2)
+    axes = R.grid_axes(U.MINI, U.MAXI, 40)
+    with torch.no_grad():
+        net.tail_k_split = True
+        va = R.evaluate_grid_mlp(net, cond[:1], axes)
+        net.tail_k_split = False
+        vb = R.evaluate_grid_mlp(net, cond[:1], axes)
+    assert torch.equal(va, vb)
+    # a workspace that is too small is refused, not overrun
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    o = torch.empty(1, 64, out, device=dev)
+    rc = lib.nphm_mlp_eval_points_ws(*net._arch(), packed.data_ptr(), state.data_ptr(), x.data_ptr(), 1, 64, 0, code, o.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+    assert rc != 0
