@@ -419,8 +419,9 @@ def _mlp_kernel_name(mlp, shape, num):
         shape = {"2,2": "4,2", "1,4": "2,4"}[shape]          # single-term everywhere: twice the points per workgroup
         return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,false,true>"
     if len(hidden) >= 2 and all(p == 1 for p in hidden[:-1]) and hidden[-1] == 2:
-        shape = {"2,2": "4,2", "1,4": "2,4"}[shape]          # ... but the last hidden layer, two-term in two point halves
-        return f"nphm::mlp::mlp_eval_kernel<{shape},1,5,true,false,true>"
+        shape = {"2,2": "4,2", "1,4": "2,4"}[shape]          # ... but the last hidden layer, two-term: in two K halves through the
+        kind = 6 if getattr(mlp, "tail_k_split", False) else 5   # workspace (KIND 6, the default) or in two point halves (KIND 5)
+        return f"nphm::mlp::mlp_eval_kernel<{shape},1,{kind},true,false,true>"
     no_wl = bool(hidden) and all(p <= 2 for p in hidden)     # no three-term layer: the variant without wl registers
     return f"nphm::mlp::mlp_eval_kernel<{shape},1,0,true,{'true' if no_wl else 'false'},false>"
 

@@ -724,11 +724,11 @@ def _run_step(step, sampler, drawn_static, drawn_cur, pair=None):
     drawn = sampler.draw()
     if pair is not None:
         drawn = torch.cat([drawn, pair.host_scalars()])
+    sampler.last_seq = None                                # (set by ring_commit when this call turns out to be a ring replay)
     if drawn.shape == drawn_static.shape:
         ring = sampler.ring is not None and getattr(step, "enabled", False)
         if ring and (step.graph is None or step._stale):
             sampler.ring_recorded = sampler.rows_logged = False      # this call may record the step: _FitInputsFn / _FitLossFn say how
-        sampler.last_seq = None
         if ring:
             sampler.ring_write(drawn)
         if not (ring and step.graph is not None and not step._stale and sampler.ring_recorded):
