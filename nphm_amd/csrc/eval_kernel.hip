@@ -191,6 +191,33 @@ __device__ __forceinline__ void softplus2_pair(float d0, float d1, float& x0, fl
 #endif
 }
 
+// Softplus of the TWO-TERM members without transcendentals: max(d', 0) + q(min(|d'|, 16))^2 with q a degree-7 polynomial
+// (weighted minimax fit of sqrt(log2(1 + 2^-u)) on [0, 16] with q(16) = 0), max abs error 5.7e-5 in the scaled domain = 3.9e-7
+// in activation units, fp32, on register pairs (v_pk_fma_f32).  Built on the reading that the two-term body is VALU-bound by
+// its 704 quarter-rate transcendentals - and MEASURED 5 % SLOWER (same box, interleaved three times: 27.9-28.0
+// against 26.5-26.8 ms per 256^3 launch, same knobs): 1.6 x the VALU instructions of the body (2 039 -> 3 174) cost more
+// than the 704 v_exp / v_log they replace - the transcendentals are not what the body waits for.  Off; kept as the record.
+#ifndef NPHM_MID_POLY
+#define NPHM_MID_POLY 0
+#endif
+typedef float f32pair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void softplus2_pair_poly(float d0, float d1, float& x0, float& x1) {
+  if (NPHM_ABLATE & 4) { x0 = d0; x1 = d1; return; }
+  const f32pair u = {fminf(fabsf(d0), 16.f), fminf(fabsf(d1), 16.f)};
+  const f32pair r = {fmaxf(d0, 0.f), fmaxf(d1, 0.f)};
+  auto k = [](float c) __attribute__((always_inline)) { const f32pair v = {c, c}; return v; };
+  f32pair q = k(5.23813419306407e-08f);
+  q = __builtin_elementwise_fma(q, u, k(-3.1760125693836017e-06f));
+  q = __builtin_elementwise_fma(q, u, k(7.663998258067295e-05f));
+  q = __builtin_elementwise_fma(q, u, k(-0.0009056642302311957f));
+  q = __builtin_elementwise_fma(q, u, k(0.0045111170038580894f));
+  q = __builtin_elementwise_fma(q, u, k(0.010661209933459759f));
+  q = __builtin_elementwise_fma(q, u, k(-0.24952375888824463f));
+  q = __builtin_elementwise_fma(q, u, k(0.9999769926071167f));
+  const f32pair f = __builtin_elementwise_fma(q, q, r);
+  x0 = f[0]; x1 = f[1];
+}
+
 // Softplus for "light" members (adaptive precision: their GEMMs run single-pass, hi x hi only): the correction term
 // g(u) = log2(1 + 2^-u), u = |d'|, as (a0 - a1 min(u, .))^8 - max abs error 4.2e-3 in the scaled
 // domain (2.9e-5 in activation units, the size of the single-pass bf16 rounding these members already
@@ -1357,14 +1384,16 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
           }
           if constexpr (r & 1) {
             float x0, x1;
-            softplus2_pair(a[r - 1], a[r], x0, x1);
+            if constexpr (NPHM_MID_POLY && decltype(LL)::value == 2) softplus2_pair_poly(a[r - 1], a[r], x0, x1);
+            else softplus2_pair(a[r - 1], a[r], x0, x1);
             part = fmaf(x0, w4q[(r - 1) % 4], part);
             part = fmaf(x1, w4q[r % 4], part);
             asm volatile("" : "+v"(part));
           }
         } else if constexpr (r & 1) {
           float x0, x1;
-          softplus2_pair(a[r - 1], a[r], x0, x1);
+          if constexpr (NPHM_MID_POLY && decltype(LL)::value == 2) softplus2_pair_poly(a[r - 1], a[r], x0, x1);
+          else softplus2_pair(a[r - 1], a[r], x0, x1);
           if constexpr (g == L1_OB - 1) {        // skip connection (see below): registers 1..3 of the upper half-wave
             if constexpr (r - 1 >= 1 && r - 1 <= 3) x0 = h ? coords[r - 2] : x0;
             if constexpr (r <= 3) x1 = h ? coords[r - 1] : x1;
@@ -1437,7 +1466,8 @@ __global__ __launch_bounds__(64 * NW, 2) void eval_kernel(EvalArgs p) {
       if constexpr (PREC >= 1) { if constexpr (NPHM_EPI_PAIRS && !LIGHT) {
         if constexpr (r & 1) {
           float x0, x1;
-          softplus2_pair(a[r - 1], a[r], x0, x1);
+          if constexpr (NPHM_MID_POLY && decltype(LL)::value == 2) softplus2_pair_poly(a[r - 1], a[r], x0, x1);
+          else softplus2_pair(a[r - 1], a[r], x0, x1);
           a[r - 1] = x0;
           a[r] = x1;
           pack_pair<r - 1, LIGHT, PREC == 2>(a, H[B]);
