@@ -277,8 +277,10 @@ class DeepSDF(nn.Module):
         self.numerics_target = float(os.environ.get("NPHM_AMD_MLP_TARGET", "5e-6"))
         self.allow_single_term = os.environ.get("NPHM_AMD_MLP_SINGLE", "1") not in ("0", "")
         # the tier set "single-term everywhere, last hidden layer two-term" with a workspace (eval_workspace): that layer's
-        # weights streamed once (two K halves) instead of twice (two point halves); same bits either way
-        self.tail_k_split = os.environ.get("NPHM_AMD_MLP_TAIL_KSPLIT", "1") not in ("0", "")
+        # weights streamed once (two K halves) instead of twice (two point halves); same bits either way.  Opt-in: measured
+        # 11.6 % fewer L2 requests, the same time (4.187 / 4.195 ms) and 1.1 GB more HBM-side traffic per launch for the
+        # parked halves - the workspace-free form stays the default
+        self.tail_k_split = os.environ.get("NPHM_AMD_MLP_TAIL_KSPLIT", "0") not in ("0", "")
         self.two_pass_min_points = 1 << 18
         self._two_pass_cache = None     # (weight key, calibrated mask, report)
         # The value+Jacobian / Broyden / gradient-saving launches (the correspondence search and the implicit differentiation
