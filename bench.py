@@ -533,7 +533,7 @@ def npm_record(args, dev, steps, warmup, cpu):
     return out
 
 
-FIT_LAUNCHES_PER_STEP = 27      # kernel launches of one replayed step (profiles/r05_fitting_kernel_stats.csv, tools/fit_launches.py; refreshed per round)
+FIT_LAUNCHES_PER_STEP = 26      # kernel launches of one replayed step (profiles/r06_fitting_launches.txt, tools/fit_launches.py; refreshed per round)
 FIT_LAMBDAS = {"surface": 2.0, "reg_expr": 0.01, "reg_global": 0.25, "reg_unobserved": 10, "reg_loc": 0.05,
                "symm_dist": 5.0}                                                   # fitting_pointclouds.py:253-259
 FIT_SCHEDULE = {"lr": {200: 2, 400: 2, 600: 2, 800: 2}, "symm_dist": {200: 10, 500: 9999},
