@@ -202,7 +202,13 @@ class _ObservationSampler:
         import os
         if not self.on_gpu or os.environ.get("NPHM_AMD_FIT_RING", "1") in ("0", ""):
             return
-        self.ring = torch.empty(self.RING_SLOTS, like.numel(), dtype=torch.int64).pin_memory()
+        try:
+            ring = torch.empty(self.RING_SLOTS, like.numel(), dtype=torch.int64).pin_memory()
+        except RuntimeError:                                  # no page-locked memory to be had: the upload path stays
+            return
+        if not ring.is_pinned():
+            return
+        self.ring = ring
         self.ring_ctl = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.ring_seq = 0                                  # replays issued so far = the value of ring_ctl[0] once they have run
         self.ring_recorded = False                         # the current recording of the step reads the ring
